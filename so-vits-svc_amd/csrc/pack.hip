@@ -1,0 +1,99 @@
+// pack.hip — weight-norm fold + repack into the [Cin][KS][CoutP] layout read by the MFMA kernels.
+// Reference: torch.nn.utils.weight_norm as applied at vdecoder/hifigan/models.py:41-56,335,340-342,355 and
+// modules/modules.py:91-108 (via modules/DSConv.py:65-70): w = v * (g / ||v||_2), norm over all dims but 0.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// one block per packed output row p
+__global__ void pack_conv1d_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ dst,
+                                   int Cout, int Cin, int KS, int CoutP, int gate_half) {
+  __shared__ double sh[256];
+  const int p = blockIdx.x;
+  int c;
+  if (gate_half > 0) {
+    const int i = p >> 6, r = p & 63;
+    c = r < 32 ? 32 * i + r : gate_half + 32 * i + (r - 32);
+    if ((r < 32 ? 32 * i + r : 32 * i + (r - 32)) >= gate_half) c = -1;
+  } else {
+    c = p;
+  }
+  if (c >= Cout) c = -1;
+  const int n = Cin * KS;
+  float scale = 0.f;
+  if (c >= 0) {
+    scale = 1.f;
+    if (g) {
+      double acc = 0.0;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = v[(long long)c * n + i];
+        acc += x * x;
+      }
+      const double ss = block_sum(acc, sh);
+      scale = g[c] / (float)sqrt(ss);
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // i = ci*KS + k  -> dst[(ci*KS + k)*CoutP + p]
+    dst[(long long)i * CoutP + p] = c >= 0 ? v[(long long)c * n + i] * scale : 0.f;
+  }
+}
+
+// ConvTranspose1d: v [Cin][Cout][KS], g [Cin]; norm over (Cout,KS) per ci. One block per ci.
+__global__ void pack_convt1d_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ dst,
+                                    int Cin, int Cout, int KS, int CoutP) {
+  __shared__ double sh[256];
+  const int ci = blockIdx.x;
+  const int n = Cout * KS;
+  float scale = 1.f;
+  if (g) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const double x = v[(long long)ci * n + i];
+      acc += x * x;
+    }
+    const double ss = block_sum(acc, sh);
+    scale = g[ci] / (float)sqrt(ss);
+  }
+  // dst[(ci*KS + k)*CoutP + co]
+  for (int i = threadIdx.x; i < KS * CoutP; i += blockDim.x) {
+    const int k = i / CoutP, co = i - k * CoutP;
+    dst[((long long)ci * KS + k) * CoutP + co] = co < Cout ? v[(long long)ci * n + co * KS + k] * scale : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int svc_pack_conv1d_weight(const float* v, const float* g, float* dst, int Cout, int Cin, int KS,
+                                      int CoutP, int gate_half, void* stream) {
+  SVC_REQUIRE(v && dst, "pack_conv1d: null tensor");
+  SVC_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && CoutP >= Cout, "pack_conv1d: bad shape");
+  if (gate_half > 0)
+    SVC_REQUIRE(Cout == 2 * gate_half && (gate_half % 32) == 0 && CoutP == Cout,
+                "pack_conv1d: gate packing needs Cout == 2*gate_half, gate_half %% 32 == 0, CoutP == Cout");
+  hipLaunchKernelGGL(pack_conv1d_kernel, dim3(CoutP), dim3(256), 0, (hipStream_t)stream, v, g, dst, Cout, Cin, KS,
+                     CoutP, gate_half);
+  return svc::check_launch("pack_conv1d");
+}
+
+extern "C" int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin, int Cout, int KS,
+                                       int CoutP, void* stream) {
+  SVC_REQUIRE(v && dst, "pack_convt1d: null tensor");
+  SVC_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && CoutP >= Cout, "pack_convt1d: bad shape");
+  hipLaunchKernelGGL(pack_convt1d_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, v, g, dst, Cin, Cout, KS,
+                     CoutP);
+  return svc::check_launch("pack_convt1d");
+}

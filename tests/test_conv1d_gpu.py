@@ -1,0 +1,120 @@
+"""GPU parity of the fused fp32-MFMA conv1d (svc_conv1d_f32) against torch CPU fp32 conv1d — the op every
+nn.Conv1d of the reference path lowers to on its CPU path (mkldnn_convolution)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+CASES = [
+    # B, Cin, Cout, T, KS, dil
+    (1, 64, 64, 300, 3, 1),
+    (2, 128, 128, 515, 7, 3),
+    (1, 256, 256, 200, 11, 5),
+    (1, 32, 32, 1000, 3, 5),
+    (1, 16, 16, 2100, 11, 3),
+    (1, 16, 16, 700, 7, 1),
+    (2, 192, 384, 77, 5, 1),
+    (1, 768, 192, 50, 5, 1),
+    (1, 192, 576, 33, 1, 1),
+    (1, 100, 50, 260, 3, 1),
+    (3, 12, 25, 97, 7, 2),
+    (1, 128, 128, 20000, 3, 1),
+    (1, 64, 64, 20000, 7, 5),
+    (1, 192, 512, 20000, 7, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,dil", CASES)
+def test_conv1d_plain(dev, B, Cin, Cout, T, KS, dil):
+    import svc_hip as S
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T + KS)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pad = (KS * dil - dil) // 2
+    ref = F.conv1d(x, w, b, dilation=dil, padding=pad)
+    wp = S.pack_conv1d_weight(w.to(dev))
+    y = S.conv1d(x.to(dev), wp, Cout, KS, bias=b.to(dev), dil=dil, pad_left=pad)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _rel(y.cpu(), ref) < 2e-6
+
+
+def test_conv1d_weight_norm_lrelu_residual(dev):
+    """ResBlock1 inner step: xt = c2(lrelu(c1(lrelu(x)))) + x with weight-normed convs
+    (vdecoder/hifigan/models.py:60-67)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(7)
+    B, C, T, KS, dil = 2, 64, 777, 7, 3
+    x = torch.randn(B, C, T, generator=g)
+    v = torch.randn(C, C, KS, generator=g) * 0.05
+    gw = torch.rand(C, 1, 1, generator=g) + 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    w = v * (gw / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    pad = (KS * dil - dil) // 2
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=dil, padding=pad) + x
+    wp = S.pack_conv1d_weight(v.to(dev), gw.to(dev))
+    xd = x.to(dev)
+    y = S.conv1d(xd, wp, C, KS, bias=b.to(dev), dil=dil, pad_left=pad, pre_slope=0.1, res=xd, res_mode=1)
+    assert _rel(y.cpu(), ref) < 2e-6
+    # accumulate + divide epilogue: xs = (xs_old + y) / 3
+    xs = torch.randn(B, C, T, generator=g)
+    out = xs.to(dev).clone()
+    S.conv1d(xd, wp, C, KS, bias=b.to(dev), dil=dil, pad_left=pad, pre_slope=0.1, res=xd, res_mode=1, out=out,
+             beta=1.0, out_div=3.0)
+    assert _rel(out.cpu(), (xs + ref) / 3) < 2e-6
+
+
+def test_conv1d_gate_and_res_skip(dev):
+    """One WN layer (modules/modules.py:118-136): in_layer conv + cond -> tanh*sigmoid gate -> res/skip 1x1."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(11)
+    B, H, T, KS = 2, 192, 333, 5
+    x = torch.randn(B, H, T, generator=g)
+    w_in = torch.randn(2 * H, H, KS, generator=g) / (H * KS) ** 0.5
+    b_in = torch.randn(2 * H, generator=g) * 0.1
+    cond = torch.randn(B, 2 * H, 1, generator=g)
+    w_rs = torch.randn(2 * H, H, 1, generator=g) / H ** 0.5
+    b_rs = torch.randn(2 * H, generator=g) * 0.1
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, T - 40])[:, None]).float().unsqueeze(1)
+    out_prev = torch.randn(B, H, T, generator=g)
+
+    x_in = F.conv1d(x, w_in, b_in, padding=2) + cond
+    acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+    rs = F.conv1d(acts, w_rs, b_rs)
+    x_new = (x + rs[:, :H]) * mask
+    out_new = out_prev + rs[:, H:]
+
+    d = dev
+    wp_in = S.pack_conv1d_weight(w_in.to(d), gate_half=H)
+    acts_d = S.conv1d(x.to(d), wp_in, 2 * H, KS, bias=b_in.to(d), pad_left=2, cond=cond.to(d), epi=S.EPI_GATE)
+    assert _rel(acts_d.cpu(), acts) < 5e-6
+    wp_rs = S.pack_conv1d_weight(w_rs.to(d))
+    xd = x.to(d).clone()
+    od = out_prev.to(d).clone()
+    S.conv1d(acts_d, wp_rs, 2 * H, 1, bias=b_rs.to(d), mask=mask.to(d), res=xd, out=xd, out2=od, beta=1.0,
+             epi=S.EPI_RES_SKIP, skip_from=H)
+    assert _rel(xd.cpu(), x_new) < 5e-6
+    assert _rel(od.cpu(), out_new) < 5e-6
+
+
+def test_conv1d_flipped_views(dev):
+    """Channel Flip (modules/modules.py:232-239) folded into strides: conv over flip(x) writing flip(y)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(3)
+    B, C, T = 2, 96, 211
+    x = torch.randn(B, 2 * C, T, generator=g)
+    w = torch.randn(192, C, 1, generator=g) / C ** 0.5
+    b = torch.randn(192, generator=g)
+    xf = torch.flip(x, [1])
+    ref = F.conv1d(xf[:, :C], w, b)
+    xd = x.to(dev)
+    wp = S.pack_conv1d_weight(w.to(dev))
+    y = S.conv1d(S.flip_view(xd).narrow_c(0, C), wp, 192, 1, bias=b.to(dev))
+    assert _rel(y.cpu(), ref) < 2e-6
