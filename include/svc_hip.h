@@ -62,9 +62,10 @@ int svc_prof_report(char* buf, int len);
 int svc_pack_conv1d_weight(const float* v, const float* g, float* dst, int Cout, int Cin, int KS,
                            int CoutP, int gate_half, void* stream);
 /* ConvTranspose1d weight v:[Cin][Cout][KS] (+ optional g:[Cin], norm over (Cout,KS): weight_norm dim=0
- * on a transposed conv, vdecoder/hifigan/models.py:340-342) -> dst:[Cin][KS][CoutP]. */
+ * on a transposed conv, vdecoder/hifigan/models.py:340-342) -> polyphase blocks
+ * dst:[stride][Cin][M][CoutP], M = ceil(KS/stride), dst[p][ci][mr][co] = w[ci][co][p + (M-1-mr)*stride]. */
 int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin, int Cout, int KS,
-                            int CoutP, void* stream);
+                            int CoutP, int stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused Conv1d, fp32 in / fp32 accumulate on the matrix pipe (v_mfma_f32_32x32x2_f32 /
@@ -80,7 +81,8 @@ int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin,
  *                    res_mode 0: none | 1: v + res | 2: (res - v) * mask | 3: v + res * mask
  *   SVC_EPI_GATE     Cout = 2H rows packed with gate_half=H; y[b,c,t] = tanh(v_c) * sigmoid(v_{H+c})
  *   SVC_EPI_RES_SKIP rows c < skip_from : y[b,c,t]  = (res[b,c,t] + v) * mask[b,t]      (y may alias res)
- *                    rows c >= skip_from: y2[b,c-skip_from,t] = v + (beta ? y2_old : 0)
+ *                    rows c >= skip_from: y2[b,c-skip_from,t] = v + (beta ? y2_old : 0)   (* mask if res_mode==1:
+ *                                         the final `output * x_mask` of WN.forward, modules/modules.py:138)
  * ---------------------------------------------------------------------------------------------- */
 enum { SVC_EPI_PLAIN = 0, SVC_EPI_GATE = 1, SVC_EPI_RES_SKIP = 2 };
 enum { SVC_ACT_NONE = 0, SVC_ACT_RELU = 1, SVC_ACT_TANH = 2, SVC_ACT_LRELU = 3 };
@@ -99,10 +101,113 @@ typedef struct svc_conv1d_args {
   long long cond_bs, cond_cs, cond_ts, mask_bs, premask_bs;
   int B, Cin, Cout, Tin, Tout, KS, dil, pad_left, CoutP;
   int epi, post_act, res_mode, skip_from;
+  /* polyphase output mapping (ordinary conv: n_phase=1, y_ts=1, y_t0=0, y_len=Tout): the kernel runs n_phase
+   * dense sub-convolutions, phase p reading the packed weight block w + p*w_phase_stride and writing output
+   * sample t_out = t*y_ts + y_t0 + p for t in [0,Tout), kept when 0 <= t_out < y_len.  mask/cond/res/y are all
+   * indexed by t_out.  This is how svc_conv_transpose1d_f32 lowers ConvTranspose1d. */
+  int n_phase, y_ts, y_t0, y_len;
+  long long w_phase_stride;
   float pre_slope, post_slope, beta, out_div;
 } svc_conv1d_args;
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ConvTranspose1d (upsampling `ups[i]`, vdecoder/hifigan/models.py:340-342,378), lowered to `stride`
+ * dense polyphase sub-convolutions on the same MFMA kernel:
+ *   y[b,co,t] = bias[co] + res[b,co,t] + sum_{ci,k} w[ci,co,k] * lrelu(x[b,ci,j], pre_slope),  t = j*stride - padding + k
+ * Tout must equal (Tin-1)*stride - 2*padding + KS.  `res` (optional) is added in the epilogue: it carries
+ * noise_convs[i](har_source) (:379-381).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svc_convt1d_args {
+  const float* x;
+  const float* w;    /* from svc_pack_convt1d_weight */
+  const float* bias; /* [Cout] or NULL */
+  const float* res;  /* NULL or [B,Cout,Tout] */
+  float* y;
+  long long x_bs, x_cs, y_bs, y_cs, res_bs, res_cs;
+  int B, Cin, Cout, Tin, Tout, KS, stride, padding, CoutP;
+  float pre_slope;
+} svc_convt1d_args;
+
+int svc_conv_transpose1d_f32(const svc_convt1d_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Direct (VALU) Conv1d for the non-GEMM-shaped layers: noise_convs[i] Conv1d(1->C, k=2s, stride s)
+ * (vdecoder/hifigan/models.py:343-348,379), conv_post Conv1d(C->1,k7) + tanh (:355,390-392),
+ * F0Decoder.f0_prenet / proj (models.py:324-326).  Same packed weight layout as svc_conv1d_f32.
+ *   y[b,co,t] = act(sum_{ci,k} w[co,ci,k]*lrelu(x[b,ci,t*stride + k*dil - pad_left], pre_slope) + bias[co])
+ *               * mask[b,t] + res[b,co,t]
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svc_conv1d_direct_args {
+  const float* x;
+  const float* w;    /* packed [Cin][KS][CoutP] */
+  const float* bias; /* [Cout] or NULL */
+  const float* mask; /* NULL or [B,Tout] */
+  const float* res;  /* NULL or [B,Cout,Tout] */
+  float* y;
+  long long x_bs, x_cs, y_bs, y_cs, res_bs, res_cs, mask_bs;
+  int B, Cin, Cout, Tin, Tout, KS, dil, stride, pad_left, CoutP, post_act;
+  float pre_slope, post_slope;
+} svc_conv1d_direct_args;
+
+int svc_conv1d_direct_f32(const svc_conv1d_direct_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NSF harmonic source: nearest x`upp` f0 upsample (vdecoder/hifigan/models.py:369), SineGen (:138-166,
+ * :250-271) and SourceModuleHnNSF (:307-320: Linear(H->1) + tanh), evaluated in closed form per frame
+ * (see csrc/nsf_source.hip).  f0:[B,T]  rand_ini:[B,H] (column 0 ignored)  noise:[B,T*upp,H]
+ * lin_w:[H] lin_b:[1]  ->  har:[B,T*upp].  `scratch` is caller-provided device memory of
+ * svc_nsf_source_scratch_bytes(B,T,H) bytes, 8-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+long long svc_nsf_source_scratch_bytes(int B, int T, int H);
+int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                       const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
+                       float sampling_rate, float sine_amp, float noise_std, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small fused element-wise pieces.
+ * ---------------------------------------------------------------------------------------------- */
+/* y[b,c,t] = x[b,c,t] * mask[b,t] for arbitrary (possibly negative) channel strides: materialises a channel
+ * Flip (modules/modules.py:232-239) or an `x * x_mask` (modules/attentions.py:97) when it cannot be folded. */
+int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs, long long x_cs,
+                     long long y_bs, long long y_cs, long long mask_bs, int B, int C, int T, void* stream);
+/* utils.f0_to_coarse (utils.py:69-80): f0:[n] fp32 -> coarse:[n] int64 in [0,255]. */
+int svc_f0_to_coarse(const float* f0, long long* coarse, long long n, void* stream);
+/* models.py:520 and :156:  x = xin + emb_uv[uv] (+ vol_w*vol + vol_b);  x_enc = (x + f0_emb[coarse(f0)]) * mask.
+ * xin,x,x_enc:[B,C,T] contiguous; uv,f0,mask,vol:[B,T]; emb_uv:[2,C]; f0_emb:[256,C]; vol_w,vol_b:[C]. */
+int svc_prenet_embed_f32(const float* xin, const float* uv, const float* f0, const float* emb_uv,
+                         const float* f0_emb, const float* mask, const float* vol, const float* vol_w,
+                         const float* vol_b, float* x, float* x_enc, int B, int C, int T, void* stream);
+/* y = LayerNorm_C(x + r) * gamma + beta, optionally * mask (modules/modules.py:23-35 applied as in
+ * modules/attentions.py:98,102).  x,r,y:[B,C,T] contiguous (r may be NULL), mask:[B,T] or NULL. */
+int svc_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta,
+                          const float* mask, float* y, int B, int C, int T, float eps, void* stream);
+/* z = (m + noise * exp(logs) * scale) * mask with stats = [m ; logs] : [B,2C,T] (models.py:158-160,122-124). */
+int svc_reparam_f32(const float* stats, const float* noise, const float* mask, float* z, int B, int C, int T,
+                    float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head self-attention with window-`w` relative-position keys/values, flash style on the fp32
+ * matrix pipe (MultiHeadAttention.attention, modules/attentions.py:207-239 and helpers :259-303).
+ * q,k,v,out are [B, H*dk, T] views, element (b,c,t) at ptr + b*_bs + c*_cs + t.  q is divided by
+ * sqrt(dk) inside.  mask_mode: 0 none | 1 padding: score(i,j) = -1e4 where mask[b,i]*mask[b,j]==0
+ * (attentions.Encoder, :96) | 2 causal: -1e4 where j > i (attentions.FFT, :52).
+ * emb_rel_k / emb_rel_v: [2*window+1, dk] (heads_share=True) or NULL when window == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svc_attention_args {
+  const float* q;
+  const float* k;
+  const float* v;
+  const float* emb_rel_k;
+  const float* emb_rel_v;
+  const float* mask; /* [B,T] or NULL */
+  float* out;
+  long long q_bs, q_cs, k_bs, k_cs, v_bs, v_cs, o_bs, o_cs, mask_bs;
+  int B, H, dk, T, window, mask_mode;
+} svc_attention_args;
+
+int svc_attention_f32(const svc_attention_args* a, void* stream);
 
 #ifdef __cplusplus
 }

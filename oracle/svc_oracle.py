@@ -88,18 +88,25 @@ def multi_head_attention(x, sd, prefix, attn_mask, n_heads, window_size=None):
     (:259-303).  Restated in the equivalent banded form: with r = j - i, |r| <= w,
         scores[i,j] += (q_i / sqrt(d)) . E_k[r + w]       out_i += sum_r p[i, i+r] * E_v[r + w]
     (E shared across heads, heads_share=True :161).  Masked scores are set to -1e4 (:231), not -inf."""
-    b, d, t = x.shape
-    kc = d // n_heads
     q = conv1d(x, sd, prefix + ".conv_q")
     k = conv1d(x, sd, prefix + ".conv_k")
     v = conv1d(x, sd, prefix + ".conv_v")
+    e_k = sd[prefix + ".emb_rel_k"][0] if window_size is not None else None
+    e_v = sd[prefix + ".emb_rel_v"][0] if window_size is not None else None
+    out = attention_core(q, k, v, attn_mask, n_heads, e_k, e_v, window_size)
+    return conv1d(out, sd, prefix + ".conv_o")
+
+
+def attention_core(q, k, v, attn_mask, n_heads, e_k=None, e_v=None, window_size=None):
+    """MultiHeadAttention.attention, modules/attentions.py:207-239, on projected q,k,v [B, H*dk, T]."""
+    b, d, t = q.shape
+    kc = d // n_heads
     q = q.view(b, n_heads, kc, t).transpose(2, 3)
     k = k.view(b, n_heads, kc, t).transpose(2, 3)
     v = v.view(b, n_heads, kc, t).transpose(2, 3)
     qs = q / math.sqrt(kc)
     scores = torch.matmul(qs, k.transpose(-2, -1))
     if window_size is not None:
-        e_k = sd[prefix + ".emb_rel_k"][0]          # [2w+1, kc]
         rel = torch.matmul(qs, e_k.t())              # [b,h,t,2w+1]
         idx = torch.arange(t)
         for m in range(2 * window_size + 1):
@@ -111,14 +118,12 @@ def multi_head_attention(x, sd, prefix, attn_mask, n_heads, window_size=None):
     p = F.softmax(scores, dim=-1)
     out = torch.matmul(p, v)
     if window_size is not None:
-        e_v = sd[prefix + ".emb_rel_v"][0]
         idx = torch.arange(t)
         for m in range(2 * window_size + 1):
             r = m - window_size
             i = idx[(idx + r >= 0) & (idx + r < t)]
             out[:, :, i, :] = out[:, :, i, :] + p[:, :, i, i + r].unsqueeze(-1) * e_v[m]
-    out = out.transpose(2, 3).contiguous().view(b, d, t)
-    return conv1d(out, sd, prefix + ".conv_o")
+    return out.transpose(2, 3).contiguous().view(b, d, t)
 
 
 def ffn(x, x_mask, sd, prefix, kernel_size, causal=False):  # modules/attentions.py:337-363

@@ -1,0 +1,241 @@
+// attention.hip — multi-head self-attention with windowed relative-position keys/values on the fp32 matrix pipe.
+// Reference: MultiHeadAttention.attention, modules/attentions.py:207-239 (+ the relative-position helpers
+// :259-303 which pad emb_rel_k/v to 2T-1 rows and skew; restated here in the banded form
+//   scores[i,j] += (q_i/sqrt(d)) . E_k[j-i+w]  and  out_i += sum_{|r|<=w} p[i,i+r] * E_v[r+w],
+// verified against the reference module in tests/golden).  Masked scores are set to -1e4 (:231), not -inf.
+//
+// Layout: q,k,v,out are [B, heads*dk, T] channel-major views (time contiguous) — exactly what the 1x1 conv
+// projections produce, so no transposes exist anywhere.  One workgroup = (32 queries, one head, one batch
+// item), 4 waves splitting the key tiles.  We compute S^T = K Q^T (M = keys, N = queries) so that in the MFMA
+// C layout every lane owns ONE query column: softmax statistics are a 16-register reduction plus one
+// lane^32 exchange, and P^T is already the B operand of the second MFMA  O^T = V^T P^T  (the k index
+// order inside the tile is permuted to match the C layout; a sum does not care).  T x T scores are never
+// materialised.  Two passes over the keys (pass 1: exact row max / sum, pass 2: normalised P and PV) keep
+// the softmax bit-compatible with exp(x - max) / sum and avoid online rescaling; attention is < 1 % of the
+// path's FLOPs, so the second QK^T is free next to the convolutions.
+#include "common.h"
+
+namespace {
+
+constexpr int NW = 4;        // waves per workgroup
+constexpr int MAXREL = 17;   // 2*window+1 <= 17
+
+struct AttnP {
+  svc_attention_args a;
+  int nJ;
+  float inv_unused;
+};
+
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int NDT>  // dk = 32 * NDT
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
+  constexpr int DK = 32 * NDT;
+  constexpr int VP = 33;  // V tile pitch
+  const svc_attention_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // carve
+  float* Vl = lds;                                  // [NW][DK][VP]   (aliased by Ol [NW][DK][32] after the loop)
+  float* Rk = Vl + NW * DK * VP;                    // [MAXREL][32]
+  float* Pl = Rk + MAXREL * 32;                     // [MAXREL][32]
+  float* Ml = Pl + MAXREL * 32;                     // [NW][32]
+  float* Ll = Ml + NW * 32;                         // [NW][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int T = a.T;
+  const int i = i0 + li;
+  const int nrel = a.window > 0 ? 2 * a.window + 1 : 0;
+  const float sqrtk = sqrtf((float)DK);
+
+  const float* qb = a.q + (long long)b * a.q_bs + (long long)h * DK * a.q_cs;
+  const float* kb = a.k + (long long)b * a.k_bs + (long long)h * DK * a.k_cs;
+  const float* vb = a.v + (long long)b * a.v_bs + (long long)h * DK * a.v_cs;
+  const float* mq = a.mask ? a.mask + (long long)b * a.mask_bs : nullptr;
+
+  // Q fragment (B operand of S^T = K Q^T): lane (half, li) holds q[d = 2s + half][i] / sqrt(dk)
+  float qreg[DK / 2];
+#pragma unroll
+  for (int s = 0; s < DK / 2; ++s) {
+    const int d = 2 * s + half;
+    qreg[s] = i < T ? qb[(long long)d * a.q_cs + i] / sqrtk : 0.f;
+  }
+  // relative-key logits for this query tile: Rk[m][ii] = sum_d q[d][i0+ii]/sqrt(dk) * E_k[m][d]
+  for (int idx = tid; idx < nrel * 32; idx += NW * 64) {
+    const int m = idx >> 5, ii = idx & 31;
+    float acc = 0.f;
+    if (i0 + ii < T)
+      for (int d = 0; d < DK; ++d) acc = fmaf(qb[(long long)d * a.q_cs + i0 + ii] / sqrtk, a.emb_rel_k[m * DK + d], acc);
+    Rk[idx] = acc;
+    Pl[idx] = 0.f;
+  }
+  __syncthreads();
+
+  const float mi = mq ? (i < T ? mq[i] : 0.f) : 1.f;
+  const int n_iter = (p.nJ + NW - 1) / NW;
+
+  // scores of key tile jt for this lane's query column -> sc[16] (rows crow(r,half)); -inf outside [0,T)
+  auto score_tile = [&](int j0, float (&sc)[16]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int jl = j0 + li;
+    const bool jok = jl < T;
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) {
+      const int d = 2 * s + half;
+      const float kv = jok ? kb[(long long)d * a.k_cs + jl] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qreg[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + crow(r, half);
+      float s = acc[r];
+      const int rel = j - i + a.window;
+      if (nrel && rel >= 0 && rel < nrel) s += Rk[rel * 32 + li];
+      bool masked = false;
+      if (a.mask_mode == 1) masked = (mi * (j < T ? mq[j] : 0.f)) == 0.f;
+      else if (a.mask_mode == 2) masked = j > i;
+      if (masked) s = -1e4f;
+      if (j >= T) s = -INFINITY;
+      sc[r] = s;
+    }
+  };
+
+  // ---------------- pass 1: row max and sum ----------------
+  float mrun = -INFINITY, lrun = 0.f;
+  for (int it = 0; it < n_iter; ++it) {
+    const int jt = it * NW + w;
+    const int j0 = jt * 32;
+    if (jt >= p.nJ) continue;
+    if (a.mask_mode == 2 && j0 > i0 + 31) continue;  // fully-masked causal tile contributes exp(-1e4 - max) == 0
+    float sc[16];
+    score_tile(j0, sc);
+    float tm = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    const float mnew = fmaxf(mrun, tm);
+    float ts = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ts += expf(sc[r] - mnew);
+    ts += __shfl_xor(ts, 32);
+    lrun = lrun * expf(mrun - mnew) + ts;
+    mrun = mnew;
+  }
+  if (half == 0) {
+    Ml[w * 32 + li] = mrun;
+    Ll[w * 32 + li] = lrun;
+  }
+  __syncthreads();
+  float M = -INFINITY, Lsum = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, Ml[ww * 32 + li]);
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) {
+    const float mw = Ml[ww * 32 + li];
+    if (mw > -INFINITY) Lsum += Ll[ww * 32 + li] * expf(mw - M);
+  }
+
+  // ---------------- pass 2: P = exp(s - M) / L, O^T += V^T P^T ----------------
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float* Vw = Vl + w * DK * VP;
+  for (int it = 0; it < n_iter; ++it) {
+    const int jt = it * NW + w;
+    const int j0 = jt * 32;
+    const bool active = jt < p.nJ && !(a.mask_mode == 2 && j0 > i0 + 31);
+    float pr[16];
+    if (active) {
+      float sc[16];
+      score_tile(j0, sc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = expf(sc[r] - M) / Lsum;
+        const int j = j0 + crow(r, half);
+        const int rel = j - i + a.window;
+        if (nrel && rel >= 0 && rel < nrel && j < T && i < T) Pl[rel * 32 + li] = pr[r];
+      }
+      // stage V tile [DK][32] (coalesced rows) into this wave's LDS slab with pitch 33
+      const int jl = j0 + li;
+      for (int d = half; d < DK; d += 2) Vw[d * VP + li] = jl < T ? vb[(long long)d * a.v_cs + jl] : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float av = Vw[(dt * 32 + li) * VP + crow(r, half)];
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- cross-wave reduction + relative values + store ----------------
+  float* Ol = Vl;  // [NW][DK][32]
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ol[(w * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r];
+  __syncthreads();
+  float* ob = a.out + (long long)b * a.o_bs + (long long)h * DK * a.o_cs;
+  for (int idx = tid; idx < DK * 32; idx += NW * 64) {
+    const int d = idx >> 5, ii = idx & 31;
+    if (i0 + ii >= T) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += Ol[(ww * DK + d) * 32 + ii];
+    for (int m = 0; m < nrel; ++m) v = fmaf(Pl[m * 32 + ii], a.emb_rel_v[m * DK + d], v);
+    ob[(long long)d * a.o_cs + i0 + ii] = v;
+  }
+}
+
+template <int NDT>
+int launch(const svc_attention_args& a, hipStream_t s) {
+  constexpr int DK = 32 * NDT;
+  AttnP p;
+  p.a = a;
+  p.nJ = svc::cdiv(a.T, 32);
+  p.inv_unused = 0.f;
+  const size_t lds = (size_t)(NW * DK * 33 + 2 * MAXREL * 32 + 2 * NW * 32) * 4;
+  auto kern = attention_kernel<NDT>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(svc::cdiv(a.T, 32), a.H, a.B), dim3(NW * 64), lds, s, p);
+  return svc::check_launch("attention");
+}
+
+}  // namespace
+
+extern "C" int svc_attention_f32(const svc_attention_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "attention: null args");
+  const svc_attention_args& a = *ap;
+  SVC_REQUIRE(a.q && a.k && a.v && a.out, "attention: null tensor");
+  SVC_REQUIRE(a.B > 0 && a.H > 0 && a.T > 0, "attention: empty shape");
+  SVC_REQUIRE(a.dk % 32 == 0 && a.dk >= 32 && a.dk <= 128, "attention: head dim %d not in {32,64,96,128}", a.dk);
+  SVC_REQUIRE(a.window >= 0 && 2 * a.window + 1 <= MAXREL, "attention: window %d too large", a.window);
+  SVC_REQUIRE(a.window == 0 || (a.emb_rel_k && a.emb_rel_v), "attention: window set without relative embeddings");
+  SVC_REQUIRE(a.mask_mode >= 0 && a.mask_mode <= 2, "attention: bad mask_mode");
+  SVC_REQUIRE(a.mask_mode != 1 || a.mask, "attention: mask_mode 1 needs mask");
+  hipStream_t s = (hipStream_t)stream;
+  const double flop = 4.0 * a.B * a.H * (double)a.T * a.T * a.dk;
+  svc::ProfScope prof(s, "attention", flop, 16.0 * a.B * a.H * a.dk * a.T);
+  switch (a.dk / 32) {
+    case 1: return launch<1>(a, s);
+    case 2: return launch<2>(a, s);
+    case 3: return launch<3>(a, s);
+    default: return launch<4>(a, s);
+  }
+}

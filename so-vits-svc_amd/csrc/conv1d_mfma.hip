@@ -76,6 +76,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
   const int t0 = tt * BN;
   const int co0 = mtile * BM;
 
+  const float* xb = a.x + (long long)b * a.x_bs;
+  const float* pm = a.premask ? a.premask + (long long)b * a.premask_bs : nullptr;
+  const int tin0 = t0 - a.pad_left;
+  const int w_rows_total = a.Cin * KS;
+
+  // Polyphase transposed conv runs n_phase dense sub-convolutions over the same input tile (n_phase = 1 and
+  // y_ts = 1 for an ordinary conv); each phase has its own packed weight block and writes outputs
+  // t_out = t * y_ts + y_t0 + phase.
+  for (int ph = 0; ph < a.n_phase; ++ph) {
+  const float* wph = a.w + (long long)ph * a.w_phase_stride;
   f32x16 acc32[MT][NT];
   f32x4 acc16[MT][NT];
 #pragma unroll
@@ -90,11 +100,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
       }
     }
 
-  const float* xb = a.x + (long long)b * a.x_bs;
-  const float* pm = a.premask ? a.premask + (long long)b * a.premask_bs : nullptr;
-  const int tin0 = t0 - a.pad_left;
-  const int w_rows_total = a.Cin * KS;
-
   for (int c0 = 0; c0 < a.Cin; c0 += BC) {
     // ---- stage W chunk: rows (ci_l,k) of BM floats, float4 granularity ----
     {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
         const int grow = row0 + r;
         const int gco = co0 + c4 * 4;
         if (grow < w_rows_total && gco < a.CoutP)
-          v = *reinterpret_cast<const float4*>(a.w + (long long)grow * a.CoutP + gco);
+          v = *reinterpret_cast<const float4*>(wph + (long long)grow * a.CoutP + gco);
         *reinterpret_cast<float4*>(Ws + r * BM + c4 * 4) = v;
       }
     }
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int t = t0 + wn * (NT * TS) + j * TS + ln;
-    const bool tok = t < a.Tout;
+    const int tq = t0 + wn * (NT * TS) + j * TS + ln;
+    const int t = tq * a.y_ts + a.y_t0 + ph;
+    const bool tok = tq < a.Tout && t >= 0 && t < a.y_len;
     const float mk = (maskb && tok) ? maskb[t] : 1.f;
     if constexpr (EPI == SVC_EPI_GATE) {
       static_assert(EPI != SVC_EPI_GATE || ((MT % 2) == 0 && !M16), "gate epilogue needs tile pairs");
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
               } else {
                 float* yp = a.y2 + (long long)b * a.y2_bs + (long long)(co - a.skip_from) * a.y2_cs + t;
                 if (a.beta != 0.f) v += a.beta * (*yp);
+                if (a.res_mode == 1) v *= mk;  // last WN layer: `output * x_mask` (modules/modules.py:138)
                 *yp = v;
               }
             } else {
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
       }
     }
   }
+  }  // phase loop
 }
 
 template <int MT, int NT, int WM, int WN, bool M16, int EPI = SVC_EPI_PLAIN>
@@ -281,20 +289,19 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {
-  SVC_REQUIRE(ap != nullptr, "conv1d: null args");
-  const svc_conv1d_args& a = *ap;
+static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   SVC_REQUIRE(a.x && a.w && a.y, "conv1d: null tensor");
   SVC_REQUIRE(a.B > 0 && a.Cin > 0 && a.Cout > 0 && a.Tin > 0 && a.Tout > 0, "conv1d: empty shape");
   SVC_REQUIRE(a.KS >= 1 && a.dil >= 1, "conv1d: bad KS/dil");
+  SVC_REQUIRE(a.n_phase >= 1 && a.y_ts >= 1 && a.y_len >= 1, "conv1d: bad n_phase/y_ts/y_len");
   SVC_REQUIRE(a.CoutP >= a.Cout && (a.CoutP % 4) == 0, "conv1d: CoutP must be >= Cout and a multiple of 4");
   SVC_REQUIRE((reinterpret_cast<uintptr_t>(a.w) & 15) == 0, "conv1d: packed weight must be 16B aligned");
   SVC_REQUIRE(a.res_mode == 0 || a.res != nullptr, "conv1d: res_mode set but res is null");
   SVC_REQUIRE(a.res_mode != 2 || a.mask != nullptr || true, "conv1d");
   hipStream_t s = (hipStream_t)stream;
-  const double flop = 2.0 * a.B * (double)a.Cout * a.Cin * a.KS * a.Tout;
+  const double flop = 2.0 * a.B * (double)a.Cout * a.Cin * a.KS * a.Tout * a.n_phase;
   const double bytes = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout) + 4.0 * a.Cin * a.KS * a.Cout;
-  svc::ProfScope prof(s, "conv1d_mfma", flop, bytes);
+  svc::ProfScope prof(s, a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma", flop, bytes);
 
   const long long cols = (long long)a.B * a.Tout;
   if (a.epi == SVC_EPI_GATE) {
@@ -317,4 +324,35 @@ extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {
   }
   if (a.Cout <= 64) return launch_cfg<2, 2, 1, 4, false>(a, s);            // 64 x 256
   return launch_cfg<2, 2, 2, 2, false>(a, s);                              // 128 x 128
+}
+
+extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "conv1d: null args");
+  return conv1d_dispatch(*ap, stream);
+}
+
+// ConvTranspose1d as `stride` dense polyphase sub-convolutions (vdecoder/hifigan/models.py:340-342,378):
+//   y[co, q*u + p - pad] = sum_ci sum_m x[ci, q - m] * W[ci, co, p + m*u],   m < M = ceil(KS/u)
+// i.e. phase p is a conv with M taps (time-reversed) and pad_left = M-1, writing every u-th output sample.
+extern "C" int svc_conv_transpose1d_f32(const svc_convt1d_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "convt1d: null args");
+  const svc_convt1d_args& t = *ap;
+  SVC_REQUIRE(t.x && t.w && t.y, "convt1d: null tensor");
+  SVC_REQUIRE(t.stride >= 1 && t.KS >= 1 && t.padding >= 0, "convt1d: bad stride/KS/padding");
+  const int u = t.stride;
+  const int M = (t.KS + u - 1) / u;
+  const int Lout = (t.Tin - 1) * u - 2 * t.padding + t.KS;
+  SVC_REQUIRE(Lout == t.Tout, "convt1d: Tout=%d but (Tin-1)*stride-2*padding+KS=%d", t.Tout, Lout);
+  svc_conv1d_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = t.x; a.w = t.w; a.bias = t.bias; a.res = t.res; a.y = t.y;
+  a.x_bs = t.x_bs; a.x_cs = t.x_cs; a.y_bs = t.y_bs; a.y_cs = t.y_cs; a.res_bs = t.res_bs; a.res_cs = t.res_cs;
+  a.B = t.B; a.Cin = t.Cin; a.Cout = t.Cout; a.Tin = t.Tin;
+  a.Tout = (Lout - 1 + t.padding) / u + 1;   // number of q positions
+  a.KS = M; a.dil = 1; a.pad_left = M - 1; a.CoutP = t.CoutP;
+  a.epi = SVC_EPI_PLAIN; a.post_act = SVC_ACT_NONE; a.res_mode = t.res ? 1 : 0;
+  a.n_phase = u; a.y_ts = u; a.y_t0 = -t.padding; a.y_len = Lout;
+  a.w_phase_stride = (long long)t.Cin * M * t.CoutP;
+  a.pre_slope = t.pre_slope; a.post_slope = 0.f; a.beta = 0.f; a.out_div = 1.f;
+  return conv1d_dispatch(a, stream);
 }

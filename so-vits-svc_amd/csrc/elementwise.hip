@@ -1,0 +1,188 @@
+// elementwise.hip — the small HBM-bound pieces between the convolutions of SynthesizerTrn.infer/forward.
+#include "common.h"
+
+namespace {
+
+// ---- f0_to_coarse (utils.py:69-80) ------------------------------------------------------------------------
+// fp32 arithmetic in the reference's order.  torch.round is round-half-to-even -> rintf.
+__device__ __forceinline__ long long f0_to_coarse_dev(float f0) {
+  const float f0_mel_min = 1127.f * logf(1.f + 50.0f / 700.f);
+  const float f0_mel_max = 1127.f * logf(1.f + 1100.0f / 700.f);
+  // a and b are Python doubles in the reference, applied to a float tensor (=> cast to fp32 per op)
+  const double mel_min_d = 1127.0 * log(1.0 + 50.0 / 700.0);
+  const double mel_max_d = 1127.0 * log(1.0 + 1100.0 / 700.0);
+  const double a_d = (256 - 2) / (mel_max_d - mel_min_d);
+  const double b_d = mel_min_d * a_d - 1.0;
+  (void)f0_mel_min;
+  (void)f0_mel_max;
+  float mel = 1127.f * logf(1.f + f0 / 700.f);
+  if (mel > 0.f) mel = mel * (float)a_d - (float)b_d;
+  long long c = (long long)rintf(mel);
+  if (c <= 0) c = 0;
+  if (c < 1) c = 1;
+  if (c >= 256) c = 0;  // reference quirk: zeroed before the ">= f0_bin -> 255" fix-up can see it (utils.py:77-79)
+  return c;
+}
+
+__global__ void f0_to_coarse_kernel(const float* __restrict__ f0, long long* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = f0_to_coarse_dev(f0[i]);
+}
+
+// ---- pre-net embedding add (models.py:520 + models.py:156) -----------------------------------------------
+//   x     = xin + emb_uv[uv] + (vol ? vol_w*vol + vol_b : 0)          (xin = pre(c) * mask, from the conv epilogue)
+//   x_enc = (x + f0_emb[f0_to_coarse(f0)]) * mask
+__global__ __launch_bounds__(256) void prenet_embed_kernel(const float* __restrict__ xin, const float* __restrict__ uv,
+                                                           const float* __restrict__ f0, const float* __restrict__ emb_uv,
+                                                           const float* __restrict__ f0_emb, const float* __restrict__ mask,
+                                                           const float* __restrict__ vol, const float* __restrict__ vol_w,
+                                                           const float* __restrict__ vol_b, float* __restrict__ x,
+                                                           float* __restrict__ x_enc, int C, int T) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int b = blockIdx.z;
+  if (t >= T) return;
+  const int uvi = uv[(long long)b * T + t] != 0.f ? 1 : 0;
+  const long long coarse = f0_to_coarse_dev(f0[(long long)b * T + t]);
+  const float mk = mask ? mask[(long long)b * T + t] : 1.f;
+  const float vv = vol ? vol[(long long)b * T + t] : 0.f;
+  for (int c = blockIdx.y * 4 + (threadIdx.x >> 6); c < C; c += gridDim.y * 4) {
+    const long long o = ((long long)b * C + c) * T + t;
+    float v = xin[o] + emb_uv[uvi * C + c];
+    if (vol) v += vol_w[c] * vv + vol_b[c];
+    x[o] = v;
+    x_enc[o] = (v + f0_emb[coarse * C + c]) * mk;
+  }
+}
+
+// ---- residual + LayerNorm over channels of [B,C,T] (modules/modules.py:23-35; attentions.py:98,102) --------
+constexpr int LN_TT = 32;  // time steps per block
+constexpr int LN_CG = 8;   // channel groups per block
+
+__global__ __launch_bounds__(LN_TT* LN_CG) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    const float* __restrict__ mask, float* __restrict__ y,
+                                                                    int C, int T, float eps) {
+  __shared__ float red[LN_CG][LN_TT];
+  const int tl = threadIdx.x % LN_TT;
+  const int cg = threadIdx.x / LN_TT;
+  const int t = blockIdx.x * LN_TT + tl;
+  const int b = blockIdx.y;
+  const bool ok = t < T;
+  const long long base = (long long)b * C * T + t;
+  float s = 0.f;
+  if (ok)
+    for (int c = cg; c < C; c += LN_CG) s += x[base + (long long)c * T] + (r ? r[base + (long long)c * T] : 0.f);
+  red[cg][tl] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_CG; ++i) mean += red[i][tl];
+  mean /= (float)C;
+  __syncthreads();
+  float q = 0.f;
+  if (ok)
+    for (int c = cg; c < C; c += LN_CG) {
+      const float v = x[base + (long long)c * T] + (r ? r[base + (long long)c * T] : 0.f) - mean;
+      q += v * v;
+    }
+  red[cg][tl] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_CG; ++i) var += red[i][tl];
+  var /= (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!ok) return;
+  const float mk = mask ? mask[(long long)b * T + t] : 1.f;
+  for (int c = cg; c < C; c += LN_CG) {
+    const float v = x[base + (long long)c * T] + (r ? r[base + (long long)c * T] : 0.f);
+    y[base + (long long)c * T] = ((v - mean) * rstd * gamma[c] + beta[c]) * mk;
+  }
+}
+
+// ---- reparameterisation (models.py:158-160 / :122-124): z = (m + noise*exp(logs)*scale) * mask -------------
+__global__ void reparam_kernel(const float* __restrict__ stats, const float* __restrict__ noise,
+                               const float* __restrict__ mask, float* __restrict__ z, int C, int T, float scale,
+                               long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i % T);
+  const long long bc = i / T;
+  const int c = (int)(bc % C);
+  const long long b = bc / C;
+  const float m = stats[(b * 2 * C + c) * T + t];
+  const float logs = stats[(b * 2 * C + C + c) * T + t];
+  const float mk = mask ? mask[b * T + t] : 1.f;
+  z[i] = (m + noise[i] * expf(logs) * scale) * mk;
+}
+
+// ---- strided [B,C,T] copy with optional mask multiply: Flip (modules/modules.py:232-239), x * x_mask ------
+__global__ void copy_bct_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mask,
+                                long long x_bs, long long x_cs, long long y_bs, long long y_cs, long long mask_bs, int C,
+                                int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  const int b = blockIdx.z;
+  if (t >= T) return;
+  float v = x[b * x_bs + c * x_cs + t];
+  if (mask) v *= mask[b * mask_bs + t];
+  y[b * y_bs + c * y_cs + t] = v;
+}
+
+}  // namespace
+
+extern "C" int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs, long long x_cs,
+                                long long y_bs, long long y_cs, long long mask_bs, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && y, "copy_bct: null tensor");
+  SVC_REQUIRE(B > 0 && C > 0 && T > 0 && C <= 65535 && B <= 65535, "copy_bct: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  svc::ProfScope prof(s, "copy_bct", 0.0, 8.0 * B * C * T);
+  hipLaunchKernelGGL(copy_bct_kernel, dim3(svc::cdiv(T, 256), C, B), dim3(256), 0, s, x, y, mask, x_bs, x_cs, y_bs, y_cs,
+                     mask_bs, C, T);
+  return svc::check_launch("copy_bct");
+}
+
+extern "C" int svc_f0_to_coarse(const float* f0, long long* coarse, long long n, void* stream) {
+  SVC_REQUIRE(f0 && coarse && n > 0, "f0_to_coarse: bad args");
+  hipLaunchKernelGGL(f0_to_coarse_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, f0,
+                     coarse, n);
+  return svc::check_launch("f0_to_coarse");
+}
+
+extern "C" int svc_prenet_embed_f32(const float* xin, const float* uv, const float* f0, const float* emb_uv,
+                                    const float* f0_emb, const float* mask, const float* vol, const float* vol_w,
+                                    const float* vol_b, float* x, float* x_enc, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(xin && uv && f0 && emb_uv && f0_emb && x && x_enc, "prenet_embed: null tensor");
+  SVC_REQUIRE(B > 0 && C > 0 && T > 0, "prenet_embed: empty shape");
+  SVC_REQUIRE(!vol || (vol_w && vol_b), "prenet_embed: vol given without emb_vol weights");
+  hipStream_t s = (hipStream_t)stream;
+  svc::ProfScope prof(s, "prenet_embed", 0.0, 12.0 * B * C * T);
+  dim3 grid(svc::cdiv(T, 64), 8, B);
+  hipLaunchKernelGGL(prenet_embed_kernel, grid, dim3(256), 0, s, xin, uv, f0, emb_uv, f0_emb, mask, vol, vol_w, vol_b, x,
+                     x_enc, C, T);
+  return svc::check_launch("prenet_embed");
+}
+
+extern "C" int svc_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta,
+                                     const float* mask, float* y, int B, int C, int T, float eps, void* stream) {
+  SVC_REQUIRE(x && gamma && beta && y, "add_layernorm: null tensor");
+  SVC_REQUIRE(B > 0 && C > 0 && T > 0, "add_layernorm: empty shape");
+  hipStream_t s = (hipStream_t)stream;
+  svc::ProfScope prof(s, "add_layernorm", 0.0, 12.0 * B * C * T);
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3(svc::cdiv(T, LN_TT), B), dim3(LN_TT * LN_CG), 0, s, x, r, gamma, beta,
+                     mask, y, C, T, eps);
+  return svc::check_launch("add_layernorm");
+}
+
+extern "C" int svc_reparam_f32(const float* stats, const float* noise, const float* mask, float* z, int B, int C, int T,
+                               float scale, void* stream) {
+  SVC_REQUIRE(stats && noise && z, "reparam: null tensor");
+  SVC_REQUIRE(B > 0 && C > 0 && T > 0, "reparam: empty shape");
+  const long long n = (long long)B * C * T;
+  hipStream_t s = (hipStream_t)stream;
+  svc::ProfScope prof(s, "reparam", 0.0, 16.0 * n);
+  hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, s, stats, noise, mask, z, C, T,
+                     scale, n);
+  return svc::check_launch("reparam");
+}

@@ -1,0 +1,127 @@
+// nsf_source.hip — harmonic-plus-noise excitation of the NSF-HiFiGAN generator.
+// Reference: SineGen._f02sine / SineGen.forward / SourceModuleHnNSF.forward,
+// vdecoder/hifigan/models.py:138-166, 250-271, 307-320, fed by the nearest x`upp` upsample of f0 (:369).
+//
+// The reference computes, per harmonic h and sample t (all fp32 tensors; torch's CPU cumsum accumulates in
+// double and stores float):
+//     rad(t)   = (f0(t)*h / sr) % 1 ;  rad(0) += rand_ini[h]
+//     wrap(t)  = frac(float(S1(t))) < frac(float(S1(t-1))),   S1 = cumsum(rad)
+//     phase(t) = float( cumsum( float(rad(t) - wrap(t)) ) )          (range reduction, :160-166)
+//     sine     = sin(phase * 2 * pi) * 0.1
+// f0 is piecewise constant over `upp` samples, so instead of a 441k-step scan we evaluate this in CLOSED FORM:
+//     S1(t)    = A_f + (n+1) * rad_f                  (frame f, sample n; A_f = prefix over frames, double)
+//     N_w(t)   = floor(float(S1(t))) - floor(float(S1(0)))        (float rounding is monotone, so a wrap is
+//                                                                  detected exactly when the integer part steps)
+//     phase(t) = S1(t) - N_w(t) + E_f + (N_w(t) - W_f) * eps_f,   eps_f = float(rad_f - 1) - (rad_f - 1)
+// where eps_f is the rounding error the reference commits each time it subtracts 1 in fp32 — carrying it (E) is
+// what makes this agree with the reference to fp32 round-off instead of the 1e-4..1e-2 drift of an exact phase
+// (SURVEY.md §8a a18).  A tiny sequential per-(batch,harmonic) frame scan produces (A_f, W_f, E_f); the
+// sample kernel is then embarrassingly parallel and HBM-bound on the 9-wide noise tensor.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXH = 16;
+
+struct ScanRec {
+  double A;  // S1 before the first sample of the frame
+  double E;  // accumulated fp32 "-1" rounding error before the frame
+  double W;  // number of wraps detected before the frame
+};
+
+// one thread per (b, h); T iterations
+__global__ void nsf_frame_scan_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                      ScanRec* __restrict__ rec, int B, int T, int upp, int H, float sr) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, h = idx % H;
+  const float hm = (float)(h + 1);
+  const float ri = h == 0 ? 0.f : rand_ini[b * H + h];
+  double A = 0.0, E = 0.0, W = 0.0;
+  double base = 0.0;  // floor(float(S1(0)))
+  for (int f = 0; f < T; ++f) {
+    const float fn = f0[(long long)b * T + f] * hm;
+    const float rad = fmodf(fn / sr, 1.0f);
+    ScanRec r;
+    r.A = A;
+    r.E = E;
+    r.W = W;
+    rec[((long long)b * H + h) * T + f] = r;
+    double s_end;
+    if (f == 0) {
+      const float rad0 = rad + ri;  // fp32 add, models.py:149
+      base = floor((double)(float)(double)rad0);
+      s_end = (double)rad0 + (double)(upp - 1) * (double)rad;
+    } else {
+      s_end = A + (double)upp * (double)rad;
+    }
+    const double w_end = floor((double)(float)s_end) - base;
+    const double eps = (double)(rad - 1.0f) - ((double)rad - 1.0);
+    E += (w_end - W) * eps;
+    W = w_end;
+    A = s_end;
+  }
+}
+
+__global__ __launch_bounds__(256) void nsf_sample_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                         const float* __restrict__ noise, const float* __restrict__ lin_w,
+                                                         const float* __restrict__ lin_b, const ScanRec* __restrict__ rec,
+                                                         float* __restrict__ har, int B, int T, int upp, int H, float sr,
+                                                         float sine_amp, float noise_std) {
+  const long long L = (long long)T * upp;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= L) return;
+  const int f = (int)(t / upp);
+  const int n = (int)(t - (long long)f * upp);
+  const float f0v = f0[(long long)b * T + f];
+  const float uv = f0v > 0.f ? 1.f : 0.f;
+  const float noise_amp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
+  const float* nz = noise + ((long long)b * L + t) * H;
+  const float pi_f = 3.14159265358979323846f;
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const float hm = (float)(h + 1);
+    const float fn = f0v * hm;
+    const float rad = fmodf(fn / sr, 1.0f);
+    const ScanRec r = rec[((long long)b * H + h) * T + f];
+    // S1(0) for the wrap base
+    const float f00 = f0[(long long)b * T] * hm;
+    const float rad00 = fmodf(f00 / sr, 1.0f) + (h == 0 ? 0.f : rand_ini[b * H + h]);
+    const double base = floor((double)rad00);
+    double s1;
+    if (f == 0) s1 = (double)rad00 + (double)n * (double)rad;
+    else s1 = r.A + (double)(n + 1) * (double)rad;
+    const double nw = floor((double)(float)s1) - base;
+    const double eps = (double)(rad - 1.0f) - ((double)rad - 1.0);
+    const double ph = s1 - nw + r.E + (nw - r.W) * eps;
+    const float ph32 = (float)ph;
+    const float sine = sinf(ph32 * 2.f * pi_f) * sine_amp;
+    const float sw = sine * uv + noise_amp * nz[h];
+    acc += lin_w[h] * sw;
+  }
+  har[(long long)b * L + t] = tanhf(acc + lin_b[0]);
+}
+
+}  // namespace
+
+extern "C" long long svc_nsf_source_scratch_bytes(int B, int T, int H) {
+  return (long long)B * H * T * (long long)sizeof(ScanRec);
+}
+
+extern "C" int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                                  const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
+                                  float sampling_rate, float sine_amp, float noise_std, void* stream) {
+  SVC_REQUIRE(f0 && rand_ini && noise && lin_w && lin_b && har && scratch, "nsf_source: null tensor");
+  SVC_REQUIRE(B > 0 && T > 0 && upp > 0 && H > 0 && H <= MAXH, "nsf_source: bad shape (H <= %d)", MAXH);
+  SVC_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "nsf_source: scratch must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ScanRec* rec = reinterpret_cast<ScanRec*>(scratch);
+  const long long L = (long long)T * upp;
+  svc::ProfScope prof(s, "nsf_source", 0.0, 4.0 * B * L * (H + 1));
+  hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(svc::cdiv(B * H, 64)), dim3(64), 0, s, f0, rand_ini, rec, B, T, upp, H,
+                     sampling_rate);
+  hipLaunchKernelGGL(nsf_sample_kernel, dim3((unsigned)svc::cdivll(L, 256), B), dim3(256), 0, s, f0, rand_ini, noise,
+                     lin_w, lin_b, rec, har, B, T, upp, H, sampling_rate, sine_amp, noise_std);
+  return svc::check_launch("nsf_source");
+}

@@ -52,9 +52,10 @@ __global__ void pack_conv1d_kernel(const float* __restrict__ v, const float* __r
   }
 }
 
-// ConvTranspose1d: v [Cin][Cout][KS], g [Cin]; norm over (Cout,KS) per ci. One block per ci.
+// ConvTranspose1d: v [Cin][Cout][KS], g [Cin]; norm over (Cout,KS) per ci.  One block per ci.
+// dst[ph][ci][mr][CoutP] = w[ci][co][ph + (M-1-mr)*u]  (taps time-reversed so each phase is a plain correlation)
 __global__ void pack_convt1d_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ dst,
-                                    int Cin, int Cout, int KS, int CoutP) {
+                                    int Cin, int Cout, int KS, int CoutP, int u, int M) {
   __shared__ double sh[256];
   const int ci = blockIdx.x;
   const int n = Cout * KS;
@@ -68,10 +69,15 @@ __global__ void pack_convt1d_kernel(const float* __restrict__ v, const float* __
     const double ss = block_sum(acc, sh);
     scale = g[ci] / (float)sqrt(ss);
   }
-  // dst[(ci*KS + k)*CoutP + co]
-  for (int i = threadIdx.x; i < KS * CoutP; i += blockDim.x) {
-    const int k = i / CoutP, co = i - k * CoutP;
-    dst[((long long)ci * KS + k) * CoutP + co] = co < Cout ? v[(long long)ci * n + co * KS + k] * scale : 0.f;
+  const int per_ph = M * CoutP;
+  for (int i = threadIdx.x; i < u * per_ph; i += blockDim.x) {
+    const int ph = i / per_ph;
+    const int r = i - ph * per_ph;
+    const int mr = r / CoutP, co = r - mr * CoutP;
+    const int k = ph + (M - 1 - mr) * u;
+    float val = 0.f;
+    if (co < Cout && k < KS) val = v[(long long)ci * n + co * KS + k] * scale;
+    dst[(((long long)ph * Cin + ci) * M + mr) * CoutP + co] = val;
   }
 }
 
@@ -90,10 +96,11 @@ extern "C" int svc_pack_conv1d_weight(const float* v, const float* g, float* dst
 }
 
 extern "C" int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin, int Cout, int KS,
-                                       int CoutP, void* stream) {
+                                       int CoutP, int stride, void* stream) {
   SVC_REQUIRE(v && dst, "pack_convt1d: null tensor");
-  SVC_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && CoutP >= Cout, "pack_convt1d: bad shape");
+  SVC_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && CoutP >= Cout && stride >= 1, "pack_convt1d: bad shape");
+  const int M = (KS + stride - 1) / stride;
   hipLaunchKernelGGL(pack_convt1d_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, v, g, dst, Cin, Cout, KS,
-                     CoutP);
+                     CoutP, stride, M);
   return svc::check_launch("pack_convt1d");
 }

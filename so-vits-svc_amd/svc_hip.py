@@ -32,7 +32,43 @@ class Conv1dArgs(C.Structure):
         ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int),
         ("KS", C.c_int), ("dil", C.c_int), ("pad_left", C.c_int), ("CoutP", C.c_int),
         ("epi", C.c_int), ("post_act", C.c_int), ("res_mode", C.c_int), ("skip_from", C.c_int),
+        ("n_phase", C.c_int), ("y_ts", C.c_int), ("y_t0", C.c_int), ("y_len", C.c_int),
+        ("w_phase_stride", C.c_longlong),
         ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float),
+    ]
+
+
+class ConvT1dArgs(C.Structure):
+    _fields_ = [
+        ("x", _f32p), ("w", _f32p), ("bias", _f32p), ("res", _f32p), ("y", _f32p),
+        ("x_bs", C.c_longlong), ("x_cs", C.c_longlong), ("y_bs", C.c_longlong), ("y_cs", C.c_longlong),
+        ("res_bs", C.c_longlong), ("res_cs", C.c_longlong),
+        ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int),
+        ("KS", C.c_int), ("stride", C.c_int), ("padding", C.c_int), ("CoutP", C.c_int),
+        ("pre_slope", C.c_float),
+    ]
+
+
+class Conv1dDirectArgs(C.Structure):
+    _fields_ = [
+        ("x", _f32p), ("w", _f32p), ("bias", _f32p), ("mask", _f32p), ("res", _f32p), ("y", _f32p),
+        ("x_bs", C.c_longlong), ("x_cs", C.c_longlong), ("y_bs", C.c_longlong), ("y_cs", C.c_longlong),
+        ("res_bs", C.c_longlong), ("res_cs", C.c_longlong), ("mask_bs", C.c_longlong),
+        ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int),
+        ("KS", C.c_int), ("dil", C.c_int), ("stride", C.c_int), ("pad_left", C.c_int), ("CoutP", C.c_int),
+        ("post_act", C.c_int),
+        ("pre_slope", C.c_float), ("post_slope", C.c_float),
+    ]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [
+        ("q", _f32p), ("k", _f32p), ("v", _f32p), ("emb_rel_k", _f32p), ("emb_rel_v", _f32p), ("mask", _f32p),
+        ("out", _f32p),
+        ("q_bs", C.c_longlong), ("q_cs", C.c_longlong), ("k_bs", C.c_longlong), ("k_cs", C.c_longlong),
+        ("v_bs", C.c_longlong), ("v_cs", C.c_longlong), ("o_bs", C.c_longlong), ("o_cs", C.c_longlong),
+        ("mask_bs", C.c_longlong),
+        ("B", C.c_int), ("H", C.c_int), ("dk", C.c_int), ("T", C.c_int), ("window", C.c_int), ("mask_mode", C.c_int),
     ]
 
 
@@ -55,15 +91,29 @@ def lib():
         L.svc_prof_report.argtypes = [C.c_char_p, C.c_int]
         L.svc_pack_conv1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_void_p]
-        L.svc_pack_convt1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svc_pack_convt1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p]
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
+        L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
+        L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
+        L.svc_nsf_source_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.svc_nsf_source_scratch_bytes.restype = C.c_longlong
+        L.svc_nsf_source_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
+        L.svc_f0_to_coarse.argtypes = [_f32p, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.svc_prenet_embed_f32.argtypes = [_f32p] * 11 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_add_layernorm_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
+        L.svc_reparam_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
+        L.svc_attention_f32.argtypes = [C.POINTER(AttentionArgs), C.c_void_p]
+        L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         _lib = L
     return _lib
 
 
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
-    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32",
+    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
+    "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32",
 ]
 
 
@@ -110,15 +160,16 @@ def pack_conv1d_weight(v, g=None, gate_half=0):
     return dst
 
 
-def pack_convt1d_weight(v, g=None):
-    """v: [Cin, Cout, KS] ConvTranspose1d weight(_v); g: [Cin,1,1] or None -> packed [Cin, KS, CoutP]."""
+def pack_convt1d_weight(v, g, stride):
+    """v: [Cin, Cout, KS] ConvTranspose1d weight(_v); g: [Cin,1,1] or None -> polyphase [stride, Cin, M, CoutP]."""
     require_gpu(v, g)
     v = v.contiguous()
     Cin, Cout, KS = v.shape
     CoutP = round_up(Cout, 32)
-    dst = torch.empty((Cin, KS, CoutP), device=v.device, dtype=torch.float32)
+    M = (KS + stride - 1) // stride
+    dst = torch.empty((stride, Cin, M, CoutP), device=v.device, dtype=torch.float32)
     gg = g.contiguous().view(-1) if g is not None else None
-    check(lib().svc_pack_convt1d_weight(ptr(v), ptr(gg), ptr(dst), Cin, Cout, KS, CoutP, stream_ptr()),
+    check(lib().svc_pack_convt1d_weight(ptr(v), ptr(gg), ptr(dst), Cin, Cout, KS, CoutP, stride, stream_ptr()),
           "pack_convt1d_weight")
     return dst
 
@@ -173,7 +224,152 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.KS, a.dil, a.pad_left, a.CoutP = KS, dil, pad_left, wp.shape[2]
     a.epi, a.post_act, a.res_mode, a.skip_from = epi, post_act, res_mode, skip_from
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
+    a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
     check(lib().svc_conv1d_f32(C.byref(a), stream_ptr()), "conv1d")
+    return out
+
+
+def conv_transpose1d(x, wp, Cout, KS, stride, padding, *, bias=None, pre_slope=1.0, res=None, out=None):
+    """ConvTranspose1d via polyphase MFMA sub-convolutions; wp from pack_convt1d_weight."""
+    require_gpu(x, wp, bias, res, out)
+    B, Cin, Tin = x.shape
+    Tout = (Tin - 1) * stride - 2 * padding + KS
+    if out is None:
+        out = torch.empty((B, Cout, Tout), device=x.device, dtype=torch.float32)
+    a = ConvT1dArgs()
+    a.x, a.w, a.bias, a.res, a.y = ptr(x), ptr(wp), ptr(bias), ptr(res), ptr(out)
+    a.x_bs, a.x_cs = _bct_strides(x)
+    a.y_bs, a.y_cs = _bct_strides(out)
+    if res is not None:
+        a.res_bs, a.res_cs = _bct_strides(res)
+    a.B, a.Cin, a.Cout, a.Tin, a.Tout = B, Cin, Cout, Tin, Tout
+    a.KS, a.stride, a.padding, a.CoutP = KS, stride, padding, wp.shape[3]
+    a.pre_slope = pre_slope
+    check(lib().svc_conv_transpose1d_f32(C.byref(a), stream_ptr()), "conv_transpose1d")
+    return out
+
+
+def conv1d_direct(x, wp, Cout, KS, *, bias=None, stride=1, dil=1, pad_left=0, Tout=None, pre_slope=1.0,
+                  post_act=ACT_NONE, post_slope=0.0, mask=None, res=None, out=None):
+    """VALU direct conv (noise_convs, conv_post, Cin=1 / Cout=1 layers); wp from pack_conv1d_weight."""
+    require_gpu(x, wp, bias, mask, res, out)
+    B, Cin, Tin = x.shape
+    if Tout is None:
+        Tout = (Tin + 2 * pad_left - dil * (KS - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Cout, Tout), device=x.device, dtype=torch.float32)
+    a = Conv1dDirectArgs()
+    a.x, a.w, a.bias, a.mask, a.res, a.y = ptr(x), ptr(wp), ptr(bias), ptr(mask), ptr(res), ptr(out)
+    a.x_bs, a.x_cs = _bct_strides(x)
+    a.y_bs, a.y_cs = _bct_strides(out)
+    if res is not None:
+        a.res_bs, a.res_cs = _bct_strides(res)
+    if mask is not None:
+        a.mask_bs = mask.stride(0)
+    a.B, a.Cin, a.Cout, a.Tin, a.Tout = B, Cin, Cout, Tin, Tout
+    a.KS, a.dil, a.stride, a.pad_left, a.CoutP, a.post_act = KS, dil, stride, pad_left, wp.shape[2], post_act
+    a.pre_slope, a.post_slope = pre_slope, post_slope
+    check(lib().svc_conv1d_direct_f32(C.byref(a), stream_ptr()), "conv1d_direct")
+    return out
+
+
+def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0.1, noise_std=0.003, out=None,
+               scratch=None):
+    """f0 [B,T], rand_ini [B,H], noise [B,T*upp,H], lin_w [1,H]|[H], lin_b [1] -> har_source [B,1,T*upp]."""
+    require_gpu(f0, rand_ini, noise, lin_w, lin_b, out)
+    B, T = f0.shape
+    H = rand_ini.shape[1]
+    L = T * upp
+    if tuple(noise.shape) != (B, L, H):
+        raise SvcError(f"nsf_source: noise shape {tuple(noise.shape)} != {(B, L, H)}")
+    if out is None:
+        out = torch.empty((B, 1, L), device=f0.device, dtype=torch.float32)
+    nbytes = lib().svc_nsf_source_scratch_bytes(B, T, H)
+    if scratch is None or scratch.numel() * scratch.element_size() < nbytes:
+        scratch = torch.empty((nbytes + 7) // 8, device=f0.device, dtype=torch.float64)
+    check(lib().svc_nsf_source_f32(ptr(f0.contiguous()), ptr(rand_ini.contiguous()), ptr(noise.contiguous()),
+                                   ptr(lin_w.contiguous()), ptr(lin_b.contiguous()), ptr(out), ptr(scratch), B, T,
+                                   upp, H, float(sampling_rate), sine_amp, noise_std, stream_ptr()), "nsf_source")
+    return out
+
+
+def f0_to_coarse(f0):
+    require_gpu(f0)
+    f0c = f0.contiguous()
+    out = torch.empty(f0c.shape, device=f0.device, dtype=torch.int64)
+    check(lib().svc_f0_to_coarse(ptr(f0c), ptr(out), f0c.numel(), stream_ptr()), "f0_to_coarse")
+    return out
+
+
+def prenet_embed(xin, uv, f0, emb_uv, f0_emb, mask=None, vol=None, vol_w=None, vol_b=None):
+    """Returns (x, x_enc): x = xin + emb_uv[uv] (+ vol); x_enc = (x + f0_emb[coarse(f0)]) * mask."""
+    require_gpu(xin, uv, f0, emb_uv, f0_emb, mask, vol, vol_w, vol_b)
+    B, Cc, T = xin.shape
+    xin = xin.contiguous()
+    x = torch.empty_like(xin)
+    x_enc = torch.empty_like(xin)
+    check(lib().svc_prenet_embed_f32(ptr(xin), ptr(uv.contiguous()), ptr(f0.contiguous()), ptr(emb_uv.contiguous()),
+                                     ptr(f0_emb.contiguous()), ptr(mask), ptr(vol), ptr(vol_w), ptr(vol_b), ptr(x),
+                                     ptr(x_enc), B, Cc, T, stream_ptr()), "prenet_embed")
+    return x, x_enc
+
+
+def add_layernorm(x, r, gamma, beta, mask=None, eps=1e-5, out=None):
+    require_gpu(x, r, gamma, beta, mask, out)
+    B, Cc, T = x.shape
+    if not x.is_contiguous() or (r is not None and not r.is_contiguous()):
+        raise SvcError("add_layernorm needs contiguous [B,C,T] tensors")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().svc_add_layernorm_f32(ptr(x), ptr(r), ptr(gamma), ptr(beta), ptr(mask), ptr(out), B, Cc, T, eps,
+                                      stream_ptr()), "add_layernorm")
+    return out
+
+
+def reparam(stats, noise, mask=None, scale=1.0, out=None):
+    require_gpu(stats, noise, mask, out)
+    B, C2, T = stats.shape
+    Cc = C2 // 2
+    if not stats.is_contiguous() or not noise.is_contiguous():
+        raise SvcError("reparam needs contiguous tensors")
+    if out is None:
+        out = torch.empty((B, Cc, T), device=stats.device, dtype=torch.float32)
+    check(lib().svc_reparam_f32(ptr(stats), ptr(noise), ptr(mask), ptr(out), B, Cc, T, scale, stream_ptr()),
+          "reparam")
+    return out
+
+
+def attention(q, k, v, n_heads, *, emb_rel_k=None, emb_rel_v=None, window=0, mask=None, mask_mode=0, out=None):
+    """q,k,v: [B, H*dk, T] views (time contiguous).  Returns [B, H*dk, T]."""
+    require_gpu(q, k, v, emb_rel_k, emb_rel_v, mask, out)
+    B, Cc, T = q.shape
+    dk = Cc // n_heads
+    if out is None:
+        out = torch.empty((B, Cc, T), device=q.device, dtype=torch.float32)
+    a = AttentionArgs()
+    a.q, a.k, a.v, a.out = ptr(q), ptr(k), ptr(v), ptr(out)
+    a.emb_rel_k, a.emb_rel_v, a.mask = ptr(emb_rel_k), ptr(emb_rel_v), ptr(mask)
+    a.q_bs, a.q_cs = _bct_strides(q)
+    a.k_bs, a.k_cs = _bct_strides(k)
+    a.v_bs, a.v_cs = _bct_strides(v)
+    a.o_bs, a.o_cs = _bct_strides(out)
+    if mask is not None:
+        a.mask_bs = mask.stride(0)
+    a.B, a.H, a.dk, a.T, a.window, a.mask_mode = B, n_heads, dk, T, window, mask_mode
+    check(lib().svc_attention_f32(C.byref(a), stream_ptr()), "attention")
+    return out
+
+
+def copy_bct(x, out=None, mask=None):
+    """out[b,c,t] = x[b,c,t] * mask[b,t]; x/out may be FlipViews or channel slices."""
+    require_gpu(x, out, mask)
+    B, Cc, T = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    xb, xc = _bct_strides(x)
+    yb, yc = _bct_strides(out)
+    check(lib().svc_copy_bct_f32(ptr(x), ptr(out), ptr(mask), xb, xc, yb, yc, mask.stride(0) if mask is not None else 0,
+                                 B, Cc, T, stream_ptr()), "copy_bct")
     return out
 
 

@@ -1,0 +1,172 @@
+"""Parameter-holding building blocks shared by the reference-API mirror modules (models.py, modules/*, vdecoder/*).
+
+They keep the reference's parameter NAMES and SHAPES (so reference checkpoints load key-for-key) —
+in particular the `weight_g` / `weight_v` pair torch.nn.utils.weight_norm leaves in a state_dict — but none of
+torch's compute: every forward goes to libsvc_hip.so through svc_hip.  Packed (weight-norm-folded, MFMA-layout)
+weights are cached per module and re-packed when a parameter's version counter changes (optimizer step,
+load_state_dict, .to()).
+
+Training (autograd through these ops) is not built yet: calling a forward with grad enabled on parameters that
+require grad raises, it never silently falls back to torch.
+"""
+import math
+
+import torch
+from torch import nn
+
+import svc_hip as S
+
+
+def _no_grad_guard(*params):
+    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
+        raise NotImplementedError(
+            "svc_hip: backward kernels for the training path are not implemented yet (inference only); "
+            "wrap the call in torch.no_grad() / module.eval() + no_grad")
+
+
+class _PackedMixin:
+    def _pack_key(self, extra=()):
+        ps = [p for p in (getattr(self, "weight", None), getattr(self, "weight_g", None),
+                          getattr(self, "weight_v", None)) if p is not None]
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps) + tuple(extra)
+
+    def _get_packed(self, extra, fn):
+        key = self._pack_key(extra)
+        cache = self.__dict__.setdefault("_svc_pack_cache", {})
+        hit = cache.get(extra)
+        if hit is None or hit[0] != key:
+            cache[extra] = (key, fn())
+        return cache[extra][1]
+
+
+class Conv1d(nn.Module, _PackedMixin):
+    """nn.Conv1d / weight_norm(nn.Conv1d) stand-in (dense, groups=1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True,
+                 weight_norm=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.is_weight_norm = weight_norm
+        w = torch.empty(out_channels, in_channels, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_channels * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    # -- weights ------------------------------------------------------------------------------------------
+    def init_normal_(self, mean=0.0, std=0.01):
+        """commons.init_weights (modules/commons.py:25-31) applied through weight_norm: sets v ~ N(mean,std)."""
+        with torch.no_grad():
+            (self.weight_v if self.is_weight_norm else self.weight).normal_(mean, std)
+
+    def packed(self, gate_half=0):
+        def fn():
+            if self.is_weight_norm:
+                return S.pack_conv1d_weight(self.weight_v.detach(), self.weight_g.detach(), gate_half)
+            return S.pack_conv1d_weight(self.weight.detach(), None, gate_half)
+        return self._get_packed(("c1", gate_half), fn)
+
+    def remove_weight_norm(self):
+        if not self.is_weight_norm:
+            raise ValueError("weight_norm of 'weight' not found")
+        with torch.no_grad():
+            v, g = self.weight_v, self.weight_g
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        del self.weight_g, self.weight_v
+        self.weight = nn.Parameter(w)
+        self.is_weight_norm = False
+
+    # -- compute ------------------------------------------------------------------------------------------
+    def _is_direct(self):
+        return self.stride != 1 or self.in_channels == 1 or self.out_channels == 1
+
+    def forward(self, x, **kw):
+        return self.run(x, **kw)
+
+    def run(self, x, pad_left=None, Tout=None, **kw):
+        """Fused conv; extra keyword arguments are the epilogue options of svc_hip.conv1d."""
+        _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
+        pl = self.padding if pad_left is None else pad_left
+        Tin = x.shape[2]
+        if Tout is None:
+            Tout = (Tin + 2 * self.padding - self.dilation * (self.kernel_size - 1) - 1) // self.stride + 1
+        if self._is_direct():
+            return S.conv1d_direct(x, self.packed(), self.out_channels, self.kernel_size, bias=self.bias,
+                                   stride=self.stride, dil=self.dilation, pad_left=pl, Tout=Tout, **kw)
+        gate_half = self.out_channels // 2 if kw.get("epi") == S.EPI_GATE else 0
+        return S.conv1d(x, self.packed(gate_half), self.out_channels, self.kernel_size, bias=self.bias,
+                        dil=self.dilation, pad_left=pl, Tout=Tout, **kw)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, dilation={self.dilation}, weight_norm={self.is_weight_norm}")
+
+
+class ConvTranspose1d(nn.Module, _PackedMixin):
+    """weight_norm(nn.ConvTranspose1d) stand-in (vdecoder/hifigan/models.py:340-342)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, weight_norm=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding = stride, padding
+        self.is_weight_norm = weight_norm
+        w = torch.empty(in_channels, out_channels, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(out_channels * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    def init_normal_(self, mean=0.0, std=0.01):
+        with torch.no_grad():
+            (self.weight_v if self.is_weight_norm else self.weight).normal_(mean, std)
+
+    def packed(self):
+        def fn():
+            if self.is_weight_norm:
+                return S.pack_convt1d_weight(self.weight_v.detach(), self.weight_g.detach(), self.stride)
+            return S.pack_convt1d_weight(self.weight.detach(), None, self.stride)
+        return self._get_packed(("ct",), fn)
+
+    def remove_weight_norm(self):
+        if not self.is_weight_norm:
+            raise ValueError("weight_norm of 'weight' not found")
+        with torch.no_grad():
+            v, g = self.weight_v, self.weight_g
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        del self.weight_g, self.weight_v
+        self.weight = nn.Parameter(w)
+        self.is_weight_norm = False
+
+    def forward(self, x, **kw):
+        return self.run(x, **kw)
+
+    def run(self, x, **kw):
+        _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
+        return S.conv_transpose1d(x, self.packed(), self.out_channels, self.kernel_size, self.stride, self.padding,
+                                  bias=self.bias, **kw)
+
+
+def mask2d(x_mask):
+    """[B,1,T] float mask -> the [B,T]-addressable tensor the C-ABI wants (same storage)."""
+    if x_mask is None:
+        return None
+    if x_mask.dim() == 3:
+        if x_mask.stride(2) != 1 and x_mask.shape[2] > 1:
+            x_mask = x_mask.contiguous()
+        return x_mask
+    return x_mask

@@ -1,0 +1,64 @@
+"""CPU suite: pins the oracle (oracle/svc_oracle.py) to vectors produced by the REAL reference
+(tests/golden/make_golden.py, run in the build container against /root/reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svc_oracle as O
+from oracle import weights as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    z = np.load(os.path.join(G, name))
+    return {k: (torch.from_numpy(z[k]) if k != "meta" else json.loads(str(z[k]))) for k in z.files}
+
+
+def test_state_dict_layout_matches_reference():
+    """751 keys, 52,402,957 parameters for the full template."""
+    with open(os.path.join(G, "state_dict_keys_full.json")) as f:
+        gold = {k: tuple(v) for k, v in json.load(f).items()}
+    mine = {k: tuple(v) for k, v in W.param_shapes(W.full_config()).items()}
+    assert mine == gold
+    assert len(mine) == 751
+    assert sum(int(np.prod(s)) for s in mine.values()) == 52402957
+
+
+def test_f0_to_coarse_bit_exact():
+    z = _load("f0_to_coarse.npz")
+    assert torch.equal(O.f0_to_coarse(z["f0"]), z["coarse"])
+    # reference quirk (utils.py:77-79): bins >= 256 are zeroed BEFORE the ">= f0_bin -> 255" fix-up, so f0 above
+    # ~1100 Hz maps to 0, everything else to [1, 255]
+    assert z["coarse"].max() == 255 and z["coarse"][z["f0"] <= 1100].min() == 1
+    assert (z["coarse"][z["f0"] > 1110] == 0).all()
+
+
+@pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
+                                          ("infer_full_T24.npz", "full")])
+def test_oracle_reproduces_reference_infer(name, cfgname):
+    z = _load(name)
+    meta = z["meta"]
+    cfg = W.small_config() if cfgname == "small" else W.full_config()
+    sd = W.make_state_dict(cfg, meta["seed"])
+    noise = dict(enc_p=z["noise_enc_p"], rand_ini=z["noise_rand_ini"], sine=z["noise_sine"])
+    with torch.no_grad():
+        out = O.synth_infer(sd, cfg, z["c"], z["f0"], z["uv"], z["sid"], noise, noice_scale=meta["noice_scale"],
+                            predict_f0=meta["predict_f0"], return_all=True)
+    # fp32 tolerance: the oracle runs the same torch CPU ops in the same order; allow thread-count jitter
+    for k, tol in (("o", 5e-6), ("har", 1e-6), ("z_p", 1e-5), ("z", 1e-5)):
+        ref = z[k]
+        err = (out[k] - ref).abs().max().item()
+        assert err <= tol * max(ref.abs().max().item(), 1.0), (k, err)
+    assert torch.allclose(out["f0"], z["f0_out"], rtol=1e-5, atol=1e-3)
+
+
+def test_inputs_and_weights_are_deterministic():
+    cfg = W.small_config()
+    a, b = W.make_state_dict(cfg, 5), W.make_state_dict(cfg, 5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = W.make_state_dict(cfg, 6)
+    assert not torch.equal(a["pre.weight"], c["pre.weight"])
