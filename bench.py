@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X so-vits-svc engine (contract: see the task brief / DESIGN.md §4).
+
+Metric (BASELINE.json): 44.1 kHz audio samples/sec (whole job), inference.
+Workload at N=1 (BASELINE.json configs[1]): configs_template/config_template.json model, single speaker id,
+ContentVec-768 units, NSF-HiFiGAN decoder, one 10.01 s clip (T = 862 frames -> 441,344 samples), B = 1, fp32,
+synthetic inputs (c ~ N(0,1), f0 ~ U(100,400) with 10 % unvoiced runs) and seeded random weights (no checkpoint
+exists in the reference tree).  A "step" = one SynthesizerTrn.infer call on that clip with the inputs already
+resident in HBM; the RNG draws (3 torch.randn/rand fills) are inside the step, as in the reference.
+
+N > 1: utterances are independent ("replicas only"): every rank runs the same step on its own clip,
+no data-path collective; value = N * samples * steps / max-over-ranks time (weak scaling).
+
+Extra objects:
+  roofline     — dominant kernel family (conv1d_mfma, the fused fp32-MFMA conv that carries the MRF ResBlocks):
+                 algorithmic FLOP per launch / mean launch duration, durations from hipEvents recorded around every
+                 launch by libsvc_hip's profiler in a separate EAGER pass over the same steps (events cannot be
+                 recorded inside a replayed hipGraph); peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md).
+  cpu_baseline — the CPU oracle (a torch-CPU fp32 restatement of the reference modules, validated against the real
+                 reference in tests/golden) timed on this host on the same clip: kind "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "so-vits-svc_amd"))
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+T_FRAMES = 862          # 10.01 s at hop 512 / 44.1 kHz
+HOP = 512
+
+
+def build_model(dev):
+    import models
+    from oracle import weights as W   # deterministic synthetic checkpoint + inputs (test infrastructure data only)
+    cfg = W.full_config()
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(W.make_state_dict(cfg, 1234))
+    net = net.to(dev).eval()
+    return net, cfg, W
+
+
+def cpu_baseline(cfg, W, inputs, max_seconds=30.0):
+    """Time the CPU oracle on the same 10 s clip (bounded: 1 warm-up + up to 3 timed runs within ~max_seconds)."""
+    from oracle import svc_oracle as O
+    c, f0, uv, sid = inputs
+    sd = W.make_state_dict(cfg, 1234)
+    noise = W.make_noise(cfg, c.shape[0], c.shape[2], seed=99)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)      # warm-up (oneDNN primitive cache)
+        warm = time.perf_counter() - t0
+        times = []
+        budget = max_seconds - warm
+        while len(times) < 3 and (not times or sum(times) + times[-1] < budget):
+            t0 = time.perf_counter()
+            O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+            times.append(time.perf_counter() - t0)
+    best = sorted(times)[len(times) // 2]
+    n = c.shape[0] * c.shape[2] * HOP
+    return dict(value=n / best, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle.synth_infer on the same {n}-sample clip, median of {len(times)} runs after 1 warm-up "
+                       f"({best:.2f} s/clip, RTF {best / (n / 44100):.3f})")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the MI355X engine has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import svc_hip as S
+    net, cfg, W = build_model(dev)
+    B = args.batch
+    cpu_in = W.make_inputs(cfg, B, T_FRAMES, seed=1234 + rank)
+    c, f0, uv, sid = [t.to(dev) for t in cpu_in]
+    net.enable_graph(not args.no_graph)
+
+    def step():
+        return net.infer(c, f0, uv, g=sid, noice_scale=0.4)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    samples_per_step = B * T_FRAMES * HOP
+    value = world * samples_per_step * args.steps / elapsed
+
+    # ---- roofline: per-launch hipEvent durations of every kernel family, eager pass over the same step ----
+    roof = None
+    if rank == 0:
+        net.enable_graph(False)
+        step()
+        torch.cuda.synchronize()
+        S.prof_enable(True)
+        S.prof_reset()
+        nprof = min(args.steps, 5)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        rep = S.prof_report()
+        S.prof_enable(False)
+        fam = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        name, r = fam
+        achieved = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv1d_mfma.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    launches_per_step=r["calls"] / nprof, avg_launch_us=round(1e3 * r["ms"] / r["calls"], 2),
+                    flop_per_launch=r["flop"] / r["calls"],
+                    families={k: dict(ms_per_step=round(v["ms"] / nprof, 4), calls=v["calls"] // nprof,
+                                      tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
+                              for k, v in rep.items()})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, W, cpu_in)
+
+    if rank == 0:
+        out = dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.infer)", value=value,
+                   unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32", data="synthetic",
+                   rtf=(elapsed / args.steps) / (samples_per_step / 44100.0),
+                   config=dict(workload="BASELINE configs[1]: config_template.json, 1 speaker id, ContentVec768 units, "
+                                        "NSF-HiFiGAN, one 10.01 s clip per step (T=862 frames, 441344 samples)",
+                               batch=B, frames=T_FRAMES, samples_per_step=samples_per_step,
+                               launch="hipGraph replay" if not args.no_graph else "eager",
+                               parallelism=f"replicas x{world}" if world > 1 else "single GPU"),
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

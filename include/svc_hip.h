@@ -172,6 +172,13 @@ int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* nois
  * Flip (modules/modules.py:232-239) or an `x * x_mask` (modules/attentions.py:97) when it cannot be folded. */
 int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs, long long x_cs,
                      long long y_bs, long long y_cs, long long mask_bs, int B, int C, int T, void* stream);
+/* Automatic-f0 helpers (models.py:523-527 + utils.normalize_f0, utils.py:31-45).  f0,uv,mask,lf0,norm_lf0:[B,T];
+ * factor:[B] or NULL (=1, inference).  lf0 = 2595*log10(1+f0/700)/500 (or f0 itself when input_is_lf0);
+ * norm_lf0 = (lf0 - mean_voiced)*factor*mask. */
+int svc_f0_norm_lf0_f32(const float* f0, const float* uv, const float* mask, const float* factor, float* lf0,
+                        float* norm_lf0, int B, int T, int input_is_lf0, void* stream);
+/* f0 = 700*(10^(lf0*500/2595) - 1) elementwise (models.py:527). */
+int svc_lf0_to_f0_f32(const float* lf0, float* f0, long long n, void* stream);
 /* utils.f0_to_coarse (utils.py:69-80): f0:[n] fp32 -> coarse:[n] int64 in [0,255]. */
 int svc_f0_to_coarse(const float* f0, long long* coarse, long long n, void* stream);
 /* models.py:520 and :156:  x = xin + emb_uv[uv] (+ vol_w*vol + vol_b);  x_enc = (x + f0_emb[coarse(f0)]) * mask.

@@ -130,7 +130,64 @@ __global__ void copy_bct_kernel(const float* __restrict__ x, float* __restrict__
   y[b * y_bs + c * y_cs + t] = v;
 }
 
+// ---- log-f0 helpers of the automatic f0 predictor (models.py:523-527, utils.py:31-45) ----------------------
+// lf0 = 2595*log10(1 + f0/700)/500 ; norm = (lf0 - sum(lf0*uv)/sum(uv)) * factor * mask.  One block per batch item.
+__global__ __launch_bounds__(256) void f0_norm_lf0_kernel(const float* __restrict__ f0, const float* __restrict__ uv,
+                                                          const float* __restrict__ mask, const float* __restrict__ factor,
+                                                          float* __restrict__ lf0, float* __restrict__ norm, int T,
+                                                          int input_is_lf0) {
+  __shared__ float sh_a[256], sh_b[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float sa = 0.f, sb = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float fin = f0[(long long)b * T + t];
+    const float l = input_is_lf0 ? fin : 2595.f * log10f(1.f + fin / 700.f) / 500.f;
+    lf0[(long long)b * T + t] = l;
+    const float u = uv[(long long)b * T + t];
+    sa += l * u;
+    sb += u;
+  }
+  sh_a[tid] = sa;
+  sh_b[tid] = sb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      sh_a[tid] += sh_a[tid + s];
+      sh_b[tid] += sh_b[tid + s];
+    }
+    __syncthreads();
+  }
+  float cnt = sh_b[0];
+  if (cnt == 0.f) cnt = 9999.f;  // utils.py:34
+  const float mean = sh_a[0] / cnt;
+  const float fac = factor ? factor[b] : 1.f;
+  for (int t = tid; t < T; t += 256) {
+    const float mk = mask ? mask[(long long)b * T + t] : 1.f;
+    norm[(long long)b * T + t] = (lf0[(long long)b * T + t] - mean) * fac * mk;
+  }
+}
+
+// f0 = 700 * (10^(lf0 * 500 / 2595) - 1)     (models.py:527)
+__global__ void lf0_to_f0_kernel(const float* __restrict__ lf0, float* __restrict__ f0, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f0[i] = 700.f * (powf(10.f, lf0[i] * 500.f / 2595.f) - 1.f);
+}
+
 }  // namespace
+
+extern "C" int svc_f0_norm_lf0_f32(const float* f0, const float* uv, const float* mask, const float* factor, float* lf0,
+                                   float* norm_lf0, int B, int T, int input_is_lf0, void* stream) {
+  SVC_REQUIRE(f0 && uv && lf0 && norm_lf0 && B > 0 && T > 0, "f0_norm_lf0: bad args");
+  hipLaunchKernelGGL(f0_norm_lf0_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f0, uv, mask, factor, lf0, norm_lf0,
+                     T, input_is_lf0);
+  return svc::check_launch("f0_norm_lf0");
+}
+
+extern "C" int svc_lf0_to_f0_f32(const float* lf0, float* f0, long long n, void* stream) {
+  SVC_REQUIRE(lf0 && f0 && n > 0, "lf0_to_f0: bad args");
+  hipLaunchKernelGGL(lf0_to_f0_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, lf0, f0, n);
+  return svc::check_launch("lf0_to_f0");
+}
 
 extern "C" int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs, long long x_cs,
                                 long long y_bs, long long y_cs, long long mask_bs, int B, int C, int T, void* stream) {

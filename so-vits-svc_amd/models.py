@@ -1,0 +1,340 @@
+"""MI355X-native mirror of the reference's models.py: SynthesizerTrn and its sub-modules with the reference's
+constructor signatures, attribute names and state_dict layout (751 keys for the full template), so
+`inference/infer_tool.Svc` / `inference_main.py` can use it unchanged.  All arithmetic runs in libsvc_hip.so.
+
+Built so far: the inference graph `SynthesizerTrn.infer` (models.py:496-532 in the reference) incl. automatic f0
+prediction, with an optional hipGraph replay of the whole path.  The training graph (`forward`, enc_q, the
+discriminators) needs backward kernels that do not exist yet and raises NotImplementedError instead of silently
+running anything else.
+"""
+import math
+
+import torch
+from torch import nn
+
+import modules.attentions as attentions
+import modules.commons as commons
+import modules.modules as modules
+import svc_hip as S
+import utils
+from svc_nn import Conv1d, mask2d
+
+
+class ResidualCouplingBlock(nn.Module):
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0,
+                 share_parameter=False):
+        super().__init__()
+        self.channels = channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.n_layers = n_layers
+        self.n_flows = n_flows
+        self.gin_channels = gin_channels
+        self.flows = nn.ModuleList()
+        self.wn = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0,
+                             gin_channels=gin_channels) if share_parameter else None
+        for _ in range(n_flows):
+            self.flows.append(modules.ResidualCouplingLayer(channels, hidden_channels, kernel_size, dilation_rate,
+                                                            n_layers, gin_channels=gin_channels, mean_only=True,
+                                                            wn_sharing_parameter=self.wn))
+            self.flows.append(modules.Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        """Reference models.py:45-52.  The channel Flip between couplings is never materialised: the working
+        buffer is addressed through a negative channel stride whenever an odd number of flips is pending."""
+        buf = S.copy_bct(x)
+        flipped = False
+        couplings = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
+        if not reverse:
+            for c in couplings:
+                c.apply_inplace(S.flip_view(buf) if flipped else buf, x_mask, g=g, reverse=False)
+                flipped = not flipped
+        else:
+            for c in reversed(couplings):
+                flipped = not flipped
+                c.apply_inplace(S.flip_view(buf) if flipped else buf, x_mask, g=g, reverse=True)
+        if flipped:
+            buf = S.copy_bct(S.flip_view(buf))
+        return buf
+
+
+class Encoder(nn.Module):
+    """Posterior encoder enc_q (reference models.py:95-125); parameters are kept for checkpoint compatibility."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                 gin_channels=0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.dilation_rate = dilation_rate
+        self.n_layers = n_layers
+        self.gin_channels = gin_channels
+        self.pre = Conv1d(in_channels, hidden_channels, 1)
+        self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, x, x_lengths, g=None, noise=None):
+        x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+        m = mask2d(x_mask)
+        h = self.pre.run(x, mask=m)
+        h = self.enc(h, x_mask, g=g)
+        stats = self.proj.run(h, mask=m)
+        if noise is None:
+            noise = torch.randn(x.shape[0], self.out_channels, x.shape[2], device=x.device)
+        z = S.reparam(stats, noise, mask=m, scale=1.0)
+        return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
+
+
+class TextEncoder(nn.Module):
+    def __init__(self, out_channels, hidden_channels, kernel_size, n_layers, gin_channels=0, filter_channels=None,
+                 n_heads=None, p_dropout=None):
+        super().__init__()
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.n_layers = n_layers
+        self.gin_channels = gin_channels
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+        self.f0_emb = nn.Embedding(256, hidden_channels)
+        self.enc_ = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+
+    def forward(self, x, x_mask, f0=None, noice_scale=1, noise=None, x_is_embedded=False, full_mask=False):
+        """Reference models.py:155-162.  `f0` is the COARSE f0 index tensor (f0_to_coarse output) unless
+        x_is_embedded=True, in which case `x` already is (x + f0_emb) * mask (fused by svc_prenet_embed_f32)."""
+        m = mask2d(x_mask)
+        if not x_is_embedded:
+            emb = self.f0_emb.weight[f0].transpose(1, 2).contiguous()      # index gather (no arithmetic)
+            x = _add_bc(x, emb)
+        h = self.enc_(x, x_mask, full_mask=full_mask)
+        stats = self.proj.run(h, mask=m)
+        if noise is None:
+            noise = torch.randn(stats.shape[0], self.out_channels, stats.shape[2], device=stats.device)   # :160
+        z = S.reparam(stats, noise, mask=m, scale=float(noice_scale))
+        return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
+
+
+class F0Decoder(nn.Module):
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                 spk_channels=0):
+        super().__init__()
+        self.out_channels = out_channels
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.spk_channels = spk_channels
+        self.prenet = Conv1d(hidden_channels, hidden_channels, 3, padding=1)
+        self.decoder = attentions.FFT(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.proj = Conv1d(hidden_channels, out_channels, 1)
+        self.f0_prenet = Conv1d(1, hidden_channels, 3, padding=1)
+        self.cond = Conv1d(spk_channels, hidden_channels, 1)
+
+    def forward(self, x, norm_f0, x_mask, spk_emb=None):
+        """Reference models.py:328-336:  x += cond(spk); x += f0_prenet(norm_f0); prenet; FFT; proj."""
+        m = mask2d(x_mask)
+        gc = self.cond(spk_emb) if spk_emb is not None else None          # [B,H,1|T]
+        # x + cond(g) + f0_prenet(norm_f0): direct conv (Cin=1) with x as residual, then the speaker bias rides as
+        # `cond` on the prenet's INPUT side — it is not a per-output bias, so materialise it once:
+        h = self.f0_prenet.run(norm_f0, res=x)
+        if gc is not None:
+            h = _add_bc(h, gc)
+        h = self.prenet.run(h, mask=m)
+        h = self.decoder(h, x_mask)
+        return self.proj.run(h, mask=m)
+
+
+def _add_bc(x, bc):
+    """x[b,c,t] += bc[b,c,0|t]  — expressed as an identity-free epilogue: a 1x1 conv would waste FLOPs, so use the
+    copy kernel's sibling: LayerNorm-free residual add via conv1d_direct is overkill; torch's add is plumbing-level
+    but we keep arithmetic in HIP: reuse svc_conv1d_f32 with a cached identity weight (C<=256)."""
+    C = x.shape[1]
+    key = (C, str(x.device))
+    w = _add_bc.cache.get(key)
+    if w is None:
+        w = S.pack_conv1d_weight(torch.eye(C, device=x.device).unsqueeze(-1).contiguous())
+        _add_bc.cache[key] = w
+    return S.conv1d(x, w, C, 1, cond=bc)
+
+
+_add_bc.cache = {}
+
+
+class SynthesizerTrn(nn.Module):
+    """Synthesizer (reference models.py:339-532)."""
+
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, gin_channels, ssl_dim, n_speakers,
+                 sampling_rate=44100, vol_embedding=False, vocoder_name="nsf-hifigan", use_depthwise_conv=False,
+                 use_automatic_f0_prediction=True, flow_share_parameter=False, n_flow_layer=4,
+                 n_layers_trans_flow=3, use_transformer_flow=False, **kwargs):
+        super().__init__()
+        self.spec_channels = spec_channels
+        self.inter_channels = inter_channels
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.resblock = resblock
+        self.resblock_kernel_sizes = resblock_kernel_sizes
+        self.resblock_dilation_sizes = resblock_dilation_sizes
+        self.upsample_rates = upsample_rates
+        self.upsample_initial_channel = upsample_initial_channel
+        self.upsample_kernel_sizes = upsample_kernel_sizes
+        self.segment_size = segment_size
+        self.gin_channels = gin_channels
+        self.ssl_dim = ssl_dim
+        self.vol_embedding = vol_embedding
+        self.emb_g = nn.Embedding(n_speakers, gin_channels)
+        self.use_depthwise_conv = use_depthwise_conv
+        self.use_automatic_f0_prediction = use_automatic_f0_prediction
+        self.n_layers_trans_flow = n_layers_trans_flow
+        if vol_embedding:
+            self.emb_vol = nn.Linear(1, hidden_channels)
+        self.pre = Conv1d(ssl_dim, hidden_channels, kernel_size=5, padding=2)
+        self.enc_p = TextEncoder(inter_channels, hidden_channels, filter_channels=filter_channels, n_heads=n_heads,
+                                 n_layers=n_layers, kernel_size=kernel_size, p_dropout=p_dropout)
+        hps = {"sampling_rate": sampling_rate, "inter_channels": inter_channels, "resblock": resblock,
+               "resblock_kernel_sizes": resblock_kernel_sizes, "resblock_dilation_sizes": resblock_dilation_sizes,
+               "upsample_rates": upsample_rates, "upsample_initial_channel": upsample_initial_channel,
+               "upsample_kernel_sizes": upsample_kernel_sizes, "gin_channels": gin_channels,
+               "use_depthwise_conv": use_depthwise_conv}
+        modules.set_Conv1dModel(self.use_depthwise_conv)
+        if vocoder_name == "nsf-snake-hifigan":
+            raise NotImplementedError("nsf-snake-hifigan (SnakeAlias) generator has no HIP kernels yet")
+        if vocoder_name != "nsf-hifigan":
+            print("[?] Unkown vocoder: use default(nsf-hifigan)")
+        from vdecoder.hifigan.models import Generator
+        self.dec = Generator(h=hps)
+        self.enc_q = Encoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        if use_transformer_flow:
+            raise NotImplementedError("use_transformer_flow has no HIP path yet")
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, n_flow_layer,
+                                          gin_channels=gin_channels, share_parameter=flow_share_parameter)
+        if self.use_automatic_f0_prediction:
+            self.f0_decoder = F0Decoder(1, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                                        spk_channels=gin_channels)
+        self.emb_uv = nn.Embedding(2, hidden_channels)
+        self.character_mix = False
+        self.use_graph = False          # hipGraph replay of the infer path (enable_graph())
+        self._graphs = {}
+
+    def EnableCharacterMix(self, n_speakers_map, device):
+        self.speaker_map = torch.zeros((n_speakers_map, 1, 1, self.gin_channels)).to(device)
+        for i in range(n_speakers_map):
+            self.speaker_map[i] = self.emb_g(torch.LongTensor([[i]]).to(device))
+        self.speaker_map = self.speaker_map.unsqueeze(0).to(device)
+        self.character_mix = True
+
+    def forward(self, c, f0, uv, spec, g=None, c_lengths=None, spec_lengths=None, vol=None):
+        raise NotImplementedError("SynthesizerTrn.forward (training graph, reference models.py:463-493) needs the "
+                                  "backward kernels, which are not built yet; only .infer() is available")
+
+    # ------------------------------------------------------------------------------------------------------
+    def enable_graph(self, on=True):
+        """Replay the whole infer path from a hipGraph (captured per input shape) instead of ~230 eager launches."""
+        self.use_graph = bool(on)
+        if not on:
+            self._graphs.clear()
+        return self
+
+    def _speaker(self, g, c):
+        if self.character_mix and len(g) > 1:    # [N, S] * [S, B, 1, H]  (reference models.py:505-509)
+            g = g.reshape((g.shape[0], g.shape[1], 1, 1, 1))
+            g = g * self.speaker_map
+            g = torch.sum(g, dim=1)
+            g = g.transpose(0, -1).transpose(0, -2).squeeze(0)        # [B, H, N]
+            return g.contiguous()
+        if g.dim() == 1:
+            g = g.unsqueeze(0)
+        return self.emb_g(g).transpose(1, 2).contiguous()            # [B, H, 1]
+
+    def _infer_body(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol):
+        """The device work of infer(): every line is one or a few HIP kernels (no torch arithmetic)."""
+        B, _, T = c.shape
+        x_mask = torch.ones((B, 1, T), device=c.device, dtype=torch.float32)      # c_lengths == T (models.py:503)
+        m = mask2d(x_mask)
+        xin = self.pre.run(c, mask=m)                                               # pre(c) * mask
+        volv = vol if (vol is not None and self.vol_embedding) else None
+        x, x_enc = S.prenet_embed(xin, uv, f0, self.emb_uv.weight, self.enc_p.f0_emb.weight, mask=m, vol=volv,
+                                  vol_w=self.emb_vol.weight.view(-1) if volv is not None else None,
+                                  vol_b=self.emb_vol.bias if volv is not None else None)
+        if self.use_automatic_f0_prediction and predict_f0:
+            lf0, norm_lf0 = S.f0_norm_lf0(f0, uv, mask=m)                 # models.py:524-525, utils.py:31-45
+            pred_lf0 = self.f0_decoder(x, norm_lf0, x_mask, spk_emb=g)
+            f0 = S.lf0_to_f0(pred_lf0).squeeze(1)                         # models.py:527
+            _, x_enc = S.prenet_embed(xin, uv, f0, self.emb_uv.weight, self.enc_p.f0_emb.weight, mask=m, vol=volv,
+                                      vol_w=self.emb_vol.weight.view(-1) if volv is not None else None,
+                                      vol_b=self.emb_vol.bias if volv is not None else None)
+        z_p, m_p, logs_p, _ = self.enc_p(x_enc, x_mask, noice_scale=noice_scale, noise=noise.get("enc_p"),
+                                         x_is_embedded=True, full_mask=True)
+        z = self.flow(z_p, x_mask, g=g, reverse=True)
+        # `z * c_mask` (models.py:531) is the identity here: the flow's last update already multiplies by the mask
+        o = self.dec(z, f0, g=g, noise=noise if "sine" in noise else None)
+        return o, f0
+
+    @torch.no_grad()
+    def infer(self, c, f0, uv, g=None, noice_scale=0.35, seed=52468, predict_f0=False, vol=None, noise=None):
+        """Reference models.py:495-532.  `noise` (optional dict enc_p/rand_ini/sine) injects the RNG draws
+        explicitly (parity tests); otherwise they are drawn from torch's generator for c.device in the reference's
+        order after seeding with `seed`."""
+        if not c.is_cuda:
+            raise S.SvcError("SynthesizerTrn.infer needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+        c = c.float().contiguous()
+        f0 = f0.float().contiguous()
+        uv = uv.float().contiguous()
+        torch.manual_seed(seed)      # seeds every device generator (reference :498-501)
+        g = self._speaker(g, c)
+        B, _, T = c.shape
+        if noise is None:
+            L = T * self.dec.upp
+            noise = dict(enc_p=torch.randn(B, self.inter_channels, T, device=c.device),       # :160
+                         rand_ini=torch.rand(B, 9, device=c.device),                          # hifigan :147
+                         sine=torch.randn(B, L, 9, device=c.device))                          # hifigan :266
+        if self.use_graph:
+            return self._infer_graph(c, f0, uv, g, noise, noice_scale, predict_f0, vol)
+        return self._infer_body(c, f0, uv, g, noise, noice_scale, predict_f0, vol)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _infer_graph(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol):
+        key = (tuple(c.shape), tuple(g.shape), float(noice_scale), bool(predict_f0), vol is not None, str(c.device))
+        ent = self._graphs.get(key)
+        ins = dict(c=c, f0=f0, uv=uv, g=g, enc_p=noise["enc_p"], rand_ini=noise["rand_ini"], sine=noise["sine"])
+        if vol is not None:
+            ins["vol"] = vol.float().contiguous()
+        if ent is None:
+            static = {k: v.clone() for k, v in ins.items()}
+            run = lambda: self._infer_body(static["c"], static["f0"], static["uv"], static["g"],
+                                           dict(enc_p=static["enc_p"], rand_ini=static["rand_ini"],
+                                                sine=static["sine"]), noice_scale, predict_f0, static.get("vol"))
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                run()                                   # warm-up: packs weights, sets kernel attributes
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
+            ent = (graph, static, out)
+            self._graphs[key] = ent
+        graph, static, out = ent
+        for k, v in ins.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out[0].clone(), out[1].clone()
+
+
+# The discriminators (reference models.py:165-252) belong to the training path; their kernels
+# (period-reshaped Conv2d(k,1), grouped Conv1d k=41) are not built yet.
+class MultiPeriodDiscriminator(nn.Module):
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        raise NotImplementedError("MultiPeriodDiscriminator (training path) is not implemented in the MI355X engine "
+                                  "yet")

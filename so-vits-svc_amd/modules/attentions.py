@@ -1,0 +1,200 @@
+"""MI355X-native mirror of the reference's modules/attentions.py (Encoder, FFT, MultiHeadAttention, FFN).
+
+Per layer the reference launches ~25 aten ops (4 projections, 2 T x T matmuls + 2 padded relative-position matmuls
+with pad/reshape skews, softmax, masked_fill, 2 convs, 2 transposed layer norms...).  Here a layer is 7 kernels:
+fused qkv projection (one MFMA conv, Cout = 3C), flash-style attention with the window-4 relative terms inside,
+output projection, residual+LayerNorm, FFN conv1 (+mask+ReLU), FFN conv2 (+masks), residual+LayerNorm (+final mask).
+"""
+import math
+
+import torch
+from torch import nn
+
+import svc_hip as S
+from svc_nn import Conv1d, _no_grad_guard, mask2d
+from modules.modules import LayerNorm
+
+MASK_NONE, MASK_PADDING, MASK_CAUSAL = 0, 1, 2
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, channels, out_channels, n_heads, p_dropout=0., window_size=None, heads_share=True,
+                 block_length=None, proximal_bias=False, proximal_init=False):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.channels = channels
+        self.out_channels = out_channels
+        self.n_heads = n_heads
+        self.p_dropout = p_dropout
+        self.window_size = window_size
+        self.heads_share = heads_share
+        self.block_length = block_length
+        self.proximal_bias = proximal_bias
+        self.proximal_init = proximal_init
+        self.attn = None
+        if block_length is not None or proximal_bias or not heads_share:
+            raise NotImplementedError("block_length / proximal_bias / per-head relative embeddings are never enabled "
+                                      "on the so-vits-svc path (modules/attentions.py:33,91)")
+        self.k_channels = channels // n_heads
+        self.conv_q = Conv1d(channels, channels, 1)
+        self.conv_k = Conv1d(channels, channels, 1)
+        self.conv_v = Conv1d(channels, channels, 1)
+        self.conv_o = Conv1d(channels, out_channels, 1)
+        if window_size is not None:
+            rel_stddev = self.k_channels ** -0.5
+            self.emb_rel_k = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * rel_stddev)
+            self.emb_rel_v = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * rel_stddev)
+        nn.init.xavier_uniform_(self.conv_q.weight)
+        nn.init.xavier_uniform_(self.conv_k.weight)
+        nn.init.xavier_uniform_(self.conv_v.weight)
+        if proximal_init:
+            with torch.no_grad():
+                self.conv_k.weight.copy_(self.conv_q.weight)
+                self.conv_k.bias.copy_(self.conv_q.bias)
+
+    # fused q|k|v projection weight, cached on the three parameter versions
+    def _qkv_packed(self):
+        ps = (self.conv_q.weight, self.conv_k.weight, self.conv_v.weight, self.conv_q.bias, self.conv_k.bias,
+              self.conv_v.bias)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        hit = self.__dict__.get("_qkv_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = torch.cat([self.conv_q.weight, self.conv_k.weight, self.conv_v.weight], 0)
+                b = torch.cat([self.conv_q.bias, self.conv_k.bias, self.conv_v.bias], 0)
+                self.__dict__["_qkv_cache"] = (key, (S.pack_conv1d_weight(w), b.contiguous()))
+        return self.__dict__["_qkv_cache"][1]
+
+    def _mask_mode(self, attn_mask, t):
+        """Classify an explicit [B,1,T,T] reference-style mask (host sync; Encoder/FFT pass hints instead)."""
+        if attn_mask is None:
+            return MASK_NONE, None
+        am = attn_mask
+        if bool((am != 0).all()):
+            return MASK_NONE, None
+        tril = torch.tril(torch.ones(t, t, device=am.device))
+        if am.shape[0] == 1 and bool(((am[0, 0] != 0) == (tril != 0)).all()):
+            return MASK_CAUSAL, None
+        vec = torch.diagonal(am[:, 0], dim1=-2, dim2=-1).contiguous().float()
+        outer = vec.unsqueeze(1) * vec.unsqueeze(2)
+        if bool(((am[:, 0] != 0) == (outer != 0)).all()):
+            return MASK_PADDING, vec
+        raise NotImplementedError("attention mask is neither all-ones, causal nor an outer product of a padding mask")
+
+    def forward(self, x, c, attn_mask=None, mask_mode=None, mask_vec=None):
+        if c is not x:
+            raise NotImplementedError("only self-attention is used on the so-vits-svc path")
+        _no_grad_guard(self.conv_q.weight)
+        B, C, T = x.shape
+        if mask_mode is None:
+            mask_mode, mask_vec = self._mask_mode(attn_mask, T)
+        wp, b = self._qkv_packed()
+        qkv = S.conv1d(x, wp, 3 * C, 1, bias=b)
+        win = self.window_size or 0
+        att = S.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.n_heads,
+                          emb_rel_k=self.emb_rel_k[0] if win else None, emb_rel_v=self.emb_rel_v[0] if win else None,
+                          window=win, mask=mask_vec, mask_mode=mask_mode)
+        return self.conv_o.run(att)
+
+
+class FFN(nn.Module):
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0., activation=None,
+                 causal=False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.filter_channels = filter_channels
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.activation = activation
+        self.causal = causal
+        if activation == "gelu":
+            raise NotImplementedError("gelu FFN is never enabled on the so-vits-svc path")
+        self.conv_1 = Conv1d(in_channels, filter_channels, kernel_size)
+        self.conv_2 = Conv1d(filter_channels, out_channels, kernel_size)
+
+    def forward(self, x, x_mask):
+        k = self.kernel_size
+        pad_l = 0 if k == 1 else (k - 1 if self.causal else (k - 1) // 2)
+        m = mask2d(x_mask)
+        T = x.shape[2]
+        h = self.conv_1.run(x, premask=m, pad_left=pad_l, Tout=T, post_act=S.ACT_RELU)
+        return self.conv_2.run(h, premask=m, pad_left=pad_l, Tout=T, mask=m)
+
+
+class Encoder(nn.Module):
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0., window_size=4,
+                 **kwargs):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.window_size = window_size
+        self.attn_layers = nn.ModuleList()
+        self.norm_layers_1 = nn.ModuleList()
+        self.ffn_layers = nn.ModuleList()
+        self.norm_layers_2 = nn.ModuleList()
+        for _ in range(n_layers):
+            self.attn_layers.append(MultiHeadAttention(hidden_channels, hidden_channels, n_heads, p_dropout=p_dropout,
+                                                       window_size=window_size))
+            self.norm_layers_1.append(LayerNorm(hidden_channels))
+            self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size,
+                                       p_dropout=p_dropout))
+            self.norm_layers_2.append(LayerNorm(hidden_channels))
+
+    def forward(self, x, x_mask, full_mask=False):
+        """`full_mask=True` promises x_mask is all ones (inference, models.py:503) and skips the padding mask."""
+        if self.training and self.p_dropout > 0:
+            raise NotImplementedError("training-mode dropout is not implemented (inference only)")
+        m = mask2d(x_mask)
+        x = S.copy_bct(x, mask=m)
+        mode = MASK_NONE if full_mask else MASK_PADDING
+        for i in range(self.n_layers):
+            y = self.attn_layers[i](x, x, mask_mode=mode, mask_vec=None if full_mask else m)
+            x = self.norm_layers_1[i](x, residual=y)
+            y = self.ffn_layers[i](x, x_mask)
+            x = self.norm_layers_2[i](x, residual=y, x_mask=x_mask if i == self.n_layers - 1 else None)
+        return x
+
+
+class FFT(nn.Module):
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers=1, kernel_size=1, p_dropout=0.,
+                 proximal_bias=False, proximal_init=True, isflow=False, **kwargs):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.proximal_bias = proximal_bias
+        self.proximal_init = proximal_init
+        if isflow:
+            raise NotImplementedError("use_transformer_flow (FFT as a coupling network) has no HIP path yet")
+        self.self_attn_layers = nn.ModuleList()
+        self.norm_layers_0 = nn.ModuleList()
+        self.ffn_layers = nn.ModuleList()
+        self.norm_layers_1 = nn.ModuleList()
+        for _ in range(n_layers):
+            self.self_attn_layers.append(MultiHeadAttention(hidden_channels, hidden_channels, n_heads,
+                                                            p_dropout=p_dropout, proximal_bias=proximal_bias,
+                                                            proximal_init=proximal_init))
+            self.norm_layers_0.append(LayerNorm(hidden_channels))
+            self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size,
+                                       p_dropout=p_dropout, causal=True))
+            self.norm_layers_1.append(LayerNorm(hidden_channels))
+
+    def forward(self, x, x_mask, g=None):
+        if self.training and self.p_dropout > 0:
+            raise NotImplementedError("training-mode dropout is not implemented (inference only)")
+        m = mask2d(x_mask)
+        x = S.copy_bct(x, mask=m)
+        for i in range(self.n_layers):
+            y = self.self_attn_layers[i](x, x, mask_mode=MASK_CAUSAL)
+            x = self.norm_layers_0[i](x, residual=y)
+            y = self.ffn_layers[i](x, x_mask)
+            x = self.norm_layers_1[i](x, residual=y, x_mask=x_mask if i == self.n_layers - 1 else None)
+        return x

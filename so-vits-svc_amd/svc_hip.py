@@ -104,6 +104,8 @@ def lib():
         L.svc_add_layernorm_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_reparam_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_attention_f32.argtypes = [C.POINTER(AttentionArgs), C.c_void_p]
+        L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         _lib = L
     return _lib
@@ -113,7 +115,7 @@ EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
 ]
 
 
@@ -357,6 +359,27 @@ def attention(q, k, v, n_heads, *, emb_rel_k=None, emb_rel_v=None, window=0, mas
         a.mask_bs = mask.stride(0)
     a.B, a.H, a.dk, a.T, a.window, a.mask_mode = B, n_heads, dk, T, window, mask_mode
     check(lib().svc_attention_f32(C.byref(a), stream_ptr()), "attention")
+    return out
+
+
+def f0_norm_lf0(f0, uv, mask=None, factor=None, input_is_lf0=False):
+    """f0, uv: [B,T]; mask [B,1,T]|[B,T]; factor [B]|[B,1] -> (lf0 [B,1,T], norm_lf0 [B,1,T])."""
+    require_gpu(f0, uv, mask, factor)
+    B, T = f0.shape
+    lf0 = torch.empty((B, 1, T), device=f0.device, dtype=torch.float32)
+    norm = torch.empty((B, 1, T), device=f0.device, dtype=torch.float32)
+    check(lib().svc_f0_norm_lf0_f32(ptr(f0.contiguous()), ptr(uv.contiguous()),
+                                    ptr(mask.contiguous() if mask is not None else None),
+                                    ptr(factor.contiguous() if factor is not None else None), ptr(lf0), ptr(norm), B, T,
+                                    1 if input_is_lf0 else 0, stream_ptr()), "f0_norm_lf0")
+    return lf0, norm
+
+
+def lf0_to_f0(lf0):
+    require_gpu(lf0)
+    x = lf0.contiguous()
+    out = torch.empty_like(x)
+    check(lib().svc_lf0_to_f0_f32(ptr(x), ptr(out), x.numel(), stream_ptr()), "lf0_to_f0")
     return out
 
 

@@ -1,0 +1,195 @@
+"""MI355X-native mirror of vdecoder/hifigan/models.py: the NSF-HiFiGAN `dec` of SynthesizerTrn (94 % of the
+inference FLOPs).
+
+Reference forward (vdecoder/hifigan/models.py:366-394) = ~165 aten launches per call (15 ResBlocks x (6 convs +
+6 leaky_relu + 3 adds), weight-norm recompute, upsample, cumsum ...).  Here:
+  * SineGen + SourceModuleHnNSF (:138-166,250-271,307-320)      -> 1 closed-form kernel   (svc_nsf_source_f32)
+  * conv_pre + cond(g) (:373-374)                               -> 1 MFMA conv, speaker bias in the epilogue
+  * per stage: leaky_relu + ups[i] + noise_convs[i] add (:376-381) -> direct noise conv + polyphase MFMA ConvT
+  * ResBlock1 (:60-67): leaky_relu -> conv(k,d) -> leaky_relu -> conv(k,1) -> +x
+                                                                -> 2 MFMA convs per dilation, activations in the
+                                                                   LDS staging, residual / sum-over-kernels / ÷3
+                                                                   in the epilogue (no standalone elementwise op)
+  * leaky_relu(0.01) + conv_post + tanh (:390-392)              -> 1 direct conv
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+import svc_hip as S
+from svc_nn import Conv1d, ConvTranspose1d, _no_grad_guard
+
+from .env import AttrDict  # noqa: F401
+from .utils import get_padding, init_weights
+
+LRELU_SLOPE = 0.1
+
+
+class ResBlock1(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.h = h
+        self.convs1 = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=d,
+                                            padding=get_padding(kernel_size, d), weight_norm=True) for d in dilation])
+        self.convs1.apply(init_weights)
+        self.convs2 = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=1,
+                                            padding=get_padding(kernel_size, 1), weight_norm=True) for _ in dilation])
+        self.convs2.apply(init_weights)
+
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
+        """out (+)= resblock(x); the optional epilogue arguments let Generator accumulate the MRF mean in place."""
+        n = len(self.convs1)
+        cur = x
+        bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
+        xt, ping, pong = bufs
+        for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            c1.run(cur, pre_slope=LRELU_SLOPE, out=xt)
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                c2.run(xt, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c2.run(xt, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst)
+            cur = dst
+
+    def remove_weight_norm(self):
+        for l in list(self.convs1) + list(self.convs2):
+            l.remove_weight_norm()
+
+
+class ResBlock2(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.h = h
+        self.convs = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=d,
+                                           padding=get_padding(kernel_size, d), weight_norm=True) for d in dilation])
+        self.convs.apply(init_weights)
+
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
+        n = len(self.convs)
+        cur = x
+        bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
+        _, ping, pong = bufs
+        for j, c in enumerate(self.convs):
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                c.run(cur, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c.run(cur, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst)
+            cur = dst
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            l.remove_weight_norm()
+
+
+class SineGen(nn.Module):
+    """Parameter-free; kept for API parity (vdecoder/hifigan/models.py:103-271).  The arithmetic lives in
+    svc_nsf_source_f32 together with SourceModuleHnNSF's Linear+tanh."""
+
+    def __init__(self, samp_rate, harmonic_num=0, sine_amp=0.1, noise_std=0.003, voiced_threshold=0,
+                 flag_for_pulse=False):
+        super().__init__()
+        self.sine_amp = sine_amp
+        self.noise_std = noise_std
+        self.harmonic_num = harmonic_num
+        self.dim = harmonic_num + 1
+        self.sampling_rate = samp_rate
+        self.voiced_threshold = voiced_threshold
+        if flag_for_pulse or voiced_threshold != 0:
+            raise NotImplementedError("pulse-train SineGen / non-zero voiced threshold are unused by so-vits-svc")
+        self.onnx = False
+
+
+class SourceModuleHnNSF(nn.Module):
+    def __init__(self, sampling_rate, harmonic_num=0, sine_amp=0.1, add_noise_std=0.003, voiced_threshod=0):
+        super().__init__()
+        self.sine_amp = sine_amp
+        self.noise_std = add_noise_std
+        self.l_sin_gen = SineGen(sampling_rate, harmonic_num, sine_amp, add_noise_std, voiced_threshod)
+        self.l_linear = nn.Linear(harmonic_num + 1, 1)   # parameters only; applied inside the source kernel
+        self.l_tanh = nn.Tanh()
+
+    def forward(self, f0, upp, noise=None):
+        """f0: FRAME-rate [B,T] (the x`upp` nearest upsample of :369 happens inside the kernel).
+        noise: optional dict(rand_ini [B,H], sine [B,T*upp,H]); drawn in the reference's order when absent.
+        Returns (har_source [B,1,T*upp], None, None)."""
+        B, T = f0.shape
+        H = self.l_sin_gen.dim
+        L = T * upp
+        if noise is None:
+            rand_ini = torch.rand(B, H, device=f0.device)                   # :147
+            nz = torch.randn(B, L, H, device=f0.device)                     # :266
+            torch.randn(B, L, 1, device=f0.device)                          # :319 (drawn, unused, keeps RNG stream aligned)
+        else:
+            rand_ini, nz = noise["rand_ini"], noise["sine"]
+        har = S.nsf_source(f0, rand_ini, nz, self.l_linear.weight, self.l_linear.bias, upp,
+                           self.l_sin_gen.sampling_rate, self.sine_amp, self.noise_std)
+        return har, None, None
+
+
+class Generator(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h["resblock_kernel_sizes"])
+        self.num_upsamples = len(h["upsample_rates"])
+        self.m_source = SourceModuleHnNSF(sampling_rate=h["sampling_rate"], harmonic_num=8)
+        self.noise_convs = nn.ModuleList()
+        c0 = h["upsample_initial_channel"]
+        self.conv_pre = Conv1d(h["inter_channels"], c0, 7, 1, padding=3, weight_norm=True)
+        resblock = ResBlock1 if h["resblock"] == '1' else ResBlock2
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+            c_cur = c0 // (2 ** (i + 1))
+            self.ups.append(ConvTranspose1d(c0 // (2 ** i), c_cur, k, u, padding=(k - u + 1) // 2, weight_norm=True))
+            if i + 1 < len(h["upsample_rates"]):
+                stride_f0 = int(np.prod(h["upsample_rates"][i + 1:]))
+                self.noise_convs.append(Conv1d(1, c_cur, kernel_size=stride_f0 * 2, stride=stride_f0,
+                                               padding=(stride_f0 + 1) // 2))
+            else:
+                self.noise_convs.append(Conv1d(1, c_cur, kernel_size=1))
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"]):
+                self.resblocks.append(resblock(h, ch, k, d))
+        self.conv_post = Conv1d(ch, 1, 7, 1, padding=3, weight_norm=True)
+        self.ups.apply(init_weights)
+        self.conv_post.apply(init_weights)
+        self.cond = Conv1d(h['gin_channels'], c0, 1)
+        self.upp = int(np.prod(h["upsample_rates"]))
+        self.onnx = False
+
+    def OnnxExport(self):
+        raise NotImplementedError("ONNX export is out of scope of the MI355X engine (SURVEY.md §2 row 23)")
+
+    def forward(self, x, f0, g=None, noise=None):
+        """x [B,inter,T] (tensor or channel-strided view), f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]."""
+        _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
+        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        gc = self.cond(g) if g is not None else None                  # [B, C0, 1|T]  (:374)
+        x = self.conv_pre.run(x, cond=gc)                              # (:373-374)
+        for i in range(self.num_upsamples):
+            xs = self.noise_convs[i](har)                              # (:379)
+            x = self.ups[i].run(x, pre_slope=LRELU_SLOPE, res=xs)      # lrelu + ConvT + add (:377-381)
+            acc = xs                                                   # reuse the noise-conv buffer as MRF accumulator
+            tmp = [torch.empty_like(x) for _ in range(3)]
+            for j in range(self.num_kernels):
+                last = j == self.num_kernels - 1
+                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
+                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmp)
+            x = acc
+        # F.leaky_relu default slope 0.01 (:390), conv_post, tanh
+        return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
+
+    def remove_weight_norm(self):
+        for l in self.ups:
+            l.remove_weight_norm()
+        for l in self.resblocks:
+            l.remove_weight_norm()
+        self.conv_pre.remove_weight_norm()
+        self.conv_post.remove_weight_norm()

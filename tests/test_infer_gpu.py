@@ -1,0 +1,103 @@
+"""End-to-end parity of the MI355X SynthesizerTrn.infer against (a) the committed reference goldens and (b) the CPU
+oracle on the same seeded inputs and injected noise.  Bar (BASELINE.json north_star): waveform MSE < 1e-4; we
+additionally require max|err| <= 2e-4 * max|ref| so the bound is not vacuous for a quiet output."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svc_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _build(cfg, seed, dev):
+    import models
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    sd = W.make_state_dict(cfg, seed)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    return net, sd
+
+
+def _check(o, ref, tol_rel=2e-4):
+    o, ref = o.float().cpu(), ref.float()
+    mse = (o - ref).pow(2).mean().item()
+    mx = (o - ref).abs().max().item()
+    assert mse < 1e-4, mse
+    assert mx <= tol_rel * max(ref.abs().max().item(), 1e-3), (mx, ref.abs().max().item())
+    return mse, mx
+
+
+@pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
+                                          ("infer_full_T24.npz", "full")])
+def test_infer_matches_reference_golden(dev, name, cfgname):
+    z = np.load(os.path.join(G, name))
+    meta = json.loads(str(z["meta"]))
+    cfg = W.small_config() if cfgname == "small" else W.full_config()
+    net, _ = _build(cfg, meta["seed"], dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    noise = dict(enc_p=t("noise_enc_p"), rand_ini=t("noise_rand_ini"), sine=t("noise_sine"))
+    o, f0 = net.infer(t("c"), t("f0"), t("uv"), g=t("sid"), noice_scale=meta["noice_scale"],
+                      predict_f0=meta["predict_f0"], noise=noise)
+    assert o.shape == z["o"].shape
+    if meta["predict_f0"]:
+        # predicted f0 feeds an integer quantiser and a phase integrator: compare f0 tightly, waveform loosely
+        assert torch.allclose(f0.cpu(), torch.from_numpy(z["f0_out"]), rtol=2e-4, atol=1e-2)
+        mse = (o.cpu() - torch.from_numpy(z["o"])).pow(2).mean().item()
+        assert mse < 1e-4, mse
+    else:
+        _check(o, torch.from_numpy(z["o"]))
+
+
+@pytest.mark.parametrize("B,T", [(1, 97), (2, 33)])
+def test_infer_matches_oracle_full_config(dev, B, T):
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=7)
+    noise = W.make_noise(cfg, B, T, seed=8)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    _check(o, ref)
+    # hipGraph replay must be bit-identical to the eager launch sequence
+    net.enable_graph(True)
+    o2, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    o3, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert torch.equal(o2, o) and torch.equal(o3, o)
+
+
+def test_blocks_match_oracle(dev):
+    """Generator / flow / text encoder individually (intermediates of the small golden)."""
+    z = np.load(os.path.join(G, "infer_small_T40.npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = W.small_config()
+    net, sd = _build(cfg, meta["seed"], dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    g = net.emb_g(t("sid")).transpose(1, 2).contiguous()
+    x_mask = torch.ones(t("c").shape[0], 1, t("c").shape[2], device=dev)
+    with torch.no_grad():
+        zz = net.flow(t("z_p"), x_mask, g=g, reverse=True)
+        assert (zz.cpu() - torch.from_numpy(z["z"])).abs().max().item() < 2e-5 * max(1.0, np.abs(z["z"]).max())
+        o = net.dec(t("z"), t("f0"), g=g, noise=dict(rand_ini=t("noise_rand_ini"), sine=t("noise_sine")))
+        _check(o, torch.from_numpy(z["o"]))
+        # forward direction of the flow inverts the reverse direction
+        back = net.flow(zz, x_mask, g=g, reverse=False)
+        assert (back - t("z_p")).abs().max().item() < 1e-4 * max(1.0, np.abs(z["z_p"]).max())
+
+
+def test_infer_rejects_cpu_tensors():
+    import models
+    cfg = W.small_config()
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw).eval()
+    c, f0, uv, sid = W.make_inputs(cfg, 1, 8)
+    import svc_hip as S
+    with pytest.raises(S.SvcError):
+        net.infer(c, f0, uv, g=sid)
