@@ -1,0 +1,13 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, bench line, rocprofv3 kernel-trace stats.  Outputs under gpurun_out/.
+set -x
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -5 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+cat gpurun_out/bench.json
+rm -rf gpurun_out/prof_stats
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err; echo "rocprof rc=$?"
+ls -R gpurun_out/prof_stats | head -30

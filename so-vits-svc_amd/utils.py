@@ -140,3 +140,19 @@ def latest_checkpoint_path(dir_path, regex="G_*.pth"):
     files = glob.glob(os.path.join(dir_path, regex))
     files.sort(key=lambda f: int("".join(filter(str.isdigit, f)) or -1))
     return files[-1]
+
+
+class Volume_Extractor:
+    """utils.py:560-572: per-frame RMS of the waveform (reflect pad hop/2, mean of squares over hop, sqrt).  Feeds
+    `vol` when vol_embedding=True; host-side plumbing on torch tensors (not on the synthesizer's kernel path)."""
+
+    def __init__(self, hop_size=512):
+        self.hop_size = hop_size
+
+    def extract(self, audio):
+        if not isinstance(audio, torch.Tensor):
+            audio = torch.as_tensor(audio, dtype=torch.float32)
+        n_frames = int(audio.size(-1) // self.hop_size)
+        a2 = torch.nn.functional.pad((audio ** 2)[:, None, :], (self.hop_size // 2, (self.hop_size + 1) // 2),
+                                     mode="reflect")[:, 0]
+        return a2[:, :n_frames * self.hop_size].reshape(a2.shape[0], n_frames, self.hop_size).mean(-1)[0].sqrt()
