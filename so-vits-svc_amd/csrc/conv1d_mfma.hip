@@ -3,38 +3,47 @@
 // Implicit GEMM, no im2col in memory:  out[co,t] = sum_{ci,k} W[co,ci,k] * X[ci, t + k*dil - pad]
 //   M = co (MFMA rows), N = t (MFMA cols), K = (ci,k).
 // A workgroup owns a BM(co) x BN(t) tile.  Per chunk of BC input channels it stages
-//   Xs[BC][BN + (KS-1)*dil]  (time contiguous: coalesced HBM reads along t, pre-activation applied once)
-//   Ws[BC][KS][BM]           (co contiguous, from the packed [Cin][KS][CoutP] weight)
-// in LDS; every wave then issues v_mfma_f32_32x32x2_f32 (or 16x16x4 for Cout<=16) where the A operand
-// is one Ws dword per lane and the B operand one Xs dword per lane (lanes contiguous in m resp. t, so
-// both ds_read_b32 are bank-conflict free and a dilated tap is just an address offset k*dil).
-// fp32 in, fp32 accumulate: bitwise an fmaf chain (MI355X_MICROARCH.md §Matrix cores), same 157.3 TF
-// peak as the packed-fp32 VALU but ~32x fewer operand reads per FMA.
+//   Xs[BC][XW]      (time contiguous: coalesced HBM reads along t — float4 when the rows are 16 B aligned —
+//                    pre-activation applied once per element, not once per tap)
+//   Ws[BC][KS][BM]  (co contiguous, from the packed [Cin][KS][CoutP] weight)
+// in LDS; every wave then issues v_mfma_f32_32x32x2_f32 (or 16x16x4 for Cout<=16) where the A operand is one Ws
+// dword per lane and the B operand one Xs dword per lane (lanes contiguous in m resp. t, so both ds_read_b32 are
+// bank-conflict free and a dilated tap is just an address offset k*dil).
+//
+// Software pipeline: the global loads of chunk i+1 are issued into registers BEFORE the MFMA loop over chunk i
+// and written to LDS after it, so HBM/L2 latency hides under the matrix work of the same workgroup (no reliance
+// on a co-resident workgroup); inside the MFMA loop the operands of step i+1 are read from LDS while step i's
+// MFMAs issue.  WK > 1 splits the K (input-channel) range of a chunk across waves that share one output tile and
+// reduces through LDS at the end: that is what fills 256 CUs when T is a few hundred frames (encoder / flow).
+// Polyphase ConvTranspose1d runs its `stride` sub-convolutions as separate workgroups.
+//
+// fp32 in, fp32 accumulate: bitwise an fmaf chain (MI355X_MICROARCH.md §Matrix cores), 157.3 TF peak.
 //
 // Replaces (reference path:line): vdecoder/hifigan/models.py:41-67 (ResBlock1 convs + leaky_relu + residual),
-// :335,:358,:373-374 (conv_pre + cond), modules/modules.py:110-138 (WN in_layers, gate, res_skip),
+// :335,:358,:373-374 (conv_pre + cond), :340-342 (ups), modules/modules.py:110-138 (WN in_layers, gate, res_skip),
 // modules/modules.py:288-307 (coupling pre/post), modules/attentions.py:198-205,337-345 (q,k,v,o,FFN),
 // models.py:400,139 (pre, proj).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
+constexpr int WLD = 16;   // float4 weight loads in flight per thread per chunk
+constexpr int XLD4 = 12;  // float4 (or 4x scalar) activation loads in flight per thread per chunk
+constexpr int MAXHALO = 50;  // (KS-1)*dil supported by the staging maps (k=11, d=5)
+
 struct ConvP {
   svc_conv1d_args a;
-  int XW;        // LDS row width of the X tile (floats)
-  int BC;        // input channels staged per chunk
-  int n_t_tiles; // number of BN tiles along t
+  int XW;         // LDS row width of the X tile (floats, multiple of 4)
+  int BC;         // input channels staged per chunk (multiple of KPI*WK)
+  int n_t_tiles;  // number of BN tiles along t
   int n_m_tiles;
+  int xvec;       // 1: X rows are 16 B aligned -> float4 staging
+  int yvec;       // 1: y / res / y2 rows are 16 B aligned and unit-stride in time -> float4 epilogue
+  int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
 };
 
-template <bool M16>
-__device__ __forceinline__ void mfma_step(float a, float b, f32x16& acc32, f32x4& acc16) {
-  if constexpr (M16) {
-    acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc16, 0, 0, 0);
-  } else {
-    acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32, 0, 0, 0);
-  }
-}
+__device__ __forceinline__ float acc_probe(const f32x16& a, const f32x4& b) { return a[0] + b[0]; }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
@@ -45,30 +54,37 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
-// MT x NT MFMA tiles per wave, WM x WN waves per workgroup.
-template <int MT, int NT, int WM, int WN, bool M16, int EPI>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
-  constexpr int TS = M16 ? 16 : 32;      // MFMA tile edge
-  constexpr int KPI = M16 ? 4 : 2;       // K indices consumed per MFMA
-  constexpr int NACC = M16 ? 4 : 16;     // accumulator regs per tile
+// MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC>
+__global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
+  constexpr int TS = M16 ? 16 : 32;   // MFMA tile edge
+  constexpr int KPI = M16 ? 4 : 2;    // K indices consumed per MFMA
+  constexpr int NACC = M16 ? 4 : 16;  // accumulator regs per tile
   constexpr int BM = WM * MT * TS;
   constexpr int BN = WN * NT * TS;
-  constexpr int NTHR = WM * WN * 64;
+  constexpr int NW = WM * WN * WK;
+  constexpr int NTHR = NW * 64;
+  constexpr int BM4 = BM / 4;
   const svc_conv1d_args& a = p.a;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KS = a.KS, BC = p.BC, XW = p.XW;
-  float* Ws = smem;                     // [BC][KS][BM]
-  float* Xs = smem + BC * KS * BM;      // [BC][XW]
+  float* Ws = smem;                 // [BC][KS][BM]
+  float* Xs = smem + BC * KS * BM;  // [BC][XW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int ln = lane & (TS - 1);       // position inside tile row/col
-  const int lk = lane / TS;             // which K index of the instruction this lane feeds
+  const int wk = wave / (WM * WN);
+  const int wmn = wave % (WM * WN);
+  const int wm = wmn / WN, wn = wmn % WN;
+  const int ln = lane & (TS - 1);  // position inside tile row/col
+  const int lk = lane / TS;        // which K index of the instruction this lane feeds
 
+  // block -> (phase, t tile, m tile, batch); phase fastest so the polyphase siblings share the X tile in L2
   int bid = blockIdx.x;
+  const int ph = bid % a.n_phase;
+  bid /= a.n_phase;
   const int tt = bid % p.n_t_tiles;
   bid /= p.n_t_tiles;
   const int mtile = bid % p.n_m_tiles;
@@ -79,13 +95,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
   const float* xb = a.x + (long long)b * a.x_bs;
   const float* pm = a.premask ? a.premask + (long long)b * a.premask_bs : nullptr;
   const int tin0 = t0 - a.pad_left;
+  const int sh = p.xvec ? (((tin0 % 4) + 4) % 4) : 0;  // tile start rounded down to a 16 B boundary
+  const int tin_base = tin0 - sh;
   const int w_rows_total = a.Cin * KS;
-
-  // Polyphase transposed conv runs n_phase dense sub-convolutions over the same input tile (n_phase = 1 and
-  // y_ts = 1 for an ordinary conv); each phase has its own packed weight block and writes outputs
-  // t_out = t * y_ts + y_t0 + phase.
-  for (int ph = 0; ph < a.n_phase; ++ph) {
   const float* wph = a.w + (long long)ph * a.w_phase_stride;
+
   f32x16 acc32[MT][NT];
   f32x4 acc16[MT][NT];
 #pragma unroll
@@ -100,181 +114,392 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_mfma_kernel(ConvP p) {
       }
     }
 
-  for (int c0 = 0; c0 < a.Cin; c0 += BC) {
-    // ---- stage W chunk: rows (ci_l,k) of BM floats, float4 granularity ----
-    {
-      constexpr int BM4 = BM / 4;
-      const int total4 = BC * KS * BM4;
-      const int row0 = c0 * KS;
-      for (int idx = tid; idx < total4; idx += NTHR) {
-        const int r = idx / BM4;
-        const int c4 = idx - r * BM4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int grow = row0 + r;
-        const int gco = co0 + c4 * 4;
-        if (grow < w_rows_total && gco < a.CoutP)
-          v = *reinterpret_cast<const float4*>(wph + (long long)grow * a.CoutP + gco);
-        *reinterpret_cast<float4*>(Ws + r * BM + c4 * 4) = v;
+  // ---- register staging of one chunk -------------------------------------------------------------------
+  // Thread -> element maps are affine in the slot index (per-thread base + wave-uniform slot offset) and every
+  // slot is branch-free: the address is clamped into the tensor and the value selected to zero when the slot is
+  // outside the chunk / tensor (no exec-mask branches in the staging code):
+  //   W slot i : row r0 + i*RSTEP of the chunk's [BC*KS][BM] block, float4 column c4      (r0 = tid / BM4)
+  //   X slot (ri,cj): channel row ri*NW + wave, column (cj*64 + lane) [float4 or float]
+  constexpr int RSTEP = NTHR / BM4;
+  constexpr int XCIV = (BN + MAXHALO + 3 + 255) / 256;  // float4 column iterations per row (vector path)
+  constexpr int XCIS = (BN + MAXHALO + 63) / 64;        // column iterations per row (scalar path)
+  constexpr int XSLV = (XLD4 / XCIV) * XCIV;            // slots used, vector path
+  constexpr int XSLS = ((4 * XLD4) / XCIS) * XCIS;      // slots used, scalar path
+  float4 wreg[WLD];
+  float xr[4 * XLD4];
+  const int w_rows_chunk = BC * KS;
+  const int wr0 = tid / BM4, wc4 = tid - wr0 * BM4;
+  const int wcol = min(co0 + wc4 * 4, a.CoutP - 4);
+  const bool wcol_ok = co0 + wc4 * 4 < a.CoutP;
+  float* wlds = Ws + wr0 * BM + wc4 * 4;
+  const int XW4 = XW >> 2;
+  float* xlds = Xs + wave * XW + (p.xvec ? lane * 4 : lane);
+
+  // premask depends only on the column: fetched once (scalar path only; the vector path is taken only without one)
+  float pmv[XCIS];
+#pragma unroll
+  for (int cj = 0; cj < XCIS; ++cj) {
+    const int tc = min(max(tin_base + cj * 64 + lane, 0), a.Tin - 1);
+    pmv[cj] = pm ? pm[tc] : 1.f;
+  }
+
+  // loads are raw (addresses clamped into the tensor); out-of-chunk / out-of-tensor slots are zeroed when the
+  // registers are written to LDS, so nothing consumes a load before the MFMA loop it overlaps with
+  auto load_chunk = [&](int c0) {
+    const int row0 = c0 * KS;
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int gr = min(row0 + wr0 + i * RSTEP, w_rows_total - 1);
+      wreg[i] = *reinterpret_cast<const float4*>(wph + (long long)gr * a.CoutP + wcol);
+    }
+    if (p.xvec) {
+#pragma unroll
+      for (int s = 0; s < XSLV; ++s) {
+        const int ri = s / XCIV, cj = s % XCIV;
+        const int ci = min(c0 + ri * NW + wave, a.Cin - 1);
+        const int tc = min(max(tin_base + (cj * 64 + lane) * 4, 0), a.Tin - 4);
+        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)ci * a.x_cs + tc);
+        xr[4 * s + 0] = v.x; xr[4 * s + 1] = v.y; xr[4 * s + 2] = v.z; xr[4 * s + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < XSLS; ++s) {
+        const int ri = s / XCIS, cj = s % XCIS;
+        const int ci = min(c0 + ri * NW + wave, a.Cin - 1);
+        const int tc = min(max(tin_base + cj * 64 + lane, 0), a.Tin - 1);
+        xr[s] = xb[(long long)ci * a.x_cs + tc];
       }
     }
-    // ---- stage X chunk: BC rows of XW floats, coalesced along t, pre-activation applied once ----
-    {
-      constexpr int NW = WM * WN;
-      for (int r = wave; r < BC; r += NW) {
-        const int ci = c0 + r;
-        const float* xr = xb + (long long)ci * a.x_cs;
-        float* dst = Xs + r * XW;
-        const bool cok = ci < a.Cin;
-        for (int c = lane; c < XW; c += 64) {
-          const int tin = tin0 + c;
-          float v = 0.f;
-          if (cok && tin >= 0 && tin < a.Tin) {
-            v = xr[tin];
-            if (pm) v *= pm[tin];
-            v = svc_lrelu(v, a.pre_slope);
-          }
-          dst[c] = v;
+  };
+
+  auto store_chunk = [&](int c0) {
+    const int row0 = c0 * KS;
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int r = wr0 + i * RSTEP;
+      if (r < w_rows_chunk) {
+        const bool ok = row0 + r < w_rows_total && wcol_ok;
+        const float4 v = wreg[i];
+        *reinterpret_cast<float4*>(wlds + i * RSTEP * BM) =
+            make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      }
+    }
+    const float ps = a.pre_slope;
+    if (p.xvec) {
+#pragma unroll
+      for (int s = 0; s < XSLV; ++s) {
+        const int ri = s / XCIV, cj = s % XCIV;
+        const int r = ri * NW + wave, c4 = cj * 64 + lane;
+        if (r < BC && c4 < XW4) {
+          const int tin = tin_base + c4 * 4;
+          const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
+          *reinterpret_cast<float4*>(xlds + ri * NW * XW + cj * 256) =
+              make_float4(ok ? svc_lrelu(xr[4 * s], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 1], ps) : 0.f,
+                          ok ? svc_lrelu(xr[4 * s + 2], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 3], ps) : 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < XSLS; ++s) {
+        const int ri = s / XCIS, cj = s % XCIS;
+        const int r = ri * NW + wave, c = cj * 64 + lane;
+        if (r < BC && c < XW) {
+          const int tin = tin_base + c;
+          const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
+          xlds[ri * NW * XW + cj * 64] = ok ? svc_lrelu(xr[s] * pmv[cj], ps) : 0.f;
         }
       }
     }
-    __syncthreads();
+  };
 
-    // ---- MFMA over the chunk ----
-    const float* wbase = Ws + wm * (MT * TS) + ln;
-    const float* xbase = Xs + wn * (NT * TS) + ln;
-    for (int k = 0; k < KS; ++k) {
-      const int xoff = k * a.dil;
-      for (int cc = 0; cc < BC; cc += KPI) {
-        const int cl = cc + lk;
+  // ---- main loop over input-channel chunks ---------------------------------------------------------------
+  const float* wbase = Ws + wm * (MT * TS) + ln;
+  const float* xbase = Xs + wn * (NT * TS) + ln + sh;
+  const int n_cc = BC / (KPI * WK);  // k-groups per wave per tap
+
+  const int dbg = p.dbg;
+  load_chunk(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += BC) {
+    __syncthreads();  // everyone finished reading the previous chunk from LDS
+    if (!(dbg & 1) || c0 == 0) store_chunk(c0);
+    __syncthreads();
+    if (c0 + BC < a.Cin && !(dbg & 1)) load_chunk(c0 + BC);  // in flight during the MFMA loop below
+    if (dbg & 2) continue;
+
+    if constexpr (KSC > 0) {
+      // compile-time tap count: all KS operand pairs of a channel group are fetched up front, then KS x MT x NT
+      // MFMAs issue back to back (the LDS latency is paid once per group, not once per tap)
+      const int dil = a.dil;
+      for (int q = 0; q < n_cc; ++q) {
+        const int cl = q * (KPI * WK) + wk * KPI + lk;
+        const float* wa = wbase + cl * (KSC * BM);
+        const float* xa = xbase + cl * XW;
+        float av[KSC][MT], bv[KSC][NT];
+#pragma unroll
+        for (int k = 0; k < KSC; ++k) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) av[k][i] = wa[k * BM + i * TS];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bv[k][j] = xa[k * dil + j * TS];
+        }
+#pragma unroll
+        for (int k = 0; k < KSC; ++k)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              if constexpr (M16)
+                acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][i], bv[k][j], acc16[i][j], 0, 0, 0);
+              else
+                acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
+            }
+      }
+    } else {
+      const int n_it = n_cc * KS;
+      const int a_step_cc = (KPI * WK) * KS * BM - KS * BM;  // extra A offset when k wraps
+      const int b_step_cc = (KPI * WK) * XW - KS * a.dil;
+      int a_off = ((wk * KPI + lk) * KS) * BM;
+      int b_off = (wk * KPI + lk) * XW;
+      int k = 0;
+      for (int it = 0; it < n_it; ++it) {
         float av[MT], bv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = wbase[(cl * KS + k) * BM + i * TS];
+        for (int i = 0; i < MT; ++i) av[i] = wbase[a_off + i * TS];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = xbase[cl * XW + xoff + j * TS];
+        for (int j = 0; j < NT; ++j) bv[j] = xbase[b_off + j * TS];
+        a_off += BM;
+        b_off += a.dil;
+        if (++k == KS) {
+          k = 0;
+          a_off += a_step_cc;
+          b_off += b_step_cc;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mfma_step<M16>(av[i], bv[j], acc32[i][j], acc16[i][j]);
+          for (int j = 0; j < NT; ++j) {
+            if constexpr (M16) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc16[i][j], 0, 0, 0);
+            else acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc32[i][j], 0, 0, 0);
+          }
       }
     }
-    __syncthreads();
   }
 
-  // ---- epilogue (one MFMA tile at a time; sched barriers keep the live set to one tile) ----
+  // ---- epilogue: accumulators -> LDS ([WK][BM][CP], the MFMA C layout has one time column per lane), then every
+  // thread owns 4 consecutive time steps of one output row: 16 B residual loads / stores, full cache lines per row.
+  // Split-K partial tiles are summed here (fixed order wk = 0..WK-1: deterministic).
+  if ((dbg & 4) && acc_probe(acc32[0][0], acc16[0][0]) != 12345.678f) return;
+  constexpr int CP = BN + 4;
+  __syncthreads();
+  {
+    float* cw = smem + (wk * BM + wm * (MT * TS)) * CP + wn * (NT * TS) + ln;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+          const int row = i * TS + (M16 ? 4 * lk + r : (r & 3) + 8 * (r >> 2) + 4 * lk);
+          if constexpr (M16) cw[row * CP + j * TS] = acc16[i][j][r];
+          else cw[row * CP + j * TS] = acc32[i][j][r];
+        }
+  }
+  __syncthreads();
+
   const float* maskb = a.mask ? a.mask + (long long)b * a.mask_bs : nullptr;
   const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
   const float* resb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
   float* yb = a.y + (long long)b * a.y_bs;
   const float* biasp = a.bias;
   const long long cond_cs = a.cond_cs, cond_ts = a.cond_ts;
+  constexpr int BN4 = BN / 4;
+  constexpr int OUT_ROWS = EPI == SVC_EPI_GATE ? BM / 2 : BM;
+  const bool yvec = p.yvec != 0;
+  const int H = a.Cout >> 1;
 
+  auto tile4 = [&](int prow, int c4) -> float4 {
+    float4 q = *reinterpret_cast<const float4*>(smem + prow * CP + c4 * 4);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int tq = t0 + wn * (NT * TS) + j * TS + ln;
-    const int t = tq * a.y_ts + a.y_t0 + ph;
-    const bool tok = tq < a.Tout && t >= 0 && t < a.y_len;
-    const float mk = (maskb && tok) ? maskb[t] : 1.f;
+    for (int w = 1; w < WK; ++w) {
+      const float4 q2 = *reinterpret_cast<const float4*>(smem + (w * BM + prow) * CP + c4 * 4);
+      q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+    }
+    return q;
+  };
+  auto tout = [&](int tq, int e) { return (tq + e) * a.y_ts + a.y_t0 + ph; };
+  auto tvalid = [&](int tq, int e) {
+    const int t = tout(tq, e);
+    return tq + e < a.Tout && t >= 0 && t < a.y_len;
+  };
+  auto tclamp = [&](int tq, int e) { return min(max(tout(tq, e), 0), a.y_len - 1); };
+  // 4 values of an output-shaped row at time steps tq..tq+3 (vector when aligned, else element-wise with bounds)
+  auto load4 = [&](const float* rowp, int tq) -> float4 {
+    if (yvec && tq + 3 < a.Tout) return *reinterpret_cast<const float4*>(rowp + tq);
+    float4 r;
+    r.x = tvalid(tq, 0) ? rowp[tclamp(tq, 0)] : 0.f;
+    r.y = tvalid(tq, 1) ? rowp[tclamp(tq, 1)] : 0.f;
+    r.z = tvalid(tq, 2) ? rowp[tclamp(tq, 2)] : 0.f;
+    r.w = tvalid(tq, 3) ? rowp[tclamp(tq, 3)] : 0.f;
+    return r;
+  };
+  auto store4 = [&](float* rowp, int tq, float4 v) {
+    if (yvec && tq + 3 < a.Tout) {
+      *reinterpret_cast<float4*>(rowp + tq) = v;
+    } else {
+      if (tvalid(tq, 0)) rowp[tout(tq, 0)] = v.x;
+      if (tvalid(tq, 1)) rowp[tout(tq, 1)] = v.y;
+      if (tvalid(tq, 2)) rowp[tout(tq, 2)] = v.z;
+      if (tvalid(tq, 3)) rowp[tout(tq, 3)] = v.w;
+    }
+  };
+  auto side4 = [&](const float* base, long long ts, int tq) -> float4 {   // base[t*ts] for the 4 (clamped) steps
+    return make_float4(base[(long long)tclamp(tq, 0) * ts], base[(long long)tclamp(tq, 1) * ts],
+                       base[(long long)tclamp(tq, 2) * ts], base[(long long)tclamp(tq, 3) * ts]);
+  };
+#define SVC_F4_MAP(dst, expr)            \
+  {                                      \
+    { const int e = 0; (dst).x = (expr); } \
+    { const int e = 1; (dst).y = (expr); } \
+    { const int e = 2; (dst).z = (expr); } \
+    { const int e = 3; (dst).w = (expr); } \
+  }
+#define F4C(q) (e == 0 ? (q).x : e == 1 ? (q).y : e == 2 ? (q).z : (q).w)
+
+  for (int idx = tid; idx < OUT_ROWS * BN4; idx += NTHR) {
+    const int row = idx / BN4, c4 = idx - row * BN4;
+    const int tq = t0 + c4 * 4;
+    if (tq >= a.Tout) continue;
+    const float4 mk = maskb ? side4(maskb, 1, tq) : make_float4(1.f, 1.f, 1.f, 1.f);
     if constexpr (EPI == SVC_EPI_GATE) {
       static_assert(EPI != SVC_EPI_GATE || ((MT % 2) == 0 && !M16), "gate epilogue needs tile pairs");
-      const int H = a.Cout >> 1;
-#pragma unroll
-      for (int i = 0; i < MT; i += 2) {
-        const int prow = co0 + wm * (MT * TS) + i * TS;  // packed row of the tanh tile (multiple of 64)
-        const int cbase = (prow >> 6) * 32 + 4 * lk;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = cbase + (r & 3) + 8 * (r >> 2);
-          if (tok && c < H) {
-            float vt = acc32[i][j][r];
-            float vs = acc32[i + 1][j][r];
-            if (biasp) {
-              vt += biasp[c];
-              vs += biasp[H + c];
-            }
-            if (condb) {
-              vt += condb[c * cond_cs + t * cond_ts];
-              vs += condb[(H + c) * cond_cs + t * cond_ts];
-            }
-            yb[(long long)c * a.y_cs + t] = tanhf(vt) * svc_sigmoid(vs);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      const int prow = (row >> 5) * 64 + (row & 31);  // packed tanh row inside the tile; +32 = its sigmoid row
+      const int c = (co0 >> 1) + row;
+      if (c >= H) continue;
+      const float4 vt = tile4(prow, c4), vs = tile4(prow + 32, c4);
+      const float bt = biasp ? biasp[c] : 0.f, bs = biasp ? biasp[H + c] : 0.f;
+      float4 ct = make_float4(0.f, 0.f, 0.f, 0.f), cs = ct;
+      if (condb) {
+        ct = side4(condb + c * cond_cs, cond_ts, tq);
+        cs = side4(condb + (H + c) * cond_cs, cond_ts, tq);
       }
+      float4 o;
+      SVC_F4_MAP(o, tanhf(F4C(vt) + bt + F4C(ct)) * svc_sigmoid(F4C(vs) + bs + F4C(cs)));
+      store4(yb + (long long)c * a.y_cs, tq, o);
     } else {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int cobase = co0 + wm * (MT * TS) + i * TS + (M16 ? 4 : 4) * lk;
-#pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-          const int co = cobase + (M16 ? r : (r & 3) + 8 * (r >> 2));
-          if (tok && co < a.Cout) {
-            float v;
-            if constexpr (M16) v = acc16[i][j][r];
-            else v = acc32[i][j][r];
-            if (biasp) v += biasp[co];
-            if (condb) v += condb[co * cond_cs + t * cond_ts];
-            if constexpr (EPI == SVC_EPI_RES_SKIP) {
-              if (co < a.skip_from) {
-                float* yp = yb + (long long)co * a.y_cs + t;
-                const float rv = resb[(long long)co * a.res_cs + t];
-                *yp = (rv + v) * mk;
-              } else {
-                float* yp = a.y2 + (long long)b * a.y2_bs + (long long)(co - a.skip_from) * a.y2_cs + t;
-                if (a.beta != 0.f) v += a.beta * (*yp);
-                if (a.res_mode == 1) v *= mk;  // last WN layer: `output * x_mask` (modules/modules.py:138)
-                *yp = v;
-              }
-            } else {
-              v = apply_act(v, a.post_act, a.post_slope);
-              v *= mk;
-              if (a.res_mode == 1) v = v + resb[(long long)co * a.res_cs + t];
-              else if (a.res_mode == 2) v = (resb[(long long)co * a.res_cs + t] - v) * mk;
-              else if (a.res_mode == 3) v = v + resb[(long long)co * a.res_cs + t] * mk;
-              float* yp = yb + (long long)co * a.y_cs + t;
-              if (a.beta != 0.f) v += a.beta * (*yp);
-              if (a.out_div != 1.f) v = v / a.out_div;
-              *yp = v;
-            }
+      const int co = co0 + row;
+      if (co >= a.Cout) continue;
+      float4 v = tile4(row, c4);
+      const float bb = biasp ? biasp[co] : 0.f;
+      float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (condb) cc = side4(condb + co * cond_cs, cond_ts, tq);
+      SVC_F4_MAP(v, F4C(v) + bb + F4C(cc));
+      if constexpr (EPI == SVC_EPI_RES_SKIP) {
+        if (co < a.skip_from) {
+          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
+          SVC_F4_MAP(v, (F4C(r) + F4C(v)) * F4C(mk));
+          store4(yb + (long long)co * a.y_cs, tq, v);
+        } else {
+          float* y2p = a.y2 + (long long)b * a.y2_bs + (long long)(co - a.skip_from) * a.y2_cs;
+          if (a.beta != 0.f) {
+            const float4 r = load4(y2p, tq);
+            SVC_F4_MAP(v, F4C(v) + a.beta * F4C(r));
           }
+          if (a.res_mode == 1) {  // last WN layer: `output * x_mask` (modules/modules.py:138)
+            SVC_F4_MAP(v, F4C(v) * F4C(mk));
+          }
+          store4(y2p, tq, v);
         }
-        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        float* yp = yb + (long long)co * a.y_cs;
+        SVC_F4_MAP(v, apply_act(F4C(v), a.post_act, a.post_slope) * F4C(mk));
+        if (a.res_mode != 0) {
+          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
+          if (a.res_mode == 1) { SVC_F4_MAP(v, F4C(v) + F4C(r)); }
+          else if (a.res_mode == 2) { SVC_F4_MAP(v, (F4C(r) - F4C(v)) * F4C(mk)); }
+          else { SVC_F4_MAP(v, F4C(v) + F4C(r) * F4C(mk)); }
+        }
+        if (a.beta != 0.f) {
+          const float4 yo = load4(yp, tq);
+          SVC_F4_MAP(v, F4C(v) + a.beta * F4C(yo));
+        }
+        if (a.out_div != 1.f) { SVC_F4_MAP(v, F4C(v) / a.out_div); }
+        store4(yp, tq, v);
       }
     }
   }
-  }  // phase loop
+#undef SVC_F4_MAP
+#undef F4C
 }
 
-template <int MT, int NT, int WM, int WN, bool M16, int EPI = SVC_EPI_PLAIN>
+int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
+int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
+int g_dbg = 0;         // debug: ConvP.dbg
+
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI = SVC_EPI_PLAIN, int KSC = 0>
 int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   constexpr int TS = M16 ? 16 : 32;
   constexpr int KPI = M16 ? 4 : 2;
+  constexpr int NACC = M16 ? 4 : 16;
   constexpr int BM = WM * MT * TS;
   constexpr int BN = WN * NT * TS;
+  constexpr int NTHR = WM * WN * WK * 64;
+  constexpr int KG = KPI * WK;
   ConvP p;
   p.a = a;
-  int xw = BN + (a.KS - 1) * a.dil;
+  const bool xvec = a.premask == nullptr && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_bs % 4) == 0 &&
+                    (a.x_cs % 4) == 0 && (a.Tin % 4) == 0;
+  p.xvec = xvec ? 1 : 0;
+  p.dbg = g_dbg;
+  auto al4 = [](const void* ptr, long long bs, long long cs) {
+    return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 4) == 0 && (cs % 4) == 0);
+  };
+  p.yvec = (a.n_phase == 1 && a.y_ts == 1 && a.y_t0 == 0 && al4(a.y, a.y_bs, a.y_cs) && al4(a.res, a.res_bs, a.res_cs) &&
+            al4(a.y2, a.y2_bs, a.y2_cs)) ? 1 : 0;
+  int xw = BN + (a.KS - 1) * a.dil + (xvec ? 3 : 0);
+  xw = (xw + 3) & ~3;
   if (M16) {  // keep consecutive channel rows on disjoint bank halves for the 16-lane groups
-    while ((xw & 31) != 16) ++xw;
+    while ((xw & 31) != 16) xw += 4;
   }
   p.XW = xw;
-  // choose BC: as many channels per chunk as fit in ~48 KiB (bounded by Cin), multiple of KPI
+  // BC: as many channels per chunk as the staging registers (WLD / XLD4 slots per thread) and ~64 KiB of LDS allow
+  constexpr int NWV = WM * WN * WK;
+  constexpr int RSTEP = NTHR / (BM / 4);
   const int per_c = (a.KS * BM + xw) * 4;
-  int bc = (48 * 1024) / per_c;
-  bc = (bc / KPI) * KPI;
-  if (bc < KPI) bc = KPI;
-  if (bc > 32) bc = 32;
-  const int cin_r = ((a.Cin + KPI - 1) / KPI) * KPI;
+  constexpr int XCIV = (BN + MAXHALO + 3 + 255) / 256, XCIS = (BN + MAXHALO + 63) / 64;
+  const int x_rows = xvec ? (XLD4 / XCIV) : ((4 * XLD4) / XCIS);   // channel-row iterations the X slots cover
+  if ((a.KS - 1) * a.dil > MAXHALO) {
+    svc::set_error("conv1d: (KS-1)*dil = %d exceeds the supported halo %d", (a.KS - 1) * a.dil, MAXHALO);
+    return SVC_ERR_UNSUPPORTED;
+  }
+  int bc = (64 * 1024) / per_c;
+  bc = std::min(bc, (WLD * RSTEP) / a.KS);
+  bc = std::min(bc, x_rows * NWV);
+  bc = (bc / KG) * KG;
+  if (bc < KG) bc = KG;
+  const int cin_r = ((a.Cin + KG - 1) / KG) * KG;
   if (bc > cin_r) bc = cin_r;
+  // balance the chunks (e.g. Cin=128, bc=48 -> 3 chunks of 44 instead of 48+48+32)
+  {
+    const int nch = (cin_r + bc - 1) / bc;
+    int bal = (cin_r + nch - 1) / nch;
+    bal = ((bal + KG - 1) / KG) * KG;
+    if (bal < bc) bc = bal;
+  }
   p.BC = bc;
-  const size_t lds = (size_t)bc * per_c;
+  if (x_rows < 1 || bc * a.KS > WLD * RSTEP || (bc + NWV - 1) / NWV > x_rows) {
+    svc::set_error("conv1d: tile does not fit the staging registers (KS=%d dil=%d Cin=%d)", a.KS, a.dil, a.Cin);
+    return SVC_ERR_UNSUPPORTED;
+  }
+  size_t lds = (size_t)bc * per_c;
+  lds = std::max(lds, (size_t)WK * BM * (BN + 4) * 4);   // epilogue transpose buffer
   if (lds > 160 * 1024) {
     svc::set_error("conv1d: LDS tile too large (KS=%d dil=%d)", a.KS, a.dil);
     return SVC_ERR_UNSUPPORTED;
   }
   p.n_t_tiles = svc::cdiv(a.Tout, BN);
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
-  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
-  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, M16, EPI>;
+  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B * a.n_phase;
+  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -283,11 +508,20 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
   return svc::check_launch("conv1d_mfma");
 }
 
 }  // namespace
+
+extern "C" int svc_debug_set_conv_cfg(int cfg) {
+  // cfg = dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; return SVC_OK; }
+  g_force_cfg = cfg % 100 - 1;
+  g_no_ksc = (cfg / 100) % 10;
+  g_dbg = cfg / 1000;
+  return SVC_OK;
+}
 
 static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   SVC_REQUIRE(a.x && a.w && a.y, "conv1d: null tensor");
@@ -297,33 +531,78 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   SVC_REQUIRE(a.CoutP >= a.Cout && (a.CoutP % 4) == 0, "conv1d: CoutP must be >= Cout and a multiple of 4");
   SVC_REQUIRE((reinterpret_cast<uintptr_t>(a.w) & 15) == 0, "conv1d: packed weight must be 16B aligned");
   SVC_REQUIRE(a.res_mode == 0 || a.res != nullptr, "conv1d: res_mode set but res is null");
-  SVC_REQUIRE(a.res_mode != 2 || a.mask != nullptr || true, "conv1d");
   hipStream_t s = (hipStream_t)stream;
   const double flop = 2.0 * a.B * (double)a.Cout * a.Cin * a.KS * a.Tout * a.n_phase;
   const double bytes = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout) + 4.0 * a.Cin * a.KS * a.Cout;
   svc::ProfScope prof(s, a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma", flop, bytes);
 
   const long long cols = (long long)a.B * a.Tout;
+  // workgroup counts of the candidate tilings for short sequences
+  const long long wg64x128 = (long long)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 128) * a.B * a.n_phase;
+  const long long wg64x32 = (long long)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 32) * a.B * a.n_phase;
+  const bool m64 = (a.Cout % 64) == 0;
+  int cfg;  // 0: 16x512  1: 32x512  2: 64x256  3: 128x128  4: 64x128  5: 64x32 split-K  6: 32x32 split-K
   if (a.epi == SVC_EPI_GATE) {
     SVC_REQUIRE((a.Cout % 64) == 0, "conv1d: gate epilogue needs Cout %% 64 == 0 (got %d)", a.Cout);
     SVC_REQUIRE(a.res_mode == 0, "conv1d: gate epilogue takes no residual");
-    if (cols >= 16384) return launch_cfg<2, 2, 2, 2, false, SVC_EPI_GATE>(a, s);
-    return launch_cfg<2, 1, 1, 4, false, SVC_EPI_GATE>(a, s);
+    cfg = cols >= 16384 ? 3 : (wg64x128 >= 200 ? 4 : 5);
+  } else if (a.epi == SVC_EPI_RES_SKIP) {
+    SVC_REQUIRE(a.res && a.y2, "conv1d: res_skip epilogue needs res and y2");
+    cfg = cols >= 16384 ? 3 : (wg64x128 >= 200 && m64 ? 4 : (m64 && wg64x32 >= 200 ? 5 : 6));
+  } else {
+    SVC_REQUIRE(a.epi == SVC_EPI_PLAIN, "conv1d: unknown epilogue %d", a.epi);
+    if (a.Cout <= 16) cfg = 0;
+    else if (a.Cout <= 32) cfg = cols >= 16384 ? 1 : 6;
+    else if (cols >= 16384) cfg = a.Cout <= 64 ? 2 : 3;
+    else if (m64 && wg64x128 >= 200) cfg = 4;
+    else if (m64 && wg64x32 >= 200) cfg = 5;
+    else cfg = 6;
+  }
+  {
+    // the wide-tile configs stage X with float4 rows; unaligned activations fall back to narrower tiles
+    const bool xvec = a.premask == nullptr && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_bs % 4) == 0 &&
+                      (a.x_cs % 4) == 0 && (a.Tin % 4) == 0;
+    if (!xvec && a.epi == SVC_EPI_PLAIN) {
+      if (cfg == 0 || cfg == 1) cfg = 6;
+      else if (cfg == 2) cfg = 4;
+    }
+  }
+  if (g_force_cfg >= 0 && a.Cout > 16) {
+    const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
+                    (a.epi != SVC_EPI_GATE && g_force_cfg <= 6 && g_force_cfg >= 1);
+    if (ok) cfg = g_force_cfg;
+  }
+  if (a.epi == SVC_EPI_GATE) {
+    switch (cfg) {
+      case 3: return launch_cfg<2, 2, 2, 2, 1, false, SVC_EPI_GATE>(a, s);
+      case 4: return launch_cfg<2, 1, 1, 4, 1, false, SVC_EPI_GATE>(a, s);
+      default: return launch_cfg<2, 1, 1, 1, 4, false, SVC_EPI_GATE>(a, s);
+    }
   }
   if (a.epi == SVC_EPI_RES_SKIP) {
-    SVC_REQUIRE(a.res && a.y2, "conv1d: res_skip epilogue needs res and y2");
-    if (cols >= 16384) return launch_cfg<2, 2, 2, 2, false, SVC_EPI_RES_SKIP>(a, s);
-    return launch_cfg<2, 1, 1, 4, false, SVC_EPI_RES_SKIP>(a, s);
+    switch (cfg) {
+      case 3: return launch_cfg<2, 2, 2, 2, 1, false, SVC_EPI_RES_SKIP>(a, s);
+      case 4: return launch_cfg<2, 1, 1, 4, 1, false, SVC_EPI_RES_SKIP>(a, s);
+      case 5: return launch_cfg<2, 1, 1, 1, 4, false, SVC_EPI_RES_SKIP>(a, s);
+      default: return launch_cfg<1, 1, 1, 1, 4, false, SVC_EPI_RES_SKIP>(a, s);
+    }
   }
-  SVC_REQUIRE(a.epi == SVC_EPI_PLAIN, "conv1d: unknown epilogue %d", a.epi);
-  if (a.Cout <= 16) return launch_cfg<1, 8, 1, 4, true>(a, s);             // 16 x 512
-  if (a.Cout <= 32) return launch_cfg<1, 4, 1, 4, false>(a, s);            // 32 x 512
-  if (cols < 16384) {                                                      // short sequences: small tiles
-    if (a.Cout <= 64 || (a.Cout % 64) != 0) return launch_cfg<1, 1, 1, 4, false>(a, s);  // 32 x 128
-    return launch_cfg<2, 1, 1, 4, false>(a, s);                            // 64 x 128
+#define SVC_KS_CASES(MT_, NT_, WM_, WN_, M16_)                                                      \
+  switch (g_no_ksc ? 0 : a.KS) {                                                                     \
+    case 3: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 3>(a, s);                  \
+    case 7: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 7>(a, s);                  \
+    case 11: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 11>(a, s);                \
+    default: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 0>(a, s);                 \
   }
-  if (a.Cout <= 64) return launch_cfg<2, 2, 1, 4, false>(a, s);            // 64 x 256
-  return launch_cfg<2, 2, 2, 2, false>(a, s);                              // 128 x 128
+  switch (cfg) {
+    case 0: SVC_KS_CASES(1, 8, 1, 4, true)    // 16 x 512
+    case 1: SVC_KS_CASES(1, 4, 1, 4, false)   // 32 x 512
+    case 2: SVC_KS_CASES(2, 2, 1, 4, false)   // 64 x 256
+    case 3: SVC_KS_CASES(2, 2, 2, 2, false)   // 128 x 128
+    case 4: SVC_KS_CASES(2, 1, 1, 4, false)   // 64 x 128
+    case 5: return launch_cfg<2, 1, 1, 1, 4, false>(a, s);   // 64 x 32, 4-way split-K
+    default: return launch_cfg<1, 1, 1, 1, 4, false>(a, s);  // 32 x 32, 4-way split-K
+  }
 }
 
 extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {
