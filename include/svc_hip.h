@@ -216,6 +216,111 @@ typedef struct svc_attention_args {
 
 int svc_attention_f32(const svc_attention_args* a, void* stream);
 
+
+/* ================================================================================================
+ * TRAINING path.  Backward of the convolutions above plus the small ops of the
+ * GAN step (train.py:150-213).  Same conventions; every gradient is fp32.
+ * ============================================================================================== */
+
+/* torch.nn.utils.weight_norm (dim=0) made explicit: w[r,:] = g[r] * v[r,:] / ||v[r,:]||;  norm[r] = ||v[r,:]||
+ * (rows = Cout for Conv1d, Cin for ConvTranspose1d; cols = the remaining extent).  bwd: (dv, dg) from dw. */
+int svc_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int rows, int cols, void* stream);
+int svc_weight_norm_bwd_f32(const float* v, const float* g, const float* norm, const float* dw, float* dv, float* dg,
+                            int rows, int cols, void* stream);
+/* dgrad weight of a Conv1d: w:[Cout][Cin][KS] -> dst:[Cout][KS][CinP], dst[co][KS-1-k][ci] = w[co][ci][k]; feeding it
+ * to svc_conv1d_f32 with x = dy, pad_left = dil*(KS-1) - pad computes dx (autograd of F.conv1d). */
+int svc_pack_conv1d_weight_T(const float* w, float* dst, int Cout, int Cin, int KS, int CinP, void* stream);
+
+/* Weight gradient (and any "correlate two [B,C,T] signals over time" product):
+ *   G[ca,cb,k] (+)= sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad],  t in [0,TA), Bm index in [0,TB), KS <= 16.
+ * G is [Ca][Cb][KS] contiguous (= nn.Conv1d.weight layout for A = dy, Bm = x). */
+typedef struct svc_wgrad_args {
+  const float* A;
+  const float* Bm;
+  float* G;
+  long long a_bs, a_cs, b_bs, b_cs;
+  int B, Ca, Cb, TA, TB, KS, dil, pad, accumulate;
+} svc_wgrad_args;
+int svc_conv1d_wgrad_f32(const svc_wgrad_args* a, void* stream);
+
+/* Batched strided fp32 GEMM on the matrix pipe: C[b,m,n] = alpha*sum_k A[b,m,k]*B[b,k,n] + beta*C[b,m,n]
+ * (training-time attention products modules/attentions.py:207-239 and their gradients, mel filterbank
+ * modules/mel_processing.py:67-76, Linear layers). */
+typedef struct svc_gemm_args {
+  const float* A;
+  const float* B;
+  float* C;
+  long long a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
+  int batch, M, N, K;
+  float alpha, beta;
+} svc_gemm_args;
+int svc_gemm_f32(const svc_gemm_args* a, void* stream);
+
+/* Reductions of [B,C,T]: mode 0 out[c] = sum_{b,t} (bias gradients), mode 1 out[b,c] = sum_t (gradient of a [B,C,1]
+ * broadcast).  out = sum + beta*out.   svc_reduce_c: out[b,t] = sum_c x[b,c,t]*(w?w[c]:1). */
+int svc_reduce_bct_f32(const float* x, float* out, long long x_bs, long long x_cs, int B, int C, int T, int mode,
+                       float beta, void* stream);
+int svc_reduce_c_f32(const float* x, const float* w, float* out, int B, int C, int T, void* stream);
+
+/* Element-wise y = op(a, b) over n contiguous floats (b may be NULL for unary ops). */
+enum {
+  SVC_EW_ADD = 0,        /* alpha*a + beta*b */
+  SVC_EW_MUL = 1,        /* alpha*a*b */
+  SVC_EW_LRELU = 2,      /* leaky_relu(a, slope=alpha) */
+  SVC_EW_LRELU_BWD = 3,  /* a=dy, b=x */
+  SVC_EW_TANH = 4,
+  SVC_EW_TANH_BWD = 5,   /* a=dy, b=y */
+  SVC_EW_RELU = 6,
+  SVC_EW_RELU_BWD = 7,   /* a=dy, b=x */
+  SVC_EW_EXP = 8,        /* exp(alpha*a) */
+  SVC_EW_LOG_CLAMP = 9,  /* log(max(a, alpha)) */
+  SVC_EW_LOG_CLAMP_BWD = 10, /* a=dy, b=x */
+  SVC_EW_SCALE = 11,     /* alpha*a + beta */
+  SVC_EW_SIGMOID = 12,
+  SVC_EW_SQUARE = 13,    /* alpha*a*a */
+  SVC_EW_SIGN_MUL = 14,  /* alpha*sign(a) */
+  SVC_EW_DIV = 15        /* alpha*a/b */
+};
+int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
+/* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:
+ * s_ts = 0), channel-flipped operands (negative strides). */
+int svc_ew_bct_f32(int op, const float* x, const float* side, float* y, long long x_bs, long long x_cs, long long s_bs,
+                   long long s_cs, long long s_ts, long long y_bs, long long y_cs, int B, int C, int T, float alpha,
+                   float beta, void* stream);
+/* commons.fused_add_tanh_sigmoid_multiply (modules/commons.py:129-136) and its gradient: in:[B,2H,T] -> acts:[B,H,T]. */
+int svc_gate_fwd_f32(const float* in, float* acts, int B, int H, int T, void* stream);
+int svc_gate_bwd_f32(const float* in, const float* dacts, float* din, int B, int H, int T, void* stream);
+
+/* Phase decimation y[b, r*C + c, q] = xpad[b, c, q*s + r + off], r < s: xpad is x reflect-padded on the right to
+ * `lp` samples when lp > T (DiscriminatorP's F.pad(..., "reflect"), models.py:185-189) and zero elsewhere.  A stride-s
+ * Conv1d / Conv2d((k,1),(s,1)) becomes a dense conv over s*C channels; the adjoint is svc_decimate_bwd_f32. */
+int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int off, int Q, int lp, void* stream);
+int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int off, int Q, int lp, void* stream);
+
+/* Grouped strided Conv1d (DiscriminatorS, models.py:206-211): w:[Cout][Cin/groups][KS]. */
+int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Tin,
+                        int Tout, int KS, int stride, int pad, int groups, void* stream);
+int svc_gconv1d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int Tin, int Tout, int KS,
+                          int stride, int pad, int groups, void* stream);
+int svc_gconv1d_wgrad_f32(const float* dy, const float* x, float* dw, int B, int Cin, int Cout, int Tin, int Tout, int KS,
+                          int stride, int pad, int groups, void* stream);
+
+/* Scalar loss reductions (modules/losses.py:4-58; train.py:202,206): *out += scale * sum_i f(...) in double. */
+enum {
+  SVC_RED_SUM = 0, SVC_RED_ABS_DIFF = 1, SVC_RED_SQ_DIFF = 2, SVC_RED_SQ_ONE_MINUS = 3, SVC_RED_SQ = 4, SVC_RED_KL = 5
+};
+int svc_reduce_scalar_f64(int op, const float* a, const float* b, const float* c, const float* d, long long n,
+                          double* out, double scale, void* stream);
+int svc_f64_to_f32(const double* in, float* out, int n, void* stream);
+
+/* Fused AdamW step over one flat parameter buffer (train.py:79-88; torch.optim.AdamW semantics, `step` >= 1).
+ * grad_scale multiplies the gradient first (1/world_size for data-parallel means). */
+int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* Tuning / debugging knob of svc_conv1d_f32 (tile-config override and ablation switches); 0 restores defaults. */
+int svc_debug_set_conv_cfg(int cfg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,441 @@
+// train_ops.hip — the small kernels of the TRAINING graph: weight-norm forward /
+// backward, transposed weight packing for conv dgrad, bias / broadcast reductions, element-wise forward / backward
+// ops, decimation (strided and transposed convolutions are lowered to dense MFMA convolutions over phase-decimated
+// signals), grouped strided Conv1d (DiscriminatorS, models.py:206-211), scalar loss reductions and the fused
+// AdamW step (train.py:79-88,191-213).  All HBM-bound.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- weight norm (torch.nn.utils.weight_norm, dim=0): w[r,:] = g[r] * v[r,:] / ||v[r,:]|| ---------------------
+__global__ void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ w,
+                                       float* __restrict__ norm, int cols) {
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < cols; i += blockDim.x) {
+    const double x = v[(long long)r * cols + i];
+    acc += x * x;
+  }
+  const float nr = (float)sqrt(block_sum_d(acc, sh));
+  const float sc = g[r] / nr;
+  if (threadIdx.x == 0 && norm) norm[r] = nr;
+  for (int i = threadIdx.x; i < cols; i += blockDim.x) w[(long long)r * cols + i] = v[(long long)r * cols + i] * sc;
+}
+
+// dg[r] = <dw, v> / ||v|| ;  dv = (g/||v||) * (dw - v * <dw,v> / ||v||^2)
+__global__ void weight_norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                       const float* __restrict__ norm, const float* __restrict__ dw,
+                                       float* __restrict__ dv, float* __restrict__ dg, int cols) {
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < cols; i += blockDim.x)
+    acc += (double)dw[(long long)r * cols + i] * (double)v[(long long)r * cols + i];
+  const double dot = block_sum_d(acc, sh);
+  const double nr = norm[r];
+  if (threadIdx.x == 0) dg[r] = (float)(dot / nr);
+  const double sc = (double)g[r] / nr;
+  const double k = dot / (nr * nr);
+  for (int i = threadIdx.x; i < cols; i += blockDim.x) {
+    const long long o = (long long)r * cols + i;
+    dv[o] = (float)(sc * ((double)dw[o] - (double)v[o] * k));
+  }
+}
+
+// dgrad weight: dst[co][KS-1-k][ci] = w[co][ci][k]  (CinP-padded rows of zeros) — the conv that maps dy -> dx
+__global__ void pack_conv1d_T_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KS,
+                                     int CinP) {
+  const long long n = (long long)Cout * KS * CinP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % CinP);
+    const long long r = i / CinP;
+    const int kk = (int)(r % KS);
+    const int co = (int)(r / KS);
+    dst[i] = ci < Cin ? w[((long long)co * Cin + ci) * KS + (KS - 1 - kk)] : 0.f;
+  }
+}
+
+// ---- reductions of [B,C,T] -----------------------------------------------------------------------------------
+// mode 0: out[c] = sum_{b,t}   (bias grads)     one block per c
+// mode 1: out[b,c] = sum_t     (grad of a [B,C,1] broadcast)   one block per (b,c)
+__global__ void reduce_bct_kernel(const float* __restrict__ x, float* __restrict__ out, long long bs, long long cs,
+                                  int B, int C, int T, int mode, float beta) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  if (mode == 0) {
+    const int c = blockIdx.x;
+    for (int b = 0; b < B; ++b)
+      for (int t = threadIdx.x; t < T; t += blockDim.x) acc += x[b * bs + c * cs + t];
+  } else {
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) acc += x[b * bs + c * cs + t];
+  }
+  const double s = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)s + (beta != 0.f ? beta * out[blockIdx.x] : 0.f);
+}
+
+// out[b,t] = sum_c x[b,c,t] * (w ? w[c] : 1)     (mode 2)
+__global__ void reduce_c_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
+                                int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) acc += x[((long long)b * C + c) * T + t] * (w ? w[c] : 1.f);
+  out[(long long)b * T + t] = acc;
+}
+
+// ---- element-wise --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha, float beta) {
+  switch (op) {
+    case SVC_EW_ADD: return alpha * a + beta * b;
+    case SVC_EW_MUL: return a * b * alpha;
+    case SVC_EW_LRELU: return a > 0.f ? a : a * alpha;
+    case SVC_EW_LRELU_BWD: return b > 0.f ? a : a * alpha;            // a = dy, b = x
+    case SVC_EW_TANH: return tanhf(a);
+    case SVC_EW_TANH_BWD: return a * (1.f - b * b);                   // a = dy, b = y
+    case SVC_EW_RELU: return a > 0.f ? a : 0.f;
+    case SVC_EW_RELU_BWD: return b > 0.f ? a : 0.f;                   // a = dy, b = x
+    case SVC_EW_EXP: return expf(a * alpha);
+    case SVC_EW_LOG_CLAMP: return logf(fmaxf(a, alpha));              // log(clamp(a, min=alpha))
+    case SVC_EW_LOG_CLAMP_BWD: return b > alpha ? a / b : 0.f;        // a = dy, b = x
+    case SVC_EW_SCALE: return a * alpha + beta;
+    case SVC_EW_SIGMOID: return svc_sigmoid(a);
+    case SVC_EW_SQUARE: return a * a * alpha;
+    case SVC_EW_SIGN_MUL: return (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) * alpha;   // d|a|/da * alpha
+    case SVC_EW_DIV: return a / b * alpha;
+    default: return a;
+  }
+}
+
+__global__ void ew_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                          long long n, float alpha, float beta) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = ew_apply(op, a[i], b ? b[i] : 0.f, alpha, beta);
+}
+
+// y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts])  with arbitrary (possibly negative / zero) strides
+__global__ void ew_bct_kernel(int op, const float* __restrict__ x, const float* __restrict__ side, float* __restrict__ y,
+                              long long x_bs, long long x_cs, long long s_bs, long long s_cs, long long s_ts,
+                              long long y_bs, long long y_cs, int C, int T, float alpha, float beta) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float sv = side[b * s_bs + c * s_cs + t * s_ts];
+  y[b * y_bs + c * y_cs + t] = ew_apply(op, x[b * x_bs + c * x_cs + t], sv, alpha, beta);
+}
+
+// WN gate: in [B,2H,T] -> acts[B,H,T] = tanh(in[:, :H]) * sigmoid(in[:, H:])   (modules/commons.py:129-136)
+__global__ void gate_fwd_kernel(const float* __restrict__ in, float* __restrict__ acts, int H, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float a = in[((long long)b * 2 * H + c) * T + t], s = in[((long long)b * 2 * H + H + c) * T + t];
+  acts[((long long)b * H + c) * T + t] = tanhf(a) * svc_sigmoid(s);
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dacts, float* __restrict__ din,
+                                int H, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const long long oa = ((long long)b * 2 * H + c) * T + t, os = ((long long)b * 2 * H + H + c) * T + t;
+  const float th = tanhf(in[oa]), sg = svc_sigmoid(in[os]);
+  const float d = dacts[((long long)b * H + c) * T + t];
+  din[oa] = d * sg * (1.f - th * th);
+  din[os] = d * th * sg * (1.f - sg);
+}
+
+// ---- decimation: y[b, r*C + c, q] = xpad[b, c, q*s + r + off]  -----------------------------------------------
+// xpad = x reflect-padded on the right up to `lp` samples when lp > T (DiscriminatorP, models.py:185-189), zero
+// elsewhere.  Lowers a stride-s conv (and the dgrad/wgrad of a transposed conv) to a dense conv over s*C channels.
+__global__ void decimate_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T, int s, int off, int Q,
+                                int lp) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rc = blockIdx.y, b = blockIdx.z;
+  if (q >= Q) return;
+  const int r = rc / C, c = rc % C;
+  int tau = q * s + r + off;
+  float v = 0.f;
+  if (tau >= 0 && tau < lp) {
+    if (tau >= T) tau = 2 * T - 2 - tau;
+    if (tau >= 0) v = x[((long long)b * C + c) * T + tau];
+  }
+  y[((long long)b * s * C + rc) * Q + q] = v;
+}
+// adjoint: dx[b,c,tau] = sum of dy over every (r,q) that read tau (direct + reflected image)
+__global__ void decimate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int T, int s, int off,
+                                    int Q, int lp) {
+  const int tau = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (tau >= T) return;
+  float acc = 0.f;
+  auto take = [&](int tp) {   // padded position tp
+    const int u = tp - off;
+    if (tp < 0 || tp >= lp || u < 0) return;
+    const int q = u / s, r = u - q * s;
+    if (q < Q) acc += dy[((long long)b * s * C + r * C + c) * Q + q];
+  };
+  take(tau);
+  const int img = 2 * T - 2 - tau;
+  if (img >= T && img < lp) take(img);
+  dx[((long long)b * C + c) * T + tau] = acc;
+}
+
+// ---- grouped strided Conv1d (DiscriminatorS: k=41, stride 4, groups 4..256; models.py:206-211) ------------------
+// w [Cout][Cg][KS], Cg = Cin/groups, Og = Cout/groups
+__global__ void gconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                 float* __restrict__ y, int Cin, int Cout, int Tin, int Tout, int KS, int stride, int pad,
+                                 int groups) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int co = blockIdx.y, b = blockIdx.z;
+  if (t >= Tout) return;
+  const int Cg = Cin / groups, Og = Cout / groups;
+  const int g = co / Og;
+  float acc = bias ? bias[co] : 0.f;
+  const float* wr = w + (long long)co * Cg * KS;
+  for (int cl = 0; cl < Cg; ++cl) {
+    const float* xr = x + ((long long)b * Cin + g * Cg + cl) * Tin;
+    for (int k = 0; k < KS; ++k) {
+      const int ti = t * stride + k - pad;
+      if (ti >= 0 && ti < Tin) acc = fmaf(wr[cl * KS + k], xr[ti], acc);
+    }
+  }
+  y[((long long)b * Cout + co) * Tout + t] = acc;
+}
+__global__ void gconv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                   int Cin, int Cout, int Tin, int Tout, int KS, int stride, int pad, int groups) {
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ci = blockIdx.y, b = blockIdx.z;
+  if (ti >= Tin) return;
+  const int Cg = Cin / groups, Og = Cout / groups;
+  const int g = ci / Cg, cl = ci % Cg;
+  float acc = 0.f;
+  for (int ol = 0; ol < Og; ++ol) {
+    const int co = g * Og + ol;
+    const float* wr = w + ((long long)co * Cg + cl) * KS;
+    const float* dr = dy + ((long long)b * Cout + co) * Tout;
+    for (int k = 0; k < KS; ++k) {
+      const int u = ti + pad - k;
+      if (u >= 0 && (u % stride) == 0) {
+        const int t = u / stride;
+        if (t < Tout) acc = fmaf(wr[k], dr[t], acc);
+      }
+    }
+  }
+  dx[((long long)b * Cin + ci) * Tin + ti] = acc;
+}
+// one block per (co, cl), threads over k then reduce over (b,t) in-thread
+__global__ void gconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                   int B, int Cin, int Cout, int Tin, int Tout, int KS, int stride, int pad, int groups) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x, cl = blockIdx.y, co = blockIdx.z;
+  const int Cg = Cin / groups, Og = Cout / groups;
+  const int g = co / Og;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* dr = dy + ((long long)b * Cout + co) * Tout;
+    const float* xr = x + ((long long)b * Cin + g * Cg + cl) * Tin;
+    for (int t = threadIdx.x; t < Tout; t += blockDim.x) {
+      const int ti = t * stride + k - pad;
+      if (ti >= 0 && ti < Tin) acc += (double)dr[t] * (double)xr[ti];
+    }
+  }
+  const double s = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) dw[((long long)co * Cg + cl) * KS + k] = (float)s;
+}
+
+// ---- scalar reductions for the losses (modules/losses.py:4-58, train.py:202,206) --------------------------------
+// out += scale * sum_i f(a_i, b_i [, c_i, d_i])   accumulated in double per block, atomically added (double)
+__global__ void reduce_scalar_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                     const float* __restrict__ c, const float* __restrict__ d, long long n,
+                                     double* __restrict__ out, double scale) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float x = a[i];
+    switch (op) {
+      case SVC_RED_SUM: acc += x; break;
+      case SVC_RED_ABS_DIFF: acc += fabsf(x - b[i]); break;
+      case SVC_RED_SQ_DIFF: { const float e = x - b[i]; acc += (double)e * e; } break;
+      case SVC_RED_SQ_ONE_MINUS: { const float e = 1.f - x; acc += (double)e * e; } break;
+      case SVC_RED_SQ: acc += (double)x * x; break;
+      case SVC_RED_KL: {   // a=z_p b=logs_q c=m_p d=logs_p  (masked by caller through e = mask in `b2`) -> see host
+        const float zp = x, lq = b[i], mp = c[i], lp = d[i];
+        acc += (double)(lp - lq - 0.5f + 0.5f * (zp - mp) * (zp - mp) * expf(-2.f * lp));
+      } break;
+      default: break;
+    }
+  }
+  const double s = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+__global__ void scalar_to_float_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+// ---- fused AdamW (train.py:79-88: lr, betas=(0.8,0.99), eps=1e-9, weight_decay default 0.01) -------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2, float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+static inline unsigned grid1d(long long n, int bs = 256, unsigned cap = 65535u * 8) {
+  long long g = (n + bs - 1) / bs;
+  if (g < 1) g = 1;
+  return (unsigned)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int svc_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int rows, int cols, void* stream) {
+  SVC_REQUIRE(v && g && w && rows > 0 && cols > 0, "weight_norm_fwd: bad args");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w, norm, cols);
+  return svc::check_launch("weight_norm_fwd");
+}
+
+int svc_weight_norm_bwd_f32(const float* v, const float* g, const float* norm, const float* dw, float* dv, float* dg,
+                            int rows, int cols, void* stream) {
+  SVC_REQUIRE(v && g && norm && dw && dv && dg && rows > 0 && cols > 0, "weight_norm_bwd: bad args");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, norm, dw, dv, dg, cols);
+  return svc::check_launch("weight_norm_bwd");
+}
+
+int svc_pack_conv1d_weight_T(const float* w, float* dst, int Cout, int Cin, int KS, int CinP, void* stream) {
+  SVC_REQUIRE(w && dst && Cout > 0 && Cin > 0 && KS > 0 && CinP >= Cin, "pack_conv1d_T: bad args");
+  const long long n = (long long)Cout * KS * CinP;
+  hipLaunchKernelGGL(pack_conv1d_T_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin, KS, CinP);
+  return svc::check_launch("pack_conv1d_T");
+}
+
+int svc_reduce_bct_f32(const float* x, float* out, long long x_bs, long long x_cs, int B, int C, int T, int mode,
+                       float beta, void* stream) {
+  SVC_REQUIRE(x && out && B > 0 && C > 0 && T > 0 && (mode == 0 || mode == 1), "reduce_bct: bad args");
+  hipLaunchKernelGGL(reduce_bct_kernel, dim3(mode == 0 ? C : B * C), dim3(256), 0, (hipStream_t)stream, x, out, x_bs, x_cs,
+                     B, C, T, mode, beta);
+  return svc::check_launch("reduce_bct");
+}
+
+int svc_reduce_c_f32(const float* x, const float* w, float* out, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "reduce_c: bad args");
+  hipLaunchKernelGGL(reduce_c_kernel, dim3(svc::cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, x, w, out, C, T);
+  return svc::check_launch("reduce_c");
+}
+
+int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream) {
+  SVC_REQUIRE(a && y && n > 0, "ew: bad args");
+  hipLaunchKernelGGL(ew_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, n, alpha, beta);
+  return svc::check_launch("ew");
+}
+
+int svc_ew_bct_f32(int op, const float* x, const float* side, float* y, long long x_bs, long long x_cs, long long s_bs,
+                   long long s_cs, long long s_ts, long long y_bs, long long y_cs, int B, int C, int T, float alpha,
+                   float beta, void* stream) {
+  SVC_REQUIRE(x && side && y && B > 0 && C > 0 && T > 0, "ew_bct: bad args");
+  hipLaunchKernelGGL(ew_bct_kernel, dim3(svc::cdiv(T, 256), C, B), dim3(256), 0, (hipStream_t)stream, op, x, side, y, x_bs,
+                     x_cs, s_bs, s_cs, s_ts, y_bs, y_cs, C, T, alpha, beta);
+  return svc::check_launch("ew_bct");
+}
+
+int svc_gate_fwd_f32(const float* in, float* acts, int B, int H, int T, void* stream) {
+  SVC_REQUIRE(in && acts && B > 0 && H > 0 && T > 0, "gate_fwd: bad args");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(svc::cdiv(T, 256), H, B), dim3(256), 0, (hipStream_t)stream, in, acts, H, T);
+  return svc::check_launch("gate_fwd");
+}
+
+int svc_gate_bwd_f32(const float* in, const float* dacts, float* din, int B, int H, int T, void* stream) {
+  SVC_REQUIRE(in && dacts && din && B > 0 && H > 0 && T > 0, "gate_bwd: bad args");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(svc::cdiv(T, 256), H, B), dim3(256), 0, (hipStream_t)stream, in, dacts, din, H, T);
+  return svc::check_launch("gate_bwd");
+}
+
+int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int off, int Q, int lp, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && T > 0 && s >= 1 && Q > 0 && lp >= T, "decimate: bad args");
+  SVC_REQUIRE(lp - T <= T - 1, "decimate: reflect padding longer than the signal");
+  hipLaunchKernelGGL(decimate_kernel, dim3(svc::cdiv(Q, 256), s * C, B), dim3(256), 0, (hipStream_t)stream, x, y, C, T, s,
+                     off, Q, lp);
+  return svc::check_launch("decimate");
+}
+
+int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int off, int Q, int lp, void* stream) {
+  SVC_REQUIRE(dy && dx && B > 0 && C > 0 && T > 0 && s >= 1 && Q > 0 && lp >= T, "decimate_bwd: bad args");
+  hipLaunchKernelGGL(decimate_bwd_kernel, dim3(svc::cdiv(T, 256), C, B), dim3(256), 0, (hipStream_t)stream, dy, dx, C, T,
+                     s, off, Q, lp);
+  return svc::check_launch("decimate_bwd");
+}
+
+int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Tin,
+                        int Tout, int KS, int stride, int pad, int groups, void* stream) {
+  SVC_REQUIRE(x && w && y && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_fwd: bad args");
+  hipLaunchKernelGGL(gconv_fwd_kernel, dim3(svc::cdiv(Tout, 64), Cout, B), dim3(64), 0, (hipStream_t)stream, x, w, bias, y,
+                     Cin, Cout, Tin, Tout, KS, stride, pad, groups);
+  return svc::check_launch("gconv_fwd");
+}
+
+int svc_gconv1d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int Tin, int Tout, int KS,
+                          int stride, int pad, int groups, void* stream) {
+  SVC_REQUIRE(dy && w && dx && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_dgrad: bad args");
+  hipLaunchKernelGGL(gconv_dgrad_kernel, dim3(svc::cdiv(Tin, 64), Cin, B), dim3(64), 0, (hipStream_t)stream, dy, w, dx, Cin,
+                     Cout, Tin, Tout, KS, stride, pad, groups);
+  return svc::check_launch("gconv_dgrad");
+}
+
+int svc_gconv1d_wgrad_f32(const float* dy, const float* x, float* dw, int B, int Cin, int Cout, int Tin, int Tout, int KS,
+                          int stride, int pad, int groups, void* stream) {
+  SVC_REQUIRE(dy && x && dw && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_wgrad: bad args");
+  hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(KS, Cin / groups, Cout), dim3(64), 0, (hipStream_t)stream, dy, x, dw, B, Cin,
+                     Cout, Tin, Tout, KS, stride, pad, groups);
+  return svc::check_launch("gconv_wgrad");
+}
+
+int svc_reduce_scalar_f64(int op, const float* a, const float* b, const float* c, const float* d, long long n,
+                          double* out, double scale, void* stream) {
+  SVC_REQUIRE(a && out && n > 0, "reduce_scalar: bad args");
+  hipLaunchKernelGGL(reduce_scalar_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, op, a, b, c, d, n,
+                     out, scale);
+  return svc::check_launch("reduce_scalar");
+}
+
+int svc_f64_to_f32(const double* in, float* out, int n, void* stream) {
+  SVC_REQUIRE(in && out && n > 0, "f64_to_f32: bad args");
+  hipLaunchKernelGGL(scalar_to_float_kernel, dim3(svc::cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, in, out, n);
+  return svc::check_launch("f64_to_f32");
+}
+
+int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  SVC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale);
+  return svc::check_launch("adamw");
+}
+
+}  // extern "C"

@@ -455,3 +455,280 @@ def device_info():
     buf = C.create_string_buffer(256)
     cus = lib().svc_device_info(buf, 256)
     return buf.value.decode(), cus
+
+
+# --------------------------------------------------------------------------------------------------------------
+# training-path entry points (include/svc_hip.h, "TRAINING path")
+# --------------------------------------------------------------------------------------------------------------
+(EW_ADD, EW_MUL, EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_RELU, EW_RELU_BWD, EW_EXP, EW_LOG_CLAMP,
+ EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV) = range(16)
+RED_SUM, RED_ABS_DIFF, RED_SQ_DIFF, RED_SQ_ONE_MINUS, RED_SQ, RED_KL = range(6)
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("A", _f32p), ("Bm", _f32p), ("G", _f32p),
+                ("a_bs", C.c_longlong), ("a_cs", C.c_longlong), ("b_bs", C.c_longlong), ("b_cs", C.c_longlong),
+                ("B", C.c_int), ("Ca", C.c_int), ("Cb", C.c_int), ("TA", C.c_int), ("TB", C.c_int), ("KS", C.c_int),
+                ("dil", C.c_int), ("pad", C.c_int), ("accumulate", C.c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", _f32p), ("B", _f32p), ("C", _f32p),
+                ("a_bs", C.c_longlong), ("a_ms", C.c_longlong), ("a_ks", C.c_longlong),
+                ("b_bs", C.c_longlong), ("b_ks", C.c_longlong), ("b_ns", C.c_longlong),
+                ("c_bs", C.c_longlong), ("c_ms", C.c_longlong), ("c_ns", C.c_longlong),
+                ("batch", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("alpha", C.c_float), ("beta", C.c_float)]
+
+
+TRAIN_EXPORTS = [
+    "svc_weight_norm_fwd_f32", "svc_weight_norm_bwd_f32", "svc_pack_conv1d_weight_T", "svc_conv1d_wgrad_f32",
+    "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
+    "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
+    "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_debug_set_conv_cfg",
+]
+EXPORTS += TRAIN_EXPORTS
+_train_bound = False
+
+
+def tlib():
+    """lib() with the training entry points' argtypes declared."""
+    global _train_bound
+    L = lib()
+    if not _train_bound:
+        i, f, ll, vp = C.c_int, C.c_float, C.c_longlong, C.c_void_p
+        L.svc_weight_norm_fwd_f32.argtypes = [_f32p] * 4 + [i, i, vp]
+        L.svc_weight_norm_bwd_f32.argtypes = [_f32p] * 6 + [i, i, vp]
+        L.svc_pack_conv1d_weight_T.argtypes = [_f32p, _f32p, i, i, i, i, vp]
+        L.svc_conv1d_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]
+        L.svc_gemm_f32.argtypes = [C.POINTER(GemmArgs), vp]
+        L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
+        L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
+        L.svc_ew_f32.argtypes = [i, _f32p, _f32p, _f32p, ll, f, f, vp]
+        L.svc_ew_bct_f32.argtypes = [i, _f32p, _f32p, _f32p] + [ll] * 7 + [i, i, i, f, f, vp]
+        L.svc_gate_fwd_f32.argtypes = [_f32p, _f32p, i, i, i, vp]
+        L.svc_gate_bwd_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
+        L.svc_decimate_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, vp]
+        L.svc_decimate_bwd_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, vp]
+        L.svc_gconv1d_fwd_f32.argtypes = [_f32p] * 4 + [i] * 9 + [vp]
+        L.svc_gconv1d_dgrad_f32.argtypes = [_f32p] * 3 + [i] * 9 + [vp]
+        L.svc_gconv1d_wgrad_f32.argtypes = [_f32p] * 3 + [i] * 9 + [vp]
+        L.svc_reduce_scalar_f64.argtypes = [i, _f32p, _f32p, _f32p, _f32p, ll, vp, C.c_double, vp]
+        L.svc_f64_to_f32.argtypes = [vp, _f32p, i, vp]
+        L.svc_adamw_f32.argtypes = [_f32p] * 4 + [ll, f, f, f, f, f, i, f, vp]
+        L.svc_debug_set_conv_cfg.argtypes = [i]
+        _train_bound = True
+    return L
+
+
+def ew(op, a, b=None, alpha=1.0, beta=0.0, out=None):
+    require_gpu(a, b, out)
+    a = a.contiguous()
+    if b is not None:
+        b = b.contiguous()
+        if b.shape != a.shape:
+            raise SvcError(f"ew: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    if out is None:
+        out = torch.empty_like(a)
+    if a.numel():
+        check(tlib().svc_ew_f32(op, ptr(a), ptr(b), ptr(out), a.numel(), alpha, beta, stream_ptr()), "ew")
+    return out
+
+
+def ew_bct(op, x, side, alpha=1.0, beta=0.0, out=None):
+    """out[b,c,t] = op(x[b,c,t], side broadcast); side is [B|1, C|1, T|1]."""
+    require_gpu(x, side, out)
+    B, Cc, T = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    sb = side.stride(0) if side.shape[0] > 1 else 0
+    sc = side.stride(1) if side.shape[1] > 1 else 0
+    st = side.stride(2) if side.shape[2] > 1 else 0
+    xb, xc = _bct_strides(x)
+    yb, yc = _bct_strides(out)
+    check(tlib().svc_ew_bct_f32(op, ptr(x), ptr(side), ptr(out), xb, xc, sb, sc, st, yb, yc, B, Cc, T, alpha, beta,
+                                stream_ptr()), "ew_bct")
+    return out
+
+
+def reduce_bct(x, mode, out=None, beta=0.0):
+    """mode 0: [C] = sum over (b,t);  mode 1: [B,C,1] = sum over t."""
+    require_gpu(x, out)
+    B, Cc, T = x.shape
+    xb, xc = _bct_strides(x)
+    if out is None:
+        out = torch.empty((Cc,) if mode == 0 else (B, Cc, 1), device=x.device, dtype=torch.float32)
+    check(tlib().svc_reduce_bct_f32(ptr(x), ptr(out), xb, xc, B, Cc, T, mode, beta, stream_ptr()), "reduce_bct")
+    return out
+
+
+def reduce_c(x, w=None):
+    require_gpu(x, w)
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    out = torch.empty((B, 1, T), device=x.device, dtype=torch.float32)
+    check(tlib().svc_reduce_c_f32(ptr(x), ptr(w), ptr(out), B, Cc, T, stream_ptr()), "reduce_c")
+    return out
+
+
+def weight_norm_fwd(v, g):
+    require_gpu(v, g)
+    v = v.contiguous()
+    rows = v.shape[0]
+    cols = v.numel() // rows
+    w = torch.empty_like(v)
+    norm = torch.empty(rows, device=v.device, dtype=torch.float32)
+    check(tlib().svc_weight_norm_fwd_f32(ptr(v), ptr(g.contiguous()), ptr(w), ptr(norm), rows, cols, stream_ptr()),
+          "weight_norm_fwd")
+    return w, norm
+
+
+def weight_norm_bwd(v, g, norm, dw):
+    require_gpu(v, g, norm, dw)
+    v = v.contiguous()
+    rows = v.shape[0]
+    cols = v.numel() // rows
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g)
+    check(tlib().svc_weight_norm_bwd_f32(ptr(v), ptr(g.contiguous()), ptr(norm), ptr(dw.contiguous()), ptr(dv), ptr(dg),
+                                         rows, cols, stream_ptr()), "weight_norm_bwd")
+    return dv, dg
+
+
+def pack_conv1d_weight_T(w):
+    """w [Cout,Cin,KS] -> dgrad packing [Cout, KS, CinP]."""
+    require_gpu(w)
+    w = w.contiguous()
+    Cout, Cin, KS = w.shape
+    CinP = round_up(Cin, 32)
+    dst = torch.empty((Cout, KS, CinP), device=w.device, dtype=torch.float32)
+    check(tlib().svc_pack_conv1d_weight_T(ptr(w), ptr(dst), Cout, Cin, KS, CinP, stream_ptr()), "pack_conv1d_T")
+    return dst
+
+
+def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False):
+    """G[ca,cb,k] = sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad]."""
+    require_gpu(A, Bm, out)
+    B, Ca, TA = A.shape
+    _, Cb, TB = Bm.shape
+    if out is None:
+        out = torch.empty((Ca, Cb, KS), device=A.device, dtype=torch.float32)
+    a = WgradArgs()
+    a.A, a.Bm, a.G = ptr(A), ptr(Bm), ptr(out)
+    a.a_bs, a.a_cs = _bct_strides(A)
+    a.b_bs, a.b_cs = _bct_strides(Bm)
+    a.B, a.Ca, a.Cb, a.TA, a.TB, a.KS, a.dil, a.pad, a.accumulate = B, Ca, Cb, TA, TB, KS, dil, pad, 1 if accumulate else 0
+    check(tlib().svc_conv1d_wgrad_f32(C.byref(a), stream_ptr()), "conv1d_wgrad")
+    return out
+
+
+def gemm(A, Bmat, a_strides, b_strides, batch, M, N, K, out=None, c_strides=None, alpha=1.0, beta=0.0):
+    """C[b,m,n] = alpha*sum_k A[b,m,k]*B[b,k,n] + beta*C.  a_strides = (bs, ms, ks), b_strides = (bs, ks, ns),
+    c_strides = (bs, ms, ns) (default contiguous [batch,M,N]).  A/Bmat/out are tensors used as base pointers."""
+    require_gpu(A, Bmat, out)
+    if out is None:
+        out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
+    if c_strides is None:
+        c_strides = (M * N, N, 1)
+    a = GemmArgs()
+    a.A, a.B, a.C = ptr(A), ptr(Bmat), ptr(out)
+    a.a_bs, a.a_ms, a.a_ks = a_strides
+    a.b_bs, a.b_ks, a.b_ns = b_strides
+    a.c_bs, a.c_ms, a.c_ns = c_strides
+    a.batch, a.M, a.N, a.K, a.alpha, a.beta = batch, M, N, K, alpha, beta
+    check(tlib().svc_gemm_f32(C.byref(a), stream_ptr()), "gemm")
+    return out
+
+
+def gate_fwd(x):
+    require_gpu(x)
+    x = x.contiguous()
+    B, C2, T = x.shape
+    out = torch.empty((B, C2 // 2, T), device=x.device, dtype=torch.float32)
+    check(tlib().svc_gate_fwd_f32(ptr(x), ptr(out), B, C2 // 2, T, stream_ptr()), "gate_fwd")
+    return out
+
+
+def gate_bwd(x, dacts):
+    require_gpu(x, dacts)
+    x = x.contiguous()
+    B, C2, T = x.shape
+    din = torch.empty_like(x)
+    check(tlib().svc_gate_bwd_f32(ptr(x), ptr(dacts.contiguous()), ptr(din), B, C2 // 2, T, stream_ptr()), "gate_bwd")
+    return din
+
+
+def decimate(x, s, off, Q, lp=None):
+    require_gpu(x)
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    y = torch.empty((B, s * Cc, Q), device=x.device, dtype=torch.float32)
+    check(tlib().svc_decimate_f32(ptr(x), ptr(y), B, Cc, T, s, off, Q, T if lp is None else lp, stream_ptr()), "decimate")
+    return y
+
+
+def decimate_bwd(dy, Cc, T, s, off, lp=None):
+    require_gpu(dy)
+    dy = dy.contiguous()
+    B, sC, Q = dy.shape
+    dx = torch.empty((B, Cc, T), device=dy.device, dtype=torch.float32)
+    check(tlib().svc_decimate_bwd_f32(ptr(dy), ptr(dx), B, Cc, T, s, off, Q, T if lp is None else lp, stream_ptr()),
+          "decimate_bwd")
+    return dx
+
+
+def gconv1d_fwd(x, w, bias, stride, pad, groups):
+    require_gpu(x, w, bias)
+    x, w = x.contiguous(), w.contiguous()
+    B, Cin, Tin = x.shape
+    Cout, Cg, KS = w.shape
+    Tout = (Tin + 2 * pad - KS) // stride + 1
+    y = torch.empty((B, Cout, Tout), device=x.device, dtype=torch.float32)
+    check(tlib().svc_gconv1d_fwd_f32(ptr(x), ptr(w), ptr(bias), ptr(y), B, Cin, Cout, Tin, Tout, KS, stride, pad, groups,
+                                     stream_ptr()), "gconv1d_fwd")
+    return y
+
+
+def gconv1d_dgrad(dy, w, Cin, Tin, stride, pad, groups):
+    require_gpu(dy, w)
+    dy, w = dy.contiguous(), w.contiguous()
+    B, Cout, Tout = dy.shape
+    KS = w.shape[2]
+    dx = torch.empty((B, Cin, Tin), device=dy.device, dtype=torch.float32)
+    check(tlib().svc_gconv1d_dgrad_f32(ptr(dy), ptr(w), ptr(dx), B, Cin, Cout, Tin, Tout, KS, stride, pad, groups,
+                                       stream_ptr()), "gconv1d_dgrad")
+    return dx
+
+
+def gconv1d_wgrad(dy, x, KS, stride, pad, groups):
+    require_gpu(dy, x)
+    dy, x = dy.contiguous(), x.contiguous()
+    B, Cout, Tout = dy.shape
+    _, Cin, Tin = x.shape
+    dw = torch.empty((Cout, Cin // groups, KS), device=dy.device, dtype=torch.float32)
+    check(tlib().svc_gconv1d_wgrad_f32(ptr(dy), ptr(x), ptr(dw), B, Cin, Cout, Tin, Tout, KS, stride, pad, groups,
+                                       stream_ptr()), "gconv1d_wgrad")
+    return dw
+
+
+def reduce_scalar(op, a, b=None, c=None, d=None, scale=1.0, acc=None):
+    """acc (float64 [1] device tensor) += scale * sum f(a,b,c,d); returns acc."""
+    require_gpu(a, b, c, d)
+    ts = [t.contiguous() if t is not None else None for t in (a, b, c, d)]
+    if acc is None:
+        acc = torch.zeros(1, device=a.device, dtype=torch.float64)
+    check(tlib().svc_reduce_scalar_f64(op, ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), ts[0].numel(),
+                                       C.c_void_p(acc.data_ptr()), float(scale), stream_ptr()), "reduce_scalar")
+    return acc
+
+
+def f64_to_f32(acc):
+    out = torch.empty(acc.shape, device=acc.device, dtype=torch.float32)
+    check(tlib().svc_f64_to_f32(C.c_void_p(acc.data_ptr()), ptr(out), acc.numel(), stream_ptr()), "f64_to_f32")
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    require_gpu(p, g, m, v)
+    check(tlib().svc_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                               grad_scale, stream_ptr()), "adamw")

@@ -1,0 +1,121 @@
+"""Forward + backward parity of the training-path primitives (svc_autograd) against torch's own CPU autograd of the
+same op (fp32).  Tolerances: 2e-5 relative to the tensor's max magnitude (fp32 fmaf chains vs oneDNN ordering)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-5, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, (what, err, scale)
+
+
+def _run_pair(fn_hip, fn_ref, tensors, dev, tol=2e-5):
+    """tensors: dict name -> CPU tensor (requires_grad as set).  Compares outputs and all input grads."""
+    torch.manual_seed(0)
+    ref_in = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in tensors.items()}
+    hip_in = {k: v.detach().clone().to(dev).requires_grad_(v.requires_grad) for k, v in tensors.items()}
+    yr = fn_ref(**ref_in)
+    yh = fn_hip(**hip_in)
+    _close(yh, yr, tol, "forward")
+    go = torch.randn_like(yr)
+    yr.backward(go)
+    yh.backward(go.to(dev))
+    for k in tensors:
+        if tensors[k].requires_grad:
+            _close(hip_in[k].grad, ref_in[k].grad, tol, f"grad {k}")
+
+
+def _p(*shape, scale=1.0):
+    return (torch.randn(*shape) * scale).requires_grad_(True)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil,pad", [
+    (2, 16, 16, 300, 3, 1, 1), (1, 64, 32, 513, 7, 3, 9), (2, 32, 32, 256, 11, 5, 25), (3, 192, 384, 77, 5, 1, 2),
+    (2, 96, 192, 130, 1, 1, 0), (1, 1, 16, 700, 15, 1, 7), (2, 1024, 1, 40, 3, 1, 1)])
+def test_conv1d_dense_fwd_bwd(dev, B, Cin, Cout, T, K, dil, pad):
+    import svc_autograd as A
+    torch.manual_seed(1)
+    t = dict(x=_p(B, Cin, T), w=_p(Cout, Cin, K, scale=(Cin * K) ** -0.5), bias=_p(Cout))
+    _run_pair(lambda x, w, bias: A.conv1d(x, w, bias, 1, pad, dil), lambda x, w, bias: F.conv1d(x, w, bias, 1, pad, dil),
+              t, dev)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,s,pad", [(2, 1, 32, 2731, 5, 3, 2), (2, 32, 128, 911, 5, 3, 2),
+                                                  (1, 1, 64, 8192, 128, 64, 32), (2, 1, 16, 4096, 4, 2, 1),
+                                                  (2, 8, 8, 100, 16, 8, 4)])
+def test_conv1d_strided_fwd_bwd(dev, B, Cin, Cout, T, K, s, pad):
+    import svc_autograd as A
+    torch.manual_seed(2)
+    t = dict(x=_p(B, Cin, T), w=_p(Cout, Cin, K, scale=(Cin * K) ** -0.5), bias=_p(Cout))
+    _run_pair(lambda x, w, bias: A.conv1d(x, w, bias, s, pad, 1), lambda x, w, bias: F.conv1d(x, w, bias, s, pad, 1), t, dev)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,u,pad", [(2, 64, 32, 50, 16, 8, 4), (1, 32, 16, 333, 4, 2, 1),
+                                                  (2, 16, 8, 40, 5, 2, 2)])
+def test_conv_transpose1d_fwd_bwd(dev, B, Cin, Cout, T, K, u, pad):
+    import svc_autograd as A
+    torch.manual_seed(3)
+    t = dict(x=_p(B, Cin, T), w=_p(Cin, Cout, K, scale=(Cin * K) ** -0.5), bias=_p(Cout))
+    _run_pair(lambda x, w, bias: A.conv_transpose1d(x, w, bias, u, pad),
+              lambda x, w, bias: F.conv_transpose1d(x, w, bias, u, pad), t, dev)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,groups", [(2, 16, 64, 2048, 4), (2, 64, 256, 512, 16), (1, 1024, 1024, 32, 256)])
+def test_grouped_conv_fwd_bwd(dev, B, Cin, Cout, T, groups):
+    import svc_autograd as A
+    torch.manual_seed(4)
+    t = dict(x=_p(B, Cin, T), w=_p(Cout, Cin // groups, 41, scale=0.05), bias=_p(Cout))
+    _run_pair(lambda x, w, bias: A.conv1d(x, w, bias, 4, 20, 1, groups),
+              lambda x, w, bias: F.conv1d(x, w, bias, 4, 20, 1, groups), t, dev)
+
+
+def test_weight_norm_fwd_bwd(dev):
+    import svc_autograd as A
+    torch.manual_seed(5)
+    t = dict(v=_p(48, 16, 7), g=_p(48, 1, 1))
+
+    def ref(v, g):
+        return v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    _run_pair(lambda v, g: A.weight_norm(v, g), ref, t, dev)
+
+
+def test_pointwise_fwd_bwd(dev):
+    import svc_autograd as A
+    torch.manual_seed(6)
+    t = dict(x=_p(2, 8, 50))
+    _run_pair(lambda x: A.leaky_relu(x, 0.1), lambda x: F.leaky_relu(x, 0.1), t, dev)
+    _run_pair(lambda x: A.tanh(x), torch.tanh, t, dev)
+    _run_pair(lambda x: A.relu(x), torch.relu, t, dev)
+    t2 = dict(x=_p(2, 16, 33))
+    _run_pair(lambda x: A.gate(x), lambda x: torch.tanh(x[:, :8]) * torch.sigmoid(x[:, 8:]), t2, dev)
+    t3 = dict(x=_p(2, 8, 50), s=_p(2, 8, 1))
+    _run_pair(lambda x, s: A.add_bcast(x, s), lambda x, s: x + s, t3, dev)
+    t4 = dict(x=_p(2, 8, 50), s=torch.rand(2, 1, 50))
+    _run_pair(lambda x, s: A.mul_bcast(x, s), lambda x, s: x * s, t4, dev)
+    t5 = dict(a=_p(2, 8, 50), b=_p(2, 8, 50))
+    _run_pair(lambda a, b: A.add(a, b), lambda a, b: a + b, t5, dev)
+
+
+def test_decimate_reflect_adjoint(dev):
+    """DiscriminatorP's reflect pad + period reshape (models.py:185-190) and the adjoint of the decimation."""
+    import svc_hip as S
+    torch.manual_seed(7)
+    B, T, p = 2, 8192, 7
+    x = torch.randn(B, 1, T)
+    n_pad = (p - T % p) % p
+    ref = F.pad(x, (0, n_pad), "reflect").view(B, 1, (T + n_pad) // p, p)       # [B,1,H,W]
+    Q = (T + n_pad) // p
+    y = S.decimate(x.to(dev), p, 0, Q, T + n_pad)                                # [B, p, Q]: y[b, w, h] = ref[b,0,h,w]
+    assert torch.equal(y.cpu(), ref[:, 0].permute(0, 2, 1))
+    # adjoint test: <decimate(x), g> == <x, decimate_bwd(g)>
+    g = torch.randn(B, p, Q)
+    dx = S.decimate_bwd(g.to(dev), 1, T, p, 0, T + n_pad).cpu()
+    lhs = (y.cpu() * g).sum().item()
+    rhs = (x * dx).sum().item()
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs))
