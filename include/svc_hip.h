@@ -318,6 +318,58 @@ int svc_f64_to_f32(const double* in, float* out, int n, void* stream);
 int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+
+/* Channel LayerNorm for training (modules/modules.py:23-35): forward also returns the per-column mean / rstd [B,T];
+ * backward returns dx and the gamma / beta gradients. */
+int svc_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int B,
+                          int C, int T, float eps, void* stream);
+int svc_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, int B, int C, int T, void* stream);
+/* Training-time attention pieces around svc_gemm_f32 (modules/attentions.py:207-303).  S:[B*H,T,T] scores (in place ->
+ * probabilities): S[i,j] += rel[i, j-i+window] inside the band, masked to -1e4 (mask_mode 1: mask[b,i]*mask[b,j]==0,
+ * 2: j>i), softmax over j.  bwd: dP -> dS in place.  band gather/scatter move the (2*window+1)-wide diagonal band
+ * between a [rows,T] matrix (row i of every T x T block) and a [rows, 2*window+1] array. */
+int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
+                             void* stream);
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, void* stream);
+int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream);
+int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream);
+/* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of
+ * their gradient into a zero-initialised dW. */
+int svc_embed_fwd_f32(const long long* idx, const float* W, float* y, int B, int C, int T, void* stream);
+int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, void* stream);
+/* Gradient of svc_reparam_f32: dstats = [dm ; dlogs]. */
+int svc_reparam_bwd_f32(const float* stats, const float* noise, const float* mask, const float* dz, float* dstats, int B,
+                        int C, int T, float scale, void* stream);
+/* Training variant of svc_nsf_source_f32 that also stores the per-harmonic waves [B,T*upp,H]; l_linear + tanh on stored
+ * waves and the (dw, db) gradients of l_linear (vdecoder/hifigan/models.py:318). */
+int svc_nsf_source_train_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                             const float* lin_b, float* har, float* waves, void* scratch, int B, int T, int upp, int H,
+                             float sampling_rate, float sine_amp, float noise_std, void* stream);
+int svc_nsf_linear_fwd_f32(const float* waves, const float* w, const float* b0, float* har, long long n, int H, void* stream);
+int svc_nsf_linear_bwd_f32(const float* waves, const float* har, const float* dhar, float* dw, float* db, long long n, int H,
+                           void* stream);
+
+
+/* Masked KL term (modules/losses.py:43-58): acc2[0] += sum(kl*mask), acc2[1] += sum(mask); backward of sum(kl*mask)
+ * scaled by the device scalar *g. */
+int svc_kl_fwd_f64(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p, const float* mask,
+                   double* acc2, int B, int C, int T, void* stream);
+int svc_kl_bwd_f32(const float* z_p, const float* m_p, const float* logs_p, const float* mask, const float* g, float* dz_p,
+                   float* dlogs_q, float* dm_p, float* dlogs_p, int B, int C, int T, void* stream);
+/* STFT front end of the mel loss (modules/mel_processing.py:40-64): reflect-pad by `pad`, frame (hop), window ->
+ * frames [B,NF,nfft]; adjoint (overlap-add with reflection folding) into dy [B,L].  The transform itself is a real DFT
+ * as two svc_gemm_f32 products against the basis from svc_dft_basis_f32 (cs = cos, sn = -sin, [nfft][NB]);
+ * |.| with the reference's 1e-6 floor and its gradient. */
+int svc_stft_frame_f32(const float* y, const float* win, float* frames, int B, int L, int NF, int nfft, int hop, int pad,
+                       void* stream);
+int svc_stft_frame_bwd_f32(const float* dframes, const float* win, float* dy, int B, int L, int NF, int nfft, int hop, int pad,
+                           void* stream);
+int svc_dft_basis_f32(float* cs, float* sn, int N, int NB, void* stream);
+int svc_cmag_f32(const float* re, const float* im, float* mag, long long n, float eps, void* stream);
+int svc_cmag_bwd_f32(const float* re, const float* im, const float* mag, const float* dmag, float* dre, float* dim, long long n,
+                     void* stream);
+
 /* Tuning / debugging knob of svc_conv1d_f32 (tile-config override and ablation switches); 0 restores defaults. */
 int svc_debug_set_conv_cfg(int cfg);
 

@@ -208,3 +208,90 @@ def make_noise(cfg, B, T, seed=4321):
     return dict(enc_p=torch.randn(B, cfg["inter_channels"], T, generator=g),
                 rand_ini=torch.rand(B, 9, generator=g),
                 sine=torch.randn(B, L, 9, generator=g))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MultiPeriodDiscriminator (models.py:165-252): fixed architecture, 46,747,132 parameters
+# ---------------------------------------------------------------------------------------------------------------
+def mpd_param_shapes():
+    P = {}
+
+    def nconv(name, shape):
+        P[name + ".bias"] = (shape[0],)
+        P[name + ".weight_g"] = (shape[0],) + (1,) * (len(shape) - 1)
+        P[name + ".weight_v"] = shape
+    s = "discriminators.0"
+    for i, sh in enumerate([(16, 1, 15), (64, 4, 41), (256, 4, 41), (1024, 4, 41), (1024, 4, 41), (1024, 1024, 5)]):
+        nconv(f"{s}.convs.{i}", sh)
+    nconv(f"{s}.conv_post", (1, 1024, 3))
+    for d in range(1, 6):
+        s = f"discriminators.{d}"
+        for i, (a, b) in enumerate([(1, 32), (32, 128), (128, 512), (512, 1024), (1024, 1024)]):
+            nconv(f"{s}.convs.{i}", (b, a, 5, 1))
+        nconv(f"{s}.conv_post", (1, 1024, 3, 1))
+    return P
+
+
+def make_mpd_state_dict(seed=4321):
+    shapes = mpd_param_shapes()
+    sd = {}
+    for name, shape in shapes.items():
+        gen = _gen("mpd." + name, seed)
+        if name.endswith(".bias"):
+            sd[name] = torch.randn(shape, generator=gen) * 0.05
+        elif name.endswith(".weight_v"):
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            sd[name] = torch.randn(shape, generator=gen) * (1.0 / math.sqrt(fan_in))
+        else:   # weight_g: around the norm of the matching v so the effective weight keeps the fan-in scale
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=gen)
+    return sd
+
+
+def train_config():
+    """small_config with dropout off (so the training graph is deterministic given the injected noise)."""
+    c = small_config()
+    c.update(p_dropout=0.0, segment_size=8)
+    return c
+
+
+def make_train_batch(cfg, B, T, seed, hop=512):
+    """(c, f0, uv, spec, y, sid, lengths) for one training step; lengths vary so the padding masks are exercised."""
+    gen = torch.Generator().manual_seed(seed)
+    c = torch.randn(B, cfg["ssl_dim"], T, generator=gen)
+    f0 = torch.rand(B, T, generator=gen) * 300 + 100
+    f0[:, : max(1, T // 10)] = 0
+    f0[0, T // 2: T // 2 + 3] = 0
+    uv = (f0 > 0).float()
+    spec = torch.randn(B, cfg["spec_channels"], T, generator=gen).abs()
+    y = (torch.rand(B, 1, T * hop, generator=gen) - 0.5)
+    sid = torch.randint(0, cfg["n_speakers"], (B, 1), generator=gen)
+    lengths = torch.tensor([T - 3 * i for i in range(B)], dtype=torch.long)
+    return c, f0, uv, spec, y, sid, lengths
+
+
+def make_train_noise(cfg, B, T, lengths, seed, hop=512):
+    gen = torch.Generator().manual_seed(seed)
+    seg = cfg["segment_size"]
+    ids_max = (lengths - seg + 1).float()
+    ids_rand = torch.rand(B, generator=gen)
+    ids = (ids_rand * ids_max).long()
+    return dict(ids_rand=ids_rand, f0_factor=torch.rand(B, 1, generator=gen) * 0.4 + 0.8,
+                enc_p=torch.randn(B, cfg["inter_channels"], T, generator=gen),
+                enc_q=torch.randn(B, cfg["inter_channels"], T, generator=gen),
+                ids_slice=ids, rand_ini=torch.rand(B, 9, generator=gen),
+                sine=torch.randn(B, seg * hop, 9, generator=gen))
+
+
+def make_train_state_dict(cfg, seed):
+    """make_state_dict with the log-variance projections damped (x0.1): with O(1) random `proj` weights exp(-2*logs_p)
+    in the KL term (modules/losses.py:52-54) reaches 1e6 and every other loss term / gradient drowns in it."""
+    sd = make_state_dict(cfg, seed)
+    inter = cfg["inter_channels"]
+    for p in ("enc_p.proj", "enc_q.proj"):
+        for suffix in (".weight", ".bias"):
+            t = sd[p + suffix].clone()
+            t[inter:] = t[inter:] * 0.1
+            sd[p + suffix] = t
+    return sd

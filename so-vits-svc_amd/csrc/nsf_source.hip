@@ -66,8 +66,8 @@ __global__ void nsf_frame_scan_kernel(const float* __restrict__ f0, const float*
 __global__ __launch_bounds__(256) void nsf_sample_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
                                                          const float* __restrict__ noise, const float* __restrict__ lin_w,
                                                          const float* __restrict__ lin_b, const ScanRec* __restrict__ rec,
-                                                         float* __restrict__ har, int B, int T, int upp, int H, float sr,
-                                                         float sine_amp, float noise_std) {
+                                                         float* __restrict__ har, float* __restrict__ waves, int B, int T,
+                                                         int upp, int H, float sr, float sine_amp, float noise_std) {
   const long long L = (long long)T * upp;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void nsf_sample_kernel(const float* __restrict
     const float ph32 = (float)ph;
     const float sine = sinf(ph32 * 2.f * pi_f) * sine_amp;
     const float sw = sine * uv + noise_amp * nz[h];
+    if (waves) waves[((long long)b * L + t) * H + h] = sw;
     acc += lin_w[h] * sw;
   }
   har[(long long)b * L + t] = tanhf(acc + lin_b[0]);
@@ -109,9 +110,9 @@ extern "C" long long svc_nsf_source_scratch_bytes(int B, int T, int H) {
   return (long long)B * H * T * (long long)sizeof(ScanRec);
 }
 
-extern "C" int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
-                                  const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
-                                  float sampling_rate, float sine_amp, float noise_std, void* stream) {
+static int nsf_source_impl(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                           const float* lin_b, float* har, float* waves, void* scratch, int B, int T, int upp, int H,
+                           float sampling_rate, float sine_amp, float noise_std, void* stream) {
   SVC_REQUIRE(f0 && rand_ini && noise && lin_w && lin_b && har && scratch, "nsf_source: null tensor");
   SVC_REQUIRE(B > 0 && T > 0 && upp > 0 && H > 0 && H <= MAXH, "nsf_source: bad shape (H <= %d)", MAXH);
   SVC_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "nsf_source: scratch must be 8-byte aligned");
@@ -122,6 +123,23 @@ extern "C" int svc_nsf_source_f32(const float* f0, const float* rand_ini, const 
   hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(svc::cdiv(B * H, 64)), dim3(64), 0, s, f0, rand_ini, rec, B, T, upp, H,
                      sampling_rate);
   hipLaunchKernelGGL(nsf_sample_kernel, dim3((unsigned)svc::cdivll(L, 256), B), dim3(256), 0, s, f0, rand_ini, noise,
-                     lin_w, lin_b, rec, har, B, T, upp, H, sampling_rate, sine_amp, noise_std);
+                     lin_w, lin_b, rec, har, waves, B, T, upp, H, sampling_rate, sine_amp, noise_std);
   return svc::check_launch("nsf_source");
+}
+
+extern "C" int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                                  const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
+                                  float sampling_rate, float sine_amp, float noise_std, void* stream) {
+  return nsf_source_impl(f0, rand_ini, noise, lin_w, lin_b, har, nullptr, scratch, B, T, upp, H, sampling_rate, sine_amp,
+                         noise_std, stream);
+}
+
+// Training variant: additionally writes the per-harmonic excitation waves [B, T*upp, H] that feed l_linear
+// (vdecoder/hifigan/models.py:318), so that its weight gradient can be formed (svc_nsf_linear_bwd_f32).
+extern "C" int svc_nsf_source_train_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                                        const float* lin_b, float* har, float* waves, void* scratch, int B, int T, int upp,
+                                        int H, float sampling_rate, float sine_amp, float noise_std, void* stream) {
+  SVC_REQUIRE(waves != nullptr, "nsf_source_train: null waves");
+  return nsf_source_impl(f0, rand_ini, noise, lin_w, lin_b, har, waves, scratch, B, T, upp, H, sampling_rate, sine_amp,
+                         noise_std, stream);
 }

@@ -1,0 +1,470 @@
+// train_ops2.hip — training-path kernels with a little more structure than train_ops.hip: channel LayerNorm
+// forward/backward (modules/modules.py:23-35), masked banded softmax forward/backward and the band gather / scatter
+// of the windowed relative-position attention (modules/attentions.py:207-303), embedding gather / scatter-add
+// (models.py:393,453,136), reparameterisation backward (models.py:158-160,122-124).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ double block_sum_d2(double v, double* sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- LayerNorm over C of [B,C,T]; one thread per (b,t) column, coalesced along t ---------------------------------
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int C, int T,
+                              float eps) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const float* xp = x + (long long)b * C * T + t;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long long)c * T];
+  const float mu = s / C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = xp[(long long)c * T] - mu;
+    v += d * d;
+  }
+  const float rs = rsqrtf(v / C + eps);
+  mean[(long long)b * T + t] = mu;
+  rstd[(long long)b * T + t] = rs;
+  float* yp = y + (long long)b * C * T + t;
+  for (int c = 0; c < C; ++c) yp[(long long)c * T] = (xp[(long long)c * T] - mu) * rs * gamma[c] + beta[c];
+}
+
+__global__ void ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                                 int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const long long o = (long long)b * C * T + t;
+  const float mu = mean[(long long)b * T + t], rs = rstd[(long long)b * T + t];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = dy[o + (long long)c * T] * gamma[c];
+    const float xh = (x[o + (long long)c * T] - mu) * rs;
+    s1 += g;
+    s2 += g * xh;
+  }
+  s1 /= C;
+  s2 /= C;
+  for (int c = 0; c < C; ++c) {
+    const float g = dy[o + (long long)c * T] * gamma[c];
+    const float xh = (x[o + (long long)c * T] - mu) * rs;
+    dx[o + (long long)c * T] = rs * (g - s1 - xh * s2);
+  }
+}
+// one block per channel: dgamma[c] = sum dy*xhat, dbeta[c] = sum dy
+__global__ void ln_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    int B, int C, int T) {
+  __shared__ double sh[256];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const long long o = ((long long)b * C + c) * T + t;
+      const float xh = (x[o] - mean[(long long)b * T + t]) * rstd[(long long)b * T + t];
+      a1 += (double)dy[o] * xh;
+      a2 += dy[o];
+    }
+  const double s1 = block_sum_d2(a1, sh);
+  const double s2 = block_sum_d2(a2, sh);
+  if (threadIdx.x == 0) {
+    dgamma[c] = (float)s1;
+    dbeta[c] = (float)s2;
+  }
+}
+
+// ---- attention score post-processing: S[bh,i,:] += band(rel[bh,i,:]); mask; softmax over j --------------------------
+// mask_mode 1: key/query padding mask m[b,i]*m[b,j] == 0 -> -1e4 (attentions.Encoder :96); 2: causal j > i -> -1e4
+// (attentions.FFT :52 via commons.subsequent_mask).  One wave per row.
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ rel,
+                                                               const float* __restrict__ mask, int H, int T, int window,
+                                                               int mask_mode, long long n_rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int i = (int)(row % T);
+  const long long bh = row / T;
+  const int b = (int)(bh / H);
+  float* sp = S + row * T;
+  const int nrel = 2 * window + 1;
+  const float* rp = rel ? rel + row * nrel : nullptr;
+  const float* mp = mask ? mask + (long long)b * T : nullptr;
+  const float mi = mp ? mp[i] : 1.f;
+  float mx = -INFINITY;
+  for (int j = lane; j < T; j += 64) {
+    float v = sp[j];
+    const int r = j - i + window;
+    if (rp && r >= 0 && r < nrel) v += rp[r];
+    if (mask_mode == 1 && mp && mi * mp[j] == 0.f) v = -1e4f;
+    if (mask_mode == 2 && j > i) v = -1e4f;
+    sp[j] = v;
+    mx = fmaxf(mx, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float e = expf(sp[j] - mx);
+    sp[j] = e;
+    sum += e;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < T; j += 64) sp[j] *= inv;
+}
+// dS = P * (dP - sum_j dP*P), in place on dP
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int T,
+                                                               long long n_rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* pp = P + row * T;
+  float* dp = dP + row * T;
+  float dot = 0.f;
+  for (int j = lane; j < T; j += 64) dot += pp[j] * dp[j];
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  for (int j = lane; j < T; j += 64) dp[j] = pp[j] * (dp[j] - dot);
+}
+// band[row, r] = M[row, i + r - window] (0 outside);   scatter: M[row, i + r - window] += band[row, r]
+__global__ void band_gather_kernel(const float* __restrict__ M, float* __restrict__ band, int T, int window,
+                                   long long n_rows) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrel = 2 * window + 1;
+  if (idx >= n_rows * nrel) return;
+  const long long row = idx / nrel;
+  const int r = (int)(idx - row * nrel);
+  const int i = (int)(row % T);
+  const int j = i + r - window;
+  band[idx] = (j >= 0 && j < T) ? M[row * T + j] : 0.f;
+}
+__global__ void band_scatter_add_kernel(float* __restrict__ M, const float* __restrict__ band, int T, int window,
+                                        long long n_rows) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrel = 2 * window + 1;
+  if (idx >= n_rows * nrel) return;
+  const long long row = idx / nrel;
+  const int r = (int)(idx - row * nrel);
+  const int i = (int)(row % T);
+  const int j = i + r - window;
+  if (j >= 0 && j < T) M[row * T + j] += band[idx];
+}
+
+// ---- embedding: y[b,c,t] = W[idx[b,t], c]  and its adjoint (atomic scatter-add into dW) ---------------------------
+__global__ void embed_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ W, float* __restrict__ y,
+                                 int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  y[((long long)b * C + c) * T + t] = W[idx[(long long)b * T + t] * C + c];
+}
+__global__ void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dW,
+                                 int C, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  atomicAdd(dW + idx[(long long)b * T + t] * C + c, dy[((long long)b * C + c) * T + t]);
+}
+
+// ---- reparameterisation backward: z = (m + n*exp(logs)*scale)*mask  ->  dstats = [dm ; dlogs] -------------------------
+__global__ void reparam_bwd_kernel(const float* __restrict__ stats, const float* __restrict__ noise,
+                                   const float* __restrict__ mask, const float* __restrict__ dz, float* __restrict__ dstats,
+                                   int C, int T, float scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float mk = mask ? mask[(long long)b * T + t] : 1.f;
+  const float g = dz[((long long)b * C + c) * T + t] * mk;
+  const long long om = ((long long)b * 2 * C + c) * T + t, ol = ((long long)b * 2 * C + C + c) * T + t;
+  dstats[om] = g;
+  dstats[ol] = g * noise[((long long)b * C + c) * T + t] * expf(stats[ol]) * scale;
+}
+
+// ---- NSF source tail for training: har = tanh(sum_h waves[.,h]*w[h] + b0)  (vdecoder/hifigan/models.py:318) ---------
+__global__ void nsf_linear_fwd_kernel(const float* __restrict__ waves, const float* __restrict__ w, const float* __restrict__ b0,
+                                      float* __restrict__ har, long long n, int H) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = b0[0];
+  for (int h = 0; h < H; ++h) acc = fmaf(waves[i * H + h], w[h], acc);
+  har[i] = tanhf(acc);
+}
+// dw[h] += sum_i dz_i * waves[i,h], db += sum_i dz_i, dz = dhar*(1-har^2)   (no gradient to waves: f0 is an input)
+__global__ void nsf_linear_bwd_kernel(const float* __restrict__ waves, const float* __restrict__ har,
+                                      const float* __restrict__ dhar, float* __restrict__ dw, float* __restrict__ db,
+                                      long long n, int H) {
+  __shared__ double sh[256];
+  double acc[17];
+  for (int h = 0; h <= H; ++h) acc[h] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float y = har[i];
+    const float dz = dhar[i] * (1.f - y * y);
+    for (int h = 0; h < H; ++h) acc[h] += (double)dz * waves[i * H + h];
+    acc[H] += dz;
+  }
+  for (int h = 0; h <= H; ++h) {
+    const double s = block_sum_d2(acc[h], sh);
+    if (threadIdx.x == 0) atomicAdd(h < H ? dw + h : db, (float)s);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svc_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int B,
+                          int C, int T, float eps, void* stream) {
+  SVC_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0 && T > 0, "layernorm_fwd: bad args");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(svc::cdiv(T, 64), B), dim3(64), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                     rstd, C, T, eps);
+  return svc::check_launch("layernorm_fwd");
+}
+
+int svc_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && gamma && dy && mean && rstd && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "layernorm_bwd: bad args");
+  hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(svc::cdiv(T, 64), B), dim3(64), 0, (hipStream_t)stream, x, gamma, dy, mean, rstd,
+                     dx, C, T);
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, dgamma, dbeta, B, C, T);
+  return svc::check_launch("layernorm_bwd");
+}
+
+int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
+                             void* stream) {
+  SVC_REQUIRE(S && B > 0 && H > 0 && T > 0 && window >= 0, "attn_softmax_fwd: bad args");
+  const long long rows = (long long)B * H * T;
+  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rel, mask,
+                     H, T, window, mask_mode, rows);
+  return svc::check_launch("attn_softmax_fwd");
+}
+
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, void* stream) {
+  SVC_REQUIRE(P && dP && B > 0 && H > 0 && T > 0, "attn_softmax_bwd: bad args");
+  const long long rows = (long long)B * H * T;
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows);
+  return svc::check_launch("attn_softmax_bwd");
+}
+
+int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream) {
+  SVC_REQUIRE(M && band && n_rows > 0 && T > 0 && window >= 0, "band_gather: bad args");
+  const long long n = n_rows * (2 * window + 1);
+  hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, band, T, window, n_rows);
+  return svc::check_launch("band_gather");
+}
+
+int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream) {
+  SVC_REQUIRE(M && band && n_rows > 0 && T > 0 && window >= 0, "band_scatter_add: bad args");
+  const long long n = n_rows * (2 * window + 1);
+  hipLaunchKernelGGL(band_scatter_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, band, T, window, n_rows);
+  return svc::check_launch("band_scatter_add");
+}
+
+int svc_embed_fwd_f32(const long long* idx, const float* W, float* y, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(idx && W && y && B > 0 && C > 0 && T > 0, "embed_fwd: bad args");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(svc::cdiv(T, 64), C, B), dim3(64), 0, (hipStream_t)stream, idx, W, y, C, T);
+  return svc::check_launch("embed_fwd");
+}
+
+int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(idx && dy && dW && B > 0 && C > 0 && T > 0, "embed_bwd: bad args");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(svc::cdiv(T, 64), C, B), dim3(64), 0, (hipStream_t)stream, idx, dy, dW, C, T);
+  return svc::check_launch("embed_bwd");
+}
+
+int svc_reparam_bwd_f32(const float* stats, const float* noise, const float* mask, const float* dz, float* dstats, int B,
+                        int C, int T, float scale, void* stream) {
+  SVC_REQUIRE(stats && noise && dz && dstats && B > 0 && C > 0 && T > 0, "reparam_bwd: bad args");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(svc::cdiv(T, 64), C, B), dim3(64), 0, (hipStream_t)stream, stats, noise, mask, dz,
+                     dstats, C, T, scale);
+  return svc::check_launch("reparam_bwd");
+}
+
+int svc_nsf_linear_fwd_f32(const float* waves, const float* w, const float* b0, float* har, long long n, int H, void* stream) {
+  SVC_REQUIRE(waves && w && b0 && har && n > 0 && H > 0 && H <= 16, "nsf_linear_fwd: bad args");
+  hipLaunchKernelGGL(nsf_linear_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, waves, w, b0, har, n, H);
+  return svc::check_launch("nsf_linear_fwd");
+}
+
+int svc_nsf_linear_bwd_f32(const float* waves, const float* har, const float* dhar, float* dw, float* db, long long n, int H,
+                           void* stream) {
+  SVC_REQUIRE(waves && har && dhar && dw && db && n > 0 && H > 0 && H <= 16, "nsf_linear_bwd: bad args");
+  if (hipMemsetAsync(dw, 0, sizeof(float) * H, (hipStream_t)stream) != hipSuccess ||
+      hipMemsetAsync(db, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    svc::set_error("nsf_linear_bwd: memset failed");
+    return SVC_ERR_HIP;
+  }
+  const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 512);
+  hipLaunchKernelGGL(nsf_linear_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, waves, har, dhar, dw, db, n, H);
+  return svc::check_launch("nsf_linear_bwd");
+}
+
+}  // extern "C"
+
+// ---- KL term of the VITS loss (modules/losses.py:43-58) and STFT framing (modules/mel_processing.py:40-64) -----------
+namespace {
+
+// acc[0] += sum kl*mask, acc[1] += sum mask (each mask element once);  kl = lp - lq - 0.5 + 0.5*(zp-mp)^2*exp(-2 lp)
+__global__ void kl_fwd_kernel(const float* __restrict__ zp, const float* __restrict__ lq, const float* __restrict__ mp,
+                              const float* __restrict__ lp, const float* __restrict__ mask, double* __restrict__ acc, int C,
+                              int T, long long n) {
+  __shared__ double sh[256];
+  double a0 = 0.0, a1 = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long long bc = i / T;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    const float mk = mask[b * T + t];
+    const float d = zp[i] - mp[i];
+    const float kl = lp[i] - lq[i] - 0.5f + 0.5f * d * d * expf(-2.f * lp[i]);
+    a0 += (double)(kl * mk);
+    if (c == 0) a1 += mk;
+  }
+  const double s0 = block_sum_d2(a0, sh);
+  const double s1 = block_sum_d2(a1, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc, s0);
+    atomicAdd(acc + 1, s1);
+  }
+}
+// gradients of sum(kl*mask) scaled by the device scalar *g
+__global__ void kl_bwd_kernel(const float* __restrict__ zp, const float* __restrict__ mp, const float* __restrict__ lp,
+                              const float* __restrict__ mask, const float* __restrict__ g, float* __restrict__ dzp,
+                              float* __restrict__ dlq, float* __restrict__ dmp, float* __restrict__ dlp, int C, int T,
+                              long long n) {
+  const float gs = g[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long long b = i / T / C;
+    const float mk = mask[b * T + t] * gs;
+    const float d = zp[i] - mp[i];
+    const float e = expf(-2.f * lp[i]);
+    dzp[i] = mk * d * e;
+    dmp[i] = -mk * d * e;
+    dlq[i] = -mk;
+    dlp[i] = mk * (1.f - d * d * e);
+  }
+}
+
+// frames[b, f, n] = ypad[b, f*hop + n] * win[n], ypad = reflect pad of y by `pad` on both sides
+__device__ __forceinline__ int reflect_idx(int p, int L) {   // p in [-pad, L+pad)
+  if (p < 0) p = -p;
+  if (p >= L) p = 2 * L - 2 - p;
+  return p;
+}
+__global__ void stft_frame_kernel(const float* __restrict__ y, const float* __restrict__ win, float* __restrict__ frames,
+                                  int L, int NF, int nfft, int hop, int pad) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y, b = blockIdx.z;
+  if (n >= nfft) return;
+  const int p = reflect_idx(f * hop + n - pad, L);
+  frames[((long long)b * NF + f) * nfft + n] = y[(long long)b * L + p] * win[n];
+}
+__global__ void stft_frame_bwd_kernel(const float* __restrict__ dframes, const float* __restrict__ win, float* __restrict__ dy,
+                                      int L, int NF, int nfft, int hop, int pad) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y, b = blockIdx.z;
+  if (n >= nfft) return;
+  const int p = reflect_idx(f * hop + n - pad, L);
+  atomicAdd(dy + (long long)b * L + p, dframes[((long long)b * NF + f) * nfft + n] * win[n]);
+}
+// DFT basis: cs[n, k] = cos(2 pi k n / N), sn[n, k] = -sin(2 pi k n / N)   ([N][NB])
+__global__ void dft_basis_kernel(float* __restrict__ cs, float* __restrict__ sn, int N, int NB) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (k >= NB) return;
+  const int r = (int)(((long long)k * n) % N);
+  const double th = 2.0 * 3.14159265358979323846 * (double)r / (double)N;
+  cs[(long long)n * NB + k] = (float)cos(th);
+  sn[(long long)n * NB + k] = (float)(-sin(th));
+}
+// mag = sqrt(re^2 + im^2 + eps);  bwd: dre = dmag*re/mag, dim = dmag*im/mag
+__global__ void cmag_kernel(const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ mag, long long n,
+                            float eps) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    mag[i] = sqrtf(re[i] * re[i] + im[i] * im[i] + eps);
+}
+__global__ void cmag_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im, const float* __restrict__ mag,
+                                const float* __restrict__ dmag, float* __restrict__ dre, float* __restrict__ dim, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float s = dmag[i] / mag[i];
+    dre[i] = s * re[i];
+    dim[i] = s * im[i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svc_kl_fwd_f64(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p, const float* mask,
+                   double* acc2, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(z_p && logs_q && m_p && logs_p && mask && acc2 && B > 0 && C > 0 && T > 0, "kl_fwd: bad args");
+  const long long n = (long long)B * C * T;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, z_p, logs_q, m_p, logs_p, mask, acc2, C, T, n);
+  return svc::check_launch("kl_fwd");
+}
+
+int svc_kl_bwd_f32(const float* z_p, const float* m_p, const float* logs_p, const float* mask, const float* g, float* dz_p,
+                   float* dlogs_q, float* dm_p, float* dlogs_p, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(z_p && m_p && logs_p && mask && g && dz_p && dlogs_q && dm_p && dlogs_p, "kl_bwd: bad args");
+  const long long n = (long long)B * C * T;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, z_p, m_p, logs_p, mask, g, dz_p, dlogs_q, dm_p, dlogs_p, C, T, n);
+  return svc::check_launch("kl_bwd");
+}
+
+int svc_stft_frame_f32(const float* y, const float* win, float* frames, int B, int L, int NF, int nfft, int hop, int pad,
+                       void* stream) {
+  SVC_REQUIRE(y && win && frames && B > 0 && L > pad && NF > 0, "stft_frame: bad args");
+  hipLaunchKernelGGL(stft_frame_kernel, dim3(svc::cdiv(nfft, 256), NF, B), dim3(256), 0, (hipStream_t)stream, y, win, frames, L,
+                     NF, nfft, hop, pad);
+  return svc::check_launch("stft_frame");
+}
+
+int svc_stft_frame_bwd_f32(const float* dframes, const float* win, float* dy, int B, int L, int NF, int nfft, int hop, int pad,
+                           void* stream) {
+  SVC_REQUIRE(dframes && win && dy && B > 0 && L > pad && NF > 0, "stft_frame_bwd: bad args");
+  if (hipMemsetAsync(dy, 0, sizeof(float) * (size_t)B * L, (hipStream_t)stream) != hipSuccess) {
+    svc::set_error("stft_frame_bwd: memset failed");
+    return SVC_ERR_HIP;
+  }
+  hipLaunchKernelGGL(stft_frame_bwd_kernel, dim3(svc::cdiv(nfft, 256), NF, B), dim3(256), 0, (hipStream_t)stream, dframes, win,
+                     dy, L, NF, nfft, hop, pad);
+  return svc::check_launch("stft_frame_bwd");
+}
+
+int svc_dft_basis_f32(float* cs, float* sn, int N, int NB, void* stream) {
+  SVC_REQUIRE(cs && sn && N > 0 && NB > 0, "dft_basis: bad args");
+  hipLaunchKernelGGL(dft_basis_kernel, dim3(svc::cdiv(NB, 256), N), dim3(256), 0, (hipStream_t)stream, cs, sn, N, NB);
+  return svc::check_launch("dft_basis");
+}
+
+int svc_cmag_f32(const float* re, const float* im, float* mag, long long n, float eps, void* stream) {
+  SVC_REQUIRE(re && im && mag && n > 0, "cmag: bad args");
+  hipLaunchKernelGGL(cmag_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     re, im, mag, n, eps);
+  return svc::check_launch("cmag");
+}
+
+int svc_cmag_bwd_f32(const float* re, const float* im, const float* mag, const float* dmag, float* dre, float* dim, long long n,
+                     void* stream) {
+  SVC_REQUIRE(re && im && mag && dmag && dre && dim && n > 0, "cmag_bwd: bad args");
+  hipLaunchKernelGGL(cmag_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, re, im, mag, dmag, dre, dim, n);
+  return svc::check_launch("cmag_bwd");
+}
+
+}  // extern "C"

@@ -15,9 +15,10 @@ from torch import nn
 import modules.attentions as attentions
 import modules.commons as commons
 import modules.modules as modules
+import svc_autograd as A
 import svc_hip as S
 import utils
-from svc_nn import Conv1d, mask2d
+from svc_nn import Conv1d, mask2d, training_call
 
 
 class ResidualCouplingBlock(nn.Module):
@@ -43,6 +44,14 @@ class ResidualCouplingBlock(nn.Module):
     def forward(self, x, x_mask, g=None, reverse=False):
         """Reference models.py:45-52.  The channel Flip between couplings is never materialised: the working
         buffer is addressed through a negative channel stride whenever an odd number of flips is pending."""
+        if training_call(self.flows[0].pre.weight) or (torch.is_grad_enabled() and x.requires_grad):
+            if not reverse:
+                for flow in self.flows:
+                    x, _ = flow(x, x_mask, g=g, reverse=False)
+            else:
+                for flow in reversed(self.flows):
+                    x = flow(x, x_mask, g=g, reverse=True)
+            return x
         buf = S.copy_bct(x)
         flipped = False
         couplings = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
@@ -79,6 +88,14 @@ class Encoder(nn.Module):
     def forward(self, x, x_lengths, g=None, noise=None):
         x_mask = torch.unsqueeze(commons.sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
         m = mask2d(x_mask)
+        if training_call(self.pre.weight):
+            h = A.mul_bcast(self.pre.forward_train(x), x_mask)
+            h = self.enc.forward_train(h, x_mask, g=g)
+            stats = A.mul_bcast(self.proj.forward_train(h), x_mask)
+            if noise is None:
+                noise = torch.randn(x.shape[0], self.out_channels, x.shape[2], device=x.device)      # models.py:123
+            z = A.reparam(stats, noise, m, 1.0)
+            return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
         h = self.pre.run(x, mask=m)
         h = self.enc(h, x_mask, g=g)
         stats = self.proj.run(h, mask=m)
@@ -105,6 +122,14 @@ class TextEncoder(nn.Module):
         """Reference models.py:155-162.  `f0` is the COARSE f0 index tensor (f0_to_coarse output) unless
         x_is_embedded=True, in which case `x` already is (x + f0_emb) * mask (fused by svc_prenet_embed_f32)."""
         m = mask2d(x_mask)
+        if training_call(self.proj.weight):
+            x = A.add(x, A.embedding_bct(f0, self.f0_emb.weight))                    # models.py:156
+            h = self.enc_.forward_train(A.mul_bcast(x, x_mask), x_mask)
+            stats = A.mul_bcast(self.proj.forward_train(h), x_mask)
+            if noise is None:
+                noise = torch.randn(stats.shape[0], self.out_channels, stats.shape[2], device=stats.device)   # :160
+            z = A.reparam(stats, noise, m, float(noice_scale))
+            return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
         if not x_is_embedded:
             emb = self.f0_emb.weight[f0].transpose(1, 2).contiguous()      # index gather (no arithmetic)
             x = _add_bc(x, emb)
@@ -137,6 +162,14 @@ class F0Decoder(nn.Module):
     def forward(self, x, norm_f0, x_mask, spk_emb=None):
         """Reference models.py:328-336:  x += cond(spk); x += f0_prenet(norm_f0); prenet; FFT; proj."""
         m = mask2d(x_mask)
+        if training_call(self.prenet.weight):
+            x = x.detach()                                                  # models.py:329
+            if spk_emb is not None:
+                x = A.add_bcast(x, self.cond.forward_train(spk_emb))
+            x = A.add(x, self.f0_prenet.forward_train(norm_f0))
+            x = A.mul_bcast(self.prenet.forward_train(x), x_mask)
+            x = self.decoder.forward_train(A.mul_bcast(x, x_mask), x_mask)
+            return A.mul_bcast(self.proj.forward_train(x), x_mask)
         gc = self.cond(spk_emb) if spk_emb is not None else None          # [B,H,1|T]
         # x + cond(g) + f0_prenet(norm_f0): direct conv (Cin=1) with x as residual, then the speaker bias rides as
         # `cond` on the prenet's INPUT side — it is not a per-output bias, so materialise it once:
@@ -233,9 +266,42 @@ class SynthesizerTrn(nn.Module):
         self.speaker_map = self.speaker_map.unsqueeze(0).to(device)
         self.character_mix = True
 
-    def forward(self, c, f0, uv, spec, g=None, c_lengths=None, spec_lengths=None, vol=None):
-        raise NotImplementedError("SynthesizerTrn.forward (training graph, reference models.py:463-493) needs the "
-                                  "backward kernels, which are not built yet; only .infer() is available")
+    def forward(self, c, f0, uv, spec, g=None, c_lengths=None, spec_lengths=None, vol=None, noise=None):
+        """Training graph, reference models.py:463-493.  Every op is a svc_autograd Function (HIP forward + backward).
+        `noise` (optional dict: enc_p, enc_q [B,inter,T], f0_factor [B,1], ids_slice [B], rand_ini [B,9],
+        sine [B, seg*hop, 9]) injects the random draws explicitly (parity tests); otherwise they come from torch's
+        generator in the reference's order."""
+        if vol is not None and self.vol_embedding:
+            raise NotImplementedError("vol_embedding=True has no training path yet")
+        noise = noise or {}
+        c, f0, uv, spec = c.float(), f0.float(), uv.float(), spec.float()
+        B, _, T = c.shape
+        gi = g if g.dim() == 2 else g.view(B, 1)
+        gemb = A.embedding_bct(gi.long(), self.emb_g.weight)                            # [B, gin, 1]
+        x_mask = torch.unsqueeze(commons.sequence_mask(c_lengths, T), 1).to(c.dtype)
+        x = A.mul_bcast(self.pre.forward_train(c), x_mask)
+        x = A.add(x, A.embedding_bct(uv.long(), self.emb_uv.weight))                    # :471
+        if self.use_automatic_f0_prediction:
+            factor = noise.get("f0_factor")
+            if factor is None:
+                factor = torch.empty(B, 1).uniform_(0.8, 1.2).to(c.device)              # utils.py:39
+            lf0, norm_lf0 = S.f0_norm_lf0(f0, uv, mask=x_mask, factor=factor.reshape(-1))   # :474-475 (no grad: inputs)
+            pred_lf0 = self.f0_decoder(x, norm_lf0, x_mask, spk_emb=gemb)
+        else:
+            lf0 = norm_lf0 = pred_lf0 = 0
+        z_ptemp, m_p, logs_p, _ = self.enc_p(x, x_mask, f0=utils.f0_to_coarse(f0), noise=noise.get("enc_p"))
+        z, m_q, logs_q, spec_mask = self.enc_q(spec, spec_lengths, g=gemb, noise=noise.get("enc_q"))
+        z_p = self.flow(z, spec_mask, g=gemb)
+        ids = noise.get("ids_slice")
+        if ids is None:
+            z_slice, pitch_slice, ids_slice = commons.rand_slice_segments_with_pitch(z, f0, spec_lengths, self.segment_size)
+        else:
+            ids_slice = ids.to(c.device)
+            z_slice = commons.slice_segments(z, ids_slice, self.segment_size)
+            pitch_slice = commons.slice_pitch_segments(f0, ids_slice, self.segment_size)
+        dn = dict(rand_ini=noise["rand_ini"], sine=noise["sine"]) if "sine" in noise else None
+        o = self.dec(z_slice, pitch_slice.contiguous(), g=gemb, noise=dn)
+        return o, ids_slice, spec_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0
 
     # ------------------------------------------------------------------------------------------------------
     def enable_graph(self, on=True):
@@ -331,10 +397,104 @@ class SynthesizerTrn(nn.Module):
         return out[0].clone(), out[1].clone()
 
 
-# The discriminators (reference models.py:165-252) belong to the training path; their kernels
-# (period-reshaped Conv2d(k,1), grouped Conv1d k=41) are not built yet.
-class MultiPeriodDiscriminator(nn.Module):
+class _NormConv(nn.Module):
+    """weight_norm(Conv1d / Conv2d((k,1))) parameter holder of the discriminators; `weight_v` keeps the REFERENCE shape
+    ([Cout,Cin,K] for Conv1d, [Cout,Cin,K,1] for Conv2d) so checkpoints (D_*.pth) load key-for-key."""
+
+    def __init__(self, cin, cout, k, stride, padding, groups=1, conv2d=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding, self.groups, self.conv2d = cin, cout, k, stride, padding, groups, conv2d
+        shape = (cout, cin // groups, k, 1) if conv2d else (cout, cin // groups, k)
+        w = torch.empty(*shape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1 / math.sqrt((cin // groups) * k)
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, *([1] * (w.dim() - 1))).clone())
+        self.weight_v = nn.Parameter(w)
+
+    def forward(self, x):
+        w = A.weight_norm(self.weight_v, self.weight_g).view(self.cout, self.cin // self.groups, self.k)
+        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups)
+
+
+class DiscriminatorP(nn.Module):
+    """Reference models.py:165-199.  The Conv2d((k,1),(s,1)) stack acts on every one of the `period` columns
+    independently, so the [B,1,T/p,p] view is realised as a phase decimation [B*p, 1, T/p] (columns -> batch,
+    svc_decimate_f32 with the reflect padding of :185-189 folded in) followed by strided Conv1d's."""
+
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise NotImplementedError("spectral_norm discriminators are not used by so-vits-svc configs")
+        self.period = period
+        self.use_spectral_norm = use_spectral_norm
+        pad = commons.get_padding(kernel_size, 1)
+        chans = [(1, 32), (32, 128), (128, 512), (512, 1024)]
+        self.convs = nn.ModuleList([_NormConv(a, b, kernel_size, stride, pad, conv2d=True) for a, b in chans] +
+                                   [_NormConv(1024, 1024, kernel_size, 1, pad, conv2d=True)])
+        self.conv_post = _NormConv(1024, 1, 3, 1, 1, conv2d=True)
+
+    def forward(self, x):
+        b, c, t = x.shape
+        p = self.period
+        n_pad = (p - t % p) % p
+        H = (t + n_pad) // p
+        xd = A._Decimate.apply(x, p, 0, H, t + n_pad)          # [B, p, H]
+        h = xd.reshape(b * p, 1, H)
+        fmap = []
+        for l in self.convs:
+            h = A.leaky_relu(l(h), modules.LRELU_SLOPE)
+            fmap.append(self._as_ref(h, b, p))
+        h = self.conv_post(h)
+        fmap.append(self._as_ref(h, b, p))
+        return torch.flatten(fmap[-1], 1, -1), fmap
+
+    @staticmethod
+    def _as_ref(h, b, p):
+        """[B*p, C, H'] -> the reference's [B, C, H', p] (a permuted view of the same storage)."""
+        return h.view(b, p, h.shape[1], h.shape[2]).permute(0, 2, 3, 1)
+
+
+class DiscriminatorS(nn.Module):
+    """Reference models.py:202-227."""
+
     def __init__(self, use_spectral_norm=False):
         super().__init__()
-        raise NotImplementedError("MultiPeriodDiscriminator (training path) is not implemented in the MI355X engine "
-                                  "yet")
+        if use_spectral_norm:
+            raise NotImplementedError("spectral_norm discriminators are not used by so-vits-svc configs")
+        self.convs = nn.ModuleList([
+            _NormConv(1, 16, 15, 1, 7), _NormConv(16, 64, 41, 4, 20, groups=4), _NormConv(64, 256, 41, 4, 20, groups=16),
+            _NormConv(256, 1024, 41, 4, 20, groups=64), _NormConv(1024, 1024, 41, 4, 20, groups=256),
+            _NormConv(1024, 1024, 5, 1, 2)])
+        self.conv_post = _NormConv(1024, 1, 3, 1, 1)
+
+    def forward(self, x):
+        fmap = []
+        for l in self.convs:
+            x = A.leaky_relu(l(x), modules.LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    """Reference models.py:230-252."""
+
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        periods = [2, 3, 5, 7, 11]
+        self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm=use_spectral_norm)] +
+                                            [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods])
+
+    def forward(self, y, y_hat):
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        n = y.shape[0]
+        yy = torch.cat([y, y_hat], 0)      # one pass over both signals (same weights): halves the launches
+        for d in self.discriminators:
+            out, fmap = d(yy)
+            y_d_rs.append(out[:n])
+            y_d_gs.append(out[n:])
+            fmap_rs.append([f[:n] for f in fmap])
+            fmap_gs.append([f[n:] for f in fmap])
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs

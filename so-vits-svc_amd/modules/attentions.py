@@ -10,8 +10,9 @@ import math
 import torch
 from torch import nn
 
+import svc_autograd as A
 import svc_hip as S
-from svc_nn import Conv1d, _no_grad_guard, mask2d
+from svc_nn import Conv1d, _no_grad_guard, mask2d, training_call
 from modules.modules import LayerNorm
 
 MASK_NONE, MASK_PADDING, MASK_CAUSAL = 0, 1, 2
@@ -81,9 +82,23 @@ class MultiHeadAttention(nn.Module):
             return MASK_PADDING, vec
         raise NotImplementedError("attention mask is neither all-ones, causal nor an outer product of a padding mask")
 
+    def forward_train(self, x, mask_mode, mask_vec):
+        """Reference modules/attentions.py:198-239: separate q/k/v projections, attention as GEMMs + masked softmax."""
+        q = self.conv_q.forward_train(x)
+        k = self.conv_k.forward_train(x)
+        v = self.conv_v.forward_train(x)
+        win = self.window_size or 0
+        att = A.attention(q, k, v, self.n_heads, self.emb_rel_k if win else None, self.emb_rel_v if win else None, win,
+                          mask_vec, mask_mode)
+        return self.conv_o.forward_train(att)
+
     def forward(self, x, c, attn_mask=None, mask_mode=None, mask_vec=None):
         if c is not x:
             raise NotImplementedError("only self-attention is used on the so-vits-svc path")
+        if training_call(self.conv_q.weight) or (torch.is_grad_enabled() and x.requires_grad):
+            if mask_mode is None:
+                mask_mode, mask_vec = self._mask_mode(attn_mask, x.shape[2])
+            return self.forward_train(x, mask_mode, mask_vec)
         _no_grad_guard(self.conv_q.weight)
         B, C, T = x.shape
         if mask_mode is None:
@@ -113,7 +128,21 @@ class FFN(nn.Module):
         self.conv_1 = Conv1d(in_channels, filter_channels, kernel_size)
         self.conv_2 = Conv1d(filter_channels, out_channels, kernel_size)
 
+    def forward_train(self, x, x_mask, drop=None):
+        """Reference modules/attentions.py:337-345."""
+        k = self.kernel_size
+        if k % 2 == 0 and not self.causal:
+            raise NotImplementedError("even FFN kernel sizes with 'same' padding are not on the so-vits-svc path")
+        h = self.conv_1.forward_train(A.mul_bcast(x, x_mask), causal=self.causal, padding=(k - 1) // 2)
+        h = A.relu(h)
+        if drop is not None:
+            h = drop(h)
+        h = self.conv_2.forward_train(A.mul_bcast(h, x_mask), causal=self.causal, padding=(k - 1) // 2)
+        return A.mul_bcast(h, x_mask)
+
     def forward(self, x, x_mask):
+        if training_call(self.conv_1.weight) or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, x_mask)
         k = self.kernel_size
         pad_l = 0 if k == 1 else (k - 1 if self.causal else (k - 1) // 2)
         m = mask2d(x_mask)
@@ -145,10 +174,14 @@ class Encoder(nn.Module):
                                        p_dropout=p_dropout))
             self.norm_layers_2.append(LayerNorm(hidden_channels))
 
+    def forward_train(self, x, x_mask):
+        """Reference modules/attentions.py:95-107."""
+        return _encoder_forward_train(self, x, x_mask, self.attn_layers, self.norm_layers_1, self.norm_layers_2, MASK_PADDING)
+
     def forward(self, x, x_mask, full_mask=False):
         """`full_mask=True` promises x_mask is all ones (inference, models.py:503) and skips the padding mask."""
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError("training-mode dropout is not implemented (inference only)")
+        if training_call(self.norm_layers_1[0].gamma) or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, x_mask)
         m = mask2d(x_mask)
         x = S.copy_bct(x, mask=m)
         mode = MASK_NONE if full_mask else MASK_PADDING
@@ -158,6 +191,34 @@ class Encoder(nn.Module):
             y = self.ffn_layers[i](x, x_mask)
             x = self.norm_layers_2[i](x, residual=y, x_mask=x_mask if i == self.n_layers - 1 else None)
         return x
+
+
+def _dropout(p, training):
+    """nn.Dropout as a mask multiply: the Bernoulli draw comes from torch's generator (as every other random tensor
+    on the path), the scaling/multiply is svc_ew_bct_f32.  None when inactive."""
+    if not training or p <= 0:
+        return None
+
+    def drop(x):
+        keep = (torch.rand_like(x) >= p).to(x.dtype).mul_(1.0 / (1.0 - p))
+        return A.mul_bcast(x, keep)
+    return drop
+
+
+def _encoder_forward_train(self, x, x_mask, attn_layers, norm_a, norm_b, mask_mode):
+    m = x_mask[:, 0].contiguous() if x_mask.dim() == 3 else x_mask
+    drop = _dropout(self.p_dropout, self.training)
+    x = A.mul_bcast(x, x_mask)
+    for i in range(self.n_layers):
+        y = attn_layers[i].forward_train(x, mask_mode, m if mask_mode == MASK_PADDING else None)
+        if drop is not None:
+            y = drop(y)
+        x = norm_a[i](A.add(x, y))
+        y = self.ffn_layers[i].forward_train(x, x_mask, drop=drop)
+        if drop is not None:
+            y = drop(y)
+        x = norm_b[i](A.add(x, y))
+    return A.mul_bcast(x, x_mask)
 
 
 class FFT(nn.Module):
@@ -187,9 +248,14 @@ class FFT(nn.Module):
                                        p_dropout=p_dropout, causal=True))
             self.norm_layers_1.append(LayerNorm(hidden_channels))
 
+    def forward_train(self, x, x_mask):
+        """Reference modules/attentions.py:43-70 (g is None on the so-vits-svc path)."""
+        return _encoder_forward_train(self, x, x_mask, self.self_attn_layers, self.norm_layers_0, self.norm_layers_1,
+                                      MASK_CAUSAL)
+
     def forward(self, x, x_mask, g=None):
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError("training-mode dropout is not implemented (inference only)")
+        if training_call(self.norm_layers_0[0].gamma) or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, x_mask)
         m = mask2d(x_mask)
         x = S.copy_bct(x, mask=m)
         for i in range(self.n_layers):

@@ -10,9 +10,10 @@ parameter names (state_dict compatible); every forward is a sequence of libsvc_h
 import torch
 from torch import nn
 
+import svc_autograd as A
 import svc_hip as S
 from modules.commons import get_padding, init_weights
-from svc_nn import Conv1d, mask2d
+from svc_nn import Conv1d, mask2d, training_call
 
 LRELU_SLOPE = 0.1
 
@@ -41,6 +42,11 @@ class LayerNorm(nn.Module):
 
     def forward(self, x, residual=None, x_mask=None):
         """LN over the channel dim of [B,C,T]; `residual` (added first) and `x_mask` (applied last) are fusions."""
+        if training_call(self.gamma, self.beta) or (torch.is_grad_enabled() and x.requires_grad):
+            if residual is not None:
+                x = A.add(x, residual)
+            y = A.layer_norm(x, self.gamma, self.beta, self.eps)
+            return A.mul_bcast(y, x_mask) if x_mask is not None else y
         return S.add_layernorm(x.contiguous(), None if residual is None else residual.contiguous(), self.gamma,
                                self.beta, mask=mask2d(x_mask), eps=self.eps)
 
@@ -69,7 +75,28 @@ class WN(nn.Module):
             rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
             self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1, weight_norm=True))
 
+    def forward_train(self, x, x_mask, g=None):
+        """Reference modules/modules.py:110-138, one autograd op per reference op."""
+        H = self.hidden_channels
+        gc = self.cond_layer.forward_train(g) if g is not None else None          # [B, 2H*L, 1|T]
+        output = None
+        for i in range(self.n_layers):
+            x_in = self.in_layers[i].forward_train(x)
+            if gc is not None:
+                x_in = A.add_bcast(x_in, gc[:, i * 2 * H:(i + 1) * 2 * H])
+            acts = A.gate(x_in)
+            rs = self.res_skip_layers[i].forward_train(acts)
+            if i < self.n_layers - 1:
+                x = A.mul_bcast(A.add(x, rs[:, :H]), x_mask)
+                skip = rs[:, H:]
+            else:
+                skip = rs
+            output = skip if output is None else A.add(output, skip)
+        return A.mul_bcast(output, x_mask)
+
     def forward(self, x, x_mask, g=None, **kwargs):
+        if training_call(self.in_layers[0].weight_v) or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, x_mask, g=g)
         H = self.hidden_channels
         B, _, T = x.shape
         m = mask2d(x_mask)
@@ -105,6 +132,9 @@ class WN(nn.Module):
 
 class Flip(nn.Module):
     def forward(self, x, *args, reverse=False, **kwargs):
+        if torch.is_grad_enabled() and x.requires_grad:
+            y = torch.flip(x, [1])                       # pure data movement (channel reversal)
+            return (y, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)) if not reverse else y
         y = S.copy_bct(S.flip_view(x))
         if not reverse:
             return y, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
@@ -146,7 +176,22 @@ class ResidualCouplingLayer(nn.Module):
         # stats = post(h) * mask ; reverse: x1 = (x1 - stats) * mask ; forward: x1 = stats + x1 * mask   (logs == 0)
         self.post.run(h, mask=m, res=x1, res_mode=2 if reverse else 3, out=x1)
 
+    def forward_train(self, x, x_mask, g=None, reverse=False):
+        """Reference modules/modules.py:288-307 with mean_only=True (logs == 0)."""
+        half = self.half_channels
+        x0, x1 = x[:, :half], x[:, half:]
+        h = A.mul_bcast(self.pre.forward_train(x0), x_mask)
+        h = self.enc.forward_train(h, x_mask, g=g)
+        m = A.mul_bcast(self.post.forward_train(h), x_mask)
+        if not reverse:
+            x1n = A.add(m, A.mul_bcast(x1, x_mask))
+            return torch.cat([x0, x1n], 1), torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+        x1n = A.mul_bcast(A.add(x1, m, 1.0, -1.0), x_mask)
+        return torch.cat([x0, x1n], 1)
+
     def forward(self, x, x_mask, g=None, reverse=False):
+        if training_call(self.pre.weight) or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, x_mask, g=g, reverse=reverse)
         y = S.copy_bct(x)
         self.apply_inplace(y, x_mask, g=g, reverse=reverse)
         if not reverse:

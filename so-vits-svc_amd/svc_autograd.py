@@ -233,6 +233,21 @@ def add(a, b, alpha=1.0, beta=1.0):
     return _Add.apply(a, b, float(alpha), float(beta))
 
 
+class _Scale(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return S.ew(S.EW_SCALE, x, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return S.ew(S.EW_SCALE, _c(dy), alpha=ctx.alpha), None
+
+
+def scale(x, alpha):
+    return _Scale.apply(x, float(alpha))
+
+
 def mul_bcast(x, side):
     return _MulBcast.apply(x, side)
 
@@ -288,3 +303,325 @@ def conv_transpose1d(x, w, bias=None, stride=1, padding=0):
     if bias is not None:
         y = add_bcast(y, bias.view(1, -1, 1))
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LayerNorm / attention / embedding / reparam / NSF source
+# ---------------------------------------------------------------------------------------------------------------
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y, mean, rstd = S.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = S.layernorm_bwd(x, gamma, dy, mean, rstd)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _Attention(Function):
+    """MultiHeadAttention.attention (modules/attentions.py:207-239) on projected q,k,v [B, H*dk, T], training form:
+    scores / probabilities are materialised per head ([B*H, T, T]) and every product runs on svc_gemm_f32."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, emb_k, emb_v, mask, n_heads, window, mask_mode):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, Cc, T = q.shape
+        H = n_heads
+        dk = Cc // H
+        BH = B * H
+        sc = dk ** -0.5
+        qs = (dk * T, 1, T)      # A[m=i, k=d] = q[bh, d, i]
+        P = S.gemm(q, k, qs, (dk * T, T, 1), BH, T, T, dk, alpha=sc)
+        rel = None
+        if window:
+            ek = _c(emb_k.view(-1, dk))
+            ev = _c(emb_v.view(-1, dk))
+            rel = S.gemm(q, ek, qs, (0, 1, dk), BH, T, 2 * window + 1, dk, alpha=sc)
+        S.attn_softmax_fwd(P, rel, mask, B, H, T, window, mask_mode)
+        out = torch.empty_like(q)
+        S.gemm(v, P, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
+        pband = None
+        if window:
+            pband = S.band_gather(P, BH * T, T, window)
+            S.gemm(ev, pband, (0, 1, dk), (T * (2 * window + 1), 1, 2 * window + 1), BH, dk, T, 2 * window + 1, out=out,
+                   c_strides=(dk * T, T, 1), beta=1.0)
+        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v)
+        ctx.cfg = (B, H, dk, T, window)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P, pband, emb_k, emb_v = ctx.saved_tensors
+        B, H, dk, T, window = ctx.cfg
+        BH = B * H
+        sc = dk ** -0.5
+        nrel = 2 * window + 1
+        dO = _c(dO)
+        dV = torch.empty_like(v)
+        S.gemm(dO, P, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=dV, c_strides=(dk * T, T, 1))
+        dP = S.gemm(dO, v, (dk * T, 1, T), (dk * T, T, 1), BH, T, T, dk)
+        dEk = dEv = None
+        if window:
+            ek = _c(emb_k.view(-1, dk))
+            ev = _c(emb_v.view(-1, dk))
+            dpband = S.gemm(dO, ev, (dk * T, 1, T), (0, 1, dk), BH, T, nrel, dk)
+            S.band_scatter_add(dP, dpband, BH * T, T, window)
+            dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T)      # [BH, nrel, dk]
+            dEv = S.reduce_bct(dEv_b.view(BH, nrel * dk, 1), 0).view(emb_v.shape)
+        S.attn_softmax_bwd(P, dP, B, H, T)          # dP -> dS in place
+        dS = dP
+        dQ = torch.empty_like(q)
+        S.gemm(k, dS, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=dQ, c_strides=(dk * T, T, 1), alpha=sc)
+        dK = torch.empty_like(k)
+        S.gemm(q, dS, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=dK, c_strides=(dk * T, T, 1), alpha=sc)
+        if window:
+            drel = S.band_gather(dS, BH * T, T, window)
+            S.gemm(ek, drel, (0, 1, dk), (T * nrel, 1, nrel), BH, dk, T, nrel, out=dQ, c_strides=(dk * T, T, 1), alpha=sc,
+                   beta=1.0)
+            dEk_b = S.gemm(drel, q, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, alpha=sc)
+            dEk = S.reduce_bct(dEk_b.view(BH, nrel * dk, 1), 0).view(emb_k.shape)
+        return dQ, dK, dV, dEk, dEv, None, None, None, None
+
+
+def attention(q, k, v, n_heads, emb_rel_k=None, emb_rel_v=None, window=0, mask=None, mask_mode=0):
+    return _Attention.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window or 0, mask_mode)
+
+
+class _Embed(Function):
+    @staticmethod
+    def forward(ctx, idx, W):
+        ctx.save_for_backward(idx)
+        ctx.n = W.shape[0]
+        return S.embed_fwd(idx, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return None, S.embed_bwd(idx, dy, ctx.n)
+
+
+def embedding_bct(idx, W):
+    """nn.Embedding(idx).transpose(1,2): idx [B,T] int64 -> [B,C,T]."""
+    return _Embed.apply(idx, W)
+
+
+class _Reparam(Function):
+    @staticmethod
+    def forward(ctx, stats, noise, mask, scale):
+        stats = _c(stats)
+        ctx.save_for_backward(stats, noise, mask)
+        ctx.scale = scale
+        return S.reparam(stats, noise, mask=mask, scale=scale)
+
+    @staticmethod
+    def backward(ctx, dz):
+        stats, noise, mask = ctx.saved_tensors
+        return S.reparam_bwd(stats, noise, mask, dz, ctx.scale), None, None, None
+
+
+def reparam(stats, noise, mask, scale=1.0):
+    return _Reparam.apply(stats, noise, mask, float(scale))
+
+
+class _NsfSource(Function):
+    @staticmethod
+    def forward(ctx, f0, rand_ini, noise, lin_w, lin_b, upp, sr, sine_amp, noise_std):
+        har, waves = S.nsf_source_train(f0, rand_ini, noise, lin_w.view(-1), lin_b.view(-1), upp, sr, sine_amp, noise_std)
+        ctx.save_for_backward(waves, har)
+        ctx.shapes = (lin_w.shape, lin_b.shape)
+        return har
+
+    @staticmethod
+    def backward(ctx, dhar):
+        waves, har = ctx.saved_tensors
+        dw, db = S.nsf_linear_bwd(waves, har, dhar)
+        return None, None, None, dw.view(ctx.shapes[0]), db.view(ctx.shapes[1]), None, None, None, None
+
+
+def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sr, sine_amp=0.1, noise_std=0.003):
+    return _NsfSource.apply(f0, rand_ini, noise, lin_w, lin_b, upp, float(sr), sine_amp, noise_std)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# scalar losses: sums computed by HIP reductions; the (0-dim) results are combined by the caller's scalar arithmetic
+# ---------------------------------------------------------------------------------------------------------------
+def _bscale(t, g):
+    """t * g with g a 0-dim / 1-element device tensor (no host sync)."""
+    flat = t.reshape(1, 1, -1)
+    return S.ew_bct(S.EW_MUL, flat, g.reshape(1, 1, 1).float()).view(t.shape)
+
+
+class _SumAbsDiff(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        return S.f64_to_f32(S.reduce_scalar(S.RED_ABS_DIFF, a, b)).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        sgn = S.ew(S.EW_SIGN_MUL, S.ew(S.EW_ADD, a, b, alpha=1.0, beta=-1.0), alpha=1.0)
+        da = _bscale(sgn, g)
+        return (da if ctx.needs_input_grad[0] else None), (S.ew(S.EW_SCALE, da, alpha=-1.0) if ctx.needs_input_grad[1] else None)
+
+
+class _SumSqDiff(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        return S.f64_to_f32(S.reduce_scalar(S.RED_SQ_DIFF, a, b)).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = _bscale(S.ew(S.EW_ADD, a, b, alpha=2.0, beta=-2.0), g)
+        return (da if ctx.needs_input_grad[0] else None), (S.ew(S.EW_SCALE, da, alpha=-1.0) if ctx.needs_input_grad[1] else None)
+
+
+class _SumSq(Function):
+    """sum(a^2) (one_minus=False) or sum((1-a)^2) (one_minus=True)."""
+
+    @staticmethod
+    def forward(ctx, a, one_minus):
+        a = _c(a)
+        ctx.save_for_backward(a)
+        ctx.one_minus = one_minus
+        return S.f64_to_f32(S.reduce_scalar(S.RED_SQ_ONE_MINUS if one_minus else S.RED_SQ, a)).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        d = S.ew(S.EW_SCALE, a, alpha=2.0, beta=-2.0) if ctx.one_minus else S.ew(S.EW_SCALE, a, alpha=2.0)
+        return _bscale(d, g), None
+
+
+class _KLSums(Function):
+    """returns a 2-vector [sum(kl*mask), sum(mask)] (modules/losses.py:43-58)."""
+
+    @staticmethod
+    def forward(ctx, z_p, logs_q, m_p, logs_p, mask):
+        z_p, logs_q, m_p, logs_p, mask = _c(z_p), _c(logs_q), _c(m_p), _c(logs_p), _c(mask)
+        ctx.save_for_backward(z_p, m_p, logs_p, mask)
+        return S.f64_to_f32(S.kl_fwd(z_p, logs_q, m_p, logs_p, mask))
+
+    @staticmethod
+    def backward(ctx, g):
+        z_p, m_p, logs_p, mask = ctx.saved_tensors
+        dz, dlq, dm, dlp = S.kl_bwd(z_p, m_p, logs_p, mask, _c(g[:1].float()))
+        return dz, dlq, dm, dlp, None
+
+
+def sum_abs_diff(a, b):
+    return _SumAbsDiff.apply(a, b)
+
+
+def sum_sq_diff(a, b):
+    return _SumSqDiff.apply(a, b)
+
+
+def sum_sq(a):
+    return _SumSq.apply(a, False)
+
+
+def sum_sq_one_minus(a):
+    return _SumSq.apply(a, True)
+
+
+def kl_sums(z_p, logs_q, m_p, logs_p, mask):
+    return _KLSums.apply(z_p, logs_q, m_p, logs_p, mask)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# STFT magnitude and mel (modules/mel_processing.py:40-83)
+# ---------------------------------------------------------------------------------------------------------------
+class _Gemm2D(Function):
+    """Y[r, n] = sum_k X[r, k] * W[k, n]  for a fixed (non-trainable) basis W; rows r may be any leading shape."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _c(x)
+        K, N = W.shape
+        R = x.numel() // K
+        ctx.save_for_backward(W)
+        ctx.xshape = x.shape
+        y = S.gemm(x, W, (0, K, 1), (0, N, 1), 1, R, N, K)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (W,) = ctx.saved_tensors
+        K, N = W.shape
+        dy = _c(dy)
+        R = dy.numel() // N
+        dx = S.gemm(dy, W, (0, N, 1), (0, 1, N), 1, R, K, N)      # dy [R,N] x W^T [N,K]
+        return dx.view(ctx.xshape), None
+
+
+class _StftFrames(Function):
+    @staticmethod
+    def forward(ctx, y, win, NF, nfft, hop, pad):
+        ctx.save_for_backward(win)
+        ctx.cfg = (y.shape[1], hop, pad)
+        return S.stft_frame(y, win, NF, nfft, hop, pad)
+
+    @staticmethod
+    def backward(ctx, d):
+        (win,) = ctx.saved_tensors
+        L, hop, pad = ctx.cfg
+        return S.stft_frame_bwd(d, win, L, hop, pad), None, None, None, None, None
+
+
+class _CMag(Function):
+    @staticmethod
+    def forward(ctx, re, im, eps):
+        re, im = _c(re), _c(im)
+        mag = S.cmag(re, im, eps)
+        ctx.save_for_backward(re, im, mag)
+        return mag
+
+    @staticmethod
+    def backward(ctx, d):
+        re, im, mag = ctx.saved_tensors
+        dre, dim = S.cmag_bwd(re, im, mag, d)
+        return dre, dim, None
+
+
+class _LogClamp(Function):
+    @staticmethod
+    def forward(ctx, x, lo):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.lo = lo
+        return S.ew(S.EW_LOG_CLAMP, x, alpha=lo)
+
+    @staticmethod
+    def backward(ctx, d):
+        (x,) = ctx.saved_tensors
+        return S.ew(S.EW_LOG_CLAMP_BWD, _c(d), x, alpha=ctx.lo), None
+
+
+def gemm2d(x, W):
+    return _Gemm2D.apply(x, W)
+
+
+def stft_frames(y, win, NF, nfft, hop, pad):
+    return _StftFrames.apply(y, win, NF, nfft, hop, pad)
+
+
+def cmag(re, im, eps):
+    return _CMag.apply(re, im, eps)
+
+
+def log_clamp(x, lo):
+    return _LogClamp.apply(x, float(lo))

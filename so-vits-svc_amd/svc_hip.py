@@ -732,3 +732,195 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     require_gpu(p, g, m, v)
     check(tlib().svc_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                grad_scale, stream_ptr()), "adamw")
+
+
+# ---- second batch of training entry points (layernorm / attention pieces / embedding / reparam / nsf / kl / stft) ----
+TRAIN_EXPORTS2 = [
+    "svc_layernorm_fwd_f32", "svc_layernorm_bwd_f32", "svc_attn_softmax_fwd_f32", "svc_attn_softmax_bwd_f32",
+    "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",
+    "svc_nsf_source_train_f32", "svc_nsf_linear_fwd_f32", "svc_nsf_linear_bwd_f32", "svc_kl_fwd_f64", "svc_kl_bwd_f32",
+    "svc_stft_frame_f32", "svc_stft_frame_bwd_f32", "svc_dft_basis_f32", "svc_cmag_f32", "svc_cmag_bwd_f32",
+]
+EXPORTS += TRAIN_EXPORTS2
+_train2_bound = False
+
+
+def t2lib():
+    global _train2_bound
+    L = tlib()
+    if not _train2_bound:
+        i, f, ll, vp = C.c_int, C.c_float, C.c_longlong, C.c_void_p
+        L.svc_layernorm_fwd_f32.argtypes = [_f32p] * 6 + [i, i, i, f, vp]
+        L.svc_layernorm_bwd_f32.argtypes = [_f32p] * 8 + [i, i, i, vp]
+        L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [vp]
+        L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [vp]
+        L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
+        L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
+        L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
+        L.svc_embed_bwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
+        L.svc_reparam_bwd_f32.argtypes = [_f32p] * 5 + [i, i, i, f, vp]
+        L.svc_nsf_source_train_f32.argtypes = [_f32p] * 8 + [i] * 4 + [f] * 3 + [vp]
+        L.svc_nsf_linear_fwd_f32.argtypes = [_f32p] * 4 + [ll, i, vp]
+        L.svc_nsf_linear_bwd_f32.argtypes = [_f32p] * 5 + [ll, i, vp]
+        L.svc_kl_fwd_f64.argtypes = [_f32p] * 5 + [vp, i, i, i, vp]
+        L.svc_kl_bwd_f32.argtypes = [_f32p] * 9 + [i, i, i, vp]
+        L.svc_stft_frame_f32.argtypes = [_f32p] * 3 + [i] * 6 + [vp]
+        L.svc_stft_frame_bwd_f32.argtypes = [_f32p] * 3 + [i] * 6 + [vp]
+        L.svc_dft_basis_f32.argtypes = [_f32p, _f32p, i, i, vp]
+        L.svc_cmag_f32.argtypes = [_f32p] * 3 + [ll, f, vp]
+        L.svc_cmag_bwd_f32.argtypes = [_f32p] * 6 + [ll, vp]
+        _train2_bound = True
+    return L
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    require_gpu(x, gamma, beta)
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((B, T), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((B, T), device=x.device, dtype=torch.float32)
+    check(t2lib().svc_layernorm_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B, Cc, T, eps,
+                                        stream_ptr()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, gamma, dy, mean, rstd):
+    require_gpu(x, gamma, dy, mean, rstd)
+    B, Cc, T = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty_like(gamma)
+    db = torch.empty_like(gamma)
+    check(t2lib().svc_layernorm_bwd_f32(ptr(x), ptr(gamma), ptr(dy.contiguous()), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
+                                        ptr(db), B, Cc, T, stream_ptr()), "layernorm_bwd")
+    return dx, dg, db
+
+
+def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode):
+    check(t2lib().svc_attn_softmax_fwd_f32(ptr(S_), ptr(rel), ptr(mask), B, H, T, window, mask_mode, stream_ptr()),
+          "attn_softmax_fwd")
+    return S_
+
+
+def attn_softmax_bwd(P, dP, B, H, T):
+    check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, stream_ptr()), "attn_softmax_bwd")
+    return dP
+
+
+def band_gather(M, n_rows, T, window):
+    band = torch.empty((n_rows, 2 * window + 1), device=M.device, dtype=torch.float32)
+    check(t2lib().svc_band_gather_f32(ptr(M), ptr(band), n_rows, T, window, stream_ptr()), "band_gather")
+    return band
+
+
+def band_scatter_add(M, band, n_rows, T, window):
+    check(t2lib().svc_band_scatter_add_f32(ptr(M), ptr(band), n_rows, T, window, stream_ptr()), "band_scatter_add")
+    return M
+
+
+def embed_fwd(idx, W):
+    """idx [B,T] int64, W [N,C] -> [B,C,T]."""
+    require_gpu(W)
+    idx = idx.contiguous()
+    B, T = idx.shape
+    Cc = W.shape[1]
+    y = torch.empty((B, Cc, T), device=W.device, dtype=torch.float32)
+    check(t2lib().svc_embed_fwd_f32(C.c_void_p(idx.data_ptr()), ptr(W.contiguous()), ptr(y), B, Cc, T, stream_ptr()),
+          "embed_fwd")
+    return y
+
+
+def embed_bwd(idx, dy, n_rows):
+    idx = idx.contiguous()
+    dy = dy.contiguous()
+    B, Cc, T = dy.shape
+    dW = torch.zeros((n_rows, Cc), device=dy.device, dtype=torch.float32)
+    check(t2lib().svc_embed_bwd_f32(C.c_void_p(idx.data_ptr()), ptr(dy), ptr(dW), B, Cc, T, stream_ptr()), "embed_bwd")
+    return dW
+
+
+def reparam_bwd(stats, noise, mask, dz, scale):
+    B, C2, T = stats.shape
+    d = torch.empty_like(stats)
+    check(t2lib().svc_reparam_bwd_f32(ptr(stats), ptr(noise), ptr(mask), ptr(dz.contiguous()), ptr(d), B, C2 // 2, T, scale,
+                                      stream_ptr()), "reparam_bwd")
+    return d
+
+
+def nsf_source_train(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0.1, noise_std=0.003):
+    require_gpu(f0, rand_ini, noise, lin_w, lin_b)
+    B, T = f0.shape
+    H = rand_ini.shape[1]
+    L = T * upp
+    har = torch.empty((B, 1, L), device=f0.device, dtype=torch.float32)
+    waves = torch.empty((B, L, H), device=f0.device, dtype=torch.float32)
+    nbytes = lib().svc_nsf_source_scratch_bytes(B, T, H)
+    scratch = torch.empty((nbytes + 7) // 8, device=f0.device, dtype=torch.float64)
+    check(t2lib().svc_nsf_source_train_f32(ptr(f0.contiguous()), ptr(rand_ini.contiguous()), ptr(noise.contiguous()),
+                                           ptr(lin_w.contiguous()), ptr(lin_b.contiguous()), ptr(har), ptr(waves),
+                                           ptr(scratch), B, T, upp, H, float(sampling_rate), sine_amp, noise_std,
+                                           stream_ptr()), "nsf_source_train")
+    return har, waves
+
+
+def nsf_linear_bwd(waves, har, dhar):
+    H = waves.shape[-1]
+    dw = torch.empty(H, device=waves.device, dtype=torch.float32)
+    db = torch.empty(1, device=waves.device, dtype=torch.float32)
+    check(t2lib().svc_nsf_linear_bwd_f32(ptr(waves), ptr(har), ptr(dhar.contiguous()), ptr(dw), ptr(db), har.numel(), H,
+                                         stream_ptr()), "nsf_linear_bwd")
+    return dw, db
+
+
+def kl_fwd(z_p, logs_q, m_p, logs_p, mask):
+    B, Cc, T = z_p.shape
+    acc = torch.zeros(2, device=z_p.device, dtype=torch.float64)
+    check(t2lib().svc_kl_fwd_f64(ptr(z_p.contiguous()), ptr(logs_q.contiguous()), ptr(m_p.contiguous()),
+                                 ptr(logs_p.contiguous()), ptr(mask.contiguous()), C.c_void_p(acc.data_ptr()), B, Cc, T,
+                                 stream_ptr()), "kl_fwd")
+    return acc
+
+
+def kl_bwd(z_p, m_p, logs_p, mask, g):
+    B, Cc, T = z_p.shape
+    outs = [torch.empty_like(z_p) for _ in range(4)]
+    check(t2lib().svc_kl_bwd_f32(ptr(z_p), ptr(m_p), ptr(logs_p), ptr(mask), ptr(g), ptr(outs[0]), ptr(outs[1]),
+                                 ptr(outs[2]), ptr(outs[3]), B, Cc, T, stream_ptr()), "kl_bwd")
+    return outs   # dz_p, dlogs_q, dm_p, dlogs_p
+
+
+def stft_frame(y, win, NF, nfft, hop, pad):
+    y = y.contiguous()
+    B, L = y.shape
+    frames = torch.empty((B, NF, nfft), device=y.device, dtype=torch.float32)
+    check(t2lib().svc_stft_frame_f32(ptr(y), ptr(win), ptr(frames), B, L, NF, nfft, hop, pad, stream_ptr()), "stft_frame")
+    return frames
+
+
+def stft_frame_bwd(dframes, win, L, hop, pad):
+    dframes = dframes.contiguous()
+    B, NF, nfft = dframes.shape
+    dy = torch.empty((B, L), device=dframes.device, dtype=torch.float32)
+    check(t2lib().svc_stft_frame_bwd_f32(ptr(dframes), ptr(win), ptr(dy), B, L, NF, nfft, hop, pad, stream_ptr()),
+          "stft_frame_bwd")
+    return dy
+
+
+def dft_basis(N, NB, device):
+    cs = torch.empty((N, NB), device=device, dtype=torch.float32)
+    sn = torch.empty((N, NB), device=device, dtype=torch.float32)
+    check(t2lib().svc_dft_basis_f32(ptr(cs), ptr(sn), N, NB, stream_ptr()), "dft_basis")
+    return cs, sn
+
+
+def cmag(re, im, eps):
+    mag = torch.empty_like(re)
+    check(t2lib().svc_cmag_f32(ptr(re), ptr(im), ptr(mag), re.numel(), eps, stream_ptr()), "cmag")
+    return mag
+
+
+def cmag_bwd(re, im, mag, dmag):
+    dre, dim = torch.empty_like(re), torch.empty_like(re)
+    check(t2lib().svc_cmag_bwd_f32(ptr(re), ptr(im), ptr(mag), ptr(dmag.contiguous()), ptr(dre), ptr(dim), re.numel(),
+                                   stream_ptr()), "cmag_bwd")
+    return dre, dim

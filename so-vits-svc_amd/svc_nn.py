@@ -6,8 +6,9 @@ torch's compute: every forward goes to libsvc_hip.so through svc_hip.  Packed (w
 weights are cached per module and re-packed when a parameter's version counter changes (optimizer step,
 load_state_dict, .to()).
 
-Training (autograd through these ops) is not built yet: calling a forward with grad enabled on parameters that
-require grad raises, it never silently falls back to torch.
+Training: when grad mode is on and the parameters require grad, `forward` routes to `forward_train`, the unfused
+autograd form built from svc_autograd Functions (every forward and backward kernel is HIP; see svc_autograd.py).  The
+fused inference epilogues (`run(...)`) are inference-only and raise under grad mode.
 """
 import math
 
@@ -15,13 +16,19 @@ import torch
 from torch import nn
 
 import svc_hip as S
+import svc_autograd as A
+
+
+def training_call(*params):
+    """True when this call must be recorded on the autograd tape."""
+    return torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)
 
 
 def _no_grad_guard(*params):
-    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
+    if training_call(*params):
         raise NotImplementedError(
-            "svc_hip: backward kernels for the training path are not implemented yet (inference only); "
-            "wrap the call in torch.no_grad() / module.eval() + no_grad")
+            "svc_hip: this fused inference kernel sequence has no autograd form; training goes through "
+            "forward_train() (module.forward under grad mode), inference must run under torch.no_grad()")
 
 
 class _PackedMixin:
@@ -88,7 +95,28 @@ class Conv1d(nn.Module, _PackedMixin):
     def _is_direct(self):
         return self.stride != 1 or self.in_channels == 1 or self.out_channels == 1
 
+    def _params(self):
+        return (getattr(self, "weight", None), getattr(self, "weight_v", None), getattr(self, "weight_g", None), self.bias)
+
+    def effective_weight(self):
+        """The [Cout,Cin,KS] weight on the autograd tape (weight-norm folded by svc_weight_norm_fwd_f32)."""
+        return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
+
+    def forward_train(self, x, causal=False, padding=None):
+        """Autograd form of the plain convolution (no fused prologue/epilogue); `padding` overrides self.padding."""
+        if padding is not None and not causal:
+            return A.conv1d(x, self.effective_weight(), self.bias, self.stride, padding, self.dilation)
+        if causal and self.kernel_size > 1:
+            T = x.shape[2]
+            y = A.conv1d(x, self.effective_weight(), self.bias, self.stride, self.kernel_size - 1, self.dilation)
+            return y[:, :, :T]
+        return A.conv1d(x, self.effective_weight(), self.bias, self.stride, self.padding, self.dilation)
+
     def forward(self, x, **kw):
+        if training_call(*self._params()) or (torch.is_grad_enabled() and x.requires_grad):
+            if kw:
+                raise NotImplementedError("fused epilogue options are inference-only")
+            return self.forward_train(x)
         return self.run(x, **kw)
 
     def run(self, x, pad_left=None, Tout=None, **kw):
@@ -152,7 +180,18 @@ class ConvTranspose1d(nn.Module, _PackedMixin):
         self.weight = nn.Parameter(w)
         self.is_weight_norm = False
 
+    def effective_weight(self):
+        return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
+
+    def forward_train(self, x):
+        return A.conv_transpose1d(x, self.effective_weight(), self.bias, self.stride, self.padding)
+
     def forward(self, x, **kw):
+        if training_call(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias) or \
+                (torch.is_grad_enabled() and x.requires_grad):
+            if kw:
+                raise NotImplementedError("fused epilogue options are inference-only")
+            return self.forward_train(x)
         return self.run(x, **kw)
 
     def run(self, x, **kw):

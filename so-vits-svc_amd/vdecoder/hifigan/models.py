@@ -18,8 +18,9 @@ import numpy as np
 import torch
 from torch import nn
 
+import svc_autograd as A
 import svc_hip as S
-from svc_nn import Conv1d, ConvTranspose1d, _no_grad_guard
+from svc_nn import Conv1d, ConvTranspose1d, _no_grad_guard, training_call
 
 from .env import AttrDict  # noqa: F401
 from .utils import get_padding, init_weights
@@ -37,6 +38,14 @@ class ResBlock1(nn.Module):
         self.convs2 = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=1,
                                             padding=get_padding(kernel_size, 1), weight_norm=True) for _ in dilation])
         self.convs2.apply(init_weights)
+
+    def forward_train(self, x):
+        """Reference vdecoder/hifigan/models.py:60-67."""
+        for c1, c2 in zip(self.convs1, self.convs2):
+            xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE))
+            xt = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE))
+            x = A.add(xt, x)
+        return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
         """out (+)= resblock(x); the optional epilogue arguments let Generator accumulate the MRF mean in place."""
@@ -66,6 +75,12 @@ class ResBlock2(nn.Module):
         self.convs = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=d,
                                            padding=get_padding(kernel_size, d), weight_norm=True) for d in dilation])
         self.convs.apply(init_weights)
+
+    def forward_train(self, x):
+        """Reference vdecoder/hifigan/models.py:88-93."""
+        for c in self.convs:
+            x = A.add(c.forward_train(A.leaky_relu(x, LRELU_SLOPE)), x)
+        return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
         n = len(self.convs)
@@ -126,6 +141,10 @@ class SourceModuleHnNSF(nn.Module):
             torch.randn(B, L, 1, device=f0.device)                          # :319 (drawn, unused, keeps RNG stream aligned)
         else:
             rand_ini, nz = noise["rand_ini"], noise["sine"]
+        if training_call(self.l_linear.weight, self.l_linear.bias):
+            har = A.nsf_source(f0, rand_ini, nz, self.l_linear.weight, self.l_linear.bias, upp,
+                               self.l_sin_gen.sampling_rate, self.sine_amp, self.noise_std)
+            return har, None, None
         har = S.nsf_source(f0, rand_ini, nz, self.l_linear.weight, self.l_linear.bias, upp,
                            self.l_sin_gen.sampling_rate, self.sine_amp, self.noise_std)
         return har, None, None
@@ -167,8 +186,29 @@ class Generator(nn.Module):
     def OnnxExport(self):
         raise NotImplementedError("ONNX export is out of scope of the MI355X engine (SURVEY.md §2 row 23)")
 
+    def forward_train(self, x, f0, g=None, noise=None):
+        """Reference vdecoder/hifigan/models.py:366-394, one autograd op per reference op."""
+        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        x = self.conv_pre.forward_train(x)
+        if g is not None:
+            x = A.add_bcast(x, self.cond.forward_train(g))
+        for i in range(self.num_upsamples):
+            x = A.leaky_relu(x, LRELU_SLOPE)
+            x = self.ups[i].forward_train(x)
+            x = A.add(x, self.noise_convs[i].forward_train(har))
+            xs = None
+            for j in range(self.num_kernels):
+                r = self.resblocks[i * self.num_kernels + j].forward_train(x)
+                xs = r if xs is None else A.add(xs, r)
+            x = A.scale(xs, 1.0 / self.num_kernels)
+        x = A.leaky_relu(x, 0.01)
+        x = self.conv_post.forward_train(x)
+        return A.tanh(x)
+
     def forward(self, x, f0, g=None, noise=None):
         """x [B,inter,T] (tensor or channel-strided view), f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]."""
+        if training_call(self.conv_post.bias) or (torch.is_grad_enabled() and getattr(x, "requires_grad", False)):
+            return self.forward_train(x, f0, g=g, noise=noise)
         _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
         har, _, _ = self.m_source(f0, self.upp, noise=noise)
         gc = self.cond(g) if g is not None else None                  # [B, C0, 1|T]  (:374)

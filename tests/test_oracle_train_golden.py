@@ -1,0 +1,50 @@
+"""CPU suite: pins oracle/train_oracle.py (training graph, losses, gradients) and oracle/mel.py to the vectors the REAL
+reference produced (tests/golden/train_small.npz)."""
+import numpy as np
+import torch
+
+from oracle import mel as OM
+from oracle import train_oracle as TO
+from oracle import weights as W
+from train_common import LOSS_KEYS, load_case
+
+
+def test_mpd_layout_matches_reference():
+    sh = W.mpd_param_shapes()
+    assert len(sh) == 111                                   # 111 D parameter tensors
+    assert sum(int(np.prod(s)) for s in sh.values()) == 46747132
+
+
+def test_mel_basis_matches_independent_implementation():
+    from transformers.audio_utils import mel_filter_bank
+    a = OM.mel_filterbank(44100, 2048, 80, 0, 22050)
+    b = mel_filter_bank(1025, 80, 0, 22050, 44100, norm="slaney", mel_scale="slaney").T
+    assert a.shape == (80, 1025) and np.abs(a - b).max() < 1e-7
+
+
+def test_oracle_reproduces_reference_training_step():
+    cs = load_case()
+    z = cs["z"]
+    sg = {k: v.clone().requires_grad_(True) for k, v in cs["sd_g"].items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in cs["sd_d"].items()}
+    out = TO.gan_step_losses(sg, sd, cs["cfg"], cs["data"], cs["batch"], cs["noise"], cs["mel_basis"])
+    for k in LOSS_KEYS:
+        ref = float(z["loss." + k])
+        assert abs(float(out[k]) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(out[k]), ref)
+    assert np.abs(out["y_hat"].detach().numpy() - z["y_hat"]).max() <= 1e-5 * max(1.0, np.abs(z["y_hat"]).max())
+    # gradient norms of every parameter + a few full gradients
+    dk = [str(k) for k in z["gnorm_d_keys"]]
+    gd = torch.autograd.grad(out["loss_disc"], [sd[k] for k in dk], retain_graph=True)
+    for k, g, n in zip(dk, gd, z["gnorm_d"]):
+        assert abs(g.norm().item() - n) <= 1e-4 * max(n, 1e-6), ("D", k)
+    gk = [str(k) for k in z["gnorm_g_keys"]]
+    gg = torch.autograd.grad(out["loss_gen_all"], [sg[k] for k in gk], allow_unused=True)
+    for k, g, n in zip(gk, gg, z["gnorm_g"]):
+        if g is None:
+            assert n == 0, k
+        elif not k.endswith("conv_k.bias"):      # exactly-zero gradient (softmax shift invariance): round-off only
+            assert abs(g.norm().item() - n) <= 2e-4 * max(n, 1e-5), ("G", k, g.norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad_g."):
+            g = gg[gk.index(name[7:])]
+            assert np.abs(g.numpy() - z[name]).max() <= 2e-4 * max(np.abs(z[name]).max(), 1e-6), name

@@ -1,0 +1,87 @@
+"""Training-graph parity on MI355X: the HIP SynthesizerTrn.forward + MultiPeriodDiscriminator + mel + losses and their
+gradients against (a) the committed vectors of the REAL reference (tests/golden/train_small.npz) and (b) the CPU oracle's
+autograd on the same seeded inputs / injected noise.  fp32 throughout.  Tolerances: losses 1e-4 relative; per-parameter
+gradient L2 norms 2e-3 relative; full gradients 1e-3 of the tensor's max magnitude (fp32 atomics / fmaf-chain order)."""
+import numpy as np
+import pytest
+import torch
+
+from train_common import LOSS_KEYS, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cs, dev):
+    import models
+    cfg = cs["cfg"]
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net_g = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net_g.load_state_dict(cs["sd_g"], strict=True)
+    net_d = models.MultiPeriodDiscriminator()
+    net_d.load_state_dict(cs["sd_d"], strict=True)
+    return net_g.to(dev).train(), net_d.to(dev).train()
+
+
+def _step(cs, net_g, net_d, dev):
+    """train.py:167-207 with the mirror modules (same code shape as the reference's loop body)."""
+    import modules.commons as commons
+    from modules.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+    from modules.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
+    import svc_autograd as A
+    d = cs["data"]
+    c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
+    noise = {k: v.to(dev) for k, v in cs["noise"].items()}
+    seg, hop = cs["cfg"]["segment_size"], d["hop"]
+    mel = spec_to_mel_torch(spec, d["n_fft"], d["n_mels"], d["sr"], d["fmin"], d["fmax"])
+    y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
+        c, f0, uv, spec, g=sid, c_lengths=lengths, spec_lengths=lengths, noise=noise)
+    y_mel = commons.slice_segments(mel, ids_slice, seg)
+    y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), d["n_fft"], d["n_mels"], d["sr"], hop, d["win"], d["fmin"], d["fmax"])
+    y_seg = commons.slice_segments(y, ids_slice * hop, seg * hop)
+    rs, gs, _, _ = net_d(y_seg, y_hat.detach())
+    loss_disc, _, _ = discriminator_loss(rs, gs)
+    rs, gs, fr, fg = net_d(y_seg, y_hat)
+    loss_mel = A.sum_abs_diff(y_mel, y_hat_mel) / y_mel.numel() * 45.0
+    loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * 1.0
+    loss_fm = feature_loss(fr, fg)
+    loss_gen, _ = generator_loss(gs)
+    loss_lf0 = A.sum_sq_diff(pred_lf0, lf0) / lf0.numel()
+    loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
+    return dict(loss_disc=loss_disc, loss_gen=loss_gen, loss_fm=loss_fm, loss_mel=loss_mel, loss_kl=loss_kl,
+                loss_lf0=loss_lf0, loss_gen_all=loss_gen_all, y_hat=y_hat)
+
+
+def test_training_step_matches_reference_and_oracle(dev):
+    cs = load_case()
+    z = cs["z"]
+    net_g, net_d = _build(cs, dev)
+    out = _step(cs, net_g, net_d, dev)
+    for k in LOSS_KEYS:
+        ref = float(z["loss." + k])
+        got = float(out[k])
+        assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref)), (k, got, ref)
+    yh = out["y_hat"].detach().cpu().numpy()
+    assert np.abs(yh - z["y_hat"]).max() <= 2e-4 * max(1.0, np.abs(z["y_hat"]).max())
+
+    # D step gradients
+    out["loss_disc"].backward(retain_graph=True)
+    gd = {k: p.grad.detach().cpu() for k, p in net_d.named_parameters()}
+    for k, n in zip([str(k) for k in z["gnorm_d_keys"]], z["gnorm_d"]):
+        assert abs(gd[k].norm().item() - n) <= 2e-3 * max(n, 1e-6), ("D", k, gd[k].norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad_d."):
+            g = gd[name[7:]].numpy()
+            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
+    net_d.zero_grad()
+    # G step gradients
+    out["loss_gen_all"].backward()
+    gg = {k: p.grad.detach().cpu() for k, p in net_g.named_parameters() if p.grad is not None}
+    for k, n in zip([str(k) for k in z["gnorm_g_keys"]], z["gnorm_g"]):
+        if k.endswith("conv_k.bias"):
+            continue
+        assert k in gg, k
+        assert abs(gg[k].norm().item() - n) <= 2e-3 * max(n, 1e-5), ("G", k, gg[k].norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad_g."):
+            g = gg[name[7:]].numpy()
+            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
