@@ -11,6 +11,12 @@ resident in HBM; the RNG draws (3 torch.randn/rand fills) are inside the step, a
 N > 1: utterances are independent ("replicas only"): every rank runs the same step on its own clip,
 no data-path collective; value = N * samples * steps / max-over-ranks time (weak scaling).
 
+Training (BASELINE.json: "train steps/sec at 1/2/4/8 MI355X", configs[2]): `--mode train` makes the step one
+iteration of train.py:150-213 (D step + G step, fp32, FusedAdamW) on B=16 items per GPU, T~U{300..790} frames padded
+to the max, segment_size 8192, full template model + MultiPeriodDiscriminator; N>1 = minibatch sharded data-parallel
+(global batch 16*N, weak scaling) with the bucketed RCCL gradient all-reduce overlapped with backward.  The default
+mode ("both") prints the inference line with the training result attached under "train".
+
 Extra objects:
   roofline     — dominant kernel family (conv1d_mfma, the fused fp32-MFMA conv that carries the MRF ResBlocks):
                  algorithmic FLOP per launch / mean launch duration, durations from hipEvents recorded around every
@@ -70,6 +76,101 @@ def cpu_baseline(cfg, W, inputs, max_seconds=30.0):
                        f"({best:.2f} s/clip, RTF {best / (n / 44100):.3f})")
 
 
+TRAIN_B = 16
+TRAIN_SEG = 8192
+
+
+def train_hps(cfg):
+    model = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    return dict(data=dict(filter_length=2048, hop_length=HOP, win_length=2048, n_mel_channels=80, sampling_rate=44100,
+                          mel_fmin=0.0, mel_fmax=22050),
+                train=dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
+                           fp16_run=False, batch_size=TRAIN_B),
+                model=model)
+
+
+def make_train_items(cfg, B, seed):
+    """T~U{300..790} padded to max, spec=|N(0,1)|, y~U(-0.5,0.5), 4 speakers."""
+    g = torch.Generator().manual_seed(seed)
+    lengths = torch.randint(300, 791, (B,), generator=g)
+    T = int(lengths.max())
+    c = torch.randn(B, cfg["ssl_dim"], T, generator=g)
+    f0 = 100 + 300 * torch.rand(B, T, generator=g)
+    for b in range(B):
+        for s0 in torch.randint(0, T - 8, (max(1, T // 80),), generator=g).tolist():
+            f0[b, s0:s0 + 8] = 0
+    uv = (f0 > 0).float()
+    spec = torch.randn(B, cfg["spec_channels"], T, generator=g).abs()
+    y = (torch.rand(B, 1, T * HOP, generator=g) - 0.5)
+    spk = torch.randint(0, 4, (B, 1), generator=g)
+    return (c, f0, spec, y, spk, lengths, uv, None), T
+
+
+def run_train(args, dev, rank, world, dist):
+    """Time K training iterations; returns the result dict (rank 0) or None."""
+    import svc_hip as S
+    import train as TR
+    from oracle import weights as W
+    cfg = W.full_config()
+    hps = train_hps(cfg)
+    torch.manual_seed(1234)
+    net_g, net_d, optim_g, optim_d = TR.build(hps, dev)
+    net_g.module.load_state_dict(W.make_train_state_dict(cfg, 1234))
+    net_d.module.load_state_dict(W.make_mpd_state_dict(1235))
+    net_g.train()
+    net_d.train()
+    step_fn = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d)
+    items_cpu, T = make_train_items(cfg, TRAIN_B, 4321 + rank)
+    items = tuple(t.to(dev) if t is not None else None for t in items_cpu)
+    torch.manual_seed(99 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps, warm = args.train_steps, args.train_warmup
+    last = None
+    for _ in range(warm):
+        last = step_fn(items)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step_fn(items)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    if rank != 0:
+        return None
+    fams = None
+    if not args.no_roofline:
+        S.prof_enable(True)
+        S.prof_reset()
+        step_fn(items)
+        torch.cuda.synchronize()
+        rep = S.prof_report()
+        S.prof_enable(False)
+        tot = sum(v["ms"] for v in rep.values())
+        fams = {k: dict(ms_per_step=round(v["ms"], 3), calls=v["calls"],
+                        tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
+                for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
+        fams["_kernel_ms_total"] = round(tot, 3)
+    red = net_g.reducer.stats if getattr(net_g, "reducer", None) is not None else None
+    return dict(metric="train steps/sec (train.py D+G iteration)", value=steps / elapsed, unit="steps/s",
+                ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak", dtype="f32",
+                items_per_s=world * TRAIN_B * steps / elapsed,
+                config=dict(workload="BASELINE configs[2]: config_template.json model + MultiPeriodDiscriminator, "
+                                     f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
+                                     "4 speakers, fp32, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
+                            global_batch=TRAIN_B * world, frames=T,
+                            parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU"),
+                losses={k: round(float(v), 4) for k, v in last.items()},
+                families=fams, allreduce=red)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +179,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--mode", choices=["infer", "train", "both"], default="both")
+    ap.add_argument("--train-steps", type=int, default=None)
+    ap.add_argument("--train-warmup", type=int, default=None)
+    ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +201,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.mode == "train":
+        args.train_steps = args.train_steps or args.steps
+        args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
+        res = run_train(args, dev, rank, world, dist)
+        if rank == 0:
+            res.update(higher_is_better=True, vs_baseline=None, data="synthetic")
+            print(json.dumps(res))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    args.train_steps = args.train_steps or min(args.steps, 8)
+    args.train_warmup = 2 if args.train_warmup is None else args.train_warmup
 
     import svc_hip as S
     net, cfg, W = build_model(dev)
@@ -130,7 +248,7 @@ def main():
 
     # ---- roofline: per-launch hipEvent durations of every kernel family, eager pass over the same step ----
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         net.enable_graph(False)
         step()
         torch.cuda.synchronize()
@@ -164,6 +282,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, W, cpu_in)
 
+    train_res = None
+    if args.mode == "both":
+        del net
+        torch.cuda.empty_cache()
+        train_res = run_train(args, dev, rank, world, dist)
+
     if rank == 0:
         out = dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.infer)", value=value,
                    unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -175,7 +299,7 @@ def main():
                                batch=B, frames=T_FRAMES, samples_per_step=samples_per_step,
                                launch="hipGraph replay" if not args.no_graph else "eager",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU"),
-                   roofline=roof, cpu_baseline=cpu)
+                   roofline=roof, cpu_baseline=cpu, train=train_res)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -156,3 +156,44 @@ def gan_step_losses(sd_g, sd_d, cfg, data, batch, noise, mel_basis, c_mel=45.0, 
     loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
     return dict(loss_disc=loss_disc, loss_gen=loss_gen, loss_fm=loss_fm, loss_mel=loss_mel, loss_kl=loss_kl,
                 loss_lf0=loss_lf0, loss_gen_all=loss_gen_all, y_hat=y_hat)
+
+
+def gan_train_loop(sd_g, sd_d, cfg, data, batch, noise, mel_basis, n_iter, lr=1e-4, betas=(0.8, 0.99), eps=1e-9,
+                   c_mel=45.0, c_kl=1.0):
+    """n_iter iterations of train.py:150-213 in the reference's ORDER (D loss -> backward -> optim_d.step -> D forward
+    again with the UPDATED discriminator -> G losses -> backward -> optim_g.step), torch.optim.AdamW as train.py:79-88,
+    the same batch and injected noise every iteration.  Returns (list of per-iteration loss dicts, sd_g, sd_d)."""
+    sg = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
+    sdd = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
+    og = torch.optim.AdamW(list(sg.values()), lr, betas=betas, eps=eps)
+    od = torch.optim.AdamW(list(sdd.values()), lr, betas=betas, eps=eps)
+    c, f0, uv, spec, y, sid, lengths = batch
+    seg, hop = cfg["segment_size"], data["hop"]
+    hist = []
+    for _ in range(n_iter):
+        y_hat, ids, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = synth_forward(
+            sg, cfg, c, f0, uv, spec, sid, lengths, lengths, noise)
+        mel = spec_to_mel(spec, mel_basis)
+        y_mel = slice_segments(mel, ids, seg)
+        y_hat_mel = spec_to_mel(spectrogram(y_hat.squeeze(1), data["n_fft"], hop, data["win"]), mel_basis)
+        y_seg = slice_segments(y, ids * hop, seg * hop)
+        rs, gs, _, _ = mpd(sdd, y_seg, y_hat.detach())
+        loss_disc = discriminator_loss(rs, gs)
+        od.zero_grad()
+        loss_disc.backward()
+        od.step()
+        rs, gs, frs, fgs = mpd(sdd, y_seg, y_hat)
+        loss_mel = F.l1_loss(y_mel, y_hat_mel) * c_mel
+        loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * c_kl
+        loss_fm = feature_loss(frs, fgs)
+        loss_gen = generator_loss(gs)
+        loss_lf0 = F.mse_loss(pred_lf0, lf0)
+        loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
+        og.zero_grad()
+        od.zero_grad()
+        loss_gen_all.backward()
+        og.step()
+        hist.append({k: float(v) for k, v in dict(loss_disc=loss_disc, loss_gen=loss_gen, loss_fm=loss_fm,
+                                                   loss_mel=loss_mel, loss_kl=loss_kl, loss_lf0=loss_lf0,
+                                                   loss_gen_all=loss_gen_all).items()})
+    return hist, {k: v.detach() for k, v in sg.items()}, {k: v.detach() for k, v in sdd.items()}

@@ -432,7 +432,7 @@ int svc_f64_to_f32(const double* in, float* out, int n, void* stream) {
 int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream) {
   SVC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2, grad_scale);
   return svc::check_launch("adamw");

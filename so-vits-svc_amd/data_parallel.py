@@ -1,0 +1,189 @@
+"""Data-parallel training over RCCL/xGMI.
+
+Reference: `DDP(net_g, device_ids=[rank])`, `DDP(net_d, device_ids=[rank])` (train.py:57,89-90) — torch's C++ reducer
+with 25 MB buckets of gathered gradient copies; and, because the reference builds its DataLoader without a
+DistributedSampler, every rank trains on the SAME minibatch.  Both are re-designed here:
+
+  * **One process per GPU, minibatch sharded across ranks** (`shard_indices` is the DistributedSampler the reference
+    omits), the only exchange being one gradient all-reduce (mean) per optimizer per step.
+  * **Buckets are contiguous slices of the optimizer's flat gradient arena** (optim.ParamArena): no gather/scatter
+    copies, bucket boundaries chosen in bytes.  A bucket's all-reduce is issued from the autograd hook of the LAST of its
+    parameters to receive a gradient, so it runs on RCCL's stream while the rest of backward is still computing;
+    `backward()` returns with every bucket waited on (same contract as DDP: grads are averaged when backward returns).
+    Buckets are laid out in REVERSE parameter order (the order backward produces gradients), and sized for xGMI:
+    ring all-reduce is per-link bound (≈153 GB/s × 7 links per GPU), so few large buckets (default 64 MiB → 4 for the
+    210 MB generator) beat many small ones; the first bucket is smaller (8 MiB) so that communication starts early.
+  * The parameter broadcast at construction is ONE collective on the arena.
+  * In the generator step the discriminator's parameters take no gradient at all (train.py's G step back-propagates
+    through `net_d` into `y_hat`; the reference computes AND all-reduces the discriminator's weight gradients there
+    only to zero them next iteration): `no_param_grads(net_d)` switches them off, skipping wgrad kernels and the
+    wasted 187 MB all-reduce.
+
+The same code runs over `gloo` on CPU tensors (tests/test_data_parallel_cpu.py, world_size 2).
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from optim import arena_for
+
+
+def shard_indices(n_items, rank, world, epoch=0, shuffle=True, seed=1234, drop_last=True):
+    """Indices of this rank's shard of an epoch (DistributedSampler semantics: same permutation on every rank, rank r
+    takes items r, r+world, ...)."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        order = torch.randperm(n_items, generator=g).tolist()
+    else:
+        order = list(range(n_items))
+    if drop_last:
+        order = order[:n_items - n_items % world]
+    else:
+        pad = (-len(order)) % world
+        order = order + order[:pad]
+    return order[rank::world]
+
+
+def shard_batch(items, rank, world):
+    """Slice every tensor of a global minibatch [B, ...] into this rank's B/world rows (B must divide)."""
+    out = []
+    for t in items:
+        B = t.shape[0]
+        if B % world:
+            raise ValueError(f"global batch {B} does not divide over {world} ranks")
+        n = B // world
+        out.append(t[rank * n:(rank + 1) * n])
+    return out
+
+
+@contextlib.contextmanager
+def no_param_grads(module):
+    """Run a forward whose backward must flow to the INPUT only (the D pass of the generator step)."""
+    ps = [p for p in module.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped all-reduce (mean) over a ParamArena's flat gradient buffer."""
+
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, first_bucket_bytes=8 << 20):
+        self.arena = arena
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.backend = dist.get_backend(process_group)
+        n = len(arena.params)
+        # walk parameters in reverse (≈ gradient production order); a bucket is a contiguous [start,end) of the arena
+        self.buckets = []           # dicts(start, end, members)
+        self.bucket_of = [0] * n
+        cur, limit = None, first_bucket_bytes
+        for i in range(n - 1, -1, -1):
+            s, e = arena.span(i)
+            if cur is not None and (cur["end"] - s) * 4 > limit and cur["members"]:
+                self.buckets.append(cur)
+                cur, limit = None, bucket_bytes
+            if cur is None:
+                cur = dict(start=s, end=e, members=[])
+            cur["start"] = s
+            cur["members"].append(i)
+            self.bucket_of[i] = len(self.buckets)
+        if cur is not None:
+            self.buckets.append(cur)
+        self.enabled = True
+        self._pending = None        # per-bucket count of members still waiting for a gradient in this backward
+        self._works = []
+        self._launched = None
+        self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0)
+        arena.add_listener(self._on_grad)
+
+    # -- construction-time parameter sync ----------------------------------------------------------------------
+    def broadcast_parameters(self, src=0):
+        dist.broadcast(self.arena.param, src=src, group=self.pg)
+        torch.autograd.graph.increment_version(self.arena.params)
+
+    # -- backward-time ---------------------------------------------------------------------------------------------
+    def _begin(self):
+        self._pending = [len(b["members"]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self.stats["backward_passes"] += 1
+        torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _on_grad(self, i):
+        if not self.enabled or self.world == 1:
+            return
+        if self._pending is None:
+            self._begin()
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        bk = self.buckets[b]
+        buf = self.arena.grad[bk["start"]:bk["end"]]
+        if self.backend == "nccl":
+            w = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:       # gloo has no AVG: sum, then scale when the work completes
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._works.append((w, buf))
+        self._launched[b] = True
+        self.stats["reduced_bytes"] += buf.numel() * 4
+        self.stats["launches"] += 1
+
+    def _finalize(self):
+        """End of this backward pass (autograd engine callback): reduce buckets that hold at least one fresh gradient
+        but were not completed (parameters unused this pass — identical on every rank because every rank runs the
+        same graph), then make the compute stream wait for every outstanding all-reduce."""
+        if self._pending is None:
+            return
+        for b, bk in enumerate(self.buckets):
+            if not self._launched[b] and self._pending[b] < len(bk["members"]):
+                self._launch(b)
+        for w, buf in self._works:
+            w.wait()
+            if self.backend != "nccl":
+                buf.mul_(1.0 / self.world)
+        self._works = []
+        self._pending = None
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation without communication (DDP.no_sync)."""
+        old, self.enabled = self.enabled, False
+        try:
+            yield
+        finally:
+            self.enabled = old
+
+
+class DataParallel(nn.Module):
+    """Drop-in for `torch.nn.parallel.DistributedDataParallel(module, device_ids=[rank])` (train.py:89-90): exposes
+    `.module` (used as `net_g.module.infer`, train.py:297; `utils.save_checkpoint` strips it, utils.py:189-193), forwards
+    calls, and keeps gradients synchronised through a GradReducer on the module's ParamArena."""
+
+    def __init__(self, module, device_ids=None, process_group=None, bucket_bytes=64 << 20, first_bucket_bytes=8 << 20,
+                 broadcast=True, **_ignored):
+        super().__init__()
+        self.module = module
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.arena = arena_for(params)
+        self.reducer = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            self.reducer = GradReducer(self.arena, process_group, bucket_bytes, first_bucket_bytes)
+            if broadcast:
+                self.reducer.broadcast_parameters(0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        return self.reducer.no_sync() if self.reducer is not None else contextlib.nullcontext()

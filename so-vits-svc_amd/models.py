@@ -498,3 +498,18 @@ class MultiPeriodDiscriminator(nn.Module):
             fmap_rs.append([f[:n] for f in fmap])
             fmap_gs.append([f[n:] for f in fmap])
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+    def forward_gen_step(self, y, y_hat):
+        """The discriminator pass of the GENERATOR step (train.py:200): same return value as forward(), but the real
+        branch — whose logits are unused and whose feature maps `feature_loss` detaches (modules/losses.py:8) — runs
+        without an autograd tape, so the generator step back-propagates through half the batch only."""
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            with torch.no_grad():
+                out_r, fmap_r = d(y)
+            out_g, fmap_g = d(y_hat)
+            y_d_rs.append(out_r)
+            y_d_gs.append(out_g)
+            fmap_rs.append(fmap_r)
+            fmap_gs.append(fmap_g)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs

@@ -1,0 +1,203 @@
+"""Flat-arena parameter storage + fused AdamW.
+
+Reference: `torch.optim.AdamW(net.parameters(), lr, betas=(0.8, 0.99), eps=1e-9)` for G and D (train.py:79-88), stepped
+through a GradScaler (train.py:191-213), with `ExponentialLR` per epoch (train.py:111-114) and the optimizer state saved
+in every checkpoint (utils.py:189-199).  The reference runs a Python loop over 751 (G) / ~180 (D) tensors per step.
+
+MI355X design: 99 M fp32 parameters are 0.4 GB — nothing next to 288 GB of HBM — so all parameters of one optimizer live
+in ONE contiguous arena (`ParamArena`): `p.data` and `p.grad` of every parameter are views into flat `param` / `grad`
+buffers, Adam moments are two more flat buffers.  Consequences:
+  * the optimizer step is ONE `svc_adamw_f32` launch over the arena (HBM-bound: 5 reads + 3 writes of 4 B / element),
+  * `zero_grad` is one memset,
+  * the data-parallel gradient all-reduce (data_parallel.py) works on contiguous slices of `grad` — buckets need no
+    gather/scatter copies and the initial parameter broadcast is one collective.
+`FusedAdamW` is a `torch.optim.Optimizer` (param_groups / state_dict / lr schedulers keep working unchanged), with
+torch.optim.AdamW's exact update rule; parameters that received no gradient since the last `zero_grad` are skipped,
+like torch does for `p.grad is None`.
+"""
+import torch
+
+import svc_hip as S
+
+_ALIGN = 64          # elements: every parameter starts on a 256-byte boundary (coalesced float4 access, RCCL alignment)
+_ARENA_OF = {}       # id(param) -> (arena, index); parameters are kept alive by the arena
+
+
+class ParamArena:
+    """Contiguous fp32 storage for a list of parameters (all on one device)."""
+
+    def __init__(self, params):
+        params = list(params)
+        if not params:
+            raise ValueError("ParamArena needs at least one parameter")
+        dev = params[0].device
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise S.SvcError("ParamArena: all parameters must be fp32 on one device "
+                                 f"(got {p.dtype} on {p.device} vs {dev})")
+            if id(p) in _ARENA_OF:
+                raise S.SvcError("ParamArena: parameter already belongs to another arena")
+        self.params = params
+        self.device = dev
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.param = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.touched = [False] * len(params)          # gradient accumulated since the last zero_grad
+        self._listeners = []                          # callables(index) fired from the post-accumulate hook
+        self._hooks = []
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(params, self.offsets)):
+                view = self.param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                gview = self.grad[o:o + p.numel()].view(p.shape)
+                if p.grad is not None:
+                    gview.copy_(p.grad)
+                    self.touched[i] = True
+                p.grad = gview
+                _ARENA_OF[id(p)] = (self, i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(p):
+            self._on_grad(i, p)
+        return hook
+
+    def _on_grad(self, i, p):
+        o = self.offsets[i]
+        if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+            # someone replaced .grad (e.g. zero_grad(set_to_none=True) on the module): move it back into the arena
+            gview = self.grad[o:o + p.numel()].view(p.shape)
+            if p.grad is not None:
+                gview.copy_(p.grad)
+            p.grad = gview
+        self.touched[i] = True
+        for fn in self._listeners:
+            fn(i)
+
+    def add_listener(self, fn):
+        self._listeners.append(fn)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.touched = [False] * len(self.params)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def span(self, i):
+        """(start, end) element range of parameter i including its alignment padding."""
+        end = self.offsets[i + 1] if i + 1 < len(self.params) else self.numel
+        return self.offsets[i], end
+
+    def touched_runs(self, keys=None):
+        """Maximal runs (start, end, key) (elements) of consecutive parameters that received a gradient (and share
+        keys[i], when given)."""
+        runs, cur = [], None
+        for i, t in enumerate(self.touched):
+            if t:
+                s, e = self.span(i)
+                k = keys[i] if keys is not None else None
+                if cur is not None and cur[1] == s and cur[2] == k:
+                    cur[1] = e
+                else:
+                    cur = [s, e, k]
+                    runs.append(cur)
+            else:
+                cur = None
+        return [tuple(r) for r in runs]
+
+    def check_views(self):
+        """Re-attach parameters whose storage was moved away (module.to()/.half() after construction is an error)."""
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != self.param.data_ptr() + 4 * o:
+                raise S.SvcError("ParamArena: a parameter's storage was replaced after the arena was built "
+                                 "(move the module to its device/dtype BEFORE constructing the optimizer)")
+
+
+def arena_for(params):
+    """The arena holding exactly `params` (created on first use)."""
+    params = list(params)
+    hit = _ARENA_OF.get(id(params[0]))
+    if hit is not None:
+        arena = hit[0]
+        if len(arena.params) == len(params) and all(a is b for a, b in zip(arena.params, params)):
+            return arena
+        raise S.SvcError("parameters already belong to a different arena")
+    return ParamArena(params)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(params, lr, betas, eps, weight_decay=0.01) semantics, one HIP launch per step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise S.SvcError("FusedAdamW takes one flat parameter list (the reference uses a single group per net)")
+        params = [p for p in params if p.requires_grad]
+        for p in params:
+            if not p.is_cuda:
+                raise S.SvcError("FusedAdamW needs CUDA/ROCm parameters: the MI355X engine has no CPU fallback")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.arena = arena_for(params)
+        n = self.arena.numel
+        self.exp_avg = torch.zeros(n, device=self.arena.device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=self.arena.device, dtype=torch.float32)
+        self._steps = [0] * len(params)     # per-parameter step counts (torch semantics: a skipped parameter lags)
+        self.grad_scale = 1.0          # multiplied into the gradient inside the kernel (GradScaler's 1/scale)
+        for i, p in enumerate(params):
+            o = self.arena.offsets[i]
+            self.state[p] = dict(step=torch.tensor(0.0),
+                                 exp_avg=self.exp_avg[o:o + p.numel()].view(p.shape),
+                                 exp_avg_sq=self.exp_avg_sq[o:o + p.numel()].view(p.shape))
+
+    def zero_grad(self, set_to_none=True):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        a = self.arena
+        a.check_views()
+        g = self.param_groups[0]
+        self._steps = [n + 1 if t else n for n, t in zip(self._steps, a.touched)]
+        runs = a.touched_runs(self._steps)       # one run == one launch; normally a single run over the whole arena
+        if not runs:
+            return loss
+        b1, b2 = g["betas"]
+        for s, e, step in runs:
+            S.adamw_step(a.param[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], float(g["lr"]), float(b1),
+                         float(b2), float(g["eps"]), float(g["weight_decay"]), step, float(self.grad_scale))
+        # the kernel wrote the arena behind torch's back: bump the version counters so that cached packed weights
+        # (svc_nn._PackedMixin, keyed on `_version`) are rebuilt and autograd's saved-tensor checks stay valid
+        torch.autograd.graph.increment_version([p for p, t in zip(a.params, a.touched) if t])
+        return loss
+
+    # -- checkpoint compatibility with torch.optim.AdamW (utils.py:155-199 saves/loads optimizer.state_dict()) --------
+    def state_dict(self):
+        for p, n in zip(self.arena.params, self._steps):
+            self.state[p]["step"] = torch.tensor(float(n))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for i, p in enumerate(self.arena.params):
+                st = self.state.get(p)
+                if not st:
+                    continue
+                o = self.arena.offsets[i]
+                for name, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                    view = flat[o:o + p.numel()].view(p.shape)
+                    if st[name].data_ptr() != view.data_ptr():
+                        view.copy_(st[name])
+                        st[name] = view
+                self._steps[i] = int(float(st["step"]))

@@ -1,0 +1,117 @@
+"""MI355X-native mirror of the reference's training step (train.py:44-213): model/optimizer construction as in `run`
+(train.py:74-90) and the body of `train_and_evaluate`'s batch loop (train.py:150-213) — D step, G step, fp32.
+
+What is re-designed rather than mirrored:
+  * optimizers are `optim.FusedAdamW` over a flat parameter arena (one launch per step),
+  * `data_parallel.DataParallel` instead of torch DDP: arena-slice buckets all-reduced over RCCL while backward runs,
+  * in the G step the discriminator runs with its parameters frozen (`no_param_grads`): no D weight gradients are
+    computed or all-reduced there, and the real branch (whose feature maps are detached by `feature_loss`) runs
+    without a tape,
+  * no `.item()` host syncs inside the step: the losses come back as device scalars.
+Out of scope here (SURVEY §8f "next"): DataLoader / on-disk formats, TensorBoard, evaluation audio, checkpoint rotation.
+fp16/bf16 autocast (`fp16_run`) is not implemented — the engine computes in fp32 like the reference's default config.
+"""
+import torch
+import torch.distributed as dist
+
+import models
+import modules.commons as commons
+import svc_autograd as A
+from data_parallel import DataParallel, no_param_grads
+from modules.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+from modules.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
+from optim import FusedAdamW
+
+
+def _get(h, name):
+    return h[name] if isinstance(h, dict) else getattr(h, name)
+
+
+def _model_kwargs(hm):
+    d = dict(hm) if isinstance(hm, dict) else {k: v for k, v in hm.items()}
+    return d
+
+
+def build(hps, device):
+    """train.py:74-90: nets on `device`, AdamW for each, data-parallel wrappers (no-ops at world size 1)."""
+    data, train, model = _get(hps, "data"), _get(hps, "train"), _get(hps, "model")
+    net_g = models.SynthesizerTrn(_get(data, "filter_length") // 2 + 1,
+                                  _get(train, "segment_size") // _get(data, "hop_length"),
+                                  **_model_kwargs(model)).to(device)
+    use_sn = model.get("use_spectral_norm", False) if isinstance(model, dict) else getattr(model, "use_spectral_norm", False)
+    net_d = models.MultiPeriodDiscriminator(use_sn).to(device)
+    kw = dict(lr=_get(train, "learning_rate"), betas=tuple(_get(train, "betas")), eps=_get(train, "eps"))
+    optim_g = FusedAdamW(net_g.parameters(), **kw)
+    optim_d = FusedAdamW(net_d.parameters(), **kw)
+    net_g = DataParallel(net_g)
+    net_d = DataParallel(net_d)
+    return net_g, net_d, optim_g, optim_d
+
+
+class TrainStep:
+    """One iteration of train.py:150-213 on a minibatch already resident on the device."""
+
+    def __init__(self, hps, net_g, net_d, optim_g, optim_d):
+        self.hps = hps
+        self.net_g, self.net_d, self.optim_g, self.optim_d = net_g, net_d, optim_g, optim_d
+        d, t = _get(hps, "data"), _get(hps, "train")
+        self.n_fft, self.n_mels, self.sr = _get(d, "filter_length"), _get(d, "n_mel_channels"), _get(d, "sampling_rate")
+        self.hop, self.win = _get(d, "hop_length"), _get(d, "win_length")
+        self.fmin, self.fmax = _get(d, "mel_fmin"), _get(d, "mel_fmax")
+        self.segment_size = _get(t, "segment_size")
+        self.c_mel, self.c_kl = _get(t, "c_mel"), _get(t, "c_kl")
+        if _get(t, "fp16_run"):
+            raise NotImplementedError("fp16_run/bf16 autocast is not implemented: the MI355X engine trains in fp32")
+
+    def _disc(self, y, y_hat):
+        return self.net_d(y, y_hat)
+
+    def __call__(self, items, noise=None):
+        """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
+        returns a dict of 0-dim device tensors."""
+        c, f0, spec, y, spk, lengths, uv, volume = items
+        net_g, net_d = self.net_g, self.net_d
+        gmod = net_g.module if hasattr(net_g, "module") else net_g
+        dmod = net_d.module if hasattr(net_d, "module") else net_d
+        seg_frames = self.segment_size // self.hop
+        mel = spec_to_mel_torch(spec, self.n_fft, self.n_mels, self.sr, self.fmin, self.fmax)            # :158-164
+        kw = dict(noise=noise) if noise is not None else {}
+        y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
+            c, f0, uv, spec, g=spk, c_lengths=lengths, spec_lengths=lengths, vol=volume, **kw)            # :167-169
+        y_mel = commons.slice_segments(mel, ids_slice, seg_frames)                                        # :171
+        y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), self.n_fft, self.n_mels, self.sr, self.hop, self.win,
+                                          self.fmin, self.fmax)                                           # :172-181
+        y = commons.slice_segments(y, ids_slice * self.hop, self.segment_size)                            # :182
+
+        # ---- discriminator step (:184-195) ----
+        y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+        loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
+        self.optim_d.zero_grad()
+        loss_disc.backward()
+        self.optim_d.step()
+
+        # ---- generator step (:198-213): D frozen, real branch tape-free ----
+        with no_param_grads(dmod):
+            _, y_d_hat_g, fmap_r, fmap_g = dmod.forward_gen_step(y, y_hat)
+        loss_mel = A.sum_abs_diff(y_mel, y_hat_mel) / y_mel.numel() * self.c_mel                           # :202
+        loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * self.c_kl                                   # :203
+        loss_fm = feature_loss(fmap_r, fmap_g)
+        loss_gen, _ = generator_loss(y_d_hat_g)
+        if gmod.use_automatic_f0_prediction:
+            loss_lf0 = A.sum_sq_diff(pred_lf0, lf0) / lf0.numel()                                         # :206
+        else:
+            loss_lf0 = 0
+        loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
+        self.optim_g.zero_grad()
+        loss_gen_all.backward()
+        self.optim_g.step()
+        return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
+                    loss_mel=loss_mel.detach(), loss_kl=loss_kl.detach(),
+                    loss_lf0=loss_lf0.detach() if torch.is_tensor(loss_lf0) else loss_lf0,
+                    loss_gen_all=loss_gen_all.detach())
+
+
+def init_distributed(rank, world, device):
+    """train.py:57: one process per GPU; backend "nccl" is RCCL on ROCm."""
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)

@@ -48,3 +48,25 @@ def test_oracle_reproduces_reference_training_step():
         if name.startswith("grad_g."):
             g = gg[gk.index(name[7:])]
             assert np.abs(g.numpy() - z[name]).max() <= 2e-4 * max(np.abs(z[name]).max(), 1e-6), name
+
+
+def test_oracle_loop_reproduces_reference_training_loop():
+    """3 iterations incl. AdamW in the reference's order (tests/golden/train_loop_small.npz, from the REAL reference)."""
+    import json
+    import os
+    from train_common import G
+    cs = load_case()
+    z = np.load(os.path.join(G, "train_loop_small.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    hist, sg, sd = TO.gan_train_loop(cs["sd_g"], cs["sd_d"], cs["cfg"], cs["data"], cs["batch"], cs["noise"],
+                                     cs["mel_basis"], meta["n_iter"], lr=meta["lr"], betas=tuple(meta["betas"]),
+                                     eps=meta["eps"])
+    for it in range(meta["n_iter"]):
+        for k in LOSS_KEYS:
+            ref = float(z[f"it{it}.{k}"])
+            assert abs(hist[it][k] - ref) <= 1e-4 * max(1.0, abs(ref)), (it, k, hist[it][k], ref)
+    for name in z.files:
+        if name.startswith("param_g."):
+            assert np.abs(sg[name[8:]].numpy() - z[name]).max() <= 2e-5, name
+        if name.startswith("param_d."):
+            assert np.abs(sd[name[8:]].numpy() - z[name]).max() <= 2e-5, name
