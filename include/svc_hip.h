@@ -172,6 +172,14 @@ int svc_nsf_source_f32(const float* f0, const float* rand_ini, const float* nois
  * Flip (modules/modules.py:232-239) or an `x * x_mask` (modules/attentions.py:97) when it cannot be folded. */
 int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs, long long x_cs,
                      long long y_bs, long long y_cs, long long mask_bs, int B, int C, int T, void* stream);
+/* Anti-aliased Snake activation of the nsf-snake-hifigan decoder: SnakeAlias.forward
+ * (vdecoder/hifiganwithsnake/alias/act.py:125-130) = UpSample1d (alias/resample.py:38-54) -> SnakeBeta log-scale
+ * (alias/act.py:79-92) -> DownSample1d (alias/filter.py:93-110), fused: y = down2(snake(up2(x))), x,y [B,C,T] with
+ * explicit batch/channel strides (time contiguous); alpha,beta [C] device; taps_host = the 12 Kaiser-sinc taps
+ * (alias/filter.py:29-58) in HOST memory (copied into the launch by value: graph-capture safe). */
+int svc_snake_alias_f32(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host,
+                        long long x_bs, long long x_cs, long long y_bs, long long y_cs, int B, int C, int T,
+                        void* stream);
 /* Automatic-f0 helpers (models.py:523-527 + utils.normalize_f0, utils.py:31-45).  f0,uv,mask,lf0,norm_lf0:[B,T];
  * factor:[B] or NULL (=1, inference).  lf0 = 2595*log10(1+f0/700)/500 (or f0 itself when input_is_lf0);
  * norm_lf0 = (lf0 - mean_voiced)*factor*mask. */

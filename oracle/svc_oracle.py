@@ -296,8 +296,45 @@ def resblock2(x, sd, prefix, kernel_size, dilations):  # vdecoder/hifigan/models
     return x
 
 
+def snake_alias(x, sd, prefix):
+    """SnakeAlias.forward, vdecoder/hifiganwithsnake/alias/act.py:125-130: UpSample1d (alias/resample.py:38-54) ->
+    SnakeBeta log-scale (alias/act.py:79-92) -> DownSample1d / LowPassFilter1d (alias/filter.py:93-110)."""
+    C = x.shape[1]
+    fu = sd[prefix + ".upsample.filter"].expand(C, -1, -1)
+    fd = sd[prefix + ".downsample.lowpass.filter"].expand(C, -1, -1)
+    x = F.pad(x, (5, 5), mode="replicate")
+    x = 2 * F.conv_transpose1d(x, fu, stride=2, groups=C)
+    x = x[..., 15:-15]
+    a = torch.exp(sd[prefix + ".act.alpha"])[None, :, None]
+    b = torch.exp(sd[prefix + ".act.beta"])[None, :, None]
+    x = x + (1.0 / (b + 1e-9)) * torch.sin(x * a) ** 2
+    x = F.pad(x, (5, 6), mode="replicate")
+    return F.conv1d(x, fd, stride=2, groups=C)
+
+
+def resblock1_snake(x, sd, prefix, kernel_size, dilations):  # vdecoder/hifiganwithsnake/models.py:71-77
+    for j, d in enumerate(dilations):
+        xt = snake_alias(x, sd, f"{prefix}.activations.{2 * j}")
+        xt = conv1d(xt, sd, f"{prefix}.convs1.{j}", dilation=d, padding=get_padding(kernel_size, d))
+        xt = snake_alias(xt, sd, f"{prefix}.activations.{2 * j + 1}")
+        xt = conv1d(xt, sd, f"{prefix}.convs2.{j}", dilation=1, padding=get_padding(kernel_size, 1))
+        x = xt + x
+    return x
+
+
+def resblock2_snake(x, sd, prefix, kernel_size, dilations):  # vdecoder/hifiganwithsnake/models.py:101-106
+    for j, d in enumerate(dilations):
+        xt = snake_alias(x, sd, f"{prefix}.activations.{j}")
+        xt = conv1d(xt, sd, f"{prefix}.convs.{j}", dilation=d, padding=get_padding(kernel_size, d))
+        x = xt + x
+    return x
+
+
 def generator(x, f0, g, sd, cfg, rand_ini, noise_sine, prefix="dec", return_source=False):
-    """hifigan.Generator.forward, vdecoder/hifigan/models.py:366-394.  x [B,inter,T], f0 [B,T], g [B,gin,1]."""
+    """hifigan.Generator.forward, vdecoder/hifigan/models.py:366-394 (and the snake variant,
+    vdecoder/hifiganwithsnake/models.py:380-413, when cfg["vocoder_name"] == "nsf-snake-hifigan").
+    x [B,inter,T], f0 [B,T], g [B,gin,1]."""
+    snake = cfg.get("vocoder_name") == "nsf-snake-hifigan"
     ups = cfg["upsample_rates"]
     upp = int(math.prod(ups))
     f0_up = f0[:, None].repeat_interleave(upp, dim=2).transpose(1, 2)   # nn.Upsample(nearest), :369
@@ -305,9 +342,12 @@ def generator(x, f0, g, sd, cfg, rand_ini, noise_sine, prefix="dec", return_sour
     x = conv1d(x, sd, prefix + ".conv_pre", padding=3)
     x = x + conv1d(g, sd, prefix + ".cond")
     nk = len(cfg["resblock_kernel_sizes"])
-    rb = resblock1 if cfg["resblock"] == "1" else resblock2
+    if snake:
+        rb = resblock1_snake if cfg["resblock"] == "1" else resblock2_snake
+    else:
+        rb = resblock1 if cfg["resblock"] == "1" else resblock2
     for i, (u, k) in enumerate(zip(ups, cfg["upsample_kernel_sizes"])):
-        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = snake_alias(x, sd, f"{prefix}.snakes.{i}") if snake else F.leaky_relu(x, LRELU_SLOPE)
         x = F.conv_transpose1d(x, weight_of(sd, f"{prefix}.ups.{i}"), sd[f"{prefix}.ups.{i}.bias"], stride=u,
                                padding=(k - u + 1) // 2)
         if i + 1 < len(ups):
@@ -321,7 +361,7 @@ def generator(x, f0, g, sd, cfg, rand_ini, noise_sine, prefix="dec", return_sour
             r = rb(x, sd, f"{prefix}.resblocks.{i * nk + j}", kk, dd)
             acc = r if acc is None else acc + r
         x = acc / nk
-    x = F.leaky_relu(x)             # default slope 0.01, :390
+    x = snake_alias(x, sd, prefix + ".snake_post") if snake else F.leaky_relu(x)   # default slope 0.01, :390
     x = conv1d(x, sd, prefix + ".conv_post", padding=3)
     x = torch.tanh(x)
     return (x, har) if return_source else x

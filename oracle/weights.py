@@ -111,6 +111,22 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
                     conv(f"{rb}.convs.{m}", ch, ch, kk, wn=True)
     conv("dec.conv_post", 1, ch, 7, wn=True)
     conv("dec.cond", c0, gin, 1)
+    if cfg.get("vocoder_name") == "nsf-snake-hifigan":
+        # SnakeAlias sites (vdecoder/hifiganwithsnake/models.py:62-65,95-99,367,374): per site alpha/beta [C] parameters
+        # and the two [1,1,12] `filter` buffers (alias/resample.py:20, alias/filter.py:83)
+        def snake(name, c):
+            P[name + ".act.alpha"] = (c,)
+            P[name + ".act.beta"] = (c,)
+            P[name + ".upsample.filter"] = (1, 1, 12)
+            P[name + ".downsample.lowpass.filter"] = (1, 1, 12)
+        for i in range(len(ups)):
+            snake(f"dec.snakes.{i}", c0 // (2 ** i))
+            chn = c0 // (2 ** (i + 1))
+            for j, dd in enumerate(cfg["resblock_dilation_sizes"]):
+                nact = 2 * len(dd) if cfg["resblock"] == "1" else len(dd)
+                for a in range(nact):
+                    snake(f"dec.resblocks.{i * nk + j}.activations.{a}", chn)
+        snake("dec.snake_post", ch)
 
     if include_enc_q:
         conv("enc_q.pre", h, cfg["spec_channels"], 1)
@@ -137,6 +153,18 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
     return P
 
 
+def snake_filter():
+    """The 12-tap Kaiser-sinc half-band low-pass of SnakeAlias (alias/filter.py:29-58 with cutoff 0.25, half_width 0.3,
+    kernel_size 12), restated: beta from the Kaiser attenuation formula, unit DC gain."""
+    half = 6
+    atten = 2.285 * (half - 1) * math.pi * (4 * 0.3) + 7.95
+    beta = 0.1102 * (atten - 8.7) if atten > 50 else (0.5842 * (atten - 21) ** 0.4 + 0.07886 * (atten - 21) if atten >= 21 else 0.0)
+    w = torch.kaiser_window(12, beta=beta, periodic=False)
+    t = torch.arange(-half, half) + 0.5
+    h = 2 * 0.25 * w * torch.sinc(2 * 0.25 * t)
+    return h / h.sum()
+
+
 def _gen(name, seed):
     g = torch.Generator()
     g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
@@ -147,6 +175,10 @@ def make_tensor(name, shape, seed, all_shapes=None):
     g = _gen(name, seed)
     r = lambda *s: torch.randn(*s, generator=g)
     leaf = name.rsplit(".", 1)[-1]
+    if leaf == "filter":
+        return snake_filter().view(shape)
+    if leaf == "alpha" or (leaf == "beta" and ".act." in name):
+        return 0.3 * r(*shape)          # log-scale: e^alpha in ~[0.5, 2]
     if leaf == "bias":
         return 0.05 * r(*shape)
     if leaf == "gamma":

@@ -241,10 +241,11 @@ class SynthesizerTrn(nn.Module):
                "use_depthwise_conv": use_depthwise_conv}
         modules.set_Conv1dModel(self.use_depthwise_conv)
         if vocoder_name == "nsf-snake-hifigan":
-            raise NotImplementedError("nsf-snake-hifigan (SnakeAlias) generator has no HIP kernels yet")
-        if vocoder_name != "nsf-hifigan":
-            print("[?] Unkown vocoder: use default(nsf-hifigan)")
-        from vdecoder.hifigan.models import Generator
+            from vdecoder.hifiganwithsnake.models import Generator
+        else:
+            if vocoder_name != "nsf-hifigan":
+                print("[?] Unkown vocoder: use default(nsf-hifigan)")
+            from vdecoder.hifigan.models import Generator
         self.dec = Generator(h=hps)
         self.enc_q = Encoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
         if use_transformer_flow:

@@ -107,6 +107,7 @@ def lib():
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_snake_alias_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [C.c_longlong] * 4 + [C.c_int] * 3 + [C.c_void_p]
         _lib = L
     return _lib
 
@@ -116,6 +117,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_snake_alias_f32",
 ]
 
 
@@ -393,6 +395,21 @@ def copy_bct(x, out=None, mask=None):
     yb, yc = _bct_strides(out)
     check(lib().svc_copy_bct_f32(ptr(x), ptr(out), ptr(mask), xb, xc, yb, yc, mask.stride(0) if mask is not None else 0,
                                  B, Cc, T, stream_ptr()), "copy_bct")
+    return out
+
+
+def snake_alias(x, alpha, beta, taps, out=None):
+    """y = DownSample1d(SnakeBeta(UpSample1d(x))) (vdecoder/hifiganwithsnake/alias/act.py:125-130), one kernel.
+    taps: sequence of the 12 filter taps (host floats)."""
+    require_gpu(x, alpha, beta, out)
+    B, Cc, T = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    xb, xc = _bct_strides(x)
+    yb, yc = _bct_strides(out)
+    tp = (C.c_float * 12)(*[float(v) for v in taps])
+    check(lib().svc_snake_alias_f32(ptr(x), ptr(out), ptr(alpha), ptr(beta), tp, xb, xc, yb, yc, B, Cc, T, stream_ptr()),
+          "snake_alias")
     return out
 
 

@@ -1,0 +1,130 @@
+"""MI355X-native mirror of vdecoder/hifiganwithsnake/models.py (vocoder_name="nsf-snake-hifigan", BASELINE configs[3]).
+
+Same NSF-HiFiGAN generator as vdecoder/hifigan/models.py, with every leaky_relu replaced by an anti-aliased Snake
+activation (`SnakeAlias`, alias/act.py): `snakes[i]` before each `ups[i]` (:394-396), two per ResBlock1 dilation
+(:62-75), `snake_post` before `conv_post` (:409).  Each activation site is one svc_snake_alias_f32 launch (1 read +
+1 write of the activation; the reference's three aten ops move the 2x-length intermediate through memory twice); the
+convolutions are the same fused MFMA kernels as the plain generator, called without a pre-activation.
+"""
+import torch
+from torch import nn
+
+import svc_hip as S
+from svc_nn import Conv1d, _no_grad_guard
+from vdecoder.hifigan import models as base
+from vdecoder.hifigan.models import SineGen, SourceModuleHnNSF  # noqa: F401
+
+from .alias.act import SnakeAlias
+from .env import AttrDict  # noqa: F401
+from .utils import get_padding, init_weights
+
+LRELU_SLOPE = 0.1
+
+
+class ResBlock1(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5), C=None):
+        super().__init__()
+        self.h = h
+        self.convs1 = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=d,
+                                            padding=get_padding(kernel_size, d), weight_norm=True) for d in dilation])
+        self.convs1.apply(init_weights)
+        self.convs2 = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=1,
+                                            padding=get_padding(kernel_size, 1), weight_norm=True) for _ in dilation])
+        self.convs2.apply(init_weights)
+        self.num_layers = len(self.convs1) + len(self.convs2)
+        self.activations = nn.ModuleList([SnakeAlias(channels, C=C) for _ in range(self.num_layers)])
+
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
+        """Reference :71-77.  out (+)= resblock(x); epilogue arguments as hifigan.ResBlock1.forward."""
+        n = len(self.convs1)
+        acts1, acts2 = self.activations[::2], self.activations[1::2]
+        bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(4)]
+        xt, ping, pong, act = bufs
+        cur = x
+        for j, (c1, c2, a1, a2) in enumerate(zip(self.convs1, self.convs2, acts1, acts2)):
+            a1(cur, out=act)
+            c1.run(act, out=xt)
+            a2(xt, out=act)
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                c2.run(act, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c2.run(act, res=cur, res_mode=1, out=dst)
+            cur = dst
+
+    def remove_weight_norm(self):
+        for l in list(self.convs1) + list(self.convs2):
+            l.remove_weight_norm()
+
+
+class ResBlock2(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3), C=None):
+        super().__init__()
+        self.h = h
+        self.convs = nn.ModuleList([Conv1d(channels, channels, kernel_size, 1, dilation=d,
+                                           padding=get_padding(kernel_size, d), weight_norm=True) for d in dilation])
+        self.convs.apply(init_weights)
+        self.num_layers = len(self.convs)
+        self.activations = nn.ModuleList([SnakeAlias(channels, C=C) for _ in range(self.num_layers)])
+
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
+        """Reference :101-106."""
+        n = len(self.convs)
+        bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(4)]
+        _, ping, pong, act = bufs
+        cur = x
+        for j, (c, a) in enumerate(zip(self.convs, self.activations)):
+            a(cur, out=act)
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                c.run(act, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c.run(act, res=cur, res_mode=1, out=dst)
+            cur = dst
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            l.remove_weight_norm()
+
+
+class Generator(base.Generator):
+    """Reference :337-418."""
+
+    def __init__(self, h):
+        super().__init__(h)
+        c0 = h["upsample_initial_channel"]
+        resblock = ResBlock1 if h["resblock"] == '1' else ResBlock2
+        self.snakes = nn.ModuleList()
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(len(self.ups)):
+            self.snakes.append(SnakeAlias(c0 // (2 ** i), C=c0 >> i))
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"]):
+                self.resblocks.append(resblock(h, ch, k, d, C=c0 >> (i + 1)))
+        self.snake_post = SnakeAlias(ch, C=c0 >> len(self.ups))
+
+    def forward_train(self, x, f0, g=None, noise=None):
+        raise NotImplementedError("the nsf-snake-hifigan decoder has no training (backward) path yet")
+
+    def forward(self, x, f0, g=None, noise=None):
+        """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.conv_post.parameters()):
+            return self.forward_train(x, f0, g=g, noise=noise)
+        _no_grad_guard()
+        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        gc = self.cond(g) if g is not None else None
+        x = self.conv_pre.run(x, cond=gc)
+        for i in range(self.num_upsamples):
+            xs = self.noise_convs[i](har)
+            x = self.ups[i].run(self.snakes[i](x), res=xs)              # snake + ConvT + noise-conv add (:395-402)
+            acc = xs
+            tmp = [torch.empty_like(x) for _ in range(4)]
+            for j in range(self.num_kernels):
+                last = j == self.num_kernels - 1
+                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
+                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmp)
+            x = acc
+        return self.conv_post.run(self.snake_post(x), post_act=S.ACT_TANH)     # (:409-411)

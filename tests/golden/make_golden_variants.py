@@ -1,0 +1,27 @@
+"""Golden vectors for the model VARIANTS from the REAL reference (build container only; see make_golden.py):
+  snake_T40   small config with vocoder_name="nsf-snake-hifigan" (vdecoder/hifiganwithsnake, SnakeAlias activations)
+
+usage: python tests/golden/make_golden_variants.py
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import import_reference, run_case  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    models, utils = import_reference()
+    from oracle import weights as W
+    snake = W.small_config()
+    snake["vocoder_name"] = "nsf-snake-hifigan"
+    run_case(models, "snake_T40", snake, B=2, T=40, seed=13)
+
+
+if __name__ == "__main__":
+    main()

@@ -35,11 +35,13 @@ def _check(o, ref, tol_rel=2e-4):
 
 
 @pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full")])
+                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake")])
 def test_infer_matches_reference_golden(dev, name, cfgname):
     z = np.load(os.path.join(G, name))
     meta = json.loads(str(z["meta"]))
-    cfg = W.small_config() if cfgname == "small" else W.full_config()
+    cfg = W.full_config() if cfgname == "full" else W.small_config()
+    if cfgname == "snake":
+        cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
     net, _ = _build(cfg, meta["seed"], dev)
     t = lambda k: torch.from_numpy(z[k]).to(dev)
     noise = dict(enc_p=t("noise_enc_p"), rand_ini=t("noise_rand_ini"), sine=t("noise_sine"))

@@ -210,3 +210,22 @@ def test_attention_on_strided_qkv_view(dev):
     qd = qkv.to(dev)
     out = S.attention(qd[:, :C], qd[:, C:2 * C], qd[:, 2 * C:], H)
     assert _rel(out.cpu(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("B,C,T", [(1, 3, 7), (2, 5, 1024), (1, 4, 1025), (2, 3, 2500), (1, 2, 1)])
+def test_snake_alias_matches_oracle(dev, B, C, T):
+    """svc_snake_alias_f32 (one kernel) vs the oracle's pad/conv_transpose/snake/pad/conv restatement of SnakeAlias
+    (alias/act.py:125-130), incl. rows shorter than the filter, tile boundaries (1024) and strided inputs."""
+    import svc_hip as S
+    from oracle import weights as W
+    g = torch.Generator().manual_seed(B * 1000 + C * 10 + T)
+    x = torch.randn(B, C + 2, T, generator=g) * 2.0
+    xv = x[:, 1:C + 1]                                   # channel-offset view: exercises the explicit strides
+    filt = W.snake_filter()
+    sd = {"s.act.alpha": 0.4 * torch.randn(C, generator=g), "s.act.beta": 0.4 * torch.randn(C, generator=g),
+          "s.upsample.filter": filt.view(1, 1, 12), "s.downsample.lowpass.filter": filt.view(1, 1, 12)}
+    ref = O.snake_alias(xv, sd, "s")
+    xd = x.to(dev)
+    y = S.snake_alias(xd[:, 1:C + 1], sd["s.act.alpha"].to(dev), sd["s.act.beta"].to(dev), filt.tolist())
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -38,18 +38,21 @@ def test_f0_to_coarse_bit_exact():
 
 
 @pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full")])
+                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake")])
 def test_oracle_reproduces_reference_infer(name, cfgname):
     z = _load(name)
     meta = z["meta"]
-    cfg = W.small_config() if cfgname == "small" else W.full_config()
+    cfg = W.full_config() if cfgname == "full" else W.small_config()
+    if cfgname == "snake":
+        cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
     sd = W.make_state_dict(cfg, meta["seed"])
     noise = dict(enc_p=z["noise_enc_p"], rand_ini=z["noise_rand_ini"], sine=z["noise_sine"])
     with torch.no_grad():
         out = O.synth_infer(sd, cfg, z["c"], z["f0"], z["uv"], z["sid"], noise, noice_scale=meta["noice_scale"],
                             predict_f0=meta["predict_f0"], return_all=True)
     # fp32 tolerance: the oracle runs the same torch CPU ops in the same order; allow thread-count jitter
-    for k, tol in (("o", 5e-6), ("har", 1e-6), ("z_p", 1e-5), ("z", 1e-5)):
+    # (the snake decoder's 33 sin^2 sites amplify round-off: 2e-5 there)
+    for k, tol in (("o", 2e-5 if cfgname == "snake" else 5e-6), ("har", 1e-6), ("z_p", 1e-5), ("z", 1e-5)):
         ref = z[k]
         err = (out[k] - ref).abs().max().item()
         assert err <= tol * max(ref.abs().max().item(), 1.0), (k, err)

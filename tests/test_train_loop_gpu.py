@@ -55,10 +55,9 @@ def test_train_loop_matches_reference_loop(dev):
             assert np.abs(pg[name[8:]].detach().cpu().numpy() - z[name]).max() <= 5e-5, name
         if name.startswith("param_d."):
             assert np.abs(pd[name[8:]].detach().cpu().numpy() - z[name]).max() <= 5e-5, name
-    # in the generator step the discriminator took no gradient at all
-    assert not any(optim_d.arena.touched) or True
     # optimizer state round-trips through torch's state_dict format (utils.save_checkpoint / load_checkpoint)
-    sd = optim_g.state_dict()
+    import copy
+    sd = copy.deepcopy(optim_g.state_dict())
     assert len(sd["state"]) == len(optim_g.arena.params) and float(sd["state"][0]["step"]) == meta["n_iter"]
     m0 = optim_g.exp_avg.clone()
     optim_g.exp_avg.zero_()
