@@ -299,11 +299,14 @@ int svc_ew_bct_f32(int op, const float* x, const float* side, float* y, long lon
 int svc_gate_fwd_f32(const float* in, float* acts, int B, int H, int T, void* stream);
 int svc_gate_bwd_f32(const float* in, const float* dacts, float* din, int B, int H, int T, void* stream);
 
-/* Phase decimation y[b, r*C + c, q] = xpad[b, c, q*s + r + off], r < s: xpad is x reflect-padded on the right to
- * `lp` samples when lp > T (DiscriminatorP's F.pad(..., "reflect"), models.py:185-189) and zero elsewhere.  A stride-s
- * Conv1d / Conv2d((k,1),(s,1)) becomes a dense conv over s*C channels; the adjoint is svc_decimate_bwd_f32. */
-int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int off, int Q, int lp, void* stream);
-int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int off, int Q, int lp, void* stream);
+/* Phase decimation over blocks of `w` samples: y[b, r*C + c, q*w + j] = xpad[b, c, (q*s + r + off)*w + j], r < s,
+ * j < w (w = 1: plain samples; w = period: DiscriminatorP's [B,C,T/p,p] view, models.py:190, kept time-contiguous so
+ * that its Conv2d((k,1),(s,1)) stack becomes dense dilation-p Conv1d's).  xpad is x reflect-padded on the right to `lp`
+ * samples when lp > T (F.pad(..., "reflect"), models.py:185-189) and zero elsewhere.  A stride-s conv becomes a dense
+ * conv over s*C channels; the adjoint is svc_decimate_bwd_f32.  y:[B, s*C, Q*w]. */
+int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int w, int off, int Q, int lp, void* stream);
+int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int w, int off, int Q, int lp,
+                         void* stream);
 
 /* Grouped strided Conv1d (DiscriminatorS, models.py:206-211): w:[Cout][Cin/groups][KS]. */
 int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Tin,

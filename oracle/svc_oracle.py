@@ -188,14 +188,22 @@ def f0_decoder(x, norm_f0, x_mask, g, sd, cfg, prefix="f0_decoder"):
 # WaveNet block + coupling flows (modules/modules.py)
 # ------------------------------------------------------------------------------------------------------------
 def wn(x, x_mask, g, sd, prefix, hidden, kernel_size, dilation_rate, n_layers):
-    """WN.forward, modules/modules.py:110-138 (dense Conv1d variant; p_dropout=0)."""
+    """WN.forward, modules/modules.py:110-138 (p_dropout=0); in_layers are dense Conv1d's or, with
+    use_depthwise_conv (modules/modules.py:16-20,95), depthwise-separable pairs."""
     output = torch.zeros_like(x)
     if g is not None:
         g = conv1d(g, sd, prefix + ".cond_layer")
     for i in range(n_layers):
         dilation = dilation_rate ** i
         padding = int((kernel_size * dilation - dilation) / 2)
-        x_in = conv1d(x, sd, f"{prefix}.in_layers.{i}", dilation=dilation, padding=padding)
+        ip = f"{prefix}.in_layers.{i}"
+        if ip + ".depth_conv.weight_v" in sd:
+            # use_depthwise_conv: Depthwise_Separable_Conv1D (modules/DSConv.py:5-27) = depthwise k-tap conv + 1x1 conv
+            d = F.conv1d(x, weight_of(sd, ip + ".depth_conv"), sd[ip + ".depth_conv.bias"], dilation=dilation,
+                         padding=padding, groups=x.shape[1])
+            x_in = conv1d(d, sd, ip + ".point_conv")
+        else:
+            x_in = conv1d(x, sd, ip, dilation=dilation, padding=padding)
         if g is not None:
             x_in = x_in + g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :]
         acts = torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:])  # modules/commons.py:129-136

@@ -12,6 +12,7 @@ reference's default init (N(0, 0.01) decoder convs, zero `post`) yields ~1e-3-am
 an absolute MSE < 1e-4 parity bound vacuous.
 """
 import math
+import re
 import zlib
 
 import torch
@@ -29,6 +30,23 @@ def full_config():
         n_speakers=200, vocoder_name="nsf-hifigan", speech_encoder="vec768l12", speaker_embedding=False,
         vol_embedding=False, use_depthwise_conv=False, flow_share_parameter=False,
         use_automatic_f0_prediction=True, use_transformer_flow=False, sampling_rate=44100)
+
+
+def tiny_config():
+    """model section of configs_template/config_tiny_template.json (:42-71): filter_channels 512,
+    upsample_initial_channel 400 (decoder channels 200/100/50/25/12), depthwise-separable WN in_layers, one WN shared by
+    the four flows."""
+    c = full_config()
+    c.update(filter_channels=512, upsample_initial_channel=400, use_depthwise_conv=True, flow_share_parameter=True)
+    return c
+
+
+def small_tiny_config():
+    """small_config with the tiny template's structural switches (odd decoder widths 100/50/25/12/6, depthwise WN,
+    shared flow WN): a few-MB state_dict for committed goldens."""
+    c = small_config()
+    c.update(upsample_initial_channel=200, use_depthwise_conv=True, flow_share_parameter=True)
+    return c
 
 
 def small_config():
@@ -74,7 +92,11 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
     def wn_block(prefix, n_layers):
         conv(prefix + ".cond_layer", 2 * h * n_layers, gin, 1, wn=True)
         for i in range(n_layers):
-            conv(f"{prefix}.in_layers.{i}", 2 * h, h, 5, wn=True)
+            if cfg.get("use_depthwise_conv"):     # Depthwise_Separable_Conv1D (modules/DSConv.py:5-27), weight-normed
+                conv(f"{prefix}.in_layers.{i}.depth_conv", h, 1, 5, wn=True)
+                conv(f"{prefix}.in_layers.{i}.point_conv", 2 * h, h, 1, wn=True)
+            else:
+                conv(f"{prefix}.in_layers.{i}", 2 * h, h, 5, wn=True)
             conv(f"{prefix}.res_skip_layers.{i}", 2 * h if i < n_layers - 1 else h, h, 1, wn=True)
 
     P["emb_g.weight"] = (cfg["n_speakers"], gin)
@@ -139,8 +161,7 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
     for f in range(4):
         fp = f"flow.flows.{2 * f}"
         conv(fp + ".pre", h, inter // 2, 1)
-        if not cfg.get("flow_share_parameter"):
-            wn_block(fp + ".enc", nfl)
+        wn_block(fp + ".enc", nfl)      # with flow_share_parameter these keys alias flow.wn.* (same module registered twice)
         conv(fp + ".post", inter // 2, h, 1)
 
     if include_f0_decoder and cfg.get("use_automatic_f0_prediction", True):
@@ -215,7 +236,14 @@ def make_tensor(name, shape, seed, all_shapes=None):
 
 def make_state_dict(cfg, seed=1234, **kw):
     shapes = param_shapes(cfg, **kw)
-    return {n: make_tensor(n, s, seed, shapes) for n, s in shapes.items()}
+    sd = {n: make_tensor(n, s, seed, shapes) for n, s in shapes.items()}
+    if cfg.get("flow_share_parameter"):
+        # models.py:37,42: one WN registered as flow.wn AND as every flow.flows.N.enc -> the state_dict lists it five times
+        for n in list(sd):
+            m = re.match(r"flow\.flows\.\d+\.enc\.(.*)", n)
+            if m:
+                sd[n] = sd["flow.wn." + m.group(1)]
+    return sd
 
 
 def make_inputs(cfg, B, T, seed=1234, unvoiced_frac=0.1):

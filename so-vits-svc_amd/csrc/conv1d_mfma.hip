@@ -589,6 +589,9 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   }
 #define SVC_KS_CASES(MT_, NT_, WM_, WN_, M16_)                                                      \
   switch (g_no_ksc ? 0 : a.KS) {                                                                     \
+    case 1: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 1>(a, s);                  \
+    case 2: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 2>(a, s);                  \
+    case 5: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 5>(a, s);                  \
     case 3: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 3>(a, s);                  \
     case 7: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 7>(a, s);                  \
     case 11: return launch_cfg<MT_, NT_, WM_, WN_, 1, M16_, SVC_EPI_PLAIN, 11>(a, s);                \

@@ -159,35 +159,41 @@ __global__ void gate_bwd_kernel(const float* __restrict__ in, const float* __res
   din[os] = d * th * sg * (1.f - sg);
 }
 
-// ---- decimation: y[b, r*C + c, q] = xpad[b, c, q*s + r + off]  -----------------------------------------------
-// xpad = x reflect-padded on the right up to `lp` samples when lp > T (DiscriminatorP, models.py:185-189), zero
-// elsewhere.  Lowers a stride-s conv (and the dgrad/wgrad of a transposed conv) to a dense conv over s*C channels.
-__global__ void decimate_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T, int s, int off, int Q,
-                                int lp) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- decimation: y[b, r*C + c, q*w + j] = xpad[b, c, (q*s + r + off)*w + j],  j < w ------------------------------
+// The signal is a sequence of blocks of `w` samples (w = 1: plain samples; w = period p: the rows of DiscriminatorP's
+// [T/p, p] view kept time-contiguous) and the decimation runs over the BLOCK index.  xpad = x reflect-padded on the
+// right up to `lp` samples when lp > T (DiscriminatorP, models.py:185-189), zero elsewhere.  Lowers a stride-s conv
+// (and the dgrad/wgrad of a transposed conv) to a dense conv (dilation w) over s*C channels.
+__global__ void decimate_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T, int s, int w, int off,
+                                int Q, int lp) {
+  const int qq = blockIdx.x * blockDim.x + threadIdx.x;
   const int rc = blockIdx.y, b = blockIdx.z;
-  if (q >= Q) return;
+  if (qq >= Q * w) return;
   const int r = rc / C, c = rc % C;
-  int tau = q * s + r + off;
+  const int q = qq / w, j = qq - q * w;
+  const int blk = q * s + r + off;
+  int tau = blk * w + j;
   float v = 0.f;
-  if (tau >= 0 && tau < lp) {
+  if (blk >= 0 && tau < lp) {
     if (tau >= T) tau = 2 * T - 2 - tau;
     if (tau >= 0) v = x[((long long)b * C + c) * T + tau];
   }
-  y[((long long)b * s * C + rc) * Q + q] = v;
+  y[((long long)b * s * C + rc) * ((long long)Q * w) + qq] = v;
 }
 // adjoint: dx[b,c,tau] = sum of dy over every (r,q) that read tau (direct + reflected image)
-__global__ void decimate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int T, int s, int off,
-                                    int Q, int lp) {
+__global__ void decimate_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int T, int s, int w,
+                                    int off, int Q, int lp) {
   const int tau = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y, b = blockIdx.z;
   if (tau >= T) return;
   float acc = 0.f;
   auto take = [&](int tp) {   // padded position tp
-    const int u = tp - off;
-    if (tp < 0 || tp >= lp || u < 0) return;
+    if (tp < 0 || tp >= lp) return;
+    const int blk = tp / w, j = tp - blk * w;
+    const int u = blk - off;
+    if (u < 0) return;
     const int q = u / s, r = u - q * s;
-    if (q < Q) acc += dy[((long long)b * s * C + r * C + c) * Q + q];
+    if (q < Q) acc += dy[((long long)b * s * C + r * C + c) * ((long long)Q * w) + q * w + j];
   };
   take(tau);
   const int img = 2 * T - 2 - tau;
@@ -376,18 +382,19 @@ int svc_gate_bwd_f32(const float* in, const float* dacts, float* din, int B, int
   return svc::check_launch("gate_bwd");
 }
 
-int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int off, int Q, int lp, void* stream) {
-  SVC_REQUIRE(x && y && B > 0 && C > 0 && T > 0 && s >= 1 && Q > 0 && lp >= T, "decimate: bad args");
+int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int w, int off, int Q, int lp, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && T > 0 && s >= 1 && w >= 1 && Q > 0 && lp >= T, "decimate: bad args");
   SVC_REQUIRE(lp - T <= T - 1, "decimate: reflect padding longer than the signal");
-  hipLaunchKernelGGL(decimate_kernel, dim3(svc::cdiv(Q, 256), s * C, B), dim3(256), 0, (hipStream_t)stream, x, y, C, T, s,
-                     off, Q, lp);
+  hipLaunchKernelGGL(decimate_kernel, dim3(svc::cdiv(Q * w, 256), s * C, B), dim3(256), 0, (hipStream_t)stream, x, y, C, T,
+                     s, w, off, Q, lp);
   return svc::check_launch("decimate");
 }
 
-int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int off, int Q, int lp, void* stream) {
-  SVC_REQUIRE(dy && dx && B > 0 && C > 0 && T > 0 && s >= 1 && Q > 0 && lp >= T, "decimate_bwd: bad args");
+int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int w, int off, int Q, int lp,
+                         void* stream) {
+  SVC_REQUIRE(dy && dx && B > 0 && C > 0 && T > 0 && s >= 1 && w >= 1 && Q > 0 && lp >= T, "decimate_bwd: bad args");
   hipLaunchKernelGGL(decimate_bwd_kernel, dim3(svc::cdiv(T, 256), C, B), dim3(256), 0, (hipStream_t)stream, dy, dx, C, T,
-                     s, off, Q, lp);
+                     s, w, off, Q, lp);
   return svc::check_launch("decimate_bwd");
 }
 

@@ -413,15 +413,19 @@ class _NormConv(nn.Module):
         self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, *([1] * (w.dim() - 1))).clone())
         self.weight_v = nn.Parameter(w)
 
-    def forward(self, x):
+    def forward(self, x, inner=1, lp=None):
         w = A.weight_norm(self.weight_v, self.weight_g).view(self.cout, self.cin // self.groups, self.k)
-        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups)
+        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups, inner=inner, lp=lp)
 
 
 class DiscriminatorP(nn.Module):
-    """Reference models.py:165-199.  The Conv2d((k,1),(s,1)) stack acts on every one of the `period` columns
-    independently, so the [B,1,T/p,p] view is realised as a phase decimation [B*p, 1, T/p] (columns -> batch,
-    svc_decimate_f32 with the reflect padding of :185-189 folded in) followed by strided Conv1d's."""
+    """Reference models.py:165-199.  The Conv2d((k,1),(s,1)) stack acts on each of the `period` columns of the
+    [B,1,T/p,p] view independently.  The view's memory order IS the time order, so the signal stays [B,C,H*p] with
+    rows = blocks of p consecutive samples: a stride-1 (k,1) conv is a dense Conv1d with dilation p, a stride-3 one a
+    block decimation (svc_decimate_f32, w = p, which also folds in the reflect padding of :185-189) followed by a
+    dense dilation-p Conv1d.  Every layer therefore sees T = H*p >= ~100 columns per batch row on the MFMA N axis
+    (turning the columns into batch rows instead leaves 9-30 columns per row in the 1024-channel layers), and the
+    feature maps come out in the reference's [B,C,H,p] layout as plain views."""
 
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
         super().__init__()
@@ -439,21 +443,16 @@ class DiscriminatorP(nn.Module):
         b, c, t = x.shape
         p = self.period
         n_pad = (p - t % p) % p
-        H = (t + n_pad) // p
-        xd = A._Decimate.apply(x, p, 0, H, t + n_pad)          # [B, p, H]
-        h = xd.reshape(b * p, 1, H)
         fmap = []
+        h = x
+        lp = t + n_pad
         for l in self.convs:
-            h = A.leaky_relu(l(h), modules.LRELU_SLOPE)
-            fmap.append(self._as_ref(h, b, p))
-        h = self.conv_post(h)
-        fmap.append(self._as_ref(h, b, p))
+            h = A.leaky_relu(l(h, inner=p, lp=lp), modules.LRELU_SLOPE)
+            lp = None
+            fmap.append(h.view(b, h.shape[1], -1, p))
+        h = self.conv_post(h, inner=p)
+        fmap.append(h.view(b, h.shape[1], -1, p))
         return torch.flatten(fmap[-1], 1, -1), fmap
-
-    @staticmethod
-    def _as_ref(h, b, p):
-        """[B*p, C, H'] -> the reference's [B, C, H', p] (a permuted view of the same storage)."""
-        return h.view(b, p, h.shape[1], h.shape[2]).permute(0, 2, 3, 1)
 
 
 class DiscriminatorS(nn.Module):

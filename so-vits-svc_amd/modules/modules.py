@@ -13,7 +13,7 @@ from torch import nn
 import svc_autograd as A
 import svc_hip as S
 from modules.commons import get_padding, init_weights
-from svc_nn import Conv1d, mask2d, training_call
+from svc_nn import Conv1d, DepthwiseSeparableConv1d, mask2d, training_call
 
 LRELU_SLOPE = 0.1
 
@@ -27,8 +27,9 @@ def set_Conv1dModel(use_depthwise_conv):
 
 
 def _conv(cin, cout, k, **kw):
+    """The reference's `Conv1dModel` (modules/modules.py:16-20)."""
     if _use_depthwise_conv:
-        raise NotImplementedError("use_depthwise_conv=True (config_tiny_template) has no HIP kernel yet")
+        return DepthwiseSeparableConv1d(cin, cout, k, **kw)
     return Conv1d(cin, cout, k, **kw)
 
 
@@ -95,7 +96,7 @@ class WN(nn.Module):
         return A.mul_bcast(output, x_mask)
 
     def forward(self, x, x_mask, g=None, **kwargs):
-        if training_call(self.in_layers[0].weight_v) or (torch.is_grad_enabled() and x.requires_grad):
+        if training_call(*self.res_skip_layers[0].parameters()) or (torch.is_grad_enabled() and x.requires_grad):
             return self.forward_train(x, x_mask, g=g)
         H = self.hidden_channels
         B, _, T = x.shape

@@ -22,14 +22,16 @@ def _c(t):
 
 
 class _Conv1dDense(Function):
-    """y = conv1d(x, w, bias, stride=1, padding=pad, dilation=dil); w is the explicit [Cout,Cin,KS] weight."""
+    """y = conv1d(x, w, bias, stride=1, padding=pad, dilation=dil)[..., :tout]; w is the explicit [Cout,Cin,KS] weight."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, pad, dil):
+    def forward(ctx, x, w, bias, pad, dil, tout=None):
         x = _c(x)
         Cout, Cin, KS = w.shape
         Tin = x.shape[2]
         Tout = Tin + 2 * pad - dil * (KS - 1)
+        if tout is not None:
+            Tout = min(Tout, tout)
         wp = S.pack_conv1d_weight(w.detach())
         y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
         ctx.save_for_backward(x, w)
@@ -50,19 +52,19 @@ class _Conv1dDense(Function):
             dw = S.conv1d_wgrad(dy, x, KS, dil, pad)
         if has_bias and ctx.needs_input_grad[2]:
             db = S.reduce_bct(dy, 0)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _Decimate(Function):
     @staticmethod
-    def forward(ctx, x, s, off, Q, lp):
-        ctx.cfg = (x.shape[1], x.shape[2], s, off, lp)
-        return S.decimate(x, s, off, Q, lp)
+    def forward(ctx, x, s, off, Q, lp, inner=1):
+        ctx.cfg = (x.shape[1], x.shape[2], s, off, lp, inner)
+        return S.decimate(x, s, off, Q, lp, inner)
 
     @staticmethod
     def backward(ctx, dy):
-        Cc, T, s, off, lp = ctx.cfg
-        return S.decimate_bwd(dy, Cc, T, s, off, lp), None, None, None, None
+        Cc, T, s, off, lp, inner = ctx.cfg
+        return S.decimate_bwd(dy, Cc, T, s, off, lp, inner), None, None, None, None, None
 
 
 class _Interleave(Function):
@@ -260,20 +262,25 @@ def gate(x):
     return _Gate.apply(x)
 
 
-def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """F.conv1d semantics on [B,Cin,T] with an explicit weight [Cout, Cin/groups, KS]."""
+def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, lp=None):
+    """F.conv1d semantics on [B,Cin,T] with an explicit weight [Cout, Cin/groups, KS].
+    inner > 1: x is [B, Cin, H*inner] — H blocks of `inner` time-contiguous samples — and the convolution runs over the
+    BLOCK index (this is Conv2d((KS,1),(stride,1)) on the [B,Cin,H,inner] view, models.py:171-177); stride/padding are
+    in blocks.  lp: length the input is (virtually) reflect-padded to on the right (models.py:185-189)."""
     Cout, Cg, KS = w.shape
     if groups != 1:
-        if dilation != 1:
+        if dilation != 1 or inner != 1:
             raise S.SvcError("grouped conv with dilation is not on the so-vits-svc path")
         return _GConv1d.apply(x, w, bias, stride, padding, groups)
     if stride == 1:
-        return _Conv1dDense.apply(x, w, bias, padding, dilation)
+        if lp is not None and lp != x.shape[2]:
+            raise S.SvcError("reflect padding is folded into the decimation of a strided conv only")
+        return _Conv1dDense.apply(x, w, bias, padding * inner, dilation * inner)
     if dilation != 1:
         raise S.SvcError("strided conv with dilation is not on the so-vits-svc path")
     # stride-s conv: input position t*s + k - pad = (t + m)*s + r with k - pad = s*m + r, r in [0,s)
     s = stride
-    Tin = x.shape[2]
+    Tin = (x.shape[2] if lp is None else lp) // inner          # in blocks
     Tout = (Tin + 2 * padding - KS) // s + 1
     m_min = (0 - padding) // s
     m_max = (KS - 1 - padding) // s
@@ -282,10 +289,9 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     wpad = torch.nn.functional.pad(w, (shift, s * KSd - KS - shift))
     wd = wpad.view(Cout, Cg, KSd, s).permute(0, 3, 1, 2).reshape(Cout, s * Cg, KSd)   # index reshapes only
     Q = (Tin + s - 1) // s
-    xd = _Decimate.apply(x, s, 0, Q, None)
-    y = _Conv1dDense.apply(xd, wd, bias, -m_min, 1)
-    # dense conv over Q samples yields Q + 2*(-m_min) - (KSd-1) outputs; keep the first Tout
-    return y[:, :, :Tout] if y.shape[2] != Tout else y
+    xd = _Decimate.apply(x, s, 0, Q, lp, inner)
+    # dense conv (dilation `inner`) over the Q blocks; only the first Tout blocks are produced
+    return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, Tout * inner)
 
 
 def conv_transpose1d(x, w, bias=None, stride=1, padding=0):

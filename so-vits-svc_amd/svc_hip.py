@@ -525,8 +525,8 @@ def tlib():
         L.svc_ew_bct_f32.argtypes = [i, _f32p, _f32p, _f32p] + [ll] * 7 + [i, i, i, f, f, vp]
         L.svc_gate_fwd_f32.argtypes = [_f32p, _f32p, i, i, i, vp]
         L.svc_gate_bwd_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
-        L.svc_decimate_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, vp]
-        L.svc_decimate_bwd_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, vp]
+        L.svc_decimate_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, i, vp]
+        L.svc_decimate_bwd_f32.argtypes = [_f32p, _f32p, i, i, i, i, i, i, i, i, vp]
         L.svc_gconv1d_fwd_f32.argtypes = [_f32p] * 4 + [i] * 9 + [vp]
         L.svc_gconv1d_dgrad_f32.argtypes = [_f32p] * 3 + [i] * 9 + [vp]
         L.svc_gconv1d_wgrad_f32.argtypes = [_f32p] * 3 + [i] * 9 + [vp]
@@ -675,22 +675,24 @@ def gate_bwd(x, dacts):
     return din
 
 
-def decimate(x, s, off, Q, lp=None):
+def decimate(x, s, off, Q, lp=None, inner=1):
+    """y[b, r*C + c, q*inner + j] = xpad[b, c, (q*s + r + off)*inner + j] -> [B, s*C, Q*inner]."""
     require_gpu(x)
     x = x.contiguous()
     B, Cc, T = x.shape
-    y = torch.empty((B, s * Cc, Q), device=x.device, dtype=torch.float32)
-    check(tlib().svc_decimate_f32(ptr(x), ptr(y), B, Cc, T, s, off, Q, T if lp is None else lp, stream_ptr()), "decimate")
+    y = torch.empty((B, s * Cc, Q * inner), device=x.device, dtype=torch.float32)
+    check(tlib().svc_decimate_f32(ptr(x), ptr(y), B, Cc, T, s, inner, off, Q, T if lp is None else lp, stream_ptr()),
+          "decimate")
     return y
 
 
-def decimate_bwd(dy, Cc, T, s, off, lp=None):
+def decimate_bwd(dy, Cc, T, s, off, lp=None, inner=1):
     require_gpu(dy)
     dy = dy.contiguous()
-    B, sC, Q = dy.shape
+    B, sC, QW = dy.shape
     dx = torch.empty((B, Cc, T), device=dy.device, dtype=torch.float32)
-    check(tlib().svc_decimate_bwd_f32(ptr(dy), ptr(dx), B, Cc, T, s, off, Q, T if lp is None else lp, stream_ptr()),
-          "decimate_bwd")
+    check(tlib().svc_decimate_bwd_f32(ptr(dy), ptr(dx), B, Cc, T, s, inner, off, QW // inner, T if lp is None else lp,
+                                      stream_ptr()), "decimate_bwd")
     return dx
 
 

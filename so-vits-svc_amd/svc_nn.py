@@ -138,6 +138,80 @@ class Conv1d(nn.Module, _PackedMixin):
                 f"padding={self.padding}, dilation={self.dilation}, weight_norm={self.is_weight_norm}")
 
 
+class DepthwiseSeparableConv1d(nn.Module):
+    """modules/DSConv.py:5-27 `Depthwise_Separable_Conv1D` (+ its weight_norm(), :23-25): depth_conv = per-channel k-tap
+    Conv1d (weight [Cin,1,K]), point_conv = 1x1 Conv1d (weight [Cout,Cin,1]); used for WN.in_layers when
+    use_depthwise_conv is set (modules/modules.py:16-20,95 — the tiny template).
+
+    point(depth(x)) is linear in x, so at PACK time (once per weight version) the pair is folded into the dense weight
+    W[co,ci,k] = Wp[co,ci] * Wd[ci,k], bias = Wp @ bd + bp (both on the GPU: svc_weight_norm_fwd_f32, svc_ew_bct_f32,
+    svc_conv1d_f32) and the layer runs as ONE fused MFMA conv with the WN gate epilogue — instead of the reference's
+    two convs + two weight-norm recomputes per call.  At 192 channels the dense form is launch-latency bound either way.
+    Inference only: the training graph of the depthwise variant is not implemented."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True,
+                 weight_norm=False):
+        super().__init__()
+        if stride != 1 or not bias:
+            raise NotImplementedError("depthwise-separable conv: only stride 1 with bias is on the so-vits-svc path")
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.is_weight_norm = weight_norm
+        # parameter holders with the reference's shapes/names (depth_conv.weight_{g,v} [Cin,1,K], point_conv... [Cout,Cin,1])
+        self.depth_conv = Conv1d(1, in_channels, kernel_size, padding=padding, dilation=dilation, weight_norm=weight_norm)
+        self.point_conv = Conv1d(in_channels, out_channels, 1, weight_norm=weight_norm)
+
+    def _all_params(self):
+        return [p for p in list(self.depth_conv.parameters()) + list(self.point_conv.parameters())]
+
+    def _folded(self, gate_half):
+        key = tuple((p.data_ptr(), p._version) for p in self._all_params()) + (gate_half,)
+        cache = self.__dict__.setdefault("_svc_fold_cache", {})
+        hit = cache.get(gate_half)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            d, pc = self.depth_conv, self.point_conv
+            if self.is_weight_norm:
+                wd, _ = S.weight_norm_fwd(d.weight_v.detach(), d.weight_g.detach().reshape(-1))
+                wp, _ = S.weight_norm_fwd(pc.weight_v.detach(), pc.weight_g.detach().reshape(-1))
+            else:
+                wd, wp = d.weight.detach(), pc.weight.detach()
+            Cin, K, Cout = self.in_channels, self.kernel_size, self.out_channels
+            wd = wd.reshape(1, Cin, K).contiguous()
+            wp = wp.reshape(Cout, Cin, 1).contiguous()
+            dense = S.ew_bct(S.EW_MUL, wd.expand(Cout, Cin, K), wp)                       # [Cout, Cin, K]
+            packed = S.pack_conv1d_weight(dense, None, gate_half)
+            # bias' = Wp @ bd + bp  (a 1x1 conv over a length-1 signal)
+            bias = S.conv1d(d.bias.detach().reshape(1, Cin, 1).contiguous(), S.pack_conv1d_weight(wp), Cout, 1,
+                            bias=pc.bias.detach()).reshape(Cout)
+        cache[gate_half] = (key, packed, bias)
+        return packed, bias
+
+    def remove_weight_norm(self):
+        self.depth_conv.remove_weight_norm()
+        self.point_conv.remove_weight_norm()
+        self.is_weight_norm = False
+
+    def forward_train(self, x, **kw):
+        raise NotImplementedError("use_depthwise_conv has no training (backward) path yet")
+
+    def forward(self, x, **kw):
+        if training_call(*self._all_params()) or (torch.is_grad_enabled() and getattr(x, "requires_grad", False)):
+            return self.forward_train(x)
+        return self.run(x, **kw)
+
+    def run(self, x, pad_left=None, Tout=None, **kw):
+        _no_grad_guard(*self._all_params())
+        gate_half = self.out_channels // 2 if kw.get("epi") == S.EPI_GATE else 0
+        packed, bias = self._folded(gate_half)
+        pl = self.padding if pad_left is None else pad_left
+        if Tout is None:
+            Tout = x.shape[2] + 2 * self.padding - self.dilation * (self.kernel_size - 1)
+        return S.conv1d(x, packed, self.out_channels, self.kernel_size, bias=bias, dil=self.dilation, pad_left=pl,
+                        Tout=Tout, **kw)
+
+
 class ConvTranspose1d(nn.Module, _PackedMixin):
     """weight_norm(nn.ConvTranspose1d) stand-in (vdecoder/hifigan/models.py:340-342)."""
 

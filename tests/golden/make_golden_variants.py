@@ -1,5 +1,7 @@
 """Golden vectors for the model VARIANTS from the REAL reference (build container only; see make_golden.py):
   snake_T40   small config with vocoder_name="nsf-snake-hifigan" (vdecoder/hifiganwithsnake, SnakeAlias activations)
+  tiny_T40    small config with the tiny template's switches (configs_template/config_tiny_template.json:
+              use_depthwise_conv, flow_share_parameter, odd decoder widths 100/50/25/12/6)
 
 usage: python tests/golden/make_golden_variants.py
 """
@@ -21,6 +23,7 @@ def main():
     snake = W.small_config()
     snake["vocoder_name"] = "nsf-snake-hifigan"
     run_case(models, "snake_T40", snake, B=2, T=40, seed=13)
+    run_case(models, "tiny_T40", W.small_tiny_config(), B=2, T=40, seed=14)
 
 
 if __name__ == "__main__":

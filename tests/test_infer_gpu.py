@@ -35,11 +35,12 @@ def _check(o, ref, tol_rel=2e-4):
 
 
 @pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake")])
+                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake"),
+                                          ("infer_tiny_T40.npz", "tiny")])
 def test_infer_matches_reference_golden(dev, name, cfgname):
     z = np.load(os.path.join(G, name))
     meta = json.loads(str(z["meta"]))
-    cfg = W.full_config() if cfgname == "full" else W.small_config()
+    cfg = W.full_config() if cfgname == "full" else (W.small_tiny_config() if cfgname == "tiny" else W.small_config())
     if cfgname == "snake":
         cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
     net, _ = _build(cfg, meta["seed"], dev)

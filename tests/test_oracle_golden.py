@@ -38,11 +38,12 @@ def test_f0_to_coarse_bit_exact():
 
 
 @pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake")])
+                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake"),
+                                          ("infer_tiny_T40.npz", "tiny")])
 def test_oracle_reproduces_reference_infer(name, cfgname):
     z = _load(name)
     meta = z["meta"]
-    cfg = W.full_config() if cfgname == "full" else W.small_config()
+    cfg = W.full_config() if cfgname == "full" else (W.small_tiny_config() if cfgname == "tiny" else W.small_config())
     if cfgname == "snake":
         cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
     sd = W.make_state_dict(cfg, meta["seed"])

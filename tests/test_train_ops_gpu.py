@@ -119,3 +119,29 @@ def test_decimate_reflect_adjoint(dev):
     lhs = (y.cpu() * g).sum().item()
     rhs = (x * dx).sum().item()
     assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,p,K,s,pad", [(2, 1, 32, 8192, 7, 5, 3, 2), (2, 32, 128, 2002, 11, 5, 3, 2),
+                                                    (2, 64, 64, 303, 3, 5, 1, 2), (1, 128, 1, 110, 11, 3, 1, 1),
+                                                    (2, 16, 48, 96, 2, 5, 3, 2), (1, 4, 8, 1000, 5, 5, 3, 2)])
+def test_period_conv2d_as_block_conv1d(dev, B, Cin, Cout, T, p, K, s, pad):
+    """DiscriminatorP's layers (models.py:171-199): reflect-pad to a multiple of p, view [B,C,T/p,p],
+    Conv2d((K,1),(s,1),padding=(pad,0)) == svc_autograd.conv1d(..., inner=p) on the time-contiguous [B,C,H*p] signal
+    (block decimation + dense dilation-p conv); forward and all gradients against torch's CPU conv2d."""
+    import svc_autograd as A
+    torch.manual_seed(3)
+    n_pad = (p - T % p) % p
+    t = dict(x=_p(B, Cin, T), w=_p(Cout, Cin, K, scale=(Cin * K) ** -0.5), bias=_p(Cout))
+
+    def ref(x, w, bias):
+        xp = F.pad(x, (0, n_pad), "reflect") if n_pad else x
+        y = F.conv2d(xp.view(B, Cin, (T + n_pad) // p, p), w.unsqueeze(-1), bias, (s, 1), (pad, 0))
+        return y.reshape(B, Cout, -1)
+
+    def hip(x, w, bias):
+        return A.conv1d(x, w, bias, s, pad, 1, 1, inner=p, lp=(T + n_pad) if s > 1 else None) if (s > 1 or n_pad == 0) \
+            else None
+
+    if s == 1 and n_pad:
+        pytest.skip("reflect padding only precedes the first (strided) layer")
+    _run_pair(hip, ref, t, dev)
