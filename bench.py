@@ -120,6 +120,8 @@ def run_train(args, dev, rank, world, dist):
     net_g.train()
     net_d.train()
     step_fn = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d)
+    use_graph = (not args.no_graph) and (world == 1 or os.environ.get("SVC_TRAIN_GRAPH") == "1")
+    step_fn.enable_graph(use_graph)
     items_cpu, T = make_train_items(cfg, TRAIN_B, 4321 + rank)
     items = tuple(t.to(dev) if t is not None else None for t in items_cpu)
     torch.manual_seed(99 + rank)
@@ -147,6 +149,7 @@ def run_train(args, dev, rank, world, dist):
         return None
     fams = None
     if not args.no_roofline:
+        step_fn.enable_graph(False)
         S.prof_enable(True)
         S.prof_reset()
         step_fn(items)
@@ -166,6 +169,7 @@ def run_train(args, dev, rank, world, dist):
                                      f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
                                      "4 speakers, fp32, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
                             global_batch=TRAIN_B * world, frames=T,
+                            launch="hipGraph replay of the whole iteration" if use_graph else "eager",
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU"),
                 losses={k: round(float(v), 4) for k, v in last.items()},
                 families=fams, allreduce=red)

@@ -324,10 +324,12 @@ int svc_reduce_scalar_f64(int op, const float* a, const float* b, const float* c
                           double* out, double scale, void* stream);
 int svc_f64_to_f32(const double* in, float* out, int n, void* stream);
 
-/* Fused AdamW step over one flat parameter buffer (train.py:79-88; torch.optim.AdamW semantics, `step` >= 1).
- * grad_scale multiplies the gradient first (1/world_size for data-parallel means). */
-int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* Fused AdamW step over one flat parameter buffer (train.py:79-88; torch.optim.AdamW semantics).  The hyper-parameters
+ * are read from DEVICE memory: hyper = float[7] {lr, beta1, beta2, eps, weight_decay, step (>= 1), grad_scale}
+ * (grad_scale multiplies the gradient first: GradScaler's 1/scale), so a hipGraph that captured the step stays valid
+ * across iterations; svc_adamw_advance does hyper[5] += 1 (call it before the step of each iteration). */
+int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, const float* hyper, void* stream);
+int svc_adamw_advance(float* hyper, void* stream);
 
 
 /* Channel LayerNorm for training (modules/modules.py:23-35): forward also returns the per-column mean / rstd [B,T];

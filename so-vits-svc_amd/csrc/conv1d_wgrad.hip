@@ -2,23 +2,29 @@
 //     G[ca, cb, k] = sum_{b,t} A[b, ca, t] * Bm[b, cb, t + k*dil - pad]          (t in [0,TA), Bm index in [0,TB))
 // With A = dy [B,Cout,Tout] and Bm = x [B,Cin,Tin] this is dW of every nn.Conv1d on the training path
 // (backward of the convs cited in conv1d_mfma.hip); with A = x and Bm = the phase-decimated dy it is dW of the
-// polyphase ConvTranspose1d (vdecoder/hifigan/models.py:340-342); strided discriminator convs (models.py:171-177)
-// go through the same kernel after svc_decimate_f32.
+// polyphase ConvTranspose1d (vdecoder/hifigan/models.py:340-342); strided / period discriminator convs
+// (models.py:171-177) go through the same kernel after svc_decimate_f32.
 //
-// GEMM view per tap: G_k = A (Ca x N) * Bm_k^T (N x Cb), N = (b,t) — the reduction runs over TIME, so the tiles
-// staged in LDS are As[64][TT] and Bs[32][TT + halo] with an ODD row pitch: an MFMA operand fetch has its 32 lanes
-// on 32 different channel rows at the same time step, which an odd pitch spreads over 32 banks.  One workgroup =
-// 64 x 32 output channels, a contiguous range of time tiles; its 4 waves either split the time steps of a tile
-// (KS <= 5: every wave accumulates all taps) or split the taps (KS <= 16).  Partial sums are combined with fp32
-// atomics into a zero-initialised G (summation order is therefore not fixed run to run, error ~1e-7 relative).
+// GEMM view per tap: G_k = A (Ca x N) * Bm_k^T (N x Cb), N = (b,t) — the reduction runs over TIME.  A workgroup owns a
+// 128 (ca) x 64 (cb) x NK (taps) block of G and a contiguous range of time tiles; its 4 waves (2 x 2) each hold a
+// 64 x 32 x NK accumulator block (2*NK MFMA tiles), so one staged time tile feeds 8*NK MFMA tiles.  Tiles staged in
+// LDS: As[128][TT] and Bs[64][TT + (NK-1)*dil] with an ODD row pitch — an MFMA operand fetch has its 32 lanes on 32
+// different channel rows at the same time step, which an odd pitch spreads over 32 banks.  The global loads of tile
+// i+1 are issued into registers before the MFMA loop over tile i and written to LDS after it (same software pipeline
+// as conv1d_mfma).  KS > 5 is split into tap groups that run as separate workgroups (blockIdx.x carries the group).
+// Partial sums over the time splits are combined with fp32 atomics into a zero-initialised G (summation order is
+// therefore not fixed run to run, error ~1e-7 relative).
 #include "common.h"
 #include <algorithm>
 
 namespace {
 
-constexpr int TT = 128;     // time steps per staged tile
-constexpr int CA_T = 64;    // rows of A per workgroup (2 MFMA tiles)
-constexpr int CB_T = 32;    // rows of Bm per workgroup (1 MFMA tile)
+constexpr int TT = 64;      // time steps per staged tile
+constexpr int CA_T = 128;   // rows of A per workgroup (2 x 2 MFMA tiles)
+constexpr int CB_T = 64;    // rows of Bm per workgroup (2 MFMA tiles)
+constexpr int PA = TT + 1;
+constexpr int MAXHALO_W = 44;            // (NK-1)*dil supported (k5 at dilation 11: DiscriminatorP period 11)
+constexpr int BCOLS = (TT + MAXHALO_W + 63) / 64;   // column iterations per B row
 
 struct WgP {
   const float* A;
@@ -26,23 +32,28 @@ struct WgP {
   float* G;
   long long a_bs, a_cs, b_bs, b_cs;
   int B, Ca, Cb, TA, TB, KS, dil, pad;
-  int tiles_per_b, n_tiles, tiles_per_wg, PB;
+  int tiles_per_b, n_tiles, tiles_per_wg, PB, n_kgroups, splits;
 };
 
-template <int MODE, int NK>  // MODE 0: waves split time, NK taps each;  MODE 1: waves split taps, NK taps each
+template <int NK>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
-  constexpr int PA = TT + 1;
   extern __shared__ float lds[];
   float* As = lds;               // [CA_T][PA]
   float* Bs = lds + CA_T * PA;   // [CB_T][PB]
   const int PB = p.PB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, lk = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
   const int ca0 = blockIdx.y * CA_T, cb0 = blockIdx.z * CB_T;
-  const int tile0 = blockIdx.x * p.tiles_per_wg;
+  const int kg = blockIdx.x % p.n_kgroups;
+  const int split = blockIdx.x / p.n_kgroups;
+  const int k0 = kg * NK;
+  const int nk = min(NK, p.KS - k0);               // taps of this group
+  const int tile0 = split * p.tiles_per_wg;
   const int tile1 = min(tile0 + p.tiles_per_wg, p.n_tiles);
-  const int halo = (p.KS - 1) * p.dil;
+  const int halo = (nk - 1) * p.dil;
   const int XWB = TT + halo;
+  const int boff = k0 * p.dil - p.pad;             // Bm index = t + boff + q*dil
 
   f32x16 acc[NK][2];
 #pragma unroll
@@ -52,70 +63,122 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
 
-  for (int tile = tile0; tile < tile1; ++tile) {
+  // staging maps: A slot i -> row i*4 + wave, column lane;  B slot (j,cj) -> row j*4 + wave, column cj*64 + lane
+  float areg[CA_T / 4];
+  float breg[(CB_T / 4) * BCOLS];
+
+  auto load_tile = [&](int tile) {
     const int b = tile / p.tiles_per_b;
     const int t0 = (tile - b * p.tiles_per_b) * TT;
-    __syncthreads();
-    // stage A tile: CA_T rows x TT, coalesced along t
-    for (int idx = tid; idx < CA_T * TT; idx += 256) {
-      const int r = idx / TT, c = idx - r * TT;
-      const int ca = ca0 + r, t = t0 + c;
-      float v = 0.f;
-      if (ca < p.Ca && t < p.TA) v = p.A[b * p.a_bs + ca * p.a_cs + t];
-      As[r * PA + c] = v;
-    }
-    for (int idx = tid; idx < CB_T * XWB; idx += 256) {
-      const int r = idx / XWB, c = idx - r * XWB;
-      const int cb = cb0 + r, t = t0 + c - p.pad;
-      float v = 0.f;
-      if (cb < p.Cb && t >= 0 && t < p.TB) v = p.Bm[b * p.b_bs + cb * p.b_cs + t];
-      Bs[r * PB + c] = v;
-    }
-    __syncthreads();
-    const float* ap = As + ln * PA + lk;
-    const float* bp = Bs + ln * PB + lk;
-    if constexpr (MODE == 0) {
-      const int s0 = wave * (TT / 4), s1 = s0 + TT / 4;
-      for (int s = s0; s < s1; s += 2) {
-        const float a0 = ap[s], a1 = ap[32 * PA + s];
+    const float* ab = p.A + (long long)b * p.a_bs;
+    const float* bb = p.Bm + (long long)b * p.b_bs;
+    const int ta = min(t0 + lane, p.TA - 1);
 #pragma unroll
-        for (int q = 0; q < NK; ++q) {
-          if (q < p.KS) {
-            const float bv = bp[s + q * p.dil];
-            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
-          }
-        }
+    for (int i = 0; i < CA_T / 4; ++i) {
+      const int ca = min(ca0 + i * 4 + wave, p.Ca - 1);
+      areg[i] = ab[(long long)ca * p.a_cs + ta];
+    }
+#pragma unroll
+    for (int j = 0; j < CB_T / 4; ++j) {
+      const int cb = min(cb0 + j * 4 + wave, p.Cb - 1);
+#pragma unroll
+      for (int cj = 0; cj < BCOLS; ++cj) {
+        const int tb = min(max(t0 + boff + cj * 64 + lane, 0), p.TB - 1);
+        breg[j * BCOLS + cj] = bb[(long long)cb * p.b_cs + tb];
       }
-    } else {
-      for (int s = 0; s < TT; s += 2) {
-        const float a0 = ap[s], a1 = ap[32 * PA + s];
+    }
+  };
+  auto store_tile = [&](int tile) {
+    const int b = tile / p.tiles_per_b;
+    const int t0 = (tile - b * p.tiles_per_b) * TT;
+    const bool ta_ok = t0 + lane < p.TA;
 #pragma unroll
-        for (int q = 0; q < NK; ++q) {
-          const int k = wave + 4 * q;
-          if (k < p.KS) {
-            const float bv = bp[s + k * p.dil];
-            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
-          }
+    for (int i = 0; i < CA_T / 4; ++i) {
+      const int r = i * 4 + wave;
+      As[r * PA + lane] = (ta_ok && ca0 + r < p.Ca) ? areg[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < CB_T / 4; ++j) {
+      const int r = j * 4 + wave;
+      const bool rok = cb0 + r < p.Cb;
+#pragma unroll
+      for (int cj = 0; cj < BCOLS; ++cj) {
+        const int c = cj * 64 + lane;
+        const int tb = t0 + boff + c;
+        if (c < XWB) Bs[r * PB + c] = (rok && tb >= 0 && tb < p.TB) ? breg[j * BCOLS + cj] : 0.f;
+      }
+    }
+  };
+
+  const float* ap = As + (wm * 64 + ln) * PA + lk;
+  const float* bp = Bs + (wn * 32 + ln) * PB + lk;
+  const int dil = p.dil;
+  if (tile0 < tile1) load_tile(tile0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    __syncthreads();   // previous tile fully consumed
+    store_tile(tile);
+    __syncthreads();
+    if (tile + 1 < tile1) load_tile(tile + 1);   // in flight during the MFMA loop
+#pragma unroll 4
+    for (int s = 0; s < TT; s += 2) {
+      const float a0 = ap[s], a1 = ap[32 * PA + s];
+      float bv[NK];
+#pragma unroll
+      for (int q = 0; q < NK; ++q) bv[q] = q < nk ? bp[s + q * dil] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        if (q < nk) {
+          acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
+          acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
         }
       }
     }
   }
-  // combine: G[ca][cb][k] += acc
-  const int cb = cb0 + ln;
+  // combine: G[ca][cb][k0..k0+nk) += acc.  The MFMA C layout has one cb column per lane (addresses KS floats apart), so
+  // each wave first transposes 16 ca rows at a time through LDS into G's own [cb][k] order: consecutive lanes then
+  // add to consecutive addresses (coalesced atomics: one request per cache line instead of one per lane).
+  __syncthreads();   // all waves are done with As / Bs
+  const int RW = 32 * nk;                 // floats per staged row
+  const int RP = RW + 1;
+  float* Wt = lds + wave * 16 * (32 * NK + 1);
+  const int cbw = cb0 + wn * 32;
 #pragma unroll
-  for (int q = 0; q < NK; ++q) {
-    const int k = MODE == 0 ? q : wave + 4 * q;
-    if (k >= p.KS || cb >= p.Cb) continue;
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ca = ca0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (ca < p.Ca) atomicAdd(p.G + ((long long)ca * p.Cb + cb) * p.KS + k, acc[q][i][r]);
+      for (int q = 0; q < NK; ++q) {
+        if (q < nk) {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = hf * 8 + rr;
+            const int rl = (rr & 3) + 8 * (rr >> 2) + 4 * lk;      // 0..15 inside this half
+            Wt[rl * RP + ln * nk + q] = acc[q][i][r];
+          }
+        }
       }
+      __syncthreads();   // slab written (uniform trip counts: every wave reaches the barriers)
+      // rows of this half: MFMA row (r&3) + 8*(r>>2) + 4*lk with r in [8hf, 8hf+8) -> 16*hf + rl
+      const int ca_base = ca0 + wm * 64 + i * 32 + 16 * hf;
+      for (int idx = lane; idx < 16 * RW; idx += 64) {
+        const int rl = idx / RW, col = idx - rl * RW;
+        const int cbl = col / nk, q = col - cbl * nk;
+        const int ca = ca_base + rl, cb = cbw + cbl;
+        if (ca < p.Ca && cb < p.Cb) {
+          float* g = p.G + ((long long)ca * p.Cb + cb) * p.KS + k0 + q;
+          const float v = Wt[rl * RP + col];
+          if (p.splits > 1) atomicAdd(g, v);
+          else *g += v;
+        }
+      }
+      __syncthreads();   // slab consumed before the next half overwrites it
+    }
   }
+}
+
+template <int NK>
+void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((conv1d_wgrad_kernel<NK>), grid, dim3(256), lds, s, p);
 }
 
 }  // namespace
@@ -125,7 +188,7 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   const svc_wgrad_args& a = *ap;
   SVC_REQUIRE(a.A && a.Bm && a.G, "wgrad: null tensor");
   SVC_REQUIRE(a.B > 0 && a.Ca > 0 && a.Cb > 0 && a.TA > 0 && a.TB > 0, "wgrad: empty shape");
-  SVC_REQUIRE(a.KS >= 1 && a.KS <= 16 && a.dil >= 1, "wgrad: KS must be in [1,16] (got %d)", a.KS);
+  SVC_REQUIRE(a.KS >= 1 && a.KS <= 256 && a.dil >= 1, "wgrad: KS must be in [1,256] (got %d)", a.KS);
   hipStream_t s = (hipStream_t)stream;
   const double flop = 2.0 * a.B * (double)a.Ca * a.Cb * a.KS * a.TA;
   svc::ProfScope prof(s, "conv1d_wgrad", flop, 4.0 * a.B * ((double)a.Ca * a.TA + (double)a.Cb * a.TB));
@@ -135,28 +198,37 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
       return SVC_ERR_HIP;
     }
   }
+  // taps per workgroup: as many as the halo budget and 5 accumulator sets allow
+  int nk = std::min(a.KS, 5);
+  while (nk > 1 && (nk - 1) * a.dil > MAXHALO_W) --nk;
+  if (a.KS > 5 && nk > 4) nk = 4;          // balanced groups for 7 (4+3) and 11 (4+4+3)
   WgP p;
   p.A = a.A; p.Bm = a.Bm; p.G = a.G;
   p.a_bs = a.a_bs; p.a_cs = a.a_cs; p.b_bs = a.b_bs; p.b_cs = a.b_cs;
   p.B = a.B; p.Ca = a.Ca; p.Cb = a.Cb; p.TA = a.TA; p.TB = a.TB; p.KS = a.KS; p.dil = a.dil; p.pad = a.pad;
+  p.n_kgroups = svc::cdiv(a.KS, nk);
   p.tiles_per_b = svc::cdiv(a.TA, TT);
   p.n_tiles = p.tiles_per_b * a.B;
   const int n_ca = svc::cdiv(a.Ca, CA_T), n_cb = svc::cdiv(a.Cb, CB_T);
-  // enough time-splits to fill the chip (~1024 workgroups), at least 1 tile each
-  int splits = std::max(1, 1024 / (n_ca * n_cb));
-  splits = std::min(splits, p.n_tiles);
+  // enough time-splits to fill the chip (~512 workgroups = 2 rounds at one workgroup per CU; every split costs one
+  // atomic pass over G), at least 2 tiles each so the prefetch has something to hide
+  int splits = std::max(1, 512 / (n_ca * n_cb * p.n_kgroups));
+  splits = std::min(splits, std::max(1, p.n_tiles / 2));
   p.tiles_per_wg = svc::cdiv(p.n_tiles, splits);
   splits = svc::cdiv(p.n_tiles, p.tiles_per_wg);
-  int pb = TT + (a.KS - 1) * a.dil;
+  p.splits = splits;
+  int pb = TT + (nk - 1) * a.dil;
   if ((pb & 1) == 0) ++pb;
   p.PB = pb;
-  const size_t lds = sizeof(float) * ((size_t)CA_T * (TT + 1) + (size_t)CB_T * pb);
-  SVC_REQUIRE(lds <= 64 * 1024, "wgrad: halo too large (KS=%d dil=%d)", a.KS, a.dil);
-  dim3 grid(splits, n_ca, n_cb);
-  if (a.KS <= 1) hipLaunchKernelGGL((conv1d_wgrad_kernel<0, 1>), grid, dim3(256), lds, s, p);
-  else if (a.KS <= 3) hipLaunchKernelGGL((conv1d_wgrad_kernel<0, 3>), grid, dim3(256), lds, s, p);
-  else if (a.KS <= 5) hipLaunchKernelGGL((conv1d_wgrad_kernel<0, 5>), grid, dim3(256), lds, s, p);
-  else if (a.KS <= 12) hipLaunchKernelGGL((conv1d_wgrad_kernel<1, 3>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((conv1d_wgrad_kernel<1, 4>), grid, dim3(256), lds, s, p);
+  size_t lds = sizeof(float) * ((size_t)CA_T * PA + (size_t)CB_T * pb);
+  lds = std::max(lds, sizeof(float) * (size_t)4 * 16 * (32 * 5 + 1));     // epilogue transpose slabs
+  dim3 grid(splits * p.n_kgroups, n_ca, n_cb);
+  switch (nk) {
+    case 1: launch<1>(p, grid, lds, s); break;
+    case 2: launch<2>(p, grid, lds, s); break;
+    case 3: launch<3>(p, grid, lds, s); break;
+    case 4: launch<4>(p, grid, lds, s); break;
+    default: launch<5>(p, grid, lds, s); break;
+  }
   return svc::check_launch("conv1d_wgrad");
 }

@@ -295,21 +295,27 @@ __global__ void scalar_to_float_kernel(const double* __restrict__ in, float* __r
 }
 
 // ---- fused AdamW (train.py:79-88: lr, betas=(0.8,0.99), eps=1e-9, weight_decay default 0.01) -------------------
+// Hyper-parameters live in DEVICE memory (hyper = [lr, beta1, beta2, eps, weight_decay, step, grad_scale]) so that a
+// captured hipGraph of the whole training step stays valid while the step count advances and the scheduler changes lr.
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2, float gscale) {
+                             float* __restrict__ v, long long n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5],
+              gscale = hyper[6];
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  const float sq_bc2 = sqrtf(bc2), step_size = lr / bc1, decay = 1.f - lr * wd;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
-    float pi = p[i] * (1.f - lr * wd);
+    float pi = p[i] * decay;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    pi -= (lr / bc1) * (mi / denom);
+    const float denom = sqrtf(vi) / sq_bc2 + eps;
+    pi -= step_size * (mi / denom);
     p[i] = pi;
   }
 }
+__global__ void adamw_advance_kernel(float* hyper) { hyper[5] += 1.f; }
 
 static inline unsigned grid1d(long long n, int bs = 256, unsigned cap = 65535u * 8) {
   long long g = (n + bs - 1) / bs;
@@ -436,13 +442,16 @@ int svc_f64_to_f32(const double* in, float* out, int n, void* stream) {
   return svc::check_launch("f64_to_f32");
 }
 
-int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, void* stream) {
-  SVC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
-  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, grad_scale);
+int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, const float* hyper, void* stream) {
+  SVC_REQUIRE(p && g && m && v && hyper && n > 0, "adamw: bad args");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper);
   return svc::check_launch("adamw");
+}
+
+int svc_adamw_advance(float* hyper, void* stream) {
+  SVC_REQUIRE(hyper != nullptr, "adamw_advance: null hyper");
+  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
+  return svc::check_launch("adamw_advance");
 }
 
 }  // extern "C"

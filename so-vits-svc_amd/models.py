@@ -285,7 +285,10 @@ class SynthesizerTrn(nn.Module):
         if self.use_automatic_f0_prediction:
             factor = noise.get("f0_factor")
             if factor is None:
-                factor = torch.empty(B, 1).uniform_(0.8, 1.2).to(c.device)              # utils.py:39
+                if commons.DEVICE_RNG:
+                    factor = torch.empty(B, 1, device=c.device).uniform_(0.8, 1.2)
+                else:
+                    factor = torch.empty(B, 1).uniform_(0.8, 1.2).to(c.device)          # utils.py:39 (CPU draw)
             lf0, norm_lf0 = S.f0_norm_lf0(f0, uv, mask=x_mask, factor=factor.reshape(-1))   # :474-475 (no grad: inputs)
             pred_lf0 = self.f0_decoder(x, norm_lf0, x_mask, spk_emb=gemb)
         else:

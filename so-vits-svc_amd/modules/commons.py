@@ -40,13 +40,21 @@ def slice_pitch_segments(x, ids_str, segment_size=4):
     return torch.gather(x, 1, idx)
 
 
+DEVICE_RNG = False   # True: draw the per-item randoms on the device (needed inside a hipGraph capture: no H2D copies)
+
+
+def _rand(b, device):
+    """Reference: `torch.rand([b]).to(device)` — a CPU draw copied over (:20); on-device when DEVICE_RNG is set."""
+    return torch.rand([b], device=device) if DEVICE_RNG else torch.rand([b]).to(device=device)
+
+
 def rand_slice_segments_with_pitch(x, pitch, x_lengths=None, segment_size=4):
     """Reference :15-23: one uniform draw per batch item, start = floor(u * (len - seg + 1))."""
     b, d, t = x.size()
     if x_lengths is None:
         x_lengths = t
     ids_str_max = x_lengths - segment_size + 1
-    ids_str = (torch.rand([b]).to(device=x.device) * ids_str_max).to(dtype=torch.long)
+    ids_str = (_rand(b, x.device) * ids_str_max).to(dtype=torch.long)
     return slice_segments(x, ids_str, segment_size), slice_pitch_segments(pitch, ids_str, segment_size), ids_str
 
 
@@ -55,7 +63,7 @@ def rand_slice_segments(x, x_lengths=None, segment_size=4):
     if x_lengths is None:
         x_lengths = t
     ids_str_max = x_lengths - segment_size + 1
-    ids_str = (torch.rand([b]).to(device=x.device) * ids_str_max).to(dtype=torch.long)
+    ids_str = (_rand(b, x.device) * ids_str_max).to(dtype=torch.long)
     return slice_segments(x, ids_str, segment_size), ids_str
 
 

@@ -149,6 +149,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, device=self.arena.device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=self.arena.device, dtype=torch.float32)
         self._steps = [0] * len(params)     # per-parameter step counts (torch semantics: a skipped parameter lags)
+        self._gstep = 0                     # number of step() calls that updated something
+        self._hyper = {}                    # lag -> dict(buf=device float[7], step=host mirror of buf[5], host=(lr, ...))
+        self._captured_plan = None
         self.grad_scale = 1.0          # multiplied into the gradient inside the kernel (GradScaler's 1/scale)
         for i, p in enumerate(params):
             o = self.arena.offsets[i]
@@ -159,6 +162,70 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         self.arena.zero_grad()
 
+    # -- hyper-parameters in device memory (svc_adamw_f32 reads them there: hipGraph-safe) ----------------------------
+    def _host_hyper(self):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        return (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), float(self.grad_scale))
+
+    def _hyper_for(self, lag, step_before):
+        """Device float[7] for the parameters whose step count lags the optimizer's by `lag` (0 for all of them unless
+        some parameter was skipped once); its step field holds `step_before` and is advanced on the device."""
+        ent = self._hyper.get(lag)
+        hh = self._host_hyper()
+        if ent is None or ent["step"] != step_before or ent["host"] != hh:
+            lr, b1, b2, eps, wd, gs = hh
+            buf = ent["buf"] if ent is not None else torch.empty(7, device=self.arena.device, dtype=torch.float32)
+            if torch.cuda.is_current_stream_capturing():
+                raise S.SvcError("FusedAdamW: hyper-parameters changed inside a hipGraph capture; call sync_hyper() "
+                                 "before capturing / replaying")
+            buf.copy_(torch.tensor([lr, b1, b2, eps, wd, float(step_before), gs], dtype=torch.float32))
+            ent = dict(buf=buf, step=step_before, host=hh)
+            self._hyper[lag] = ent
+        return ent
+
+    def sync_hyper(self):
+        """Push lr / betas / eps / weight_decay / grad_scale changes (lr scheduler, GradScaler) to the device copies.
+        step() does this itself; a captured training step must call it before every replay."""
+        hh = self._host_hyper()
+        for lag, ent in self._hyper.items():
+            if ent["host"] != hh:
+                lr, b1, b2, eps, wd, gs = hh
+                ent["buf"].copy_(torch.tensor([lr, b1, b2, eps, wd, float(ent["step"]), gs], dtype=torch.float32))
+                ent["host"] = hh
+
+    def note_replayed_step(self):
+        """Host bookkeeping for one replay of a hipGraph that captured step(): the device-side step counters advanced
+        by themselves; mirror that in the per-parameter step counts / hyper mirrors (same parameters as at capture)."""
+        if self._captured_plan is None:
+            raise S.SvcError("FusedAdamW.note_replayed_step: no step() was captured")
+        touched, lags = self._captured_plan
+        self._steps = [n + 1 if t else n for n, t in zip(self._steps, touched)]
+        self._gstep += 1
+        for lag in lags:
+            self._hyper[lag]["step"] += 1
+        torch.autograd.graph.increment_version([p for p, t in zip(self.arena.params, touched) if t])
+
+    def snapshot(self):
+        """Everything step() changes (used to run un-counted warm-up iterations before a hipGraph capture)."""
+        return dict(param=self.arena.param.clone(), m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(),
+                    steps=list(self._steps), gstep=self._gstep, hsteps={k: e["step"] for k, e in self._hyper.items()})
+
+    def restore(self, snap, device=True):
+        self._steps = list(snap["steps"])
+        self._gstep = snap["gstep"]
+        for lag, ent in self._hyper.items():
+            ent["step"] = snap["hsteps"].get(lag, self._gstep - lag)
+        if device:
+            with torch.no_grad():
+                self.arena.param.copy_(snap["param"])
+                self.exp_avg.copy_(snap["m"])
+                self.exp_avg_sq.copy_(snap["v"])
+                for lag, ent in self._hyper.items():
+                    lr, b1, b2, eps, wd, gs = ent["host"]
+                    ent["buf"].copy_(torch.tensor([lr, b1, b2, eps, wd, float(ent["step"]), gs], dtype=torch.float32))
+            torch.autograd.graph.increment_version(self.arena.params)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -167,15 +234,22 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         a = self.arena
         a.check_views()
-        g = self.param_groups[0]
-        self._steps = [n + 1 if t else n for n, t in zip(self._steps, a.touched)]
-        runs = a.touched_runs(self._steps)       # one run == one launch; normally a single run over the whole arena
-        if not runs:
+        if not any(a.touched):
             return loss
-        b1, b2 = g["betas"]
-        for s, e, step in runs:
-            S.adamw_step(a.param[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], float(g["lr"]), float(b1),
-                         float(b2), float(g["eps"]), float(g["weight_decay"]), step, float(self.grad_scale))
+        self._gstep += 1
+        self._steps = [n + 1 if t else n for n, t in zip(self._steps, a.touched)]
+        lags = [self._gstep - n for n in self._steps]
+        runs = a.touched_runs(lags)              # one run == one launch; normally a single run over the whole arena
+        used = []
+        for lag in sorted(set(r[2] for r in runs)):
+            ent = self._hyper_for(lag, self._gstep - lag - 1)
+            S.adamw_advance(ent["buf"])
+            ent["step"] += 1
+            used.append(lag)
+        for s, e, lag in runs:
+            S.adamw_step(a.param[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self._hyper[lag]["buf"])
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_plan = (list(a.touched), used)
         # the kernel wrote the arena behind torch's back: bump the version counters so that cached packed weights
         # (svc_nn._PackedMixin, keyed on `_version`) are rebuilt and autograd's saved-tensor checks stay valid
         torch.autograd.graph.increment_version([p for p, t in zip(a.params, a.touched) if t])
@@ -201,3 +275,5 @@ class FusedAdamW(torch.optim.Optimizer):
                         view.copy_(st[name])
                         st[name] = view
                 self._steps[i] = int(float(st["step"]))
+        self._gstep = max(self._steps) if self._steps else 0
+        self._hyper = {}

@@ -502,7 +502,7 @@ TRAIN_EXPORTS = [
     "svc_weight_norm_fwd_f32", "svc_weight_norm_bwd_f32", "svc_pack_conv1d_weight_T", "svc_conv1d_wgrad_f32",
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
-    "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_debug_set_conv_cfg",
+    "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_adamw_advance", "svc_debug_set_conv_cfg",
 ]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
@@ -532,7 +532,8 @@ def tlib():
         L.svc_gconv1d_wgrad_f32.argtypes = [_f32p] * 3 + [i] * 9 + [vp]
         L.svc_reduce_scalar_f64.argtypes = [i, _f32p, _f32p, _f32p, _f32p, ll, vp, C.c_double, vp]
         L.svc_f64_to_f32.argtypes = [vp, _f32p, i, vp]
-        L.svc_adamw_f32.argtypes = [_f32p] * 4 + [ll, f, f, f, f, f, i, f, vp]
+        L.svc_adamw_f32.argtypes = [_f32p] * 4 + [ll, _f32p, vp]
+        L.svc_adamw_advance.argtypes = [_f32p, vp]
         L.svc_debug_set_conv_cfg.argtypes = [i]
         _train_bound = True
     return L
@@ -747,10 +748,14 @@ def f64_to_f32(acc):
     return out
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    require_gpu(p, g, m, v)
-    check(tlib().svc_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                               grad_scale, stream_ptr()), "adamw")
+def adamw_step(p, g, m, v, hyper):
+    """One fused AdamW update of the flat buffers; hyper = device float[7] (lr, b1, b2, eps, wd, step, grad_scale)."""
+    require_gpu(p, g, m, v, hyper)
+    check(tlib().svc_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), stream_ptr()), "adamw")
+
+
+def adamw_advance(hyper):
+    check(tlib().svc_adamw_advance(ptr(hyper), stream_ptr()), "adamw_advance")
 
 
 # ---- second batch of training entry points (layernorm / attention pieces / embedding / reparam / nsf / kl / stft) ----

@@ -63,12 +63,64 @@ class TrainStep:
         if _get(t, "fp16_run"):
             raise NotImplementedError("fp16_run/bf16 autocast is not implemented: the MI355X engine trains in fp32")
 
-    def _disc(self, y, y_hat):
-        return self.net_d(y, y_hat)
+        self.use_graph = False
+        self._graphs = {}
+
+    def enable_graph(self, on=True):
+        """Replay the whole iteration (forward, both backwards, both optimizer steps: ~7000 launches) from ONE hipGraph
+        per input shape — the eager step is bound by the host's launch rate, not by the GPU.  Random draws then come
+        from the device generator (commons.DEVICE_RNG).  Bucket / pad T in the data pipeline to bound the graph count."""
+        self.use_graph = bool(on)
+        if not on:
+            self._graphs.clear()
+        return self
 
     def __call__(self, items, noise=None):
         """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
         returns a dict of 0-dim device tensors."""
+        if self.use_graph:
+            return self._call_graph(items, noise)
+        return self._step_body(items, noise)
+
+    def _call_graph(self, items, noise=None):
+        nkeys = sorted(noise) if noise is not None else []
+        items = list(items) + [noise[k] for k in nkeys]
+        key = tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
+        ent = self._graphs.get(key)
+        n_in = len(items) - len(nkeys)
+        if ent is None:
+            commons.DEVICE_RNG = True
+            static = [t.clone() if t is not None else None for t in items]
+            run = lambda: self._step_body(static[:n_in], dict(zip(nkeys, static[n_in:])) if nkeys else None)
+            snaps = (self.optim_g.snapshot(), self.optim_d.snapshot())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                       # warm-up: weight packs, kernel attributes, allocator pools
+                    run()
+            torch.cuda.current_stream().wait_stream(side)
+            self.optim_g.restore(snaps[0])               # ... without counting as training steps
+            self.optim_d.restore(snaps[1])
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
+            self.optim_g.restore(snaps[0], device=False)   # capture ran the host bookkeeping but no kernels
+            self.optim_d.restore(snaps[1], device=False)
+            ent = (graph, static, out)
+            self._graphs[key] = ent
+        graph, static, out = ent
+        for s, t in zip(static, items):
+            if s is not None:
+                s.copy_(t, non_blocking=True)
+        self.optim_g.sync_hyper()
+        self.optim_d.sync_hyper()
+        graph.replay()
+        self.optim_d.note_replayed_step()
+        self.optim_g.note_replayed_step()
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+    def _step_body(self, items, noise=None):
         c, f0, spec, y, spk, lengths, uv, volume = items
         net_g, net_d = self.net_g, self.net_d
         gmod = net_g.module if hasattr(net_g, "module") else net_g

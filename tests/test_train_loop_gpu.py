@@ -26,7 +26,10 @@ def _hps(cs, lr):
                 model=model)
 
 
-def test_train_loop_matches_reference_loop(dev):
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_loop_matches_reference_loop(dev, graph):
+    """graph=True: the whole iteration replayed from one hipGraph (TrainStep.enable_graph) must give the same losses and
+    parameters — incl. the device-side AdamW step counter / bias correction advancing across replays."""
     import train as T
     cs = load_case()
     z = np.load(os.path.join(G, "train_loop_small.npz"), allow_pickle=False)
@@ -38,7 +41,7 @@ def test_train_loop_matches_reference_loop(dev):
     optim_g.arena.check_views()                      # load_state_dict copies in place: the arena views survive
     net_g.train()
     net_d.train()
-    step = T.TrainStep(hps, net_g, net_d, optim_g, optim_d)
+    step = T.TrainStep(hps, net_g, net_d, optim_g, optim_d).enable_graph(graph)
     c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
     noise = {k: v.to(dev) for k, v in cs["noise"].items()}
     items = (c, f0, spec, y, sid, lengths, uv, None)
