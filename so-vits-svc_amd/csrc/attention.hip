@@ -6,18 +6,19 @@
 //
 // Layout: q,k,v,out are [B, heads*dk, T] channel-major views (time contiguous) — exactly what the 1x1 conv
 // projections produce, so no transposes exist anywhere.  One workgroup = (32 queries, one head, one batch
-// item), 4 waves splitting the key tiles.  We compute S^T = K Q^T (M = keys, N = queries) so that in the MFMA
+// item), 8 waves splitting the key tiles.  We compute S^T = K Q^T (M = keys, N = queries) so that in the MFMA
 // C layout every lane owns ONE query column: softmax statistics are a 16-register reduction plus one
 // lane^32 exchange, and P^T is already the B operand of the second MFMA  O^T = V^T P^T  (the k index
 // order inside the tile is permuted to match the C layout; a sum does not care).  T x T scores are never
-// materialised.  Two passes over the keys (pass 1: exact row max / sum, pass 2: normalised P and PV) keep
-// the softmax bit-compatible with exp(x - max) / sum and avoid online rescaling; attention is < 1 % of the
-// path's FLOPs, so the second QK^T is free next to the convolutions.
+// materialised.  One pass over the keys with an online softmax: every wave keeps a running (max, sum) per query
+// column and rescales its O accumulators when the max grows; the 8 waves of a workgroup split the key tiles and are
+// combined at the end (M = max m_w, L = sum l_w e^{m_w-M}); the 2w+1 band probabilities the relative-VALUE term needs
+// are recomputed from q.k once M and L are known (9 dot products per query).
 #include "common.h"
 
 namespace {
 
-constexpr int NW = 4;        // waves per workgroup
+constexpr int NW = 8;        // waves per workgroup (they split the key tiles)
 constexpr int MAXREL = 17;   // 2*window+1 <= 17
 
 struct AttnP {
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // carve
   float* Vl = lds;                                  // [NW][DK][VP]   (aliased by Ol [NW][DK][32] after the loop)
-  float* Rk = Vl + NW * DK * VP;                    // [MAXREL][32]
-  float* Pl = Rk + MAXREL * 32;                     // [MAXREL][32]
+  float* Rk = Vl + NW * DK * VP;                    // [MAXREL][32]  relative-key logits of this query tile
+  float* Pl = Rk + MAXREL * 32;                     // [MAXREL][32]  normalised band probabilities
   float* Ml = Pl + MAXREL * 32;                     // [NW][32]
   float* Ll = Ml + NW * 32;                         // [NW][32]
 
@@ -68,26 +69,48 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
     if (i0 + ii < T)
       for (int d = 0; d < DK; ++d) acc = fmaf(qb[(long long)d * a.q_cs + i0 + ii] / sqrtk, a.emb_rel_k[m * DK + d], acc);
     Rk[idx] = acc;
-    Pl[idx] = 0.f;
   }
   __syncthreads();
 
   const float mi = mq ? (i < T ? mq[i] : 0.f) : 1.f;
   const int n_iter = (p.nJ + NW - 1) / NW;
 
-  // scores of key tile jt for this lane's query column -> sc[16] (rows crow(r,half)); -inf outside [0,T)
-  auto score_tile = [&](int j0, float (&sc)[16]) {
+  // ---------------- one pass over this wave's key tiles: online softmax (running max / sum per query column, which
+  // is one LANE in the MFMA C layout), O^T += V^T P^T with P = exp(s - m_run) ----------------
+  float mrun = -INFINITY, lrun = 0.f;
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float* Vw = Vl + w * DK * VP;
+  for (int it = 0; it < n_iter; ++it) {
+    const int jt = it * NW + w;
+    const int j0 = jt * 32;
+    if (jt >= p.nJ) continue;
+    if (a.mask_mode == 2 && j0 > i0 + 31) continue;  // fully-masked causal tile contributes exp(-1e4 - max) == 0
+    // ---- scores S^T tile (keys x queries) ----
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int jl = j0 + li;
     const bool jok = jl < T;
+    const int jc = jok ? jl : T - 1;
+    const int koff = half * (int)a.k_cs + jc, voff = half * (int)a.v_cs + jc;
+    // 16 K rows at a time (a scheduling barrier between groups keeps at most 16 loads in flight: the fully hoisted
+    // form needs DK/2 more live registers than the 256 available at two waves per SIMD)
 #pragma unroll
-    for (int s = 0; s < DK / 2; ++s) {
-      const int d = 2 * s + half;
-      const float kv = jok ? kb[(long long)d * a.k_cs + jl] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qreg[s], acc, 0, 0, 0);
+    for (int c = 0; c < DK / 32; ++c) {
+      float kv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) kv[u] = (kb + (long long)(2 * (c * 16 + u)) * a.k_cs)[koff];   // uniform row + lane offset
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jok ? kv[u] : 0.f, qreg[c * 16 + u], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    float sc[16];
+    float tm = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + crow(r, half);
@@ -100,30 +123,52 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
       if (masked) s = -1e4f;
       if (j >= T) s = -INFINITY;
       sc[r] = s;
+      tm = fmaxf(tm, s);
     }
-  };
-
-  // ---------------- pass 1: row max and sum ----------------
-  float mrun = -INFINITY, lrun = 0.f;
-  for (int it = 0; it < n_iter; ++it) {
-    const int jt = it * NW + w;
-    const int j0 = jt * 32;
-    if (jt >= p.nJ) continue;
-    if (a.mask_mode == 2 && j0 > i0 + 31) continue;  // fully-masked causal tile contributes exp(-1e4 - max) == 0
-    float sc[16];
-    score_tile(j0, sc);
-    float tm = sc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
     tm = fmaxf(tm, __shfl_xor(tm, 32));
-    const float mnew = fmaxf(mrun, tm);
+    const float mnew = fmaxf(mrun, tm);          // finite: every tile has at least one key < T
+    const float resc = __expf(mrun - mnew);      // exp(-inf) = 0 on the first tile
+    float pr[16];
     float ts = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ts += expf(sc[r] - mnew);
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = __expf(sc[r] - mnew);
+      ts += pr[r];
+    }
     ts += __shfl_xor(ts, 32);
-    lrun = lrun * expf(mrun - mnew) + ts;
+    lrun = lrun * resc + ts;
     mrun = mnew;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= resc;
+    // ---- stage V (pitch 33: the A-operand fetch below has its 32 lanes on 32 different d rows) ----
+#pragma unroll
+    for (int c = 0; c < DK / 32; ++c) {
+      float vv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) vv[u] = (vb + (long long)(2 * (c * 16 + u)) * a.v_cs)[voff];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Vw[(2 * (c * 16 + u) + half) * VP + li] = jok ? vv[u] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the slab is private to this wave: LDS ops of one wave complete in order, no workgroup barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float av = Vw[(dt * 32 + li) * VP + crow(r, half)];
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+
+  // ---------------- combine the waves: M = max m_w, L = sum l_w e^{m_w - M}, O = sum O_w e^{m_w - M} / L ----------------
   if (half == 0) {
     Ml[w * 32 + li] = mrun;
     Ll[w * 32 + li] = lrun;
@@ -135,55 +180,42 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
 #pragma unroll
   for (int ww = 0; ww < NW; ++ww) {
     const float mw = Ml[ww * 32 + li];
-    if (mw > -INFINITY) Lsum += Ll[ww * 32 + li] * expf(mw - M);
+    if (mw > -INFINITY) Lsum += Ll[ww * 32 + li] * __expf(mw - M);
   }
-
-  // ---------------- pass 2: P = exp(s - M) / L, O^T += V^T P^T ----------------
-  f32x16 oacc[NDT];
+  const float wsc = mrun > -INFINITY ? __expf(mrun - M) / Lsum : 0.f;
+  // relative-value band: p[i, i+r] for |r| <= window recomputed from q.k (9 dot products per query; needs M and L)
+  for (int idx = tid; idx < nrel * 32; idx += NW * 64) {
+    const int m = idx >> 5, ii = idx & 31;
+    const int iq = i0 + ii, j = iq + m - a.window;
+    float pv = 0.f;
+    if (iq < T && j >= 0 && j < T) {
+      float s = 0.f;
+      for (int d = 0; d < DK; ++d)
+        s = fmaf(kb[(long long)d * a.k_cs + j], qb[(long long)d * a.q_cs + iq] / sqrtk, s);
+      s += Rk[idx];
+      bool masked = false;
+      if (a.mask_mode == 1) masked = (mq[iq] * mq[j]) == 0.f;
+      else if (a.mask_mode == 2) masked = j > iq;
+      if (masked) s = -1e4f;
+      // M, L of query column ii live in lanes li == ii: read them back through LDS-free recomputation
+      float Mq = -INFINITY, Lq = 0.f;
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt)
+      for (int ww = 0; ww < NW; ++ww) Mq = fmaxf(Mq, Ml[ww * 32 + ii]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float* Vw = Vl + w * DK * VP;
-  for (int it = 0; it < n_iter; ++it) {
-    const int jt = it * NW + w;
-    const int j0 = jt * 32;
-    const bool active = jt < p.nJ && !(a.mask_mode == 2 && j0 > i0 + 31);
-    float pr[16];
-    if (active) {
-      float sc[16];
-      score_tile(j0, sc);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pr[r] = expf(sc[r] - M) / Lsum;
-        const int j = j0 + crow(r, half);
-        const int rel = j - i + a.window;
-        if (nrel && rel >= 0 && rel < nrel && j < T && i < T) Pl[rel * 32 + li] = pr[r];
+      for (int ww = 0; ww < NW; ++ww) {
+        const float mw = Ml[ww * 32 + ii];
+        if (mw > -INFINITY) Lq += Ll[ww * 32 + ii] * __expf(mw - Mq);
       }
-      // stage V tile [DK][32] (coalesced rows) into this wave's LDS slab with pitch 33
-      const int jl = j0 + li;
-      for (int d = half; d < DK; d += 2) Vw[d * VP + li] = jl < T ? vb[(long long)d * a.v_cs + jl] : 0.f;
+      pv = __expf(s - Mq) / Lq;
     }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float av = Vw[(dt * 32 + li) * VP + crow(r, half)];
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
+    Pl[idx] = pv;
   }
-
-  // ---------------- cross-wave reduction + relative values + store ----------------
+  __syncthreads();   // every wave is past its V slab; Pl complete
   float* Ol = Vl;  // [NW][DK][32]
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ol[(w * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r];
+    for (int r = 0; r < 16; ++r) Ol[(w * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r] * wsc;
   __syncthreads();
   float* ob = a.out + (long long)b * a.o_bs + (long long)h * DK * a.o_cs;
   for (int idx = tid; idx < DK * 32; idx += NW * 64) {

@@ -25,6 +25,7 @@
 // models.py:400,139 (pre, proj).
 #include "common.h"
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -56,7 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC>
-__global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
   constexpr int TS = M16 ? 16 : 32;   // MFMA tile edge
   constexpr int KPI = M16 ? 4 : 2;    // K indices consumed per MFMA
   constexpr int NACC = M16 ? 4 : 16;  // accumulator regs per tile
@@ -471,7 +472,9 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     svc::set_error("conv1d: (KS-1)*dil = %d exceeds the supported halo %d", (a.KS - 1) * a.dil, MAXHALO);
     return SVC_ERR_UNSUPPORTED;
   }
-  int bc = (64 * 1024) / per_c;
+  // LDS budget per workgroup: 64 KiB, or what the epilogue transpose buffer needs anyway when that is larger
+  const int lds_budget = std::max(64 * 1024, WK * BM * (BN + 4) * 4);
+  int bc = lds_budget / per_c;
   bc = std::min(bc, (WLD * RSTEP) / a.KS);
   bc = std::min(bc, x_rows * NWV);
   bc = (bc / KG) * KG;
@@ -542,6 +545,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   const long long wg64x32 = (long long)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 32) * a.B * a.n_phase;
   const bool m64 = (a.Cout % 64) == 0;
   int cfg;  // 0: 16x512  1: 32x512  2: 64x256  3: 128x128  4: 64x128  5: 64x32 split-K  6: 32x32 split-K
+            // 7: 128x224 (one workgroup per CU, 7 MFMA column tiles per wave)
   if (a.epi == SVC_EPI_GATE) {
     SVC_REQUIRE((a.Cout % 64) == 0, "conv1d: gate epilogue needs Cout %% 64 == 0 (got %d)", a.Cout);
     SVC_REQUIRE(a.res_mode == 0, "conv1d: gate epilogue takes no residual");
@@ -557,6 +561,19 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     else if (m64 && wg64x128 >= 200) cfg = 4;
     else if (m64 && wg64x32 >= 200) cfg = 5;
     else cfg = 6;
+    // Long sequences: the decoder's lengths are 862 * 2^k samples, so any power-of-two tile leaves the last round of
+    // workgroups ~2/3 full (431 tiles of 128 on 512 slots).  The 128 x 224 config (7 MFMA column tiles per wave) covers
+    // such a sequence in ONE round of one workgroup per CU (247 tiles on 256 CUs) with 1.75 x the matrix work per
+    // staged weight byte; measured +8..13 % for KS >= 7, -6 % for KS = 3 (the staging phases are not overlapped by a
+    // second resident workgroup), so it is picked by modelled time = rounds * resident workgroups * padded tile area
+    // only for the wide kernels.
+    if (cfg == 3 && a.KS >= 7 && a.n_phase == 1) {
+      const double n128 = (double)svc::cdiv(a.Cout, 128) * svc::cdiv(a.Tout, 128) * a.B;
+      const double n224 = (double)svc::cdiv(a.Cout, 128) * svc::cdiv(a.Tout, 224) * a.B;
+      const double t128 = std::ceil(n128 / 512.0) * 2.0 * 128 * 128;
+      const double t224 = std::ceil(n224 / 256.0) * 1.0 * 128 * 224 * 1.04;
+      if (t224 < t128) cfg = 7;
+    }
   }
   {
     // the wide-tile configs stage X with float4 rows; unaligned activations fall back to narrower tiles
@@ -565,11 +582,12 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     if (!xvec && a.epi == SVC_EPI_PLAIN) {
       if (cfg == 0 || cfg == 1) cfg = 6;
       else if (cfg == 2) cfg = 4;
+      else if (cfg == 7) cfg = 3;
     }
   }
   if (g_force_cfg >= 0 && a.Cout > 16) {
     const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
-                    (a.epi != SVC_EPI_GATE && g_force_cfg <= 6 && g_force_cfg >= 1);
+                    (a.epi != SVC_EPI_GATE && g_force_cfg <= 7 && g_force_cfg >= 1);
     if (ok) cfg = g_force_cfg;
   }
   if (a.epi == SVC_EPI_GATE) {
@@ -604,6 +622,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     case 3: SVC_KS_CASES(2, 2, 2, 2, false)   // 128 x 128
     case 4: SVC_KS_CASES(2, 1, 1, 4, false)   // 64 x 128
     case 5: return launch_cfg<2, 1, 1, 1, 4, false>(a, s);   // 64 x 32, 4-way split-K
+    case 7: SVC_KS_CASES(1, 7, 4, 1, false)   // 128 x 224
     default: return launch_cfg<1, 1, 1, 1, 4, false>(a, s);  // 32 x 32, 4-way split-K
   }
 }
