@@ -248,6 +248,8 @@ typedef struct svc_wgrad_args {
   float* G;
   long long a_bs, a_cs, b_bs, b_cs;
   int B, Ca, Cb, TA, TB, KS, dil, pad, accumulate;
+  float* dbias; /* optional [Ca]: also produces the bias gradient sum_{b,t} A[b,ca,t] (zeroed by the call unless
+                   `accumulate`), from the A tiles already staged in LDS — saves a separate reduction pass over dy */
 } svc_wgrad_args;
 int svc_conv1d_wgrad_f32(const svc_wgrad_args* a, void* stream);
 
@@ -350,7 +352,7 @@ int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int 
 /* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of
  * their gradient into a zero-initialised dW. */
 int svc_embed_fwd_f32(const long long* idx, const float* W, float* y, int B, int C, int T, void* stream);
-int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, void* stream);
+int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, int n_rows, void* stream);
 /* Gradient of svc_reparam_f32: dstats = [dm ; dlogs]. */
 int svc_reparam_bwd_f32(const float* stats, const float* noise, const float* mask, const float* dz, float* dstats, int B,
                         int C, int T, float scale, void* stream);

@@ -30,6 +30,7 @@ struct WgP {
   const float* A;
   const float* Bm;
   float* G;
+  float* dbias;
   long long a_bs, a_cs, b_bs, b_cs;
   int B, Ca, Cb, TA, TB, KS, dil, pad;
   int tiles_per_b, n_tiles, tiles_per_wg, PB, n_kgroups, splits;
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   float* As = lds;               // [CA_T][PA]
   float* Bs = lds + CA_T * PA;   // [CB_T][PB]
   const int PB = p.PB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): row pointers below stay scalar
   const int ln = lane & 31, lk = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int ca0 = blockIdx.y * CA_T, cb0 = blockIdx.z * CB_T;
@@ -72,20 +74,22 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     const int t0 = (tile - b * p.tiles_per_b) * TT;
     const float* ab = p.A + (long long)b * p.a_bs;
     const float* bb = p.Bm + (long long)b * p.b_bs;
+    // addresses = wave-uniform row pointer (SGPRs) + one 32-bit lane offset: no per-slot 64-bit address registers
     const int ta = min(t0 + lane, p.TA - 1);
 #pragma unroll
     for (int i = 0; i < CA_T / 4; ++i) {
       const int ca = min(ca0 + i * 4 + wave, p.Ca - 1);
-      areg[i] = ab[(long long)ca * p.a_cs + ta];
+      areg[i] = (ab + (long long)ca * p.a_cs)[ta];
     }
+    int tb[BCOLS];
+#pragma unroll
+    for (int cj = 0; cj < BCOLS; ++cj) tb[cj] = min(max(t0 + boff + cj * 64 + lane, 0), p.TB - 1);
 #pragma unroll
     for (int j = 0; j < CB_T / 4; ++j) {
       const int cb = min(cb0 + j * 4 + wave, p.Cb - 1);
+      const float* brow = bb + (long long)cb * p.b_cs;
 #pragma unroll
-      for (int cj = 0; cj < BCOLS; ++cj) {
-        const int tb = min(max(t0 + boff + cj * 64 + lane, 0), p.TB - 1);
-        breg[j * BCOLS + cj] = bb[(long long)cb * p.b_cs + tb];
-      }
+      for (int cj = 0; cj < BCOLS; ++cj) breg[j * BCOLS + cj] = brow[tb[cj]];
     }
   };
   auto store_tile = [&](int tile) {
@@ -110,6 +114,11 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     }
   };
 
+  // bias gradient (optional): row sums of the A tiles, taken by the workgroups of the first cb tile / tap group
+  const bool do_bias = p.dbias != nullptr && blockIdx.z == 0 && kg == 0;
+  float bsum = 0.f;                       // thread tid: row tid >> 1, columns (tid & 1) * 32 .. + 32
+  const float* brow_sum = As + (tid >> 1) * PA + (tid & 1) * 32;
+
   const float* ap = As + (wm * 64 + ln) * PA + lk;
   const float* bp = Bs + (wn * 32 + ln) * PB + lk;
   const int dil = p.dil;
@@ -119,6 +128,10 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     store_tile(tile);
     __syncthreads();
     if (tile + 1 < tile1) load_tile(tile + 1);   // in flight during the MFMA loop
+    if (do_bias) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) bsum += brow_sum[c];
+    }
 #pragma unroll 4
     for (int s = 0; s < TT; s += 2) {
       const float a0 = ap[s], a1 = ap[32 * PA + s];
@@ -133,6 +146,11 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
         }
       }
     }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1);
+    const int ca = ca0 + (tid >> 1);
+    if ((tid & 1) == 0 && ca < p.Ca) atomicAdd(p.dbias + ca, bsum);
   }
   // combine: G[ca][cb][k0..k0+nk) += acc.  The MFMA C layout has one cb column per lane (addresses KS floats apart), so
   // each wave first transposes 16 ca rows at a time through LDS into G's own [cb][k] order: consecutive lanes then
@@ -202,8 +220,14 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   int nk = std::min(a.KS, 5);
   while (nk > 1 && (nk - 1) * a.dil > MAXHALO_W) --nk;
   if (a.KS > 5 && nk > 4) nk = 4;          // balanced groups for 7 (4+3) and 11 (4+4+3)
+  if (a.dbias && !a.accumulate) {
+    if (hipMemsetAsync(a.dbias, 0, sizeof(float) * (size_t)a.Ca, s) != hipSuccess) {
+      svc::set_error("wgrad: memset failed");
+      return SVC_ERR_HIP;
+    }
+  }
   WgP p;
-  p.A = a.A; p.Bm = a.Bm; p.G = a.G;
+  p.A = a.A; p.Bm = a.Bm; p.G = a.G; p.dbias = a.dbias;
   p.a_bs = a.a_bs; p.a_cs = a.a_cs; p.b_bs = a.b_bs; p.b_cs = a.b_cs;
   p.B = a.B; p.Ca = a.Ca; p.Cb = a.Cb; p.TA = a.TA; p.TB = a.TB; p.KS = a.KS; p.dil = a.dil; p.pad = a.pad;
   p.n_kgroups = svc::cdiv(a.KS, nk);

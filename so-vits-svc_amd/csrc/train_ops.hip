@@ -229,18 +229,15 @@ __global__ void gconv_dgrad_kernel(const float* __restrict__ dy, const float* __
   if (ti >= Tin) return;
   const int Cg = Cin / groups, Og = Cout / groups;
   const int g = ci / Cg, cl = ci % Cg;
+  const int kfirst = (ti + pad) % stride, tfirst = (ti + pad - kfirst) / stride;
   float acc = 0.f;
   for (int ol = 0; ol < Og; ++ol) {
     const int co = g * Og + ol;
     const float* wr = w + ((long long)co * Cg + cl) * KS;
     const float* dr = dy + ((long long)b * Cout + co) * Tout;
-    for (int k = 0; k < KS; ++k) {
-      const int u = ti + pad - k;
-      if (u >= 0 && (u % stride) == 0) {
-        const int t = u / stride;
-        if (t < Tout) acc = fmaf(wr[k], dr[t], acc);
-      }
-    }
+    // only taps k == (ti + pad) mod stride reach an output sample: t = (ti + pad - k) / stride
+    for (int k = kfirst, t = tfirst; k < KS && t >= 0; k += stride, --t)
+      if (t < Tout) acc = fmaf(wr[k], dr[t], acc);
   }
   dx[((long long)b * Cin + ci) * Tin + ti] = acc;
 }

@@ -169,12 +169,30 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ idx, const float*
   if (t >= T) return;
   y[((long long)b * C + c) * T + t] = W[idx[(long long)b * T + t] * C + c];
 }
-__global__ void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dW,
-                                 int C, int T) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y, b = blockIdx.z;
-  if (t >= T) return;
-  atomicAdd(dW + idx[(long long)b * T + t] * C + c, dy[((long long)b * C + c) * T + t]);
+// One workgroup = one channel c and EB_POS consecutive (b,t) positions: the gradient rows are first summed in an LDS
+// table (the path's tables have 2 (emb_uv), 200 (emb_g) or 256 (f0_emb) rows), so only n_rows global atomics leave the
+// workgroup instead of one per position (2.4 M atomics onto 384 addresses for emb_uv at B=16, T=768).
+constexpr int EB_POS = 2048;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dy,
+                                                        float* __restrict__ dW, int B, int C, int T, int n_rows) {
+  extern __shared__ float hist[];
+  const int c = blockIdx.y;
+  const long long n = (long long)B * T;
+  for (int r = threadIdx.x; r < n_rows; r += 256) hist[r] = 0.f;
+  __syncthreads();
+  const long long p0 = (long long)blockIdx.x * EB_POS;
+  for (int i = threadIdx.x; i < EB_POS; i += 256) {
+    const long long pos = p0 + i;
+    if (pos >= n) break;
+    const int b = (int)(pos / T), t = (int)(pos - (long long)b * T);
+    const long long row = idx[pos];
+    if (row >= 0 && row < n_rows) atomicAdd(&hist[row], dy[((long long)b * C + c) * T + t]);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < n_rows; r += 256) {
+    const float v = hist[r];
+    if (v != 0.f) atomicAdd(dW + (long long)r * C + c, v);
+  }
 }
 
 // ---- reparameterisation backward: z = (m + n*exp(logs)*scale)*mask  ->  dstats = [dm ; dlogs] -------------------------
@@ -276,9 +294,12 @@ int svc_embed_fwd_f32(const long long* idx, const float* W, float* y, int B, int
   return svc::check_launch("embed_fwd");
 }
 
-int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, void* stream) {
-  SVC_REQUIRE(idx && dy && dW && B > 0 && C > 0 && T > 0, "embed_bwd: bad args");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(svc::cdiv(T, 64), C, B), dim3(64), 0, (hipStream_t)stream, idx, dy, dW, C, T);
+int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, int C, int T, int n_rows, void* stream) {
+  SVC_REQUIRE(idx && dy && dW && B > 0 && C > 0 && T > 0 && n_rows > 0, "embed_bwd: bad args");
+  SVC_REQUIRE(n_rows <= 16384, "embed_bwd: table of %d rows does not fit the LDS accumulator", n_rows);
+  const long long n = (long long)B * T;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((n + EB_POS - 1) / EB_POS), C), dim3(256), sizeof(float) * n_rows,
+                     (hipStream_t)stream, idx, dy, dW, B, C, T, n_rows);
   return svc::check_launch("embed_bwd");
 }
 

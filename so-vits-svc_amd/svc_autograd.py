@@ -48,9 +48,12 @@ class _Conv1dDense(Function):
         if ctx.needs_input_grad[0]:
             wt = S.pack_conv1d_weight_T(w)
             dx = S.conv1d(dy, wt, Cin, KS, dil=dil, pad_left=dil * (KS - 1) - pad, Tout=x.shape[2])
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = S.conv1d_wgrad(dy, x, KS, dil, pad)
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_db:      # bias gradient from the dy tiles the wgrad kernel stages anyway
+                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+            dw = S.conv1d_wgrad(dy, x, KS, dil, pad, dbias=db)
+        elif want_db:
             db = S.reduce_bct(dy, 0)
         return dx, dw, db, None, None, None
 

@@ -486,7 +486,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("A", _f32p), ("Bm", _f32p), ("G", _f32p),
                 ("a_bs", C.c_longlong), ("a_cs", C.c_longlong), ("b_bs", C.c_longlong), ("b_cs", C.c_longlong),
                 ("B", C.c_int), ("Ca", C.c_int), ("Cb", C.c_int), ("TA", C.c_int), ("TB", C.c_int), ("KS", C.c_int),
-                ("dil", C.c_int), ("pad", C.c_int), ("accumulate", C.c_int)]
+                ("dil", C.c_int), ("pad", C.c_int), ("accumulate", C.c_int), ("dbias", _f32p)]
 
 
 class GemmArgs(C.Structure):
@@ -624,9 +624,10 @@ def pack_conv1d_weight_T(w):
     return dst
 
 
-def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False):
-    """G[ca,cb,k] = sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad]."""
-    require_gpu(A, Bm, out)
+def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None):
+    """G[ca,cb,k] = sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad]; dbias (optional [Ca] buffer) also receives
+    sum_{b,t} A[b,ca,t]."""
+    require_gpu(A, Bm, out, dbias)
     B, Ca, TA = A.shape
     _, Cb, TB = Bm.shape
     if out is None:
@@ -636,6 +637,7 @@ def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False):
     a.a_bs, a.a_cs = _bct_strides(A)
     a.b_bs, a.b_cs = _bct_strides(Bm)
     a.B, a.Ca, a.Cb, a.TA, a.TB, a.KS, a.dil, a.pad, a.accumulate = B, Ca, Cb, TA, TB, KS, dil, pad, 1 if accumulate else 0
+    a.dbias = ptr(dbias)
     check(tlib().svc_conv1d_wgrad_f32(C.byref(a), stream_ptr()), "conv1d_wgrad")
     return out
 
@@ -781,7 +783,7 @@ def t2lib():
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
-        L.svc_embed_bwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
+        L.svc_embed_bwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, i, vp]
         L.svc_reparam_bwd_f32.argtypes = [_f32p] * 5 + [i, i, i, f, vp]
         L.svc_nsf_source_train_f32.argtypes = [_f32p] * 8 + [i] * 4 + [f] * 3 + [vp]
         L.svc_nsf_linear_fwd_f32.argtypes = [_f32p] * 4 + [ll, i, vp]
@@ -859,7 +861,7 @@ def embed_bwd(idx, dy, n_rows):
     dy = dy.contiguous()
     B, Cc, T = dy.shape
     dW = torch.zeros((n_rows, Cc), device=dy.device, dtype=torch.float32)
-    check(t2lib().svc_embed_bwd_f32(C.c_void_p(idx.data_ptr()), ptr(dy), ptr(dW), B, Cc, T, stream_ptr()), "embed_bwd")
+    check(t2lib().svc_embed_bwd_f32(C.c_void_p(idx.data_ptr()), ptr(dy), ptr(dW), B, Cc, T, n_rows, stream_ptr()), "embed_bwd")
     return dW
 
 
