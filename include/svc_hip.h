@@ -334,6 +334,21 @@ int svc_adamw_f32(float* p, const float* g, float* m, float* v, long long n, con
 int svc_adamw_advance(float* hyper, void* stream);
 
 
+/* rocFFT-backed STFT magnitude (modules/mel_processing.py:40-64: torch.stft(..., onesided) -> sqrt(re^2+im^2+1e-6)).
+ * A plan is an opaque handle for batched length-n real transforms (n even); *work_bytes is the size of the caller-owned
+ * work buffer to pass to every execute (may be 0).  Forward: x:[batch][n] -> z:[batch][n/2+1][2] interleaved complex,
+ * unnormalised.  Inverse: the unnormalised complex-to-real transform (it may overwrite gz); with the interior bins of
+ * the spectrum gradient halved (svc_cmag_c_bwd_f32 does that) it is the exact adjoint of the forward.  Execution only
+ * enqueues kernels on `stream`. */
+int svc_rfft_plan_create(int n, int batch, void** plan_out, long long* work_bytes);
+int svc_rfft_plan_destroy(void* plan);
+int svc_rfft_forward_f32(void* plan, const float* x, float* z, void* work, void* stream);
+int svc_rfft_inverse_f32(void* plan, float* gz, float* gx, void* work, void* stream);
+/* mag = sqrt(re^2 + im^2 + eps) over n interleaved complex values; backward writes the C2R-ready gradient
+ * gz = dmag/mag * z (interior bins x 1/2, imaginary parts of bins 0 and bins-1 zeroed). */
+int svc_cmag_c_f32(const float* z, float* mag, long long n, float eps, void* stream);
+int svc_cmag_c_bwd_f32(const float* z, const float* mag, const float* dmag, float* gz, long long n, int bins, void* stream);
+
 /* Channel LayerNorm for training (modules/modules.py:23-35): forward also returns the per-column mean / rstd [B,T];
  * backward returns dx and the gamma / beta gradients. */
 int svc_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int B,

@@ -2,10 +2,9 @@
 :40-83) for the mel-reconstruction loss of train.py:171-182,202.
 
   framing   reflect pad (n_fft-hop)/2, hop, hann window          -> svc_stft_frame_f32 (+ adjoint)
-  transform real DFT as two fp32-MFMA GEMMs against a cos / -sin basis [n_fft, n_fft/2+1] -> svc_gemm_f32
-            (16 frames x B per step: the transform is ~2 GFLOP; a GEMM keeps the whole loss on kernels whose
-             backward is the same kernel with swapped strides)
-  |.|       sqrt(re^2 + im^2 + 1e-6)                             -> svc_cmag_f32 (+ bwd)
+  transform ONE batched real-to-complex rocFFT over all B*frames windows  -> svc_rfft_forward_f32
+            (backward = the complex-to-real rocFFT on the halved-interior spectrum gradient, its exact adjoint)
+  |.|       sqrt(re^2 + im^2 + 1e-6) on the interleaved half spectrum -> svc_cmag_c_f32 (+ bwd)
   mel       Slaney filterbank product, log(clamp(., 1e-5))       -> svc_gemm_f32, svc_ew_f32
 
 The Slaney mel basis is restated from librosa.filters.mel (librosa==0.9.1, requirements.txt:23; htk=False,
@@ -22,7 +21,6 @@ import svc_hip as S
 
 mel_basis = {}
 hann_window = {}
-_dft = {}
 
 
 def _hz_to_mel(f):
@@ -70,13 +68,6 @@ def _window(win_size, device):
     return hann_window[key]
 
 
-def _basis(n_fft, device):
-    key = f"{n_fft}_{device}"
-    if key not in _dft:
-        _dft[key] = S.dft_basis(n_fft, n_fft // 2 + 1, device)
-    return _dft[key]
-
-
 def _melmat(n_fft, num_mels, sampling_rate, fmin, fmax, device):
     key = f"{fmax}_{n_fft}_{num_mels}_{sampling_rate}_{fmin}_{device}"
     if key not in mel_basis:
@@ -103,10 +94,7 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
     pad = int((n_fft - hop_size) / 2)
     NF = (L + 2 * pad - n_fft) // hop_size + 1
     frames = A.stft_frames(y, _window(win_size, y.device), NF, n_fft, hop_size, pad)      # [B, NF, n_fft]
-    cs, sn = _basis(n_fft, y.device)
-    re = A.gemm2d(frames, cs)                                                              # [B, NF, bins]
-    im = A.gemm2d(frames, sn)
-    mag = A.cmag(re, im, 1e-6)
+    mag = A.rfft_mag(frames, 1e-6)                     # batched rocFFT R2C + fused magnitude -> [B, NF, bins]
     return mag.transpose(1, 2)
 
 

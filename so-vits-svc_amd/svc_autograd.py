@@ -606,6 +606,30 @@ class _CMag(Function):
         return dre, dim, None
 
 
+class _RfftMag(Function):
+    """|rFFT(frames)| with the 1e-6 floor (modules/mel_processing.py:61-63): rocFFT forward + fused magnitude; backward
+    = magnitude gradient + rocFFT complex-to-real (the adjoint)."""
+
+    @staticmethod
+    def forward(ctx, frames, eps):
+        shp = frames.shape
+        z, mag = S.rfft_mag(frames.reshape(-1, shp[-1]), eps)
+        ctx.save_for_backward(z, mag)
+        ctx.n = shp[-1]
+        ctx.shp = shp
+        return mag.view(*shp[:-1], mag.shape[-1])
+
+    @staticmethod
+    def backward(ctx, d):
+        z, mag = ctx.saved_tensors
+        dx = S.rfft_mag_bwd(z, mag, _c(d).reshape(mag.shape), ctx.n)
+        return dx.view(ctx.shp), None
+
+
+def rfft_mag(frames, eps):
+    return _RfftMag.apply(frames, float(eps))
+
+
 class _LogClamp(Function):
     @staticmethod
     def forward(ctx, x, lo):

@@ -761,6 +761,67 @@ def adamw_advance(hyper):
 
 
 # ---- second batch of training entry points (layernorm / attention pieces / embedding / reparam / nsf / kl / stft) ----
+FFT_EXPORTS = ["svc_rfft_plan_create", "svc_rfft_plan_destroy", "svc_rfft_forward_f32", "svc_rfft_inverse_f32",
+               "svc_cmag_c_f32", "svc_cmag_c_bwd_f32"]
+EXPORTS += FFT_EXPORTS
+_fft_bound = False
+_fft_plans = {}
+
+
+def _fftlib():
+    global _fft_bound
+    L = lib()
+    if not _fft_bound:
+        i, ll, vp = C.c_int, C.c_longlong, C.c_void_p
+        L.svc_rfft_plan_create.argtypes = [i, i, C.POINTER(vp), C.POINTER(ll)]
+        L.svc_rfft_plan_destroy.argtypes = [vp]
+        L.svc_rfft_forward_f32.argtypes = [vp, _f32p, _f32p, vp, vp]
+        L.svc_rfft_inverse_f32.argtypes = [vp, _f32p, _f32p, vp, vp]
+        L.svc_cmag_c_f32.argtypes = [_f32p, _f32p, ll, C.c_float, vp]
+        L.svc_cmag_c_bwd_f32.argtypes = [_f32p, _f32p, _f32p, _f32p, ll, i, vp]
+        _fft_bound = True
+    return L
+
+
+def _rfft_plan(n, batch, device):
+    """(plan handle, work buffer) for batched length-n real FFTs, created once per (n, batch, device)."""
+    key = (n, batch, str(device))
+    ent = _fft_plans.get(key)
+    if ent is None:
+        plan, wb = C.c_void_p(), C.c_longlong()
+        check(_fftlib().svc_rfft_plan_create(n, batch, C.byref(plan), C.byref(wb)), "rfft_plan_create")
+        work = torch.empty(max(int(wb.value), 16), device=device, dtype=torch.uint8)
+        ent = (plan, work)
+        _fft_plans[key] = ent
+    return ent
+
+
+def rfft_mag(frames, eps):
+    """frames [R, n] -> (z [R, n/2+1, 2] interleaved half spectrum, mag [R, n/2+1] = sqrt(re^2+im^2+eps))."""
+    require_gpu(frames)
+    frames = frames.contiguous()
+    R, n = frames.shape
+    plan, work = _rfft_plan(n, R, frames.device)
+    z = torch.empty((R, n // 2 + 1, 2), device=frames.device, dtype=torch.float32)
+    check(_fftlib().svc_rfft_forward_f32(plan, ptr(frames), ptr(z), ptr(work), stream_ptr()), "rfft_forward")
+    mag = torch.empty((R, n // 2 + 1), device=frames.device, dtype=torch.float32)
+    check(_fftlib().svc_cmag_c_f32(ptr(z), ptr(mag), mag.numel(), eps, stream_ptr()), "cmag_c")
+    return z, mag
+
+
+def rfft_mag_bwd(z, mag, dmag, n):
+    """Gradient of rfft_mag w.r.t. the frames: [R, n]."""
+    require_gpu(z, mag, dmag)
+    dmag = dmag.contiguous()
+    R, bins = mag.shape
+    plan, work = _rfft_plan(n, R, z.device)
+    gz = torch.empty_like(z)
+    check(_fftlib().svc_cmag_c_bwd_f32(ptr(z), ptr(mag), ptr(dmag), ptr(gz), mag.numel(), bins, stream_ptr()), "cmag_c_bwd")
+    dx = torch.empty((R, n), device=z.device, dtype=torch.float32)
+    check(_fftlib().svc_rfft_inverse_f32(plan, ptr(gz), ptr(dx), ptr(work), stream_ptr()), "rfft_inverse")
+    return dx
+
+
 TRAIN_EXPORTS2 = [
     "svc_layernorm_fwd_f32", "svc_layernorm_bwd_f32", "svc_attn_softmax_fwd_f32", "svc_attn_softmax_bwd_f32",
     "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",

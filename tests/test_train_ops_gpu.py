@@ -145,3 +145,21 @@ def test_period_conv2d_as_block_conv1d(dev, B, Cin, Cout, T, p, K, s, pad):
     if s == 1 and n_pad:
         pytest.skip("reflect padding only precedes the first (strided) layer")
     _run_pair(hip, ref, t, dev)
+
+
+@pytest.mark.parametrize("B,L,n_fft,hop", [(2, 8192, 2048, 512), (3, 1024, 128, 32), (1, 4096, 512, 128)])
+def test_spectrogram_rocfft_fwd_bwd(dev, B, L, n_fft, hop):
+    """modules/mel_processing.spectrogram_torch (reflect pad + frames + batched rocFFT R2C + magnitude) against
+    torch.stft on the CPU (reference :40-64), forward and the gradient w.r.t. the waveform (C2R adjoint)."""
+    from modules.mel_processing import spectrogram_torch
+    torch.manual_seed(11)
+    y = (torch.rand(B, L) - 0.5).requires_grad_(True)
+
+    def ref(y):
+        pad = int((n_fft - hop) / 2)
+        yp = F.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        sp = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
+                        pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        return torch.sqrt(torch.view_as_real(sp).pow(2).sum(-1) + 1e-6)
+
+    _run_pair(lambda y: spectrogram_torch(y, n_fft, 44100, hop, n_fft), ref, dict(y=y), dev, tol=5e-5)
