@@ -106,6 +106,33 @@ def make_train_items(cfg, B, seed):
     return (c, f0, spec, y, spk, lengths, uv, None), T
 
 
+def cpu_baseline_train(cfg, hps, items_cpu, max_items=2):
+    """One iteration of the CPU oracle's training loop (oracle.train_oracle.gan_train_loop: torch-CPU autograd + AdamW in
+    the reference's order) on a BOUNDED sample of the workload: the first `max_items` items of the same minibatch (the
+    full B=16 iteration is ~4 TFLOP — minutes on host cores).  steps/s is reported for the full batch by scaling with
+    items (work is linear in the batch)."""
+    from oracle import mel as OM
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    c, f0, spec, y, spk, lengths, uv, _ = [t[:max_items] if t is not None else None for t in items_cpu]
+    T = int(lengths.max())
+    c, f0, spec, uv, y = c[:, :, :T], f0[:, :T], spec[:, :, :T], uv[:, :T], y[:, :, :T * HOP]
+    d = hps["data"]
+    data = dict(n_fft=d["filter_length"], hop=d["hop_length"], win=d["win_length"], n_mels=d["n_mel_channels"],
+                sr=d["sampling_rate"], fmin=d["mel_fmin"], fmax=d["mel_fmax"])
+    ocfg = dict(cfg, p_dropout=0.0)
+    sd_g = W.make_train_state_dict(cfg, 1234)
+    sd_d = W.make_mpd_state_dict(1235)
+    noise = W.make_train_noise(ocfg, max_items, T, lengths, 7, hop=HOP)
+    mb = torch.from_numpy(OM.mel_filterbank(data["sr"], data["n_fft"], data["n_mels"], data["fmin"], data["fmax"]))
+    t0 = time.perf_counter()
+    TO.gan_train_loop(sd_g, sd_d, ocfg, data, (c, f0, uv, spec, y, spk, lengths), noise, mb, 1)
+    dt = time.perf_counter() - t0
+    return dict(value=(max_items / TRAIN_B) / dt, unit="steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle.gan_train_loop, 1 iteration on the first {max_items} of the {TRAIN_B} items "
+                       f"(T={T} frames): {dt:.1f} s; steps/s scaled by {max_items}/{TRAIN_B}")
+
+
 def run_train(args, dev, rank, world, dist):
     """Time K training iterations; returns the result dict (rank 0) or None."""
     import svc_hip as S
@@ -162,6 +189,9 @@ def run_train(args, dev, rank, world, dist):
                 for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
         fams["_kernel_ms_total"] = round(tot, 3)
     red = net_g.reducer.stats if getattr(net_g, "reducer", None) is not None else None
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_train(cfg, hps, items_cpu)
     return dict(metric="train steps/sec (train.py D+G iteration)", value=steps / elapsed, unit="steps/s",
                 ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak", dtype="f32",
                 items_per_s=world * TRAIN_B * steps / elapsed,
@@ -172,7 +202,7 @@ def run_train(args, dev, rank, world, dist):
                             launch="hipGraph replay of the whole iteration" if use_graph else "eager",
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU"),
                 losses={k: round(float(v), 4) for k, v in last.items()},
-                families=fams, allreduce=red)
+                families=fams, allreduce=red, cpu_baseline=cpu)
 
 
 def main():

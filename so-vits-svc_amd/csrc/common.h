@@ -12,6 +12,7 @@ void set_error(const char* fmt, ...);
 
 // Per-launch profiling hooks (profile.hip).
 bool prof_on();
+bool prof_shapes();   // SVC_PROF_SHAPES=1: profile rows keyed by kernel shape
 void prof_begin(hipStream_t s, const char* name, double flop, double bytes);
 void prof_end(hipStream_t s);
 

@@ -537,7 +537,13 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const double flop = 2.0 * a.B * (double)a.Cout * a.Cin * a.KS * a.Tout * a.n_phase;
   const double bytes = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout) + 4.0 * a.Cin * a.KS * a.Cout;
-  svc::ProfScope prof(s, a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma", flop, bytes);
+  char pname[160];
+  if (svc::prof_on() && svc::prof_shapes())   // SVC_PROF_SHAPES=1: one profile row per shape (tuning aid)
+    snprintf(pname, sizeof(pname), "%s[B%d,Ci%d,Co%d,K%d,d%d,T%d,e%d]", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma", a.B,
+             a.Cin, a.Cout, a.KS, a.dil, a.Tout, a.epi);
+  else
+    snprintf(pname, sizeof(pname), "%s", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma");
+  svc::ProfScope prof(s, pname, flop, bytes);
 
   const long long cols = (long long)a.B * a.Tout;
   // workgroup counts of the candidate tilings for short sequences

@@ -209,7 +209,12 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   SVC_REQUIRE(a.KS >= 1 && a.KS <= 256 && a.dil >= 1, "wgrad: KS must be in [1,256] (got %d)", a.KS);
   hipStream_t s = (hipStream_t)stream;
   const double flop = 2.0 * a.B * (double)a.Ca * a.Cb * a.KS * a.TA;
-  svc::ProfScope prof(s, "conv1d_wgrad", flop, 4.0 * a.B * ((double)a.Ca * a.TA + (double)a.Cb * a.TB));
+  char pname[160];
+  if (svc::prof_on() && svc::prof_shapes())
+    snprintf(pname, sizeof(pname), "conv1d_wgrad[B%d,Ca%d,Cb%d,K%d,d%d,T%d]", a.B, a.Ca, a.Cb, a.KS, a.dil, a.TA);
+  else
+    snprintf(pname, sizeof(pname), "conv1d_wgrad");
+  svc::ProfScope prof(s, pname, flop, 4.0 * a.B * ((double)a.Ca * a.TA + (double)a.Cb * a.TB));
   if (!a.accumulate) {
     if (hipMemsetAsync(a.G, 0, sizeof(float) * (size_t)a.Ca * a.Cb * a.KS, s) != hipSuccess) {
       svc::set_error("wgrad: memset failed");

@@ -1,6 +1,7 @@
 // core.hip — error reporting, device info and per-launch hipEvent profiling for libsvc_hip.so.
 #include "common.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -36,6 +37,10 @@ static std::vector<std::string> g_order;
 static thread_local ProfRec g_cur;
 
 bool prof_on() { return g_prof; }
+bool prof_shapes() {
+  static const bool on = getenv("SVC_PROF_SHAPES") != nullptr;
+  return on;
+}
 
 static hipEvent_t get_event() {
   if (!g_pool.empty()) {

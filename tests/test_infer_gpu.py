@@ -104,3 +104,37 @@ def test_infer_rejects_cpu_tensors():
     import svc_hip as S
     with pytest.raises(S.SvcError):
         net.infer(c, f0, uv, g=sid)
+
+
+def test_snake_long_form_batch8_properties(dev):
+    """BASELINE configs[3]: nsf-snake-hifigan, B=8 clips of 30 s (T=2584 frames -> 1,323,008 samples each), full-size
+    template.  The CPU oracle needs minutes at this size, so the full-size run is checked through size-independent
+    properties — (1) every item of the batch equals the same item run alone (B=1), bit for bit (no cross-item leakage,
+    tile-boundary independence), (2) outputs are finite and inside tanh's range — and the arithmetic itself against the
+    oracle on a short prefix (T=96) of the same weights/inputs."""
+    cfg = W.full_config()
+    cfg["vocoder_name"] = "nsf-snake-hifigan"
+    net, sd = _build(cfg, 77, dev)
+    B, T = 8, 2584
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=21)
+    sid[:] = sid[0]
+    noise = W.make_noise(cfg, B, T, seed=22)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert o.shape == (B, 1, T * 512)
+    assert torch.isfinite(o).all() and o.abs().max().item() <= 1.0
+    for b in (0, 5):
+        nb = {k: v[b:b + 1].contiguous() for k, v in nd.items()}
+        ob, _ = net.infer(c[b:b + 1].to(dev), f0[b:b + 1].to(dev), uv[b:b + 1].to(dev), g=sid[b:b + 1].to(dev),
+                          noice_scale=0.4, noise=nb)
+        assert torch.equal(ob[0], o[b]), b
+    # short-prefix parity against the oracle (same weights)
+    Ts = 96
+    cs, f0s, uvs = c[:2, :, :Ts].contiguous(), f0[:2, :Ts].contiguous(), uv[:2, :Ts].contiguous()
+    ns = dict(enc_p=noise["enc_p"][:2, :, :Ts].contiguous(), rand_ini=noise["rand_ini"][:2].contiguous(),
+              sine=noise["sine"][:2, :Ts * 512].contiguous())
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, cs, f0s, uvs, sid[:2], ns, noice_scale=0.4)
+    os_, _ = net.infer(cs.to(dev), f0s.to(dev), uvs.to(dev), g=sid[:2].to(dev), noice_scale=0.4,
+                       noise={k: v.to(dev) for k, v in ns.items()})
+    _check(os_, ref)
