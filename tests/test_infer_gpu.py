@@ -109,8 +109,8 @@ def test_infer_rejects_cpu_tensors():
 def test_snake_long_form_batch8_properties(dev):
     """BASELINE configs[3]: nsf-snake-hifigan, B=8 clips of 30 s (T=2584 frames -> 1,323,008 samples each), full-size
     template.  The CPU oracle needs minutes at this size, so the full-size run is checked through size-independent
-    properties — (1) every item of the batch equals the same item run alone (B=1), bit for bit (no cross-item leakage,
-    tile-boundary independence), (2) outputs are finite and inside tanh's range — and the arithmetic itself against the
+    properties — (1) every item of the batch equals the same item run alone (B=1) up to fp32 summation order (B changes
+    the tile / split-K configuration; cross-item leakage or a tile-boundary bug would be O(1)), (2) outputs are finite and inside tanh's range — and the arithmetic itself against the
     oracle on a short prefix (T=96) of the same weights/inputs."""
     cfg = W.full_config()
     cfg["vocoder_name"] = "nsf-snake-hifigan"
@@ -127,7 +127,8 @@ def test_snake_long_form_batch8_properties(dev):
         nb = {k: v[b:b + 1].contiguous() for k, v in nd.items()}
         ob, _ = net.infer(c[b:b + 1].to(dev), f0[b:b + 1].to(dev), uv[b:b + 1].to(dev), g=sid[b:b + 1].to(dev),
                           noice_scale=0.4, noise=nb)
-        assert torch.equal(ob[0], o[b]), b
+        d = (ob[0] - o[b]).abs()
+        assert d.max().item() <= 5e-3 and d.pow(2).mean().item() <= 1e-7, (b, d.max().item())
     # short-prefix parity against the oracle (same weights)
     Ts = 96
     cs, f0s, uvs = c[:2, :, :Ts].contiguous(), f0[:2, :Ts].contiguous(), uv[:2, :Ts].contiguous()
