@@ -216,15 +216,17 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   // ---- main loop over input-channel chunks ---------------------------------------------------------------
   const float* wbase = Ws + wm * (MT * TS) + ln;
   const float* xbase = Xs + wn * (NT * TS) + ln + sh;
-  const int n_cc = BC / (KPI * WK);  // k-groups per wave per tap
-
   const int dbg = p.dbg;
+  // (tried: offsetting the chunk phase of co-resident workgroups by half a chunk — no gain, −3 %: the two workgroups
+  // of a CU are not phase-locked)
+  const int cur = BC;
   load_chunk(0);
-  for (int c0 = 0; c0 < a.Cin; c0 += BC) {
+  for (int c0 = 0; c0 < a.Cin; c0 += cur) {
+    const int n_cc = cur / (KPI * WK);  // k-groups per wave per tap
     __syncthreads();  // everyone finished reading the previous chunk from LDS
     if (!(dbg & 1) || c0 == 0) store_chunk(c0);
     __syncthreads();
-    if (c0 + BC < a.Cin && !(dbg & 1)) load_chunk(c0 + BC);  // in flight during the MFMA loop below
+    if (c0 + cur < a.Cin && !(dbg & 1)) load_chunk(c0 + cur);  // in flight during the MFMA loop below
     if (dbg & 2) continue;
 
     if constexpr (KSC > 0) {
@@ -254,6 +256,18 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
               else
                 acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
             }
+        // Instruction order inside this block: the LDS operand reads of tap k+2 are issued BEFORE the MFMAs of tap k
+        // (left alone, the scheduler sinks each tap's reads next to its MFMAs to save registers, and the matrix pipe
+        // idles for an LDS round trip per tap whenever no second wave is resident on the SIMD).
+        if constexpr (KSC >= 3) {
+          constexpr int DSPT = (MT + 1) / 2 + (NT + 1) / 2;   // ds_read(2)_b32 instructions per tap
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * DSPT, 0);
+#pragma unroll
+          for (int k = 0; k < KSC; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            if (k + 2 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, DSPT, 0);
+          }
+        }
       }
     } else {
       const int n_it = n_cc * KS;

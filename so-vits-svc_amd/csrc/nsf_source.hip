@@ -29,37 +29,48 @@ struct ScanRec {
   double W;  // number of wraps detected before the frame
 };
 
-// one thread per (b, h); T iterations
-__global__ void nsf_frame_scan_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
-                                      ScanRec* __restrict__ rec, int B, int T, int upp, int H, float sr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * H) return;
-  const int b = idx / H, h = idx % H;
+// one workgroup per batch item: f0[b,:] is staged in LDS once (the sequential scan below would otherwise pay a global
+// load latency per frame), thread h < H runs the T-step recurrence for its harmonic out of LDS
+constexpr int SCAN_CHUNK = 1024;   // frames staged per pass
+__global__ __launch_bounds__(64) void nsf_frame_scan_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                            ScanRec* __restrict__ rec, int B, int T, int upp, int H,
+                                                            float sr) {
+  __shared__ float f0s[SCAN_CHUNK];
+  const int b = blockIdx.x, h = threadIdx.x;
   const float hm = (float)(h + 1);
-  const float ri = h == 0 ? 0.f : rand_ini[b * H + h];
+  const float ri = (h == 0 || h >= H) ? 0.f : rand_ini[b * H + h];
   double A = 0.0, E = 0.0, W = 0.0;
   double base = 0.0;  // floor(float(S1(0)))
-  for (int f = 0; f < T; ++f) {
-    const float fn = f0[(long long)b * T + f] * hm;
-    const float rad = fmodf(fn / sr, 1.0f);
-    ScanRec r;
-    r.A = A;
-    r.E = E;
-    r.W = W;
-    rec[((long long)b * H + h) * T + f] = r;
-    double s_end;
-    if (f == 0) {
-      const float rad0 = rad + ri;  // fp32 add, models.py:149
-      base = floor((double)(float)(double)rad0);
-      s_end = (double)rad0 + (double)(upp - 1) * (double)rad;
-    } else {
-      s_end = A + (double)upp * (double)rad;
+  for (int c0 = 0; c0 < T; c0 += SCAN_CHUNK) {
+    const int nc = min(SCAN_CHUNK, T - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += 64) f0s[i] = f0[(long long)b * T + c0 + i];
+    __syncthreads();
+    if (h < H) {
+      for (int i = 0; i < nc; ++i) {
+        const int f = c0 + i;
+        const float fn = f0s[i] * hm;
+        const float rad = fmodf(fn / sr, 1.0f);
+        ScanRec r;
+        r.A = A;
+        r.E = E;
+        r.W = W;
+        rec[((long long)b * H + h) * T + f] = r;
+        double s_end;
+        if (f == 0) {
+          const float rad0 = rad + ri;  // fp32 add, models.py:149
+          base = floor((double)(float)(double)rad0);
+          s_end = (double)rad0 + (double)(upp - 1) * (double)rad;
+        } else {
+          s_end = A + (double)upp * (double)rad;
+        }
+        const double w_end = floor((double)(float)s_end) - base;
+        const double eps = (double)(rad - 1.0f) - ((double)rad - 1.0);
+        E += (w_end - W) * eps;
+        W = w_end;
+        A = s_end;
+      }
     }
-    const double w_end = floor((double)(float)s_end) - base;
-    const double eps = (double)(rad - 1.0f) - ((double)rad - 1.0);
-    E += (w_end - W) * eps;
-    W = w_end;
-    A = s_end;
   }
 }
 
@@ -120,7 +131,7 @@ static int nsf_source_impl(const float* f0, const float* rand_ini, const float* 
   ScanRec* rec = reinterpret_cast<ScanRec*>(scratch);
   const long long L = (long long)T * upp;
   svc::ProfScope prof(s, "nsf_source", 0.0, 4.0 * B * L * (H + 1));
-  hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(svc::cdiv(B * H, 64)), dim3(64), 0, s, f0, rand_ini, rec, B, T, upp, H,
+  hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(B), dim3(64), 0, s, f0, rand_ini, rec, B, T, upp, H,
                      sampling_rate);
   hipLaunchKernelGGL(nsf_sample_kernel, dim3((unsigned)svc::cdivll(L, 256), B), dim3(256), 0, s, f0, rand_ini, noise,
                      lin_w, lin_b, rec, har, waves, B, T, upp, H, sampling_rate, sine_amp, noise_std);
