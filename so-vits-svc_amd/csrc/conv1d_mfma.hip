@@ -39,7 +39,8 @@ struct ConvP {
   int BC;         // input channels staged per chunk (multiple of KPI*WK)
   int n_t_tiles;  // number of BN tiles along t
   int n_m_tiles;
-  int xvec;       // 1: X rows are 16 B aligned -> float4 staging
+  int dump_off;   // float offset of the per-thread dump slots (staging writes of out-of-chunk slots)
+  int xvec;       // 1: X rows are 16 B aligned -> float4 staging (selects the XVEC kernel instantiation)
   int yvec;       // 1: y / res / y2 rows are 16 B aligned and unit-stride in time -> float4 epilogue
   int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
 };
@@ -56,7 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC>
 __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
   constexpr int TS = M16 ? 16 : 32;   // MFMA tile edge
   constexpr int KPI = M16 ? 4 : 2;    // K indices consumed per MFMA
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   const float* xb = a.x + (long long)b * a.x_bs;
   const float* pm = a.premask ? a.premask + (long long)b * a.premask_bs : nullptr;
   const int tin0 = t0 - a.pad_left;
-  const int sh = p.xvec ? (((tin0 % 4) + 4) % 4) : 0;  // tile start rounded down to a 16 B boundary
+  const int sh = XVEC ? (((tin0 % 4) + 4) % 4) : 0;  // tile start rounded down to a 16 B boundary
   const int tin_base = tin0 - sh;
   const int w_rows_total = a.Cin * KS;
   const float* wph = a.w + (long long)ph * a.w_phase_stride;
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   const bool wcol_ok = co0 + wc4 * 4 < a.CoutP;
   float* wlds = Ws + wr0 * BM + wc4 * 4;
   const int XW4 = XW >> 2;
-  float* xlds = Xs + wave * XW + (p.xvec ? lane * 4 : lane);
+  float* xlds = Xs + wave * XW + (XVEC ? lane * 4 : lane);
+  // slots that fall outside the chunk write to a per-thread dump slot behind the tiles: the staging code is
+  // straight-line (no exec-mask branches), which matters because every wave runs it between two barriers
+  float* dump = smem + p.dump_off + tid * 4;
 
   // premask depends only on the column: fetched once (scalar path only; the vector path is taken only without one)
   float pmv[XCIS];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
       const int gr = min(row0 + wr0 + i * RSTEP, w_rows_total - 1);
       wreg[i] = *reinterpret_cast<const float4*>(wph + (long long)gr * a.CoutP + wcol);
     }
-    if (p.xvec) {
+    if constexpr (XVEC) {
 #pragma unroll
       for (int s = 0; s < XSLV; ++s) {
         const int ri = s / XCIV, cj = s % XCIV;
@@ -178,37 +182,33 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
       const int r = wr0 + i * RSTEP;
-      if (r < w_rows_chunk) {
-        const bool ok = row0 + r < w_rows_total && wcol_ok;
-        const float4 v = wreg[i];
-        *reinterpret_cast<float4*>(wlds + i * RSTEP * BM) =
-            make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-      }
+      const bool ok = row0 + r < w_rows_total && wcol_ok;
+      const float4 v = wreg[i];
+      float* dst = r < w_rows_chunk ? wlds + i * RSTEP * BM : dump;
+      *reinterpret_cast<float4*>(dst) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
     const float ps = a.pre_slope;
-    if (p.xvec) {
+    if constexpr (XVEC) {
 #pragma unroll
       for (int s = 0; s < XSLV; ++s) {
         const int ri = s / XCIV, cj = s % XCIV;
         const int r = ri * NW + wave, c4 = cj * 64 + lane;
-        if (r < BC && c4 < XW4) {
-          const int tin = tin_base + c4 * 4;
-          const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
-          *reinterpret_cast<float4*>(xlds + ri * NW * XW + cj * 256) =
-              make_float4(ok ? svc_lrelu(xr[4 * s], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 1], ps) : 0.f,
-                          ok ? svc_lrelu(xr[4 * s + 2], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 3], ps) : 0.f);
-        }
+        const int tin = tin_base + c4 * 4;
+        const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
+        float* dst = (r < BC && c4 < XW4) ? xlds + ri * NW * XW + cj * 256 : dump;
+        *reinterpret_cast<float4*>(dst) =
+            make_float4(ok ? svc_lrelu(xr[4 * s], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 1], ps) : 0.f,
+                        ok ? svc_lrelu(xr[4 * s + 2], ps) : 0.f, ok ? svc_lrelu(xr[4 * s + 3], ps) : 0.f);
       }
     } else {
 #pragma unroll
       for (int s = 0; s < XSLS; ++s) {
         const int ri = s / XCIS, cj = s % XCIS;
         const int r = ri * NW + wave, c = cj * 64 + lane;
-        if (r < BC && c < XW) {
-          const int tin = tin_base + c;
-          const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
-          xlds[ri * NW * XW + cj * 64] = ok ? svc_lrelu(xr[s] * pmv[cj], ps) : 0.f;
-        }
+        const int tin = tin_base + c;
+        const bool ok = c0 + r < a.Cin && tin >= 0 && tin < a.Tin;
+        float* dst = (r < BC && c < XW) ? xlds + ri * NW * XW + cj * 64 : dump;
+        *dst = ok ? svc_lrelu(xr[s] * pmv[cj], ps) : 0.f;
       }
     }
   };
@@ -509,6 +509,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   }
   size_t lds = (size_t)bc * per_c;
   lds = std::max(lds, (size_t)WK * BM * (BN + 4) * 4);   // epilogue transpose buffer
+  p.dump_off = (int)(lds / 4);
+  lds += (size_t)NTHR * 16;                              // per-thread dump slots
   if (lds > 160 * 1024) {
     svc::set_error("conv1d: LDS tile too large (KS=%d dil=%d)", a.KS, a.dil);
     return SVC_ERR_UNSUPPORTED;
@@ -516,16 +518,18 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   p.n_t_tiles = svc::cdiv(a.Tout, BN);
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
   const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B * a.n_phase;
-  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC>;
+  auto kv = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true>;
+  auto ks = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, false>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+  if (xvec) hipLaunchKernelGGL(kv, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+  else hipLaunchKernelGGL(ks, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
   return svc::check_launch("conv1d_mfma");
 }
 
