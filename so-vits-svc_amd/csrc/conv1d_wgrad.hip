@@ -194,6 +194,161 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   }
 }
 
+// ---- small-channel variant (Ca, Cb <= 32: the 16/32-channel MRF stages of the decoder, first / last layers) ----------
+// The 128 x 64 tile above would be >= 94 % padding there.  Here a workgroup owns the WHOLE [Ca][Cb][NKS taps] gradient and
+// a range of 256-step time tiles; each of its 4 waves reduces a quarter of every tile with v_mfma_f32_16x16x4_f32
+// (M = ca, N = cb, K = 4 time steps), one accumulator quad per (tap, 16x16 block).
+constexpr int STT = 192;          // time steps per staged tile (48 per wave); As + Bs stay under 64 KiB of LDS
+constexpr int SPA = STT + 1;
+
+struct WgSP {
+  const float* A;
+  const float* Bm;
+  float* G;
+  float* dbias;
+  long long a_bs, a_cs, b_bs, b_cs;
+  int B, Ca, Cb, TA, TB, KS, dil, pad;
+  int tiles_per_b, n_tiles, tiles_per_wg, PB, n_kgroups, splits;
+};
+
+template <int NKS, int MA, int NB>   // taps per workgroup, 16-row blocks of ca / cb
+__global__ __launch_bounds__(256) void conv1d_wgrad_small_kernel(WgSP p) {
+  extern __shared__ float lds[];
+  float* As = lds;                       // [16*MA][SPA]
+  float* Bs = lds + 16 * MA * SPA;       // [16*NB][PB]
+  const int PB = p.PB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int kg = blockIdx.x % p.n_kgroups, split = blockIdx.x / p.n_kgroups;
+  const int k0 = kg * NKS;
+  const int nk = min(NKS, p.KS - k0);
+  const int tile0 = split * p.tiles_per_wg, tile1 = min(tile0 + p.tiles_per_wg, p.n_tiles);
+  const int XWB = STT + (nk - 1) * p.dil;
+  const int boff = k0 * p.dil - p.pad;
+  const int dil = p.dil;
+
+  f32x4 acc[NKS][MA][NB];
+#pragma unroll
+  for (int q = 0; q < NKS; ++q)
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = p.dbias != nullptr && kg == 0;
+
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int b = tile / p.tiles_per_b;
+    const int t0 = (tile - b * p.tiles_per_b) * STT;
+    const float* ab = p.A + (long long)b * p.a_bs;
+    const float* bb = p.Bm + (long long)b * p.b_bs;
+    __syncthreads();
+    for (int r = wave; r < 16 * MA; r += 4) {            // rows wave-uniform, lanes along time (coalesced)
+      const float* arow = ab + (long long)min(r, p.Ca - 1) * p.a_cs;
+      for (int c = lane; c < STT; c += 64) {
+        const int t = t0 + c;
+        As[r * SPA + c] = (r < p.Ca && t < p.TA) ? arow[t] : 0.f;
+      }
+    }
+    for (int r = wave; r < 16 * NB; r += 4) {
+      const float* brow = bb + (long long)min(r, p.Cb - 1) * p.b_cs;
+      for (int c = lane; c < XWB; c += 64) {
+        const int t = t0 + boff + c;
+        Bs[r * PB + c] = (r < p.Cb && t >= 0 && t < p.TB) ? brow[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (do_bias && tid < 16 * MA * 8) {                   // 8 threads per row, STT/8 columns each
+      const float* rp = As + (tid >> 3) * SPA + (tid & 7) * (STT / 8);
+#pragma unroll
+      for (int c = 0; c < STT / 8; ++c) bsum += rp[c];
+    }
+    const float* ap = As + ln * SPA + wave * (STT / 4) + lk;
+    const float* bp = Bs + ln * PB + wave * (STT / 4) + lk;
+#pragma unroll 2
+    for (int s = 0; s < STT / 4; s += 4) {
+      float av[MA];
+#pragma unroll
+      for (int i = 0; i < MA; ++i) av[i] = ap[i * 16 * SPA + s];
+#pragma unroll
+      for (int q = 0; q < NKS; ++q) {
+        if (q < nk) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const float bv = bp[j * 16 * PB + s + q * dil];
+#pragma unroll
+            for (int i = 0; i < MA; ++i) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (do_bias && tid < 16 * MA * 8) {
+    bsum += __shfl_xor(bsum, 1);
+    bsum += __shfl_xor(bsum, 2);
+    bsum += __shfl_xor(bsum, 4);
+    const int ca = tid >> 3;
+    if ((tid & 7) == 0 && ca < p.Ca) atomicAdd(p.dbias + ca, bsum);
+  }
+  // Every wave holds a partial sum of the SAME [taps][ca][cb] block (the waves split time): fold waves 2,3 into 0,1 and
+  // then 1 into 0 through LDS so that the workgroup issues one set of atomics, not four (the gradient is a few KB that
+  // every workgroup of the launch adds into: same-address atomics serialise in L2).
+  constexpr int NQ = NKS * MA * NB;       // accumulator quads per wave
+  float* red = lds;                        // [2][NQ*4][64]
+  for (int round = 0; round < 2; ++round) {
+    const int src_lo = round == 0 ? 2 : 1;            // waves >= src_lo write, waves < src_lo add
+    __syncthreads();
+    if (wave >= src_lo && wave < 2 * src_lo) {
+      float* dst = red + (wave - src_lo) * NQ * 256 + lane;
+#pragma unroll
+      for (int q = 0; q < NKS; ++q)
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(((q * MA + i) * NB + j) * 4 + r) * 64] = acc[q][i][j][r];
+    }
+    __syncthreads();
+    if (wave < src_lo) {
+      const float* src = red + wave * NQ * 256 + lane;
+#pragma unroll
+      for (int q = 0; q < NKS; ++q)
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][i][j][r] += src[(((q * MA + i) * NB + j) * 4 + r) * 64];
+    }
+  }
+  if (wave != 0) return;
+  // MFMA 16x16 C layout: column n = ln, rows 4*lk + r
+#pragma unroll
+  for (int q = 0; q < NKS; ++q) {
+    if (q >= nk) continue;
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ca = i * 16 + 4 * lk + r, cb = j * 16 + ln;
+          if (ca < p.Ca && cb < p.Cb) {
+            float* g = p.G + ((long long)ca * p.Cb + cb) * p.KS + k0 + q;
+            if (p.splits > 1) atomicAdd(g, acc[q][i][j][r]);
+            else *g += acc[q][i][j][r];
+          }
+        }
+  }
+}
+
+template <int NKS, int MA, int NB>
+void launch_small(const WgSP& p, dim3 grid, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((conv1d_wgrad_small_kernel<NKS, MA, NB>), grid, dim3(256), lds, s, p);
+}
+
 template <int NK>
 void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL((conv1d_wgrad_kernel<NK>), grid, dim3(256), lds, s, p);
@@ -221,16 +376,57 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
       return SVC_ERR_HIP;
     }
   }
-  // taps per workgroup: as many as the halo budget and 5 accumulator sets allow
-  int nk = std::min(a.KS, 5);
-  while (nk > 1 && (nk - 1) * a.dil > MAXHALO_W) --nk;
-  if (a.KS > 5 && nk > 4) nk = 4;          // balanced groups for 7 (4+3) and 11 (4+4+3)
   if (a.dbias && !a.accumulate) {
     if (hipMemsetAsync(a.dbias, 0, sizeof(float) * (size_t)a.Ca, s) != hipSuccess) {
       svc::set_error("wgrad: memset failed");
       return SVC_ERR_HIP;
     }
   }
+  if (a.Ca <= 32 && a.Cb <= 32) {
+    WgSP q;
+    q.A = a.A; q.Bm = a.Bm; q.G = a.G; q.dbias = a.dbias;
+    q.a_bs = a.a_bs; q.a_cs = a.a_cs; q.b_bs = a.b_bs; q.b_cs = a.b_cs;
+    q.B = a.B; q.Ca = a.Ca; q.Cb = a.Cb; q.TA = a.TA; q.TB = a.TB; q.KS = a.KS; q.dil = a.dil; q.pad = a.pad;
+    const int MA = a.Ca > 16 ? 2 : 1, NB = a.Cb > 16 ? 2 : 1;
+    // taps per workgroup: 4 accumulator registers per (tap, block); keep the LDS halo (nks-1)*dil <= 64
+    int nks = (MA * NB == 1) ? 12 : (MA * NB == 2 ? 8 : 4);
+    nks = std::min(nks, a.KS);
+    while (nks > 1 && (nks - 1) * a.dil > 64) --nks;
+    nks = nks > 8 ? 12 : (nks > 4 ? 8 : (nks > 2 ? 4 : nks));     // instantiated: 1, 2, 4, 8, 12
+    if ((nks - 1) * a.dil > 64 && nks > 1) nks = nks == 12 ? 8 : nks / 2;
+    q.n_kgroups = svc::cdiv(a.KS, nks);
+    q.tiles_per_b = svc::cdiv(a.TA, STT);
+    q.n_tiles = q.tiles_per_b * a.B;
+    // few time splits: every split adds the whole (tiny) gradient with same-address atomics
+    int splits = std::max(1, 128 / q.n_kgroups);
+    splits = std::min(splits, q.n_tiles);
+    q.tiles_per_wg = svc::cdiv(q.n_tiles, splits);
+    q.splits = svc::cdiv(q.n_tiles, q.tiles_per_wg);
+    int pb = STT + (std::min(nks, a.KS) - 1) * a.dil;
+    if ((pb & 1) == 0) ++pb;
+    q.PB = pb;
+    size_t lds = sizeof(float) * ((size_t)16 * MA * SPA + (size_t)16 * NB * pb);
+    lds = std::max(lds, sizeof(float) * (size_t)2 * nks * MA * NB * 256);      // cross-wave reduction slabs
+    dim3 grid(q.splits * q.n_kgroups);
+#define SVC_WGS(NKS_)                                                     \
+  if (MA == 1 && NB == 1) launch_small<NKS_, 1, 1>(q, grid, lds, s);      \
+  else if (MA == 2 && NB == 1) launch_small<NKS_, 2, 1>(q, grid, lds, s); \
+  else if (MA == 1 && NB == 2) launch_small<NKS_, 1, 2>(q, grid, lds, s); \
+  else launch_small<NKS_, 2, 2>(q, grid, lds, s);
+    switch (nks) {
+      case 1: SVC_WGS(1) break;
+      case 2: SVC_WGS(2) break;
+      case 4: SVC_WGS(4) break;
+      case 8: if (MA * NB <= 2) { SVC_WGS(8) } else { SVC_WGS(4) } break;
+      default: if (MA * NB == 1) { launch_small<12, 1, 1>(q, grid, lds, s); } else { SVC_WGS(4) } break;
+    }
+#undef SVC_WGS
+    return svc::check_launch("conv1d_wgrad_small");
+  }
+  // taps per workgroup: as many as the halo budget and 5 accumulator sets allow
+  int nk = std::min(a.KS, 5);
+  while (nk > 1 && (nk - 1) * a.dil > MAXHALO_W) --nk;
+  if (a.KS > 5 && nk > 4) nk = 4;          // balanced groups for 7 (4+3) and 11 (4+4+3)
   WgP p;
   p.A = a.A; p.Bm = a.Bm; p.G = a.G; p.dbias = a.dbias;
   p.a_bs = a.a_bs; p.a_cs = a.a_cs; p.b_bs = a.b_bs; p.b_cs = a.b_cs;

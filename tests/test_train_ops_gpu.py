@@ -37,7 +37,10 @@ def _p(*shape, scale=1.0):
 
 @pytest.mark.parametrize("B,Cin,Cout,T,K,dil,pad", [
     (2, 16, 16, 300, 3, 1, 1), (1, 64, 32, 513, 7, 3, 9), (2, 32, 32, 256, 11, 5, 25), (3, 192, 384, 77, 5, 1, 2),
-    (2, 96, 192, 130, 1, 1, 0), (1, 1, 16, 700, 15, 1, 7), (2, 1024, 1, 40, 3, 1, 1)])
+    (2, 96, 192, 130, 1, 1, 0), (1, 1, 16, 700, 15, 1, 7), (2, 1024, 1, 40, 3, 1, 1),
+    # small-channel weight-gradient kernel (Ca, Cb <= 32: 16x16x4 MFMA, tap groups, several time tiles per workgroup)
+    (2, 16, 16, 5000, 11, 5, 25), (2, 32, 32, 3000, 7, 3, 9), (3, 32, 16, 1000, 11, 1, 5), (2, 25, 12, 777, 3, 1, 1),
+    (1, 12, 25, 4001, 11, 3, 15), (2, 3, 32, 2731, 2, 11, 11)])
 def test_conv1d_dense_fwd_bwd(dev, B, Cin, Cout, T, K, dil, pad):
     import svc_autograd as A
     torch.manual_seed(1)
