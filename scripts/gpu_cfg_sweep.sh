@@ -7,10 +7,10 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bc", "scripts/bench_conv.py")
 # inline re-implementation to choose shapes
 dev = torch.device("cuda:0")
-def run(Cin, L, k, d, Cout, code):
+def run(Cin, L, k, d, Cout, code, B=16):
     S.lib().svc_debug_set_conv_cfg(code)
-    x = torch.randn(1, Cin, L, device=dev); w = torch.randn(Cout, Cin, k, device=dev) / (Cin*k)**0.5; b = torch.randn(Cout, device=dev)
-    wp = S.pack_conv1d_weight(w); out = torch.empty(1, Cout, L, device=dev); pad = (k*d-d)//2
+    x = torch.randn(B, Cin, L, device=dev); w = torch.randn(Cout, Cin, k, device=dev) / (Cin*k)**0.5; b = torch.randn(Cout, device=dev)
+    wp = S.pack_conv1d_weight(w); out = torch.empty(B, Cout, L, device=dev); pad = (k*d-d)//2
     kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, res=x if Cout==Cin else None, res_mode=1 if Cout==Cin else 0, out=out)
     S.conv1d(x, wp, Cout, k, **kw); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -20,9 +20,9 @@ def run(Cin, L, k, d, Cout, code):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)/20
-    print(f"code {code:3d} Cin={Cin:4d} Cout={Cout:4d} L={L:7d} k={k:2d} d={d} {ms*1e3:8.1f} us {2.0*Cout*Cin*k*L/ms/1e9:7.1f} TF", flush=True)
-for sh in [(256,6896,3,1,256),(256,6896,7,5,256),(256,6896,11,5,256),(192,862,5,1,384),(768,862,3,1,192),(192,862,3,1,768),(192,862,1,1,576)]:
-    for code in (0,4,5,6,7):
+    print(f"code {code:3d} Cin={Cin:4d} Cout={Cout:4d} L={L:7d} k={k:2d} d={d} {ms*1e3:8.1f} us {2.0*B*Cout*Cin*k*L/ms/1e9:7.1f} TF", flush=True)
+for sh in [(192,768,1,1,192),(192,768,1,1,384),(384,768,1,1,192),(192,768,5,1,384),(384,768,5,1,192),(768,768,3,1,192),(192,768,3,1,768),(128,1024,11,1,128),(128,1024,7,1,128),(256,128,11,1,256)]:
+    for code in (0,3,4,5,6,7):
         try: run(*sh, code)
         except Exception as e: print("fail", sh, code, str(e)[:80])
 PY

@@ -585,18 +585,26 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     else if (m64 && wg64x128 >= 200) cfg = 4;
     else if (m64 && wg64x32 >= 200) cfg = 5;
     else cfg = 6;
-    // Long sequences: the decoder's lengths are 862 * 2^k samples, so any power-of-two tile leaves the last round of
-    // workgroups ~2/3 full (431 tiles of 128 on 512 slots).  The 128 x 224 config (7 MFMA column tiles per wave) covers
-    // such a sequence in ONE round of one workgroup per CU (247 tiles on 256 CUs) with 1.75 x the matrix work per
-    // staged weight byte; measured +8..13 % for KS >= 7, -6 % for KS = 3 (the staging phases are not overlapped by a
-    // second resident workgroup), so it is picked by modelled time = rounds * resident workgroups * padded tile area
-    // only for the wide kernels.
-    if (cfg == 3 && a.KS >= 7 && a.n_phase == 1) {
+    // Wide outputs (Cout > 64) with enough columns to fill the chip: pick among 128x128, 64x128 and 128x224 by modelled
+    // time = (rounds of 256 CUs) * tile area.  Two effects it captures, both measured: (1) the decoder's lengths are
+    // 862 * 2^k samples, so power-of-two tiles leave the last round ~2/3 full (431 tiles of 128) while 128x224 covers the
+    // sequence in ONE round of one workgroup per CU (247 tiles; +8..13 % for KS >= 7, -6 % for KS = 3 where its
+    // un-overlapped staging phases weigh more); (2) for batched medium sequences (training: B=16, T~1000) the smaller
+    // 64x128 tile fills all CUs where 128x128 / 128x224 would occupy a third of them (76 vs 48 vs 30 TFLOP/s).
+    if (a.Cout > 64 && a.n_phase == 1 && (cfg == 3 || cfg == 4)) {
       const double n128 = (double)svc::cdiv(a.Cout, 128) * svc::cdiv(a.Tout, 128) * a.B;
+      const double n64 = (double)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 128) * a.B;
       const double n224 = (double)svc::cdiv(a.Cout, 128) * svc::cdiv(a.Tout, 224) * a.B;
-      const double t128 = std::ceil(n128 / 512.0) * 2.0 * 128 * 128;
-      const double t224 = std::ceil(n224 / 256.0) * 1.0 * 128 * 224 * 1.04;
-      if (t224 < t128) cfg = 7;
+      double best = std::ceil(n128 / 256.0) * 128 * 128;
+      cfg = 3;
+      if (m64) {
+        const double t64 = std::ceil(n64 / 256.0) * 64 * 128 * 1.05;
+        if (t64 < best) { best = t64; cfg = 4; }
+      }
+      if (a.KS >= 7 && n224 >= 200) {
+        const double t224 = std::ceil(n224 / 256.0) * 128 * 224 * 1.04;
+        if (t224 < best) { best = t224; cfg = 7; }
+      }
     }
   }
   {
