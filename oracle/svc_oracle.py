@@ -378,12 +378,19 @@ def generator(x, f0, g, sd, cfg, rand_ini, noise_sine, prefix="dec", return_sour
 # ------------------------------------------------------------------------------------------------------------
 # whole-path inference (models.py:496-532)
 # ------------------------------------------------------------------------------------------------------------
-def synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.35, predict_f0=False, vol=None, return_all=False):
+def synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.35, predict_f0=False, vol=None, return_all=False,
+                g_mix=None):
     """SynthesizerTrn.infer.  c [B,ssl,T], f0 [B,T], uv [B,T], sid [B,1] int64.
+    g_mix [T, S] (B = 1): the character-mix branch models.py:505-509 after EnableCharacterMix(S) (:456-461) — a
+    per-frame convex mix of the first S speaker embeddings, i.e. a time-varying g [1, gin, T].
     noise: dict(enc_p [B,inter,T], rand_ini [B,9], sine [B,L,9]) — the reference's draw order is
     randn_like (models.py:160), rand (vdecoder/hifigan/models.py:147), randn_like (:266), randn_like (:319, unused)."""
     B, _, T = c.shape
-    g = sd["emb_g.weight"][sid].transpose(1, 2)                      # models.py:513
+    if g_mix is not None:
+        S_ = g_mix.shape[1]
+        g = (g_mix @ sd["emb_g.weight"][:S_]).t().unsqueeze(0)       # [1, gin, T]
+    else:
+        g = sd["emb_g.weight"][sid].transpose(1, 2)                  # models.py:513
     x_mask = torch.ones(B, 1, T)
     volp = 0
     if vol is not None and cfg.get("vol_embedding", False):

@@ -139,3 +139,32 @@ def test_snake_long_form_batch8_properties(dev):
     os_, _ = net.infer(cs.to(dev), f0s.to(dev), uvs.to(dev), g=sid[:2].to(dev), noice_scale=0.4,
                        noise={k: v.to(dev) for k, v in ns.items()})
     _check(os_, ref)
+
+
+def test_infer_character_mix_and_vol_golden(dev):
+    """Speaker-mix branch (EnableCharacterMix + g [T,S], models.py:456-461,505-509) with vol_embedding (:517) against
+    the real reference's vector."""
+    z = np.load(os.path.join(G, "infer_mixvol_T40.npz"))
+    meta = json.loads(str(z["meta"]))
+    cfg = W.small_config()
+    cfg["vol_embedding"] = True
+    net, _ = _build(cfg, meta["seed"], dev)
+    net.EnableCharacterMix(meta["S"], dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    noise = dict(enc_p=t("noise_enc_p"), rand_ini=t("noise_rand_ini"), sine=t("noise_sine"))
+    o, _ = net.infer(t("c"), t("f0"), t("uv"), g=t("mix"), noice_scale=meta["noice_scale"], vol=t("vol"), noise=noise)
+    _check(o, torch.from_numpy(z["o"]))
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (1, 3), (3, 7), (1, 17)])
+def test_infer_very_short_inputs(dev, B, T):
+    """Edge case: clips of 1..17 frames (shorter than every tile, halo and attention window) against the oracle."""
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=40 + T)
+    noise = W.make_noise(cfg, B, T, seed=41 + T)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4,
+                     noise={k: v.to(dev) for k, v in noise.items()})
+    _check(o, ref)

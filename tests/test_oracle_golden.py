@@ -66,3 +66,16 @@ def test_inputs_and_weights_are_deterministic():
     assert all(torch.equal(a[k], b[k]) for k in a)
     c = W.make_state_dict(cfg, 6)
     assert not torch.equal(a["pre.weight"], c["pre.weight"])
+
+
+def test_oracle_reproduces_reference_character_mix_and_vol():
+    """models.py:456-461,505-509,517: EnableCharacterMix + per-frame speaker mix g [T,S] + vol embedding."""
+    z = _load("infer_mixvol_T40.npz")
+    cfg = W.small_config()
+    cfg["vol_embedding"] = True
+    sd = W.make_state_dict(cfg, z["meta"]["seed"])
+    noise = dict(enc_p=z["noise_enc_p"], rand_ini=z["noise_rand_ini"], sine=z["noise_sine"])
+    with torch.no_grad():
+        o, _ = O.synth_infer(sd, cfg, z["c"], z["f0"], z["uv"], None, noise, noice_scale=z["meta"]["noice_scale"],
+                             vol=z["vol"], g_mix=z["mix"])
+    assert (o - z["o"]).abs().max().item() <= 5e-6 * max(z["o"].abs().max().item(), 1.0)
