@@ -15,13 +15,15 @@ from . import svc_oracle as O
 LRELU_SLOPE = 0.1
 
 
-def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise):
+def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise, vol=None):
     """models.py:463-493 with the random draws explicit: noise = dict(f0_factor [B,1], enc_p, enc_q [B,inter,T],
     ids_slice [B] int64, rand_ini [B,9], sine [B, seg*hop, 9])."""
     B, _, T = c.shape
     g = sd["emb_g.weight"][sid].transpose(1, 2)
     x_mask = O.sequence_mask(c_lengths, T).unsqueeze(1).to(c.dtype)
     x = O.conv1d(c, sd, "pre", padding=2) * x_mask + sd["emb_uv.weight"][uv.long()].transpose(1, 2)
+    if vol is not None and cfg.get("vol_embedding", False):      # models.py:469
+        x = x + F.linear(vol[:, :, None], sd["emb_vol.weight"], sd["emb_vol.bias"]).transpose(1, 2)
     lf0 = 2595. * torch.log10(1. + f0.unsqueeze(1) / 700.) / 500
     norm_lf0 = O.normalize_f0(lf0, x_mask, uv, noise["f0_factor"])
     pred_lf0 = O.f0_decoder(x.detach(), norm_lf0, x_mask, g, sd, cfg)

@@ -272,8 +272,6 @@ class SynthesizerTrn(nn.Module):
         `noise` (optional dict: enc_p, enc_q [B,inter,T], f0_factor [B,1], ids_slice [B], rand_ini [B,9],
         sine [B, seg*hop, 9]) injects the random draws explicitly (parity tests); otherwise they come from torch's
         generator in the reference's order."""
-        if vol is not None and self.vol_embedding:
-            raise NotImplementedError("vol_embedding=True has no training path yet")
         noise = noise or {}
         c, f0, uv, spec = c.float(), f0.float(), uv.float(), spec.float()
         B, _, T = c.shape
@@ -282,6 +280,10 @@ class SynthesizerTrn(nn.Module):
         x_mask = torch.unsqueeze(commons.sequence_mask(c_lengths, T), 1).to(c.dtype)
         x = A.mul_bcast(self.pre.forward_train(c), x_mask)
         x = A.add(x, A.embedding_bct(uv.long(), self.emb_uv.weight))                    # :471
+        if vol is not None and self.vol_embedding:                                      # :469 emb_vol(vol[:,:,None])
+            H = self.hidden_channels
+            vt = A.mul_bcast(vol.float().unsqueeze(1).expand(B, H, T), self.emb_vol.weight.view(1, H, 1))
+            x = A.add(x, A.add_bcast(vt, self.emb_vol.bias.view(1, H, 1)))
         if self.use_automatic_f0_prediction:
             factor = noise.get("f0_factor")
             if factor is None:

@@ -85,3 +85,37 @@ def test_training_step_matches_reference_and_oracle(dev):
         if name.startswith("grad_g."):
             g = gg[name[7:]].numpy()
             assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
+
+
+def test_training_forward_with_vol_embedding_matches_oracle(dev):
+    """vol_embedding=True (models.py:469): HIP training forward + the gradients of emb_vol / pre against the oracle's
+    torch-CPU autograd on the same injected noise."""
+    import models
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    cs = load_case()
+    cfg = dict(cs["cfg"], vol_embedding=True)
+    sd = W.make_train_state_dict(cfg, 31)
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = cs["batch"]
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand(c.shape[0], c.shape[2], generator=g)
+    sg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = TO.synth_forward(sg, cfg, c, f0, uv, spec, sid, lengths, lengths, cs["noise"], vol=vol)
+    out = net(c.to(dev), f0.to(dev), uv.to(dev), spec.to(dev), g=sid.to(dev), c_lengths=lengths.to(dev),
+              spec_lengths=lengths.to(dev), vol=vol.to(dev), noise={k: v.to(dev) for k, v in cs["noise"].items()})
+    yh, yr = out[0].detach().cpu(), ref[0].detach()
+    assert (yh - yr).abs().max().item() <= 2e-4 * max(1.0, yr.abs().max().item())
+    import svc_autograd as A
+    # y_hat depends on the posterior path only; the prior statistics m_p carry the emb_vol / pre gradients
+    mh, mr = out[3][2], ref[3][2]
+    assert (mh.detach().cpu() - mr.detach()).abs().max().item() <= 2e-4 * max(1.0, mr.abs().max().item())
+    (A.sum_sq(mh) / mh.numel()).backward()
+    mr.pow(2).mean().backward()
+    for k in ("emb_vol.weight", "emb_vol.bias", "pre.weight"):
+        gh = dict(net.named_parameters())[k].grad.cpu()
+        gr = sg[k].grad
+        assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k
