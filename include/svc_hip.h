@@ -180,6 +180,11 @@ int svc_copy_bct_f32(const float* x, float* y, const float* mask, long long x_bs
 int svc_snake_alias_f32(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host,
                         long long x_bs, long long x_cs, long long y_bs, long long y_cs, int B, int C, int T,
                         void* stream);
+/* Backward of svc_snake_alias_f32: dx = U^T[(D^T dy) (1 + sin(2 e^alpha u) e^alpha / (e^beta + 1e-9))], u = U x recomputed;
+ * dalpha, dbeta [C] are zeroed by the call and receive the parameter gradients.  T >= 6. */
+int svc_snake_alias_bwd_f32(const float* x, const float* dy, const float* alpha, const float* beta, const float* taps_host,
+                            float* dx, float* dalpha, float* dbeta, long long x_bs, long long x_cs, long long g_bs,
+                            long long g_cs, long long d_bs, long long d_cs, int B, int C, int T, void* stream);
 /* Automatic-f0 helpers (models.py:523-527 + utils.normalize_f0, utils.py:31-45).  f0,uv,mask,lf0,norm_lf0:[B,T];
  * factor:[B] or NULL (=1, inference).  lf0 = 2595*log10(1+f0/700)/500 (or f0 itself when input_is_lf0);
  * norm_lf0 = (lf0 - mean_voiced)*factor*mask. */

@@ -606,6 +606,27 @@ class _CMag(Function):
         return dre, dim, None
 
 
+class _SnakeAlias(Function):
+    """SnakeAlias (vdecoder/hifiganwithsnake/alias/act.py:125-130): fused up2 -> snake -> down2, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta, taps):
+        x = _c(x)
+        ctx.save_for_backward(x, alpha, beta)
+        ctx.taps = taps
+        return S.snake_alias(x, alpha.detach(), beta.detach(), taps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha, beta = ctx.saved_tensors
+        dx, da, db = S.snake_alias_bwd(x, _c(dy), alpha.detach(), beta.detach(), ctx.taps)
+        return dx, da, db, None
+
+
+def snake_alias(x, alpha, beta, taps):
+    return _SnakeAlias.apply(x, alpha, beta, tuple(taps))
+
+
 class _RfftMag(Function):
     """|rFFT(frames)| with the 1e-6 floor (modules/mel_processing.py:61-63): rocFFT forward + fused magnitude; backward
     = magnitude gradient + rocFFT complex-to-real (the adjoint)."""

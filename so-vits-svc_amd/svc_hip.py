@@ -108,6 +108,8 @@ def lib():
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_snake_alias_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [C.c_longlong] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
+            [C.c_int] * 3 + [C.c_void_p]
         _lib = L
     return _lib
 
@@ -117,7 +119,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_snake_alias_f32",
+    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32",
 ]
 
 
@@ -411,6 +413,21 @@ def snake_alias(x, alpha, beta, taps, out=None):
     check(lib().svc_snake_alias_f32(ptr(x), ptr(out), ptr(alpha), ptr(beta), tp, xb, xc, yb, yc, B, Cc, T, stream_ptr()),
           "snake_alias")
     return out
+
+
+def snake_alias_bwd(x, dy, alpha, beta, taps):
+    """(dx, dalpha, dbeta) of snake_alias."""
+    require_gpu(x, dy, alpha, beta)
+    B, Cc, T = x.shape
+    dx = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    da = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    db = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    xb, xc = _bct_strides(x)
+    gb, gc = _bct_strides(dy)
+    tp = (C.c_float * 12)(*[float(v) for v in taps])
+    check(lib().svc_snake_alias_bwd_f32(ptr(x), ptr(dy), ptr(alpha), ptr(beta), tp, ptr(dx), ptr(da), ptr(db), xb, xc, gb, gc,
+                                        Cc * T, T, B, Cc, T, stream_ptr()), "snake_alias_bwd")
+    return dx, da, db
 
 
 def flip_view(x):

@@ -147,7 +147,7 @@ class DepthwiseSeparableConv1d(nn.Module):
     W[co,ci,k] = Wp[co,ci] * Wd[ci,k], bias = Wp @ bd + bp (both on the GPU: svc_weight_norm_fwd_f32, svc_ew_bct_f32,
     svc_conv1d_f32) and the layer runs as ONE fused MFMA conv with the WN gate epilogue — instead of the reference's
     two convs + two weight-norm recomputes per call.  At 192 channels the dense form is launch-latency bound either way.
-    Inference only: the training graph of the depthwise variant is not implemented."""
+    Training (forward_train) keeps the two-conv form so that depth_conv / point_conv get their own gradients."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True,
                  weight_norm=False):
@@ -194,7 +194,11 @@ class DepthwiseSeparableConv1d(nn.Module):
         self.is_weight_norm = False
 
     def forward_train(self, x, **kw):
-        raise NotImplementedError("use_depthwise_conv has no training (backward) path yet")
+        """Autograd form, as the reference computes it (modules/DSConv.py:19-20): depthwise conv (svc_gconv1d_*, groups =
+        channels) then the 1x1 conv; weight-norm of both through svc_weight_norm_{fwd,bwd}_f32."""
+        wd = self.depth_conv.effective_weight()                      # [Cin, 1, K]
+        h = A.conv1d(x, wd, self.depth_conv.bias, 1, self.padding, self.dilation, groups=self.in_channels)
+        return self.point_conv.forward_train(h)
 
     def forward(self, x, **kw):
         if training_call(*self._all_params()) or (torch.is_grad_enabled() and getattr(x, "requires_grad", False)):

@@ -5,6 +5,7 @@ import torch
 from torch import nn
 from torch.nn import Parameter
 
+import svc_autograd as A
 import svc_hip as S
 
 from .resample import DownSample1d, UpSample1d
@@ -47,5 +48,5 @@ class SnakeAlias(nn.Module):
 
     def forward(self, x, C=None, out=None):
         if torch.is_grad_enabled() and (self.act.alpha.requires_grad or getattr(x, "requires_grad", False)):
-            raise NotImplementedError("SnakeAlias has no backward kernel yet: run the snake decoder under torch.no_grad()")
+            return A.snake_alias(x, self.act.alpha, self.act.beta, self._taps)      # training: HIP forward + backward
         return S.snake_alias(x, self.act.alpha, self.act.beta, self._taps, out=out)

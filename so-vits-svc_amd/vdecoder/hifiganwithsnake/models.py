@@ -9,6 +9,7 @@ convolutions are the same fused MFMA kernels as the plain generator, called with
 import torch
 from torch import nn
 
+import svc_autograd as A
 import svc_hip as S
 from svc_nn import Conv1d, _no_grad_guard
 from vdecoder.hifigan import models as base
@@ -33,6 +34,15 @@ class ResBlock1(nn.Module):
         self.convs2.apply(init_weights)
         self.num_layers = len(self.convs1) + len(self.convs2)
         self.activations = nn.ModuleList([SnakeAlias(channels, C=C) for _ in range(self.num_layers)])
+
+    def forward_train(self, x):
+        """Reference :71-77, one autograd op per reference op."""
+        acts1, acts2 = self.activations[::2], self.activations[1::2]
+        for c1, c2, a1, a2 in zip(self.convs1, self.convs2, acts1, acts2):
+            xt = c1.forward_train(a1(x))
+            xt = c2.forward_train(a2(xt))
+            x = A.add(xt, x)
+        return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
         """Reference :71-77.  out (+)= resblock(x); epilogue arguments as hifigan.ResBlock1.forward."""
@@ -67,6 +77,12 @@ class ResBlock2(nn.Module):
         self.convs.apply(init_weights)
         self.num_layers = len(self.convs)
         self.activations = nn.ModuleList([SnakeAlias(channels, C=C) for _ in range(self.num_layers)])
+
+    def forward_train(self, x):
+        """Reference :101-106."""
+        for c, a in zip(self.convs, self.activations):
+            x = A.add(c.forward_train(a(x)), x)
+        return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
         """Reference :101-106."""
@@ -107,7 +123,23 @@ class Generator(base.Generator):
         self.snake_post = SnakeAlias(ch, C=c0 >> len(self.ups))
 
     def forward_train(self, x, f0, g=None, noise=None):
-        raise NotImplementedError("the nsf-snake-hifigan decoder has no training (backward) path yet")
+        """Reference :380-413, one autograd op per reference op (SnakeAlias: HIP forward + backward kernels)."""
+        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        x = self.conv_pre.forward_train(x)
+        if g is not None:
+            x = A.add_bcast(x, self.cond.forward_train(g))
+        for i in range(self.num_upsamples):
+            x = self.snakes[i](x)
+            x = self.ups[i].forward_train(x)
+            x = A.add(x, self.noise_convs[i].forward_train(har))
+            xs = None
+            for j in range(self.num_kernels):
+                r = self.resblocks[i * self.num_kernels + j].forward_train(x)
+                xs = r if xs is None else A.add(xs, r)
+            x = A.scale(xs, 1.0 / self.num_kernels)
+        x = self.snake_post(x)
+        x = self.conv_post.forward_train(x)
+        return A.tanh(x)
 
     def forward(self, x, f0, g=None, noise=None):
         """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413)."""

@@ -119,3 +119,74 @@ def test_training_forward_with_vol_embedding_matches_oracle(dev):
         gh = dict(net.named_parameters())[k].grad.cpu()
         gr = sg[k].grad
         assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k
+
+
+def test_snake_decoder_training_matches_oracle(dev):
+    """vocoder_name="nsf-snake-hifigan" in the TRAINING graph: y_hat and the gradients of decoder parameters (incl. the
+    SnakeAlias alpha / beta of several sites) against the oracle's torch-CPU autograd on the same injected noise."""
+    import models
+    import svc_autograd as A
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    cs = load_case()
+    cfg = dict(cs["cfg"], vocoder_name="nsf-snake-hifigan")
+    sd = W.make_train_state_dict(cfg, 41)
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = cs["batch"]
+    sg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(".filter") else v.clone())
+          for k, v in sd.items()}
+    ref = TO.synth_forward(sg, cfg, c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
+    out = net(c.to(dev), f0.to(dev), uv.to(dev), spec.to(dev), g=sid.to(dev), c_lengths=lengths.to(dev),
+              spec_lengths=lengths.to(dev), noise={k: v.to(dev) for k, v in cs["noise"].items()})
+    yh, yr = out[0], ref[0]
+    assert (yh.detach().cpu() - yr.detach()).abs().max().item() <= 2e-4 * max(1.0, yr.abs().max().item())
+    (A.sum_sq(yh) / yh.numel()).backward()
+    yr.pow(2).mean().backward()
+    named = dict(net.named_parameters())
+    for k in ("dec.snakes.0.act.alpha", "dec.snakes.2.act.beta", "dec.resblocks.0.activations.1.act.alpha",
+              "dec.resblocks.7.activations.4.act.beta", "dec.snake_post.act.alpha", "dec.conv_pre.weight_v",
+              "dec.ups.1.weight_g", "enc_q.pre.weight"):
+        gh, gr = named[k].grad.cpu(), sg[k].grad
+        assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k
+
+
+def test_tiny_template_training_matches_oracle(dev):
+    """use_depthwise_conv + flow_share_parameter (config_tiny_template) in the TRAINING graph: z_p / y_hat and gradients of
+    the depthwise / pointwise / shared-WN parameters against the oracle's torch-CPU autograd."""
+    import models
+    import svc_autograd as A
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    cs = load_case()
+    cfg = dict(cs["cfg"], use_depthwise_conv=True, flow_share_parameter=True)
+    sd = W.make_train_state_dict(cfg, 43)
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = cs["batch"]
+    # the shared WN appears under five prefixes in the state_dict: build the oracle's leaf tensors once per storage
+    leaves = {}
+    sg = {}
+    for k, v in sd.items():
+        key = v.data_ptr()
+        if key not in leaves:
+            leaves[key] = v.clone().requires_grad_(True)
+        sg[k] = leaves[key]
+    ref = TO.synth_forward(sg, cfg, c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
+    out = net(c.to(dev), f0.to(dev), uv.to(dev), spec.to(dev), g=sid.to(dev), c_lengths=lengths.to(dev),
+              spec_lengths=lengths.to(dev), noise={k: v.to(dev) for k, v in cs["noise"].items()})
+    zh, zr = out[3][1], ref[3][1]                       # z_p = flow(z): exercises enc_q (depthwise WN) and the shared flow WN
+    assert (zh.detach().cpu() - zr.detach()).abs().max().item() <= 2e-4 * max(1.0, zr.abs().max().item())
+    assert (out[0].detach().cpu() - ref[0].detach()).abs().max().item() <= 2e-4 * max(1.0, ref[0].abs().max().item())
+    (A.sum_sq(zh) / zh.numel()).backward()
+    zr.pow(2).mean().backward()
+    named = net.state_dict(keep_vars=True)          # lists the shared WN under all of its aliases
+    for k in ("flow.wn.in_layers.0.depth_conv.weight_v", "flow.wn.in_layers.2.point_conv.weight_g",
+              "flow.wn.in_layers.1.depth_conv.bias", "flow.wn.res_skip_layers.3.weight_v",
+              "enc_q.enc.in_layers.5.depth_conv.weight_g", "enc_q.enc.in_layers.0.point_conv.weight_v", "enc_q.pre.weight"):
+        gh, gr = named[k].grad.cpu(), sg[k].grad
+        assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k

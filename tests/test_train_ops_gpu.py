@@ -166,3 +166,24 @@ def test_spectrogram_rocfft_fwd_bwd(dev, B, L, n_fft, hop):
         return torch.sqrt(torch.view_as_real(sp).pow(2).sum(-1) + 1e-6)
 
     _run_pair(lambda y: spectrogram_torch(y, n_fft, 44100, hop, n_fft), ref, dict(y=y), dev, tol=5e-5)
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 3, 7), (1, 5, 1024), (2, 4, 1025), (1, 3, 2500), (2, 2, 6)])
+def test_snake_alias_fwd_bwd(dev, B, C, T):
+    """SnakeAlias (alias/act.py:125-130) forward and the gradients w.r.t. x, alpha, beta against torch's CPU autograd
+    of the oracle restatement (pad / conv_transpose1d / snake / pad / conv1d), incl. the replicate-padded edges, rows
+    shorter than the filter and tile boundaries."""
+    import svc_autograd as A
+    from oracle import svc_oracle as O
+    from oracle import weights as W
+    torch.manual_seed(17)
+    filt = W.snake_filter()
+    taps = filt.tolist()
+    t = dict(x=_p(B, C, T, scale=1.5), alpha=_p(C, scale=0.4), beta=_p(C, scale=0.4))
+
+    def ref(x, alpha, beta):
+        sd = {"s.act.alpha": alpha, "s.act.beta": beta, "s.upsample.filter": filt.view(1, 1, 12),
+              "s.downsample.lowpass.filter": filt.view(1, 1, 12)}
+        return O.snake_alias(x, sd, "s")
+
+    _run_pair(lambda x, alpha, beta: A.snake_alias(x, alpha, beta, taps), ref, t, dev, tol=5e-5)
