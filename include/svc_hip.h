@@ -85,7 +85,7 @@ int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin,
  *                                         the final `output * x_mask` of WN.forward, modules/modules.py:138)
  * ---------------------------------------------------------------------------------------------- */
 enum { SVC_EPI_PLAIN = 0, SVC_EPI_GATE = 1, SVC_EPI_RES_SKIP = 2 };
-enum { SVC_ACT_NONE = 0, SVC_ACT_RELU = 1, SVC_ACT_TANH = 2, SVC_ACT_LRELU = 3 };
+enum { SVC_ACT_NONE = 0, SVC_ACT_RELU = 1, SVC_ACT_TANH = 2, SVC_ACT_LRELU = 3, SVC_ACT_GELU = 4 /* exact erf GELU */ };
 
 typedef struct svc_conv1d_args {
   const float* x;
@@ -185,6 +185,11 @@ int svc_snake_alias_f32(const float* x, float* y, const float* alpha, const floa
 int svc_snake_alias_bwd_f32(const float* x, const float* dy, const float* alpha, const float* beta, const float* taps_host,
                             float* dx, float* dalpha, float* dbeta, long long x_bs, long long x_cs, long long g_bs,
                             long long g_cs, long long d_bs, long long d_cs, int B, int C, int T, void* stream);
+/* GroupNorm with one channel per group + GELU (vencoder/hubert/hubert_model.py:76,87: norm0 = GroupNorm(512, 512) after
+ * conv0): y[b,c,t] = gelu((x - mean_t) / sqrt(var_t + eps) * gamma[c] + beta[c]), statistics over the T samples of each
+ * (b, c) row (biased variance, like torch).  x, y:[B,C,T] contiguous. */
+int svc_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                              float eps, int apply_gelu, void* stream);
 /* Automatic-f0 helpers (models.py:523-527 + utils.normalize_f0, utils.py:31-45).  f0,uv,mask,lf0,norm_lf0:[B,T];
  * factor:[B] or NULL (=1, inference).  lf0 = 2595*log10(1+f0/700)/500 (or f0 itself when input_is_lf0);
  * norm_lf0 = (lf0 - mean_voiced)*factor*mask. */
@@ -294,7 +299,8 @@ enum {
   SVC_EW_SIGMOID = 12,
   SVC_EW_SQUARE = 13,    /* alpha*a*a */
   SVC_EW_SIGN_MUL = 14,  /* alpha*sign(a) */
-  SVC_EW_DIV = 15        /* alpha*a/b */
+  SVC_EW_DIV = 15,       /* alpha*a/b */
+  SVC_EW_GELU = 16       /* 0.5 a (1 + erf(a / sqrt 2))  (vencoder/hubert/hubert_model.py:87-93,127) */
 };
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
 /* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:

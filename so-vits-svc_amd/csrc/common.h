@@ -55,3 +55,4 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float svc_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float svc_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float svc_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(DT) void conv1d_direct_kernel(DirectP p) {
       if (a.post_act == SVC_ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (a.post_act == SVC_ACT_TANH) v = tanhf(v);
       else if (a.post_act == SVC_ACT_LRELU) v = svc_lrelu(v, a.post_slope);
+      else if (a.post_act == SVC_ACT_GELU) v = svc_gelu(v);
       v *= mk;
       if (a.res) v += a.res[(long long)b * a.res_bs + (long long)co * a.res_cs + t];
       a.y[(long long)b * a.y_bs + (long long)co * a.y_cs + t] = v;

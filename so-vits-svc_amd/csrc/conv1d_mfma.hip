@@ -52,6 +52,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     case SVC_ACT_RELU: return v > 0.f ? v : 0.f;
     case SVC_ACT_TANH: return tanhf(v);
     case SVC_ACT_LRELU: return svc_lrelu(v, slope);
+    case SVC_ACT_GELU: return svc_gelu(v);
     default: return v;
   }
 }

@@ -173,6 +173,43 @@ __global__ void lf0_to_f0_kernel(const float* __restrict__ lf0, float* __restric
   if (i < n) f0[i] = 700.f * (powf(10.f, lf0[i] * 500.f / 2595.f) - 1.f);
 }
 
+// ---- GroupNorm(C, C) + GELU: per-(b,c) statistics over time (vencoder/hubert/hubert_model.py:76,87) ---------------
+// One workgroup per row; the row (32000 samples for 10 s of 16 kHz audio) is read twice (statistics, then normalise);
+// double accumulation keeps the variance stable for long rows.
+__global__ __launch_bounds__(256) void channel_norm_gelu_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                int C, int T, float eps, int apply_gelu) {
+  __shared__ double sh[2][256];
+  const long long row = blockIdx.x;
+  const int c = (int)(row % C);
+  const float* xr = x + row * T;
+  float* yr = y + row * T;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const double v = xr[t];
+    s1 += v;
+    s2 += v * v;
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const double mean = sh[0][0] / T;
+  const double var = fmax(sh[1][0] / T - mean * mean, 0.0);
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean, g = gamma[c], bt = beta[c];
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = (xr[t] - mu) * rstd * g + bt;
+    yr[t] = apply_gelu ? svc_gelu(v) : v;
+  }
+}
+
 }  // namespace
 
 extern "C" int svc_f0_norm_lf0_f32(const float* f0, const float* uv, const float* mask, const float* factor, float* lf0,
@@ -242,4 +279,13 @@ extern "C" int svc_reparam_f32(const float* stats, const float* noise, const flo
   hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, s, stats, noise, mask, z, C, T,
                      scale, n);
   return svc::check_launch("reparam");
+}
+
+extern "C" int svc_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                                         float eps, int apply_gelu, void* stream) {
+  SVC_REQUIRE(x && gamma && beta && y && B > 0 && C > 0 && T > 0, "channel_norm_gelu: bad args");
+  svc::ProfScope ps((hipStream_t)stream, "channel_norm_gelu", 0.0, 12.0 * B * C * (double)T);
+  hipLaunchKernelGGL(channel_norm_gelu_kernel, dim3((unsigned)((long long)B * C)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, y, C, T, eps, apply_gelu);
+  return svc::check_launch("channel_norm_gelu");
 }

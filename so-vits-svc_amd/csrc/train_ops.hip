@@ -118,6 +118,7 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
     case SVC_EW_SQUARE: return a * a * alpha;
     case SVC_EW_SIGN_MUL: return (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) * alpha;   // d|a|/da * alpha
     case SVC_EW_DIV: return a / b * alpha;
+    case SVC_EW_GELU: return svc_gelu(a);
     default: return a;
   }
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvc_hip.so")
 
 EPI_PLAIN, EPI_GATE, EPI_RES_SKIP = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_GELU = 0, 1, 2, 3, 4
 
 _f32p = C.c_void_p
 
@@ -108,6 +108,7 @@ def lib():
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_snake_alias_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [C.c_longlong] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_channel_norm_gelu_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
         _lib = L
@@ -119,7 +120,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32",
+    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32",
 ]
 
 
@@ -415,6 +416,17 @@ def snake_alias(x, alpha, beta, taps, out=None):
     return out
 
 
+def channel_norm_gelu(x, gamma, beta, eps=1e-5, gelu=True):
+    """GroupNorm(C, C) over time + GELU (vencoder/hubert/hubert_model.py:76,87)."""
+    require_gpu(x, gamma, beta)
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    y = torch.empty_like(x)
+    check(lib().svc_channel_norm_gelu_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), B, Cc, T, eps, 1 if gelu else 0, stream_ptr()),
+          "channel_norm_gelu")
+    return y
+
+
 def snake_alias_bwd(x, dy, alpha, beta, taps):
     """(dx, dalpha, dbeta) of snake_alias."""
     require_gpu(x, dy, alpha, beta)
@@ -495,7 +507,7 @@ def device_info():
 # training-path entry points (include/svc_hip.h, "TRAINING path")
 # --------------------------------------------------------------------------------------------------------------
 (EW_ADD, EW_MUL, EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_RELU, EW_RELU_BWD, EW_EXP, EW_LOG_CLAMP,
- EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV) = range(16)
+ EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU) = range(17)
 RED_SUM, RED_ABS_DIFF, RED_SQ_DIFF, RED_SQ_ONE_MINUS, RED_SQ, RED_KL = range(6)
 
 

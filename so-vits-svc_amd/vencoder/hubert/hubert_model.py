@@ -1,0 +1,209 @@
+"""MI355X-native mirror of vencoder/hubert/hubert_model.py (HuBERT-base "soft" unit encoder).
+
+Same classes, constructor signatures and `state_dict` keys as the reference (the torch modules below are used ONLY as
+parameter containers, so a reference checkpoint — `hubert-soft-0d54a1f4.pt` — loads key-for-key); every forward op runs
+on libsvc_hip.so in the engine's [B, C, T] layout (the reference's [B,T,C] Linear / LayerNorm are 1x1 convs / channel
+LayerNorms there, so the two `transpose(1, 2)` of :42,:124-127 never materialise):
+
+  FeatureExtractor (:71-94)   conv0 (1->512, k10, s5)            svc_conv1d_direct_f32
+                              GroupNorm(512,512) + GELU          svc_channel_norm_gelu_f32
+                              conv1..6 (512->512, k3|k2, s2)     svc_decimate_f32 + svc_conv1d_f32 (MFMA, GELU epilogue)
+  FeatureProjection (:97-108) LayerNorm(512) + Linear(512,768)   svc_add_layernorm_f32 + 1x1 MFMA conv
+  PositionalConvEmbedding     weight-normed (dim=2) grouped conv k128, groups 16, drop last, GELU   svc_gconv1d_fwd_f32
+  (:111-127)
+  TransformerEncoder (:130-152) 12 x post-norm layers: fused qkv 1x1 conv, flash attention (12 heads x 64),
+                              out_proj, add+LayerNorm, FFN 768->3072 (GELU epilogue) ->768, add+LayerNorm
+  proj (:26,:68)              Linear(768,256)                    1x1 MFMA conv
+
+The fairseq ContentVec encoders (vencoder/ContentVec768L12.py etc.) are the same architecture under different
+parameter names (q_proj/k_proj/v_proj, fc1/fc2, post_extract_proj, ...); fairseq and its checkpoint are absent here, so
+only this in-tree variant is parity-pinned (tests/golden/hubert_soft_1s.npz from the real module).  Inference only.
+"""
+import copy
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+import svc_hip as S
+
+
+def _pack(w):
+    return S.pack_conv1d_weight(w.detach().contiguous())
+
+
+class Hubert(nn.Module):
+    def __init__(self, num_label_embeddings: int = 100, mask: bool = True):
+        super().__init__()
+        self._mask = mask
+        self.feature_extractor = FeatureExtractor()
+        self.feature_projection = FeatureProjection()
+        self.positional_embedding = PositionalConvEmbedding()
+        self.norm = nn.LayerNorm(768)
+        self.dropout = nn.Dropout(0.1)
+        self.encoder = TransformerEncoder(nn.TransformerEncoderLayer(768, 12, 3072, activation="gelu", batch_first=True), 12)
+        self.proj = nn.Linear(768, 256)
+        self.masked_spec_embed = nn.Parameter(torch.FloatTensor(768).uniform_())
+        self.label_embedding = nn.Embedding(num_label_embeddings, 256)
+        self._cache = {}
+
+    def _packed(self, name, fn):
+        """Packed weights keyed by the parameter versions they were built from."""
+        params = [p for p in self.parameters()]
+        key = (name, sum(p._version for p in params), str(params[0].device))
+        hit = self._cache.get(name)
+        if hit is None or hit[0] != key:
+            self._cache[name] = (key, fn())
+        return self._cache[name][1]
+
+    def encode(self, x: torch.Tensor, layer: Optional[int] = None):
+        """x: [B, 1, n] 16 kHz waveform -> ([B, 768, T] features in the engine's channel-major layout, None)."""
+        if self.training and self._mask:
+            raise NotImplementedError("masked training of the unit encoder is out of scope (inference only)")
+        if not x.is_cuda:
+            raise S.SvcError("Hubert.encode needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+        with torch.no_grad():
+            x = self.feature_extractor(x.float().contiguous(), self)
+            x = self.feature_projection(x, self)
+            x = self.positional_embedding(x, self)
+            x = S.add_layernorm(x, None, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+            x = self.encoder(x, self, output_layer=layer)
+        return x, None
+
+    def logits(self, x):
+        raise NotImplementedError("label logits are a training-time head of HuBERT (out of scope)")
+
+    def forward(self, x):
+        raise NotImplementedError("Hubert.forward (masked prediction) is out of scope; use HubertSoft.units")
+
+
+class HubertSoft(Hubert):
+    def __init__(self):
+        super().__init__()
+
+    @torch.no_grad()
+    def units(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B, 1, n] -> soft units [B, T, 256] (reference :63-68: zero-pad 40 samples each side, encode, proj)."""
+        x, _ = self._encode_padded(wav)
+        wp = self._packed("proj", lambda: _pack(self.proj.weight.unsqueeze(-1)))
+        u = S.conv1d(x, wp, 256, 1, bias=self.proj.bias)
+        return u.transpose(1, 2)
+
+    def _encode_padded(self, wav):
+        self.feature_extractor.pad = (400 - 320) // 2
+        try:
+            return self.encode(wav)
+        finally:
+            self.feature_extractor.pad = 0
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv0 = nn.Conv1d(1, 512, 10, 5, bias=False)
+        self.norm0 = nn.GroupNorm(512, 512)
+        self.conv1 = nn.Conv1d(512, 512, 3, 2, bias=False)
+        self.conv2 = nn.Conv1d(512, 512, 3, 2, bias=False)
+        self.conv3 = nn.Conv1d(512, 512, 3, 2, bias=False)
+        self.conv4 = nn.Conv1d(512, 512, 3, 2, bias=False)
+        self.conv5 = nn.Conv1d(512, 512, 2, 2, bias=False)
+        self.conv6 = nn.Conv1d(512, 512, 2, 2, bias=False)
+        self.pad = 0
+
+    @staticmethod
+    def _strided_pack(w, s):
+        """Weight of a stride-s conv re-indexed for decimate + dense conv (svc_autograd.conv1d's lowering, padding 0):
+        input position t*s + k = (t + m)*s + r  ->  channel r*Cin + ci, tap m."""
+        Cout, Cin, KS = w.shape
+        KSd = (KS - 1) // s + 1
+        wpad = torch.nn.functional.pad(w.detach(), (0, s * KSd - KS))
+        wd = wpad.view(Cout, Cin, KSd, s).permute(0, 3, 1, 2).reshape(Cout, s * Cin, KSd).contiguous()
+        return _pack(wd), KSd
+
+    def forward(self, x, owner):
+        B, _, n = x.shape
+        w0 = owner._packed("conv0", lambda: _pack(self.conv0.weight))
+        T = (n + 2 * self.pad - 10) // 5 + 1
+        h = S.conv1d_direct(x, w0, 512, 10, stride=5, pad_left=self.pad, Tout=T)
+        h = S.channel_norm_gelu(h, self.norm0.weight, self.norm0.bias, eps=self.norm0.eps)
+        for i in range(1, 7):
+            conv = getattr(self, f"conv{i}")
+            KS = conv.kernel_size[0]
+            wp, KSd = owner._packed(f"conv{i}", lambda conv=conv: self._strided_pack(conv.weight, 2))
+            Tin = h.shape[2]
+            Tout = (Tin - KS) // 2 + 1
+            hd = S.decimate(h, 2, 0, (Tin + 1) // 2)                                  # [B, 1024, Q]
+            h = S.conv1d(hd, wp, 512, KSd, pad_left=0, Tout=Tout, post_act=S.ACT_GELU)
+        return h
+
+
+class FeatureProjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.norm = nn.LayerNorm(512)
+        self.projection = nn.Linear(512, 768)
+        self.dropout = nn.Dropout(0.1)
+
+    def forward(self, x, owner):
+        x = S.add_layernorm(x, None, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+        wp = owner._packed("projection", lambda: _pack(self.projection.weight.unsqueeze(-1)))
+        return S.conv1d(x, wp, 768, 1, bias=self.projection.bias)
+
+
+class PositionalConvEmbedding(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv1d(768, 768, kernel_size=128, padding=128 // 2, groups=16)
+        self.conv = nn.utils.weight_norm(self.conv, name="weight", dim=2)
+
+    def _weight(self):
+        """weight_norm over dim=2 (reference :121): w[:, :, k] = g[k] * v[:, :, k] / ||v[:, :, k]||_F."""
+        v, g = self.conv.weight_v.detach(), self.conv.weight_g.detach()
+        K = v.shape[2]
+        vt = v.permute(2, 0, 1).reshape(K, -1).contiguous()                             # rows = taps (index reshape)
+        wt, _ = S.weight_norm_fwd(vt, g.reshape(K).contiguous())
+        return wt.view(K, v.shape[0], v.shape[1]).permute(1, 2, 0).contiguous()
+
+    def forward(self, x, owner):
+        w = owner._packed("pos_conv", self._weight)
+        y = S.gconv1d_fwd(x, w, self.conv.bias, 1, 64, 16)                              # [B, 768, T + 1]
+        y = S.ew(S.EW_GELU, y[:, :, :-1].contiguous())
+        return S.ew(S.EW_ADD, x, y, alpha=1.0, beta=1.0)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer: nn.TransformerEncoderLayer, num_layers: int) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    def forward(self, src, owner, mask=None, src_key_padding_mask=None, output_layer: Optional[int] = None):
+        if mask is not None or src_key_padding_mask is not None:
+            raise NotImplementedError("attention masks are not used by the so-vits-svc unit encoders")
+        x = src
+        for li, layer in enumerate(self.layers[:output_layer]):
+            sa = layer.self_attn
+            E, H = sa.embed_dim, sa.num_heads
+            wqkv = owner._packed(f"l{li}.qkv", lambda sa=sa: _pack(sa.in_proj_weight.unsqueeze(-1)))
+            wo = owner._packed(f"l{li}.o", lambda sa=sa: _pack(sa.out_proj.weight.unsqueeze(-1)))
+            w1 = owner._packed(f"l{li}.w1", lambda layer=layer: _pack(layer.linear1.weight.unsqueeze(-1)))
+            w2 = owner._packed(f"l{li}.w2", lambda layer=layer: _pack(layer.linear2.weight.unsqueeze(-1)))
+            qkv = S.conv1d(x, wqkv, 3 * E, 1, bias=sa.in_proj_bias)
+            att = S.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], H)
+            y = S.conv1d(att, wo, E, 1, bias=sa.out_proj.bias)
+            x = S.add_layernorm(x, y, layer.norm1.weight, layer.norm1.bias, eps=layer.norm1.eps)
+            h = S.conv1d(x, w1, layer.linear1.out_features, 1, bias=layer.linear1.bias, post_act=S.ACT_GELU)
+            y = S.conv1d(h, w2, E, 1, bias=layer.linear2.bias)
+            x = S.add_layernorm(x, y, layer.norm2.weight, layer.norm2.bias, eps=layer.norm2.eps)
+        return x
+
+
+def hubert_soft(path: str) -> HubertSoft:
+    """Reference :222-232: build HubertSoft and load a checkpoint (keys may carry a "module." prefix)."""
+    from torch.nn.modules.utils import consume_prefix_in_state_dict_if_present
+    hubert = HubertSoft()
+    checkpoint = torch.load(path, map_location="cpu")
+    consume_prefix_in_state_dict_if_present(checkpoint, "module.")
+    hubert.load_state_dict(checkpoint)
+    hubert.eval()
+    return hubert

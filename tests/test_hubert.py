@@ -1,0 +1,67 @@
+"""HuBERT-soft unit encoder (reference vencoder/hubert/hubert_model.py, vencoder/HubertSoft.py).
+CPU: the oracle restatement against the vector of the REAL in-tree module.  GPU: the HIP mirror against that vector and
+against the oracle on other lengths (incl. a length whose conv stack leaves odd intermediate sizes).
+Tolerance: 2e-4 of max|ref| (12 post-norm transformer layers of fp32 MFMA / fmaf-chain reductions)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hubert_oracle as HO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden():
+    z = np.load(os.path.join(G, "hubert_soft_1s.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def test_oracle_reproduces_reference_hubert_units():
+    z, meta = _golden()
+    sd = HO.make_state_dict(meta["seed"])
+    assert len(sd) == 166 and sum(v.numel() for v in sd.values()) == 94594176
+    with torch.no_grad():
+        u = HO.units(sd, torch.from_numpy(z["wav"]))
+    assert u.shape == z["units"].shape
+    assert np.abs(u.numpy() - z["units"]).max() <= 2e-5 * max(1.0, np.abs(z["units"]).max())
+
+
+def _mirror(seed, dev):
+    from vencoder.hubert import hubert_model as HM
+    net = HM.HubertSoft()
+    missing, unexpected = net.load_state_dict(HO.make_state_dict(seed), strict=True)
+    return net.to(dev).eval()
+
+
+@pytest.mark.gpu
+def test_hubert_units_match_reference_golden(dev):
+    z, meta = _golden()
+    net = _mirror(meta["seed"], dev)
+    u = net.units(torch.from_numpy(z["wav"]).to(dev))
+    ref = torch.from_numpy(z["units"])
+    assert u.shape == ref.shape
+    err = (u.cpu() - ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
+    # the SpeechEncoder wrapper Svc talks to (vencoder/HubertSoft.py): [n] -> [1, 256, T]
+    from vencoder.HubertSoft import HubertSoft
+    enc = HubertSoft(device=dev, model=net)
+    c = enc.encoder(torch.from_numpy(z["wav"][0, 0]).to(dev))
+    assert c.shape == (1, 256, ref.shape[1]) and torch.equal(c, u.transpose(1, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n", [(1, 40321), (2, 8000), (1, 401)])
+def test_hubert_units_match_oracle(dev, B, n):
+    sd = HO.make_state_dict(5)
+    net = _mirror(5, dev)
+    g = torch.Generator().manual_seed(n)
+    wav = 0.3 * torch.randn(B, 1, n, generator=g)
+    with torch.no_grad():
+        ref = HO.units(sd, wav)
+    u = net.units(wav.to(dev))
+    assert u.shape == ref.shape
+    err = (u.cpu() - ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
