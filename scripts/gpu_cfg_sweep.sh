@@ -21,8 +21,8 @@ def run(Cin, L, k, d, Cout, code, B=16):
     e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)/20
     print(f"code {code:3d} Cin={Cin:4d} Cout={Cout:4d} L={L:7d} k={k:2d} d={d} {ms*1e3:8.1f} us {2.0*B*Cout*Cin*k*L/ms/1e9:7.1f} TF", flush=True)
-for sh in [(192,768,1,1,192),(192,768,1,1,384),(384,768,1,1,192),(192,768,5,1,384),(384,768,5,1,192),(768,768,3,1,192),(192,768,3,1,768),(128,1024,11,1,128),(128,1024,7,1,128),(256,128,11,1,256)]:
+for sh in [(768,500,1,1,2304,1),(768,500,1,1,768,1),(768,500,1,1,3072,1),(3072,500,1,1,768,1),(768,862,1,1,2304,1),(192,862,1,1,576,1)]:
     for code in (0,3,4,5,6,7):
-        try: run(*sh, code)
+        try: run(sh[0],sh[1],sh[2],sh[3],sh[4],code,B=sh[5])
         except Exception as e: print("fail", sh, code, str(e)[:80])
 PY

@@ -583,7 +583,8 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     if (a.Cout <= 16) cfg = 0;
     else if (a.Cout <= 32) cfg = cols >= 16384 ? 1 : 6;
     else if (cols >= 16384) cfg = a.Cout <= 64 ? 2 : 3;
-    else if (m64 && wg64x128 >= 200) cfg = 4;
+    else if (m64 && wg64x128 >= 128) cfg = 4;   // measured (768 -> 2304/3072, T=500): 64x128 at 144..192 workgroups beats
+                                                // the 64x32 split-K tiling by 1.5x (4x the operand reuse per LDS byte)
     else if (m64 && wg64x32 >= 200) cfg = 5;
     else cfg = 6;
     // Wide outputs (Cout > 64) with enough columns to fill the chip: pick among 128x128, 64x128 and 128x224 by modelled

@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void prenet_embed_kernel(const float* __restri
 }
 
 // ---- residual + LayerNorm over channels of [B,C,T] (modules/modules.py:23-35; attentions.py:98,102) --------
-constexpr int LN_TT = 32;  // time steps per block
-constexpr int LN_CG = 8;   // channel groups per block
-
+// LN_TT time steps x LN_CG channel groups per 256-thread block: 32 x 8 for long sequences (full 128 B segments per
+// channel row), 4 x 64 when T / 32 would leave most CUs without a block (T = 500..862 frames).
+template <int LN_TT, int LN_CG>
 __global__ __launch_bounds__(LN_TT* LN_CG) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
@@ -264,8 +264,12 @@ extern "C" int svc_add_layernorm_f32(const float* x, const float* r, const float
   SVC_REQUIRE(B > 0 && C > 0 && T > 0, "add_layernorm: empty shape");
   hipStream_t s = (hipStream_t)stream;
   svc::ProfScope prof(s, "add_layernorm", 0.0, 12.0 * B * C * T);
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3(svc::cdiv(T, LN_TT), B), dim3(LN_TT * LN_CG), 0, s, x, r, gamma, beta,
-                     mask, y, C, T, eps);
+  if ((long long)svc::cdiv(T, 32) * B >= 256)
+    hipLaunchKernelGGL((add_layernorm_kernel<32, 8>), dim3(svc::cdiv(T, 32), B), dim3(256), 0, s, x, r, gamma, beta, mask, y,
+                       C, T, eps);
+  else
+    hipLaunchKernelGGL((add_layernorm_kernel<4, 64>), dim3(svc::cdiv(T, 4), B), dim3(256), 0, s, x, r, gamma, beta, mask, y,
+                       C, T, eps);
   return svc::check_launch("add_layernorm");
 }
 
