@@ -126,6 +126,9 @@ class TrainStep:
         gmod = net_g.module if hasattr(net_g, "module") else net_g
         dmod = net_d.module if hasattr(net_d, "module") else net_d
         seg_frames = self.segment_size // self.hop
+        if spec is None:          # loader items without a cached .spec.pt / vol-augmented audio: STFT of the batch on the GPU
+            from data_utils import batch_spectrogram
+            spec = batch_spectrogram(y, lengths, self.n_fft, self.sr, self.hop, self.win)
         mel = spec_to_mel_torch(spec, self.n_fft, self.n_mels, self.sr, self.fmin, self.fmax)            # :158-164
         kw = dict(noise=noise) if noise is not None else {}
         y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(

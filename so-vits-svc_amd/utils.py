@@ -15,6 +15,7 @@ import logging
 import os
 import re
 
+import numpy as np
 import torch
 
 import svc_hip as S
@@ -140,6 +141,36 @@ def latest_checkpoint_path(dir_path, regex="G_*.pth"):
     files = glob.glob(os.path.join(dir_path, regex))
     files.sort(key=lambda f: int("".join(filter(str.isdigit, f)) or -1))
     return files[-1]
+
+
+def load_wav_to_torch(full_path):
+    """utils.py:301-303 (scipy.io.wavfile)."""
+    from scipy.io.wavfile import read
+    sampling_rate, data = read(full_path)
+    return torch.FloatTensor(data.astype(np.float32)), sampling_rate
+
+
+def load_filepaths_and_text(filename, split="|"):
+    """utils.py:306-309."""
+    with open(filename, encoding="utf-8") as f:
+        return [line.strip().split(split) for line in f]
+
+
+def repeat_expand_2d(content, target_len, mode="left"):
+    """utils.py:396-424: stretch [H, Tsrc] units to target_len frames ('left' = the reference's sequential fill,
+    vectorised; other modes = F.interpolate)."""
+    if mode != "left":
+        return torch.nn.functional.interpolate(content[None], size=target_len, mode=mode)[0]
+    src_len = content.shape[-1]
+    edges = torch.arange(src_len + 1) * target_len / src_len
+    # frame i takes source column p(i) = number of edges[1:] that are <= i, advanced at most one per frame
+    idx = torch.zeros(target_len, dtype=torch.long)
+    cur = 0
+    for i in range(target_len):
+        if not i < edges[cur + 1]:
+            cur += 1
+        idx[i] = cur
+    return content[:, idx.to(content.device)].float()
 
 
 class Volume_Extractor:

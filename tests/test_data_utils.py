@@ -1,0 +1,128 @@
+"""data_utils mirror (reference data_utils.py:17-186): on-disk formats, item tuple, collate.
+CPU: synthetic dataset in the reference's formats -> loader + collate invariants, and (when /root/reference is mounted,
+i.e. in the build container) equality with the reference's own TextAudioSpeakerLoader / TextAudioCollate on the same
+files.  GPU: batch_spectrogram == per-item spectrogram for ragged lengths."""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+SR, HOP, NFFT, SSL = 44100, 512, 2048, 24
+
+
+def _make_dataset(root, n_items=5, with_spec=True, with_vol=False):
+    from scipy.io.wavfile import write
+    g = torch.Generator().manual_seed(3)
+    lines = []
+    for i in range(n_items):
+        spk = "alice" if i % 2 == 0 else "bob"
+        d = os.path.join(root, "dataset", spk)
+        os.makedirs(d, exist_ok=True)
+        T = 40 + 7 * i
+        wav = ((torch.rand(T * HOP + 100 * (i % 2), generator=g) - 0.5) * 20000).to(torch.int16).numpy()
+        p = os.path.join(d, f"u{i}.wav")
+        write(p, SR, wav)
+        torch.save(torch.randn(1, SSL, T // 2 + 1, generator=g), p + ".soft.pt")
+        f0 = (100 + 200 * torch.rand(T, generator=g)).numpy()
+        f0[:3] = 0
+        np.save(p + ".f0.npy", np.asanyarray((f0, (f0 > 0).astype(float)), dtype=object), allow_pickle=True)
+        if with_spec:
+            torch.save(torch.rand(NFFT // 2 + 1, T + (i % 2), generator=g), p.replace(".wav", ".spec.pt"))
+        if with_vol:
+            np.save(p + ".vol.npy", torch.rand(T, generator=g).numpy())
+        lines.append(p)
+    fl = os.path.join(root, "train.txt")
+    with open(fl, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    conf = dict(train=dict(use_sr=True, max_speclen=512, vol_aug=with_vol, segment_size=8192),
+                data=dict(max_wav_value=32768.0, sampling_rate=SR, filter_length=NFFT, hop_length=HOP, win_length=NFFT,
+                          unit_interpolate_mode="nearest", training_files=fl),
+                model=dict(vol_embedding=with_vol), spk=dict(alice=0, bob=1))
+    cj = os.path.join(root, "config.json")
+    with open(cj, "w") as f:
+        json.dump(conf, f)
+    return fl, cj
+
+
+def _ours(fl, cj):
+    import data_utils
+    import utils
+    hps = utils.get_hparams_from_file(cj)
+    return data_utils.TextAudioSpeakerLoader(fl, hps), data_utils.TextAudioCollate()
+
+
+def test_loader_and_collate_invariants(tmp_path):
+    fl, cj = _make_dataset(str(tmp_path), with_vol=True)
+    ds, collate = _ours(fl, cj)
+    assert len(ds) == 5
+    random.seed(7)
+    items = [ds[i] for i in range(len(ds))]
+    for c, f0, spec, wav, spk, uv, vol in items:
+        T = c.shape[1]
+        assert c.shape[0] == SSL and f0.shape == (T,) and uv.shape == (T,) and wav.shape == (1, T * HOP) and vol.shape == (T,)
+        assert spec is None or spec.shape == (NFFT // 2 + 1, T)
+        assert wav.abs().max() <= 1.0 * 10 and int(spk) in (0, 1)
+    c_p, f0_p, spec_p, wav_p, spk_p, lengths, uv_p, vol_p = collate(items)
+    assert list(lengths) == sorted(lengths.tolist(), reverse=True) and c_p.shape == (5, SSL, int(lengths[0]))
+    assert wav_p.shape == (5, 1, int(lengths[0]) * HOP) and spk_p.shape == (5, 1) and vol_p.shape == f0_p.shape
+    for i in range(5):
+        L = int(lengths[i])
+        assert c_p[i, :, L:].abs().sum() == 0 and f0_p[i, L:].abs().sum() == 0 and wav_p[i, 0, L * HOP:].abs().sum() == 0
+    assert spec_p is None or spec_p.shape == (5, NFFT // 2 + 1, int(lengths[0]))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only mounted in the build container")
+def test_matches_reference_loader_and_collate(tmp_path):
+    fl, cj = _make_dataset(str(tmp_path), with_spec=True, with_vol=False)
+    ds, collate = _ours(fl, cj)
+    random.seed(11)
+    ours = collate([ds[i] for i in range(len(ds))])
+    # the reference's own classes (utils.py imports faiss / librosa at the top: stub them)
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    try:
+        for name in ("faiss", "librosa", "librosa.filters"):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules["librosa.filters"].mel = lambda **kw: None
+        for m in ("utils", "data_utils", "modules", "modules.mel_processing", "modules.commons"):
+            sys.modules.pop(m, None)
+        sys.path.insert(0, "/root/reference")
+        import data_utils as RD
+        import utils as RU
+        hps = RU.get_hparams_from_file(cj)
+        rds = RD.TextAudioSpeakerLoader(fl, hps)
+        random.seed(11)
+        ref = RD.TextAudioCollate()([rds[i] for i in range(len(rds))])
+    finally:
+        sys.path[:] = saved_path
+        for m in list(sys.modules):
+            if m not in saved_mods:
+                del sys.modules[m]
+        sys.modules.update(saved_mods)
+    assert len(ours) == len(ref) == 8
+    for a, b in zip(ours, ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_batch_spectrogram_equals_per_item(dev):
+    from data_utils import batch_spectrogram
+    from modules.mel_processing import spectrogram_torch
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.tensor([37, 30, 23, 16])
+    L = int(lengths.max()) * HOP
+    wav = torch.zeros(4, 1, L)
+    for b, n in enumerate(lengths.tolist()):
+        wav[b, 0, :n * HOP] = torch.rand(n * HOP, generator=g) - 0.5
+    spec = batch_spectrogram(wav.to(dev), lengths.to(dev), NFFT, SR, HOP, NFFT)
+    assert spec.shape == (4, NFFT // 2 + 1, 37)
+    for b, n in enumerate(lengths.tolist()):
+        one = spectrogram_torch(wav[b, :, :n * HOP].to(dev), NFFT, SR, HOP, NFFT)[0]            # [bins, n]
+        assert (spec[b, :, :n] - one).abs().max().item() <= 1e-4 * one.abs().max().item()
+        assert spec[b, :, n:].abs().max().item() == 0 if n < 37 else True
