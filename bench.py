@@ -228,13 +228,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the MI355X engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; SVC_DIST_BACKEND=gloo + fewer GPUs than ranks (a 1-GPU box) folds the ranks onto the available
+    # devices — a functional check of the multi-rank path, not a scaling measurement (RCCL refuses two ranks per device)
+    backend = os.environ.get("SVC_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps

@@ -1,0 +1,86 @@
+"""Data-parallel TRAINING with the real HIP modules, world_size 2.  The box has one GPU and RCCL
+refuses two ranks per device, so both ranks share cuda:0 and talk over gloo: a functional check of everything except
+the transport — parameter broadcast on the flat arena, autograd-hook driven bucket all-reduce issued from the backward
+thread, the frozen-discriminator generator step, FusedAdamW on the averaged gradients.  After two iterations on
+DIFFERENT per-rank items both ranks must hold bit-identical generator and discriminator parameters."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        root = os.path.dirname(HERE)
+        for p in (root, os.path.join(root, "so-vits-svc_amd"), HERE):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        import train as T
+        from test_train_loop_gpu import _hps
+        from train_common import load_case
+        cs = load_case()
+        hps = _hps(cs, 2e-4)
+        torch.manual_seed(100 + rank)                      # different init per rank: the broadcast must fix it
+        net_g, net_d, og, od = T.build(hps, dev)
+        if rank == 0:
+            net_g.module.load_state_dict(cs["sd_g"])
+            net_d.module.load_state_dict(cs["sd_d"])
+        net_g.reducer.broadcast_parameters(0)
+        net_d.reducer.broadcast_parameters(0)
+        net_g.train()
+        net_d.train()
+        step = T.TrainStep(hps, net_g, net_d, og, od)
+        c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
+        noise = {k: v.to(dev) for k, v in cs["noise"].items()}
+        sl = slice(rank, rank + 1)                          # rank r trains on item r of the 2-item batch
+        items = (c[sl], f0[sl], spec[sl], y[sl], sid[sl], lengths[sl], uv[sl], None)
+        nz = {k: v[sl].contiguous() for k, v in noise.items()}
+        for _ in range(2):
+            out = step(items, noise=nz)
+        flat = torch.cat([net_g.arena.param.detach(), net_d.arena.param.detach()]).cpu()
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        same = torch.equal(parts[0], parts[1])
+        fin = all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v))
+        stats = (dict(net_g.reducer.stats), dict(net_d.reducer.stats))
+        dist.destroy_process_group()
+        q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats))
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+
+
+def test_two_rank_training_keeps_parameters_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, stats in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+        g, d = stats
+        assert g["backward_passes"] == 2 and g["launches"] >= 2 and d["backward_passes"] == 2     # D: only the D steps
