@@ -382,6 +382,13 @@ int svc_embed_bwd_f32(const long long* idx, const float* dy, float* dW, int B, i
 /* Gradient of svc_reparam_f32: dstats = [dm ; dlogs]. */
 int svc_reparam_bwd_f32(const float* stats, const float* noise, const float* mask, const float* dz, float* dstats, int B,
                         int C, int T, float scale, void* stream);
+/* The source module of vdecoder/nsf_hifigan (SineGen.forward, vdecoder/nsf_hifigan/models.py:136-181, + SourceModuleHnNSF
+ * :216-218): same interface as svc_nsf_source_f32 but that generator integrates the phase in double at the sample rate
+ * (rand_ini added to every sample of frame 0), so the sine is sin(2 pi frac(prefix)) evaluated in double.
+ * scratch: B*H*T doubles, 8-byte aligned. */
+int svc_nsf_source_exact_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                             const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
+                             float sampling_rate, float sine_amp, float noise_std, void* stream);
 /* Training variant of svc_nsf_source_f32 that also stores the per-harmonic waves [B,T*upp,H]; l_linear + tanh on stored
  * waves and the (dw, db) gradients of l_linear (vdecoder/hifigan/models.py:318). */
 int svc_nsf_source_train_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,

@@ -115,6 +115,62 @@ __global__ __launch_bounds__(256) void nsf_sample_kernel(const float* __restrict
   har[(long long)b * L + t] = tanhf(acc + lin_b[0]);
 }
 
+// ---- vdecoder/nsf_hifigan variant (SineGen.forward, vdecoder/nsf_hifigan/models.py:136-181) ----------------------------
+// That generator integrates the phase in DOUBLE at the sample rate: sin(2 pi cumsum(rad_up + shift)), rad_up = the
+// frame-rate rad (fp32 `(f0*h/sr) % 1`, rand_ini added to FRAME 0, i.e. to each of its upp samples) nearest-upsampled,
+// shift = -1 at detected wraps (integers: they only keep the argument small).  So sine(t) = sin(2 pi frac(A_f + (n+1) rad_f))
+// with A_f the double prefix over frames — no fp32 error to carry.  Scratch: double A[B][H][T].
+__global__ __launch_bounds__(64) void nsf_frame_scan_exact_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                                  double* __restrict__ A, int T, int upp, int H, float sr) {
+  __shared__ float f0s[SCAN_CHUNK];
+  const int b = blockIdx.x, h = threadIdx.x;
+  const float hm = (float)(h + 1);
+  const float ri = (h == 0 || h >= H) ? 0.f : rand_ini[b * H + h];
+  double acc = 0.0;
+  for (int c0 = 0; c0 < T; c0 += SCAN_CHUNK) {
+    const int nc = min(SCAN_CHUNK, T - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += 64) f0s[i] = f0[(long long)b * T + c0 + i];
+    __syncthreads();
+    if (h < H) {
+      for (int i = 0; i < nc; ++i) {
+        const int f = c0 + i;
+        float rad = fmodf(f0s[i] * hm / sr, 1.0f);
+        if (f == 0) rad = rad + ri;
+        A[((long long)b * H + h) * T + f] = acc;
+        acc += (double)upp * (double)rad;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nsf_sample_exact_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                               const float* __restrict__ noise, const float* __restrict__ lin_w,
+                                                               const float* __restrict__ lin_b, const double* __restrict__ A,
+                                                               float* __restrict__ har, int T, int upp, int H, float sr,
+                                                               float sine_amp, float noise_std) {
+  const long long L = (long long)T * upp;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= L) return;
+  const int f = (int)(t / upp);
+  const int n = (int)(t - (long long)f * upp);
+  const float f0v = f0[(long long)b * T + f];
+  const float uv = f0v > 0.f ? 1.f : 0.f;
+  const float noise_amp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
+  const float* nz = noise + ((long long)b * L + t) * H;
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h) {
+    float rad = fmodf(f0v * (float)(h + 1) / sr, 1.0f);
+    if (f == 0 && h > 0) rad = rad + rand_ini[b * H + h];
+    const double ph = A[((long long)b * H + h) * T + f] + (double)(n + 1) * (double)rad;
+    const double fr = ph - floor(ph);
+    const float sine = (float)sin(fr * 6.283185307179586476925287) * sine_amp;
+    acc += lin_w[h] * (sine * uv + noise_amp * nz[h]);
+  }
+  har[(long long)b * L + t] = tanhf(acc + lin_b[0]);
+}
+
 }  // namespace
 
 extern "C" long long svc_nsf_source_scratch_bytes(int B, int T, int H) {
@@ -153,4 +209,22 @@ extern "C" int svc_nsf_source_train_f32(const float* f0, const float* rand_ini, 
   SVC_REQUIRE(waves != nullptr, "nsf_source_train: null waves");
   return nsf_source_impl(f0, rand_ini, noise, lin_w, lin_b, har, waves, scratch, B, T, upp, H, sampling_rate, sine_amp,
                          noise_std, stream);
+}
+
+// vdecoder/nsf_hifigan SineGen + SourceModuleHnNSF (vdecoder/nsf_hifigan/models.py:136-218): double-precision phase.
+// scratch: B*H*T doubles (8-byte aligned).
+extern "C" int svc_nsf_source_exact_f32(const float* f0, const float* rand_ini, const float* noise, const float* lin_w,
+                                        const float* lin_b, float* har, void* scratch, int B, int T, int upp, int H,
+                                        float sampling_rate, float sine_amp, float noise_std, void* stream) {
+  SVC_REQUIRE(f0 && rand_ini && noise && lin_w && lin_b && har && scratch, "nsf_source_exact: null tensor");
+  SVC_REQUIRE(B > 0 && T > 0 && upp > 0 && H > 0 && H <= MAXH, "nsf_source_exact: bad shape (H <= %d)", MAXH);
+  SVC_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "nsf_source_exact: scratch must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  double* A = reinterpret_cast<double*>(scratch);
+  const long long L = (long long)T * upp;
+  svc::ProfScope prof(s, "nsf_source", 0.0, 4.0 * B * L * (H + 1));
+  hipLaunchKernelGGL(nsf_frame_scan_exact_kernel, dim3(B), dim3(64), 0, s, f0, rand_ini, A, T, upp, H, sampling_rate);
+  hipLaunchKernelGGL(nsf_sample_exact_kernel, dim3((unsigned)svc::cdivll(L, 256), B), dim3(256), 0, s, f0, rand_ini, noise,
+                     lin_w, lin_b, A, har, T, upp, H, sampling_rate, sine_amp, noise_std);
+  return svc::check_launch("nsf_source_exact");
 }

@@ -108,6 +108,7 @@ def lib():
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_snake_alias_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [C.c_longlong] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_nsf_source_exact_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
         L.svc_channel_norm_gelu_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
@@ -120,7 +121,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32",
+    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32",
 ]
 
 
@@ -297,6 +298,22 @@ def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0
     check(lib().svc_nsf_source_f32(ptr(f0.contiguous()), ptr(rand_ini.contiguous()), ptr(noise.contiguous()),
                                    ptr(lin_w.contiguous()), ptr(lin_b.contiguous()), ptr(out), ptr(scratch), B, T,
                                    upp, H, float(sampling_rate), sine_amp, noise_std, stream_ptr()), "nsf_source")
+    return out
+
+
+def nsf_source_exact(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0.1, noise_std=0.003):
+    """vdecoder/nsf_hifigan source module (double-precision phase): same shapes as nsf_source."""
+    require_gpu(f0, rand_ini, noise, lin_w, lin_b)
+    B, T = f0.shape
+    H = rand_ini.shape[1]
+    L = T * upp
+    if tuple(noise.shape) != (B, L, H):
+        raise SvcError(f"nsf_source_exact: noise shape {tuple(noise.shape)} != {(B, L, H)}")
+    out = torch.empty((B, 1, L), device=f0.device, dtype=torch.float32)
+    scratch = torch.empty(B * H * T, device=f0.device, dtype=torch.float64)
+    check(lib().svc_nsf_source_exact_f32(ptr(f0.contiguous()), ptr(rand_ini.contiguous()), ptr(noise.contiguous()),
+                                         ptr(lin_w.contiguous()), ptr(lin_b.contiguous()), ptr(out), ptr(scratch), B, T,
+                                         upp, H, float(sampling_rate), sine_amp, noise_std, stream_ptr()), "nsf_source_exact")
     return out
 
 
