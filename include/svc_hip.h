@@ -190,6 +190,9 @@ int svc_snake_alias_bwd_f32(const float* x, const float* dy, const float* alpha,
  * (b, c) row (biased variance, like torch).  x, y:[B,C,T] contiguous. */
 int svc_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                               float eps, int apply_gelu, void* stream);
+/* SinusoidalPosEmb (diffusion/wavenet.py:16-28): out[b, i] = sin(t[b] f_i), out[b, dim/2 + i] = cos(t[b] f_i),
+ * f_i = exp(-i ln(10000) / (dim/2 - 1)); t:[B] float, out:[B, dim]. */
+int svc_sinusoidal_emb_f32(const float* t, float* out, int B, int dim, void* stream);
 /* Automatic-f0 helpers (models.py:523-527 + utils.normalize_f0, utils.py:31-45).  f0,uv,mask,lf0,norm_lf0:[B,T];
  * factor:[B] or NULL (=1, inference).  lf0 = 2595*log10(1+f0/700)/500 (or f0 itself when input_is_lf0);
  * norm_lf0 = (lf0 - mean_voiced)*factor*mask. */
@@ -300,7 +303,9 @@ enum {
   SVC_EW_SQUARE = 13,    /* alpha*a*a */
   SVC_EW_SIGN_MUL = 14,  /* alpha*sign(a) */
   SVC_EW_DIV = 15,       /* alpha*a/b */
-  SVC_EW_GELU = 16       /* 0.5 a (1 + erf(a / sqrt 2))  (vencoder/hubert/hubert_model.py:87-93,127) */
+  SVC_EW_GELU = 16,      /* 0.5 a (1 + erf(a / sqrt 2))  (vencoder/hubert/hubert_model.py:87-93,127) */
+  SVC_EW_MISH = 17,      /* a tanh(softplus(a))  (diffusion/wavenet.py:76) */
+  SVC_EW_CLAMP = 18      /* min(max(a, alpha), beta)  (diffusion/diffusion.py:139) */
 };
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
 /* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:

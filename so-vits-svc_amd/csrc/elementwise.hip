@@ -210,6 +210,19 @@ __global__ __launch_bounds__(256) void channel_norm_gelu_kernel(const float* __r
   }
 }
 
+// ---- SinusoidalPosEmb (diffusion/wavenet.py:16-28) ---------------------------------------------------------------
+__global__ void sinusoidal_emb_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, j = i - b * half;
+  const float scale = logf(10000.f) / (float)(half - 1);
+  const float f = expf((float)j * -scale);
+  const float v = t[b] * f;
+  out[(long long)b * dim + j] = sinf(v);
+  out[(long long)b * dim + half + j] = cosf(v);
+}
+
 }  // namespace
 
 extern "C" int svc_f0_norm_lf0_f32(const float* f0, const float* uv, const float* mask, const float* factor, float* lf0,
@@ -292,4 +305,11 @@ extern "C" int svc_channel_norm_gelu_f32(const float* x, const float* gamma, con
   hipLaunchKernelGGL(channel_norm_gelu_kernel, dim3((unsigned)((long long)B * C)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                      beta, y, C, T, eps, apply_gelu);
   return svc::check_launch("channel_norm_gelu");
+}
+
+extern "C" int svc_sinusoidal_emb_f32(const float* t, float* out, int B, int dim, void* stream) {
+  SVC_REQUIRE(t && out && B > 0 && dim >= 4 && (dim % 2) == 0, "sinusoidal_emb: bad args");
+  hipLaunchKernelGGL(sinusoidal_emb_kernel, dim3(svc::cdiv(B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, out, B,
+                     dim);
+  return svc::check_launch("sinusoidal_emb");
 }

@@ -119,6 +119,8 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
     case SVC_EW_SIGN_MUL: return (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) * alpha;   // d|a|/da * alpha
     case SVC_EW_DIV: return a / b * alpha;
     case SVC_EW_GELU: return svc_gelu(a);
+    case SVC_EW_MISH: return a * tanhf(a > 20.f ? a : log1pf(expf(a)));   // softplus with torch's threshold 20
+    case SVC_EW_CLAMP: return fminf(fmaxf(a, alpha), beta);
     default: return a;
   }
 }

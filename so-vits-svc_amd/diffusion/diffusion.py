@@ -1,0 +1,186 @@
+"""MI355X-native mirror of diffusion/diffusion.py: GaussianDiffusion (schedules, samplers) around the WaveNet denoiser
+(SURVEY.md §8f row 2).  Same constructor, buffers (`state_dict` keys) and `forward` signature as the reference.
+
+Inference samplers implemented: plain ancestral sampling (`p_sample`, :155-162), DDIM (`p_sample_ddim`, :143-153) and
+PNDM/PLMS (`p_sample_plms`, :164-199) — the ones defined in this file.  Every per-step update is a scalar-coefficient
+combination of [B,1,M,T] tensors: the coefficients come from the host copy of the schedule (all batch items share the
+step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  'dpm-solver(++)' and 'unipc' call
+into two third-party solver libraries (diffusion/dpm_solver_pytorch.py, uni_pc.py: 2000 lines) that are not mirrored;
+training (`infer=False`, p_losses) is not implemented either — both raise NotImplementedError."""
+from collections import deque
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+import svc_hip as S
+
+
+def linear_beta_schedule(timesteps, max_beta=0.02):
+    return np.linspace(1e-4, max_beta, timesteps)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    alphas_cumprod = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return np.clip(betas, a_min=0, a_max=0.999)
+
+
+beta_schedule = {"cosine": cosine_beta_schedule, "linear": linear_beta_schedule}
+
+
+def _lin(a, x, b, y):
+    """a*x + b*y on the device (one svc_ew_f32 launch)."""
+    return S.ew(S.EW_ADD, x.contiguous(), y.contiguous(), alpha=float(a), beta=float(b))
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoise_fn, out_dims=128, timesteps=1000, k_step=1000, max_beta=0.02, spec_min=-12, spec_max=2):
+        super().__init__()
+        self.denoise_fn = denoise_fn
+        self.out_dims = out_dims
+        betas = beta_schedule["linear"](timesteps, max_beta=max_beta)
+        alphas = 1. - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.k_step = k_step if 0 < k_step < timesteps else timesteps
+        self.noise_list = deque(maxlen=4)
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        self.register_buffer("betas", to_torch(betas))
+        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", to_torch(alphas_cumprod_prev))
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(alphas_cumprod)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1. - alphas_cumprod)))
+        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1. - alphas_cumprod)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1. / alphas_cumprod)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1. / alphas_cumprod - 1)))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        self.register_buffer("posterior_variance", to_torch(posterior_variance))
+        self.register_buffer("posterior_log_variance_clipped", to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
+        self.register_buffer("posterior_mean_coef1", to_torch(betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod)))
+        self.register_buffer("posterior_mean_coef2", to_torch((1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod)))
+        self.register_buffer("spec_min", torch.FloatTensor([spec_min])[None, None, :out_dims])
+        self.register_buffer("spec_max", torch.FloatTensor([spec_max])[None, None, :out_dims])
+        self._host = None
+
+    # -- host copy of the (fp32) schedule: step coefficients without device round trips -------------------------------
+    def _h(self, name, t):
+        if self._host is None or self._host[0] != self.betas._version:
+            self._host = (self.betas._version, {k: v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                                                for k, v in self.named_buffers(recurse=False)})
+        return np.float32(self._host[1][name][int(t)])
+
+    def _tvec(self, i, b, device):
+        return torch.full((b,), int(i), device=device, dtype=torch.long)
+
+    def _denoise(self, x, i, cond):
+        return self.denoise_fn(x, self._tvec(i, x.shape[0], x.device), cond=cond)
+
+    # -- samplers -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def p_sample_ddim(self, x, t, interval, cond):
+        """Reference :143-153; t: python int step shared by the batch."""
+        a_t = self._h("alphas_cumprod", t)
+        a_prev = self._h("alphas_cumprod", max(t - interval, 0))
+        noise_pred = self._denoise(x, t, cond)
+        c1 = np.sqrt(a_prev) / np.sqrt(a_t)
+        c2 = np.sqrt(a_prev) * (np.sqrt((1 - a_prev) / a_prev) - np.sqrt((1 - a_t) / a_t))
+        return _lin(c1, x, c2, noise_pred)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, cond, clip_denoised=True, repeat_noise=False, noise=None):
+        """Reference :134-141,155-162."""
+        noise_pred = self._denoise(x, t, cond)
+        x_recon = _lin(self._h("sqrt_recip_alphas_cumprod", t), x, -self._h("sqrt_recipm1_alphas_cumprod", t), noise_pred)
+        x_recon = S.ew(S.EW_CLAMP, x_recon, alpha=-1.0, beta=1.0)
+        mean = _lin(self._h("posterior_mean_coef1", t), x_recon, self._h("posterior_mean_coef2", t), x)
+        if t == 0:
+            return mean
+        if noise is None:
+            noise = torch.randn(x.shape, device=x.device)
+        return _lin(1.0, mean, np.exp(np.float32(0.5) * self._h("posterior_log_variance_clipped", t)), noise)
+
+    @torch.no_grad()
+    def p_sample_plms(self, x, t, interval, cond, clip_denoised=True, repeat_noise=False):
+        """Reference :164-199 (pseudo linear multi-step)."""
+        def get_x_pred(x, noise_t, t):
+            a_t = self._h("alphas_cumprod", t)
+            a_prev = self._h("alphas_cumprod", max(t - interval, 0))
+            a_t_sq, a_prev_sq = np.sqrt(a_t), np.sqrt(a_prev)
+            kx = (a_prev - a_t) * (1 / (a_t_sq * (a_t_sq + a_prev_sq)))
+            kn = (a_prev - a_t) * (1 / (a_t_sq * (np.sqrt((1 - a_prev) * a_t) + np.sqrt((1 - a_t) * a_prev))))
+            return _lin(1 + kx, x, -kn, noise_t)
+
+        nl = self.noise_list
+        noise_pred = self._denoise(x, t, cond)
+        if len(nl) == 0:
+            x_pred = get_x_pred(x, noise_pred, t)
+            noise_pred_prev = self._denoise(x_pred, max(t - interval, 0), cond)
+            prime = _lin(0.5, noise_pred, 0.5, noise_pred_prev)
+        elif len(nl) == 1:
+            prime = _lin(1.5, noise_pred, -0.5, nl[-1])
+        elif len(nl) == 2:
+            prime = _lin(1.0, _lin(23 / 12, noise_pred, -16 / 12, nl[-1]), 5 / 12, nl[-2])
+        else:
+            prime = _lin(1.0, _lin(55 / 24, noise_pred, -59 / 24, nl[-1]), 1.0, _lin(37 / 24, nl[-2], -9 / 24, nl[-3]))
+        x_prev = get_x_pred(x, prime, t)
+        nl.append(noise_pred)
+        return x_prev
+
+    def q_sample(self, x_start, t, noise=None):
+        """Reference :201-206; t python int."""
+        if noise is None:
+            noise = torch.randn(x_start.shape, device=x_start.device)
+        return _lin(self._h("sqrt_alphas_cumprod", t), x_start, self._h("sqrt_one_minus_alphas_cumprod", t), noise)
+
+    def p_losses(self, *a, **k):
+        raise NotImplementedError("diffusion training (p_losses / train_diff.py) has no HIP backward path yet")
+
+    @torch.no_grad()
+    def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=300, use_tqdm=True,
+                noise=None):
+        """Reference :222-390.  condition [B,T,H] (the reference's layout) or [B,H,T] when `channel_major`; returns mel
+        [B,T,M].  `noise`: optional dict(x_T [B,1,M,T], steps = list of per-step noises for the ancestral sampler)."""
+        if not infer:
+            return self.p_losses()
+        cond = condition.transpose(1, 2).float().contiguous()
+        b, device = cond.shape[0], cond.device
+        shape = (b, 1, self.out_dims, cond.shape[2])
+        noise = noise or {}
+        if gt_spec is None:
+            t = self.k_step
+            x = noise["x_T"] if "x_T" in noise else torch.randn(shape, device=device)
+        else:
+            t = k_step
+            norm_spec = self.norm_spec(gt_spec).transpose(1, 2)[:, None, :, :].contiguous()
+            x = self.q_sample(norm_spec, t - 1, noise=noise.get("x_T"))
+        if method is not None and infer_speedup > 1:
+            if method in ("dpm-solver", "dpm-solver++", "unipc"):
+                raise NotImplementedError(f"sampler '{method}' (third-party solver library) is not mirrored; use 'ddim' or 'pndm'")
+            if method == "pndm":
+                self.noise_list = deque(maxlen=4)
+                for i in reversed(range(0, t, infer_speedup)):
+                    x = self.p_sample_plms(x, i, infer_speedup, cond=cond)
+            elif method == "ddim":
+                for i in reversed(range(0, t, infer_speedup)):
+                    x = self.p_sample_ddim(x, i, infer_speedup, cond=cond)
+            else:
+                raise NotImplementedError(method)
+        else:
+            steps = noise.get("steps")
+            for n, i in enumerate(reversed(range(0, t))):
+                x = self.p_sample(x, i, cond, noise=None if steps is None else steps[n])
+        x = x.squeeze(1).transpose(1, 2)
+        return self.denorm_spec(x)
+
+    def norm_spec(self, x):
+        return (x - self.spec_min) / (self.spec_max - self.spec_min) * 2 - 1
+
+    def denorm_spec(self, x):
+        return (x + 1) / 2 * (self.spec_max - self.spec_min) + self.spec_min

@@ -1,0 +1,106 @@
+"""MI355X-native mirror of diffusion/unit2mel.py: Unit2Mel = conditioning embeddings + GaussianDiffusion(WaveNet)
+(SURVEY.md §8f row 2).  Same constructor / `state_dict` keys / forward signature; inference only.
+
+The conditioning sum (:139-155) is assembled directly in the engine's [B, H, T] layout: unit_embed = 1x1 MFMA conv,
+f0_embed / volume_embed = Cin=1 direct convs (log(1 + f0/700) from the lf0 kernel, rescaled), spk_embed = lookup."""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+import svc_hip as S
+
+from .diffusion import GaussianDiffusion
+from .wavenet import WaveNet
+
+
+class DotDict(dict):
+    def __getattr__(*args):
+        val = dict.get(*args)
+        return DotDict(val) if type(val) is dict else val
+
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+
+
+class Unit2Mel(nn.Module):
+    def __init__(self, input_channel, n_spk, use_pitch_aug=False, out_dims=128, n_layers=20, n_chans=384, n_hidden=256,
+                 timesteps=1000, k_step_max=1000):
+        super().__init__()
+        self.unit_embed = nn.Linear(input_channel, n_hidden)
+        self.f0_embed = nn.Linear(1, n_hidden)
+        self.volume_embed = nn.Linear(1, n_hidden)
+        self.aug_shift_embed = nn.Linear(1, n_hidden, bias=False) if use_pitch_aug else None
+        self.n_spk = n_spk
+        if n_spk is not None and n_spk > 1:
+            self.spk_embed = nn.Embedding(n_spk, n_hidden)
+        self.timesteps = timesteps if timesteps is not None else 1000
+        self.k_step_max = k_step_max if k_step_max is not None and 0 < k_step_max < self.timesteps else self.timesteps
+        self.n_hidden = n_hidden
+        self.decoder = GaussianDiffusion(WaveNet(out_dims, n_layers, n_chans, n_hidden), timesteps=self.timesteps,
+                                         k_step=self.k_step_max, out_dims=out_dims)
+        self.input_channel = input_channel
+
+    def _condition(self, units, f0, volume, spk_id, spk_mix_dict, aug_shift):
+        """[B,T,n_unit], [B,T,1], [B,T,1] -> cond [B, n_hidden, T]."""
+        B, T, _ = units.shape
+        H = self.n_hidden
+        pk = lambda w: S.pack_conv1d_weight(w.detach().contiguous())
+        x = S.conv1d(units.float().transpose(1, 2).contiguous(), pk(self.unit_embed.weight.unsqueeze(-1)), H, 1,
+                     bias=self.unit_embed.bias)
+        # log(1 + f0/700) = lf0 * 500 ln(10) / 2595  (svc_f0_norm_lf0_f32 computes lf0 = 2595 log10(1 + f0/700) / 500)
+        f0r = f0.float().reshape(B, T).contiguous()
+        lf0, _ = S.f0_norm_lf0(f0r, (f0r > 0).float(), mask=None)
+        lg = S.ew(S.EW_SCALE, lf0.reshape(B, 1, T).contiguous(), alpha=500.0 * math.log(10.0) / 2595.0)
+        x = S.ew(S.EW_ADD, x, S.conv1d_direct(lg, pk(self.f0_embed.weight.unsqueeze(-1)), H, 1, bias=self.f0_embed.bias),
+                 alpha=1.0, beta=1.0)
+        vol = volume.float().reshape(B, 1, T).contiguous()
+        x = S.ew(S.EW_ADD, x, S.conv1d_direct(vol, pk(self.volume_embed.weight.unsqueeze(-1)), H, 1,
+                                               bias=self.volume_embed.bias), alpha=1.0, beta=1.0)
+        if self.n_spk is not None and self.n_spk > 1:
+            if spk_mix_dict is not None:
+                for k, v in spk_mix_dict.items():
+                    e = self.spk_embed.weight[int(k)].detach().view(1, H, 1).expand(B, H, 1).contiguous()
+                    x = S.ew_bct(S.EW_ADD, x, e, alpha=1.0, beta=float(v))
+            else:
+                if spk_id.shape[1] > 1:
+                    raise NotImplementedError("per-frame speaker mix tracks (speaker_map) are not mirrored for Unit2Mel")
+                e = self.spk_embed(spk_id.long()).detach().transpose(1, 2).contiguous()           # [B, H, 1] lookup
+                x = S.ew_bct(S.EW_ADD, x, e, alpha=1.0, beta=1.0)
+        if self.aug_shift_embed is not None and aug_shift is not None:
+            sh = (aug_shift.float() / 5).reshape(B, 1, 1).expand(B, 1, T).contiguous()
+            x = S.ew(S.EW_ADD, x, S.conv1d_direct(sh, pk(self.aug_shift_embed.weight.unsqueeze(-1)), H, 1), alpha=1.0, beta=1.0)
+        return x
+
+    @torch.no_grad()
+    def forward(self, units, f0, volume, spk_id=None, spk_mix_dict=None, aug_shift=None, gt_spec=None, infer=True,
+                infer_speedup=10, method="dpm-solver", k_step=300, use_tqdm=True, noise=None):
+        """Reference :124-167: units [B,T,n_unit], f0 / volume [B,T,1] -> mel [B,T,out_dims]."""
+        if not infer or self.training:
+            raise NotImplementedError("Unit2Mel training (train_diff.py) has no HIP backward path yet: call .eval()")
+        if gt_spec is not None and k_step > self.k_step_max:
+            raise Exception("The shallow diffusion k_step is greater than the maximum diffusion k_step(k_step_max)!")
+        if gt_spec is None and self.k_step_max != self.timesteps:
+            raise Exception("This model can only be used for shallow diffusion and can not infer alone!")
+        if not units.is_cuda:
+            raise S.SvcError("Unit2Mel needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+        cond = self._condition(units, f0, volume, spk_id, spk_mix_dict, aug_shift)
+        return self.decoder(cond.transpose(1, 2), gt_spec=gt_spec, infer=True, infer_speedup=infer_speedup, method=method,
+                            k_step=k_step, use_tqdm=use_tqdm, noise=noise)
+
+
+def load_model_vocoder(model_path, device="cuda", config_path=None):
+    """Reference :22-58 — the vocoder wrapper (diffusion/vocoder.py, nvSTFT mel extraction with librosa) is out of
+    scope: returns (model, None, args); pair the mel output with vdecoder.nsf_hifigan.models.load_model."""
+    config_file = os.path.join(os.path.split(model_path)[0], "config.yaml") if config_path is None else config_path
+    with open(config_file, "r") as config:
+        args = DotDict(yaml.safe_load(config))
+    model = Unit2Mel(args.data.encoder_out_channels, args.model.n_spk, args.model.use_pitch_aug, 128,
+                     args.model.n_layers, args.model.n_chans, args.model.n_hidden, args.model.timesteps,
+                     args.model.k_step_max)
+    ckpt = torch.load(model_path, map_location="cpu")
+    model.load_state_dict(ckpt["model"])
+    return model.to(device).eval(), None, args

@@ -108,6 +108,7 @@ def lib():
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_snake_alias_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [C.c_longlong] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        L.svc_sinusoidal_emb_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_void_p]
         L.svc_nsf_source_exact_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
         L.svc_channel_norm_gelu_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
@@ -121,7 +122,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32",
+    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
 
@@ -298,6 +299,15 @@ def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0
     check(lib().svc_nsf_source_f32(ptr(f0.contiguous()), ptr(rand_ini.contiguous()), ptr(noise.contiguous()),
                                    ptr(lin_w.contiguous()), ptr(lin_b.contiguous()), ptr(out), ptr(scratch), B, T,
                                    upp, H, float(sampling_rate), sine_amp, noise_std, stream_ptr()), "nsf_source")
+    return out
+
+
+def sinusoidal_emb(t, dim):
+    """SinusoidalPosEmb (diffusion/wavenet.py:16-28): t [B] -> [B, dim]."""
+    require_gpu(t)
+    t = t.float().contiguous()
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(lib().svc_sinusoidal_emb_f32(ptr(t), ptr(out), t.shape[0], dim, stream_ptr()), "sinusoidal_emb")
     return out
 
 
@@ -524,7 +534,7 @@ def device_info():
 # training-path entry points (include/svc_hip.h, "TRAINING path")
 # --------------------------------------------------------------------------------------------------------------
 (EW_ADD, EW_MUL, EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_RELU, EW_RELU_BWD, EW_EXP, EW_LOG_CLAMP,
- EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU) = range(17)
+ EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU, EW_MISH, EW_CLAMP) = range(19)
 RED_SUM, RED_ABS_DIFF, RED_SQ_DIFF, RED_SQ_ONE_MINUS, RED_SQ, RED_KL = range(6)
 
 
