@@ -161,3 +161,42 @@ def sample(sd, c, cond_btH, method, infer_speedup, gt_spec=None, k_step=None, x_
             x = mean + (0. if i == 0 else 1.) * (0.5 * ex("posterior_log_variance_clipped", i)).exp() * step_noise[k]
     x = x.squeeze(1).transpose(1, 2)
     return (x + 1) / 2 * (spec_max - spec_min) + spec_min
+
+
+# ---- training (diffusion/diffusion.py:210-243, diffusion/solver.py:116-147, train_diff.py:55-60) -------------------------
+def train_loss(sd, c, units, f0, volume, spk_id, gt_spec, t, noise, spec_min=-12., spec_max=2.):
+    """Unit2Mel.forward(infer=False) with the random draws explicit: t [B] long, noise [B,1,M,T].  `sd` tensors may require
+    grad (torch autograd on the CPU restatement is the gradient oracle)."""
+    S_ = schedule(c["timesteps"])
+    cond = condition(sd, c, units, f0, volume, spk_id).transpose(1, 2)
+    ns = ((gt_spec - spec_min) / (spec_max - spec_min) * 2 - 1).transpose(1, 2)[:, None, :, :]
+    a = S_["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    s = S_["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    x_noisy = a * ns + s * noise
+    return F.mse_loss(noise, wavenet(sd, c, x_noisy, t, cond))
+
+
+def train_loop(sd, c, batches, lr=1e-4, weight_decay=0.0, gamma=0.5, decay_step=100000):
+    """`batches`: list of dicts(units, f0, volume, spk_id, gt, t, noise).  torch.optim.AdamW defaults (betas .9/.999,
+    eps 1e-8) with lr / weight_decay overridden and StepLR, as train_diff.py:55-60 sets them up.  Returns (losses,
+    first-step grads, final parameters)."""
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    losses, grads0 = [], None
+    for step, bt in enumerate(batches, 1):
+        loss = train_loss(P, c, bt["units"], bt["f0"], bt["volume"], bt["spk_id"], bt["gt"], bt["t"], bt["noise"])
+        gs = torch.autograd.grad(loss, list(P.values()))
+        losses.append(float(loss))
+        if grads0 is None:
+            grads0 = {k: g.clone() for k, g in zip(P, gs)}
+        cur_lr = lr * gamma ** ((step - 1) // decay_step)
+        with torch.no_grad():
+            for (k, p), g in zip(P.items(), gs):
+                p.mul_(1 - cur_lr * weight_decay)
+                m[k].mul_(b1).add_(g, alpha=1 - b1)
+                v2[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v2[k].sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+                p.addcdiv_(m[k], denom, value=-cur_lr / (1 - b1 ** step))
+    return losses, grads0, {k: p.detach() for k, p in P.items()}

@@ -121,6 +121,11 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
     case SVC_EW_GELU: return svc_gelu(a);
     case SVC_EW_MISH: return a * tanhf(a > 20.f ? a : log1pf(expf(a)));   // softplus with torch's threshold 20
     case SVC_EW_CLAMP: return fminf(fmaxf(a, alpha), beta);
+    case SVC_EW_MISH_BWD: {                                           // a = dy, b = x
+      const float sp = b > 20.f ? b : log1pf(expf(b));
+      const float th = tanhf(sp);
+      return a * (th + b * (1.f - th * th) * svc_sigmoid(b));
+    }
     default: return a;
   }
 }

@@ -6,7 +6,8 @@ PNDM/PLMS (`p_sample_plms`, :164-199) — the ones defined in this file.  Every 
 combination of [B,1,M,T] tensors: the coefficients come from the host copy of the schedule (all batch items share the
 step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  'dpm-solver(++)' and 'unipc' call
 into two third-party solver libraries (diffusion/dpm_solver_pytorch.py, uni_pc.py: 2000 lines) that are not mirrored;
-training (`infer=False`, p_losses) is not implemented either — both raise NotImplementedError."""
+they raise NotImplementedError.  Training (`infer=False` -> p_losses, :210-243) runs on the autograd ops of
+svc_autograd.py."""
 from collections import deque
 from functools import partial
 
@@ -14,6 +15,7 @@ import numpy as np
 import torch
 from torch import nn
 
+import svc_autograd as A
 import svc_hip as S
 
 
@@ -139,16 +141,42 @@ class GaussianDiffusion(nn.Module):
             noise = torch.randn(x_start.shape, device=x_start.device)
         return _lin(self._h("sqrt_alphas_cumprod", t), x_start, self._h("sqrt_one_minus_alphas_cumprod", t), noise)
 
-    def p_losses(self, *a, **k):
-        raise NotImplementedError("diffusion training (p_losses / train_diff.py) has no HIP backward path yet")
+    def p_losses(self, x_start, t, cond, noise=None, loss_type="l2"):
+        """Reference :210-223: x_start [B,1,M,T], t [B] long (per-item steps), cond [B,H,T] -> scalar loss with a HIP
+        backward path into the denoiser and `cond`."""
+        B, _, M, T = x_start.shape
+        if noise is None:
+            noise = torch.randn(x_start.shape, device=x_start.device)
+        x0, nz = x_start.reshape(B, M, T).float().contiguous(), noise.reshape(B, M, T).float().contiguous()
+        a = self.sqrt_alphas_cumprod[t].view(B, 1, 1)                        # extract(): per-item coefficient gathers
+        s = self.sqrt_one_minus_alphas_cumprod[t].view(B, 1, 1)
+        x_noisy = S.ew(S.EW_ADD, S.ew_bct(S.EW_MUL, x0, a), S.ew_bct(S.EW_MUL, nz, s), alpha=1.0, beta=1.0)   # q_sample :201-206
+        x_recon = self.denoise_fn(x_noisy.view(B, 1, M, T), t, cond)
+        xr = x_recon.reshape(B, M, T)
+        if loss_type == "l1":
+            return A.sum_abs_diff(nz, xr) / nz.numel()
+        if loss_type == "l2":
+            return A.sum_sq_diff(nz, xr) / nz.numel()
+        raise NotImplementedError()
 
-    @torch.no_grad()
     def forward(self, condition, gt_spec=None, infer=True, infer_speedup=10, method="dpm-solver", k_step=300, use_tqdm=True,
                 noise=None):
-        """Reference :222-390.  condition [B,T,H] (the reference's layout) or [B,H,T] when `channel_major`; returns mel
-        [B,T,M].  `noise`: optional dict(x_T [B,1,M,T], steps = list of per-step noises for the ancestral sampler)."""
+        """Reference :222-390.  condition [B,T,H] (the reference's layout); returns mel [B,T,M] (infer) or the training
+        loss (infer=False).  `noise`: optional dict(x_T [B,1,M,T], steps = list of per-step noises for the ancestral
+        sampler; for training: t [B] long, noise [B,1,M,T])."""
         if not infer:
-            return self.p_losses()
+            noise = noise or {}
+            cond = A._c(condition.transpose(1, 2).float())
+            b, device = cond.shape[0], cond.device
+            with torch.no_grad():
+                spec = self.norm_spec(gt_spec.float())
+                t = noise["t"] if "t" in noise else torch.randint(0, self.k_step, (b,), device=device).long()
+                norm_spec = spec.transpose(1, 2)[:, None, :, :].contiguous()
+            return self.p_losses(norm_spec, t, cond=cond, noise=noise.get("noise"))
+        with torch.no_grad():
+            return self._sample(condition, gt_spec, infer_speedup, method, k_step, noise)
+
+    def _sample(self, condition, gt_spec, infer_speedup, method, k_step, noise):
         cond = condition.transpose(1, 2).float().contiguous()
         b, device = cond.shape[0], cond.device
         shape = (b, 1, self.out_dims, cond.shape[2])

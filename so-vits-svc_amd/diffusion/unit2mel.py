@@ -1,5 +1,5 @@
 """MI355X-native mirror of diffusion/unit2mel.py: Unit2Mel = conditioning embeddings + GaussianDiffusion(WaveNet)
-(SURVEY.md §8f row 2).  Same constructor / `state_dict` keys / forward signature; inference only.
+(SURVEY.md §8f row 2).  Same constructor / `state_dict` keys / forward signature; inference (samplers) and training (infer=False -> loss).
 
 The conditioning sum (:139-155) is assembled directly in the engine's [B, H, T] layout: unit_embed = 1x1 MFMA conv,
 f0_embed / volume_embed = Cin=1 direct convs (log(1 + f0/700) from the lf0 kernel, rescaled), spk_embed = lookup."""
@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import yaml
 
+import svc_autograd as A
 import svc_hip as S
 
 from .diffusion import GaussianDiffusion
@@ -75,18 +76,49 @@ class Unit2Mel(nn.Module):
             x = S.ew(S.EW_ADD, x, S.conv1d_direct(sh, pk(self.aug_shift_embed.weight.unsqueeze(-1)), H, 1), alpha=1.0, beta=1.0)
         return x
 
-    @torch.no_grad()
+    def _condition_train(self, units, f0, volume, spk_id, aug_shift):
+        """The conditioning sum on the autograd ops (HIP forward + backward): gradients reach every embedding."""
+        B, T, _ = units.shape
+        H = self.n_hidden
+        x = A.conv1d(units.float().transpose(1, 2).contiguous(), self.unit_embed.weight.unsqueeze(-1), self.unit_embed.bias)
+        f0r = f0.float().reshape(B, T).contiguous()
+        lf0, _ = S.f0_norm_lf0(f0r, (f0r > 0).float(), mask=None)
+        lg = S.ew(S.EW_SCALE, lf0.reshape(B, 1, T).contiguous(), alpha=500.0 * math.log(10.0) / 2595.0)
+
+        def lin1(inp, lin):            # nn.Linear(1, H) on a [B,1,T] track: w[h] * inp[b,t] (+ b[h])
+            y = A.mul_bcast(inp.expand(B, H, T), lin.weight.view(1, H, 1))
+            return y if lin.bias is None else A.add_bcast(y, lin.bias.view(1, H, 1))
+        x = A.add(x, lin1(lg, self.f0_embed))
+        x = A.add(x, lin1(volume.float().reshape(B, 1, T).contiguous(), self.volume_embed))
+        if self.n_spk is not None and self.n_spk > 1:
+            if spk_id.shape[1] > 1:
+                raise NotImplementedError("per-frame speaker mix tracks (speaker_map) are not mirrored for Unit2Mel")
+            x = A.add_bcast(x, A.embedding_bct(spk_id.long().reshape(B, 1), self.spk_embed.weight))
+        if self.aug_shift_embed is not None and aug_shift is not None:
+            sh = (aug_shift.float() / 5).reshape(B, 1, 1).expand(B, 1, T).contiguous()
+            x = A.add(x, lin1(sh, self.aug_shift_embed))
+        return x
+
     def forward(self, units, f0, volume, spk_id=None, spk_mix_dict=None, aug_shift=None, gt_spec=None, infer=True,
                 infer_speedup=10, method="dpm-solver", k_step=300, use_tqdm=True, noise=None):
-        """Reference :124-167: units [B,T,n_unit], f0 / volume [B,T,1] -> mel [B,T,out_dims]."""
-        if not infer or self.training:
-            raise NotImplementedError("Unit2Mel training (train_diff.py) has no HIP backward path yet: call .eval()")
+        """Reference :124-167: units [B,T,n_unit], f0 / volume [B,T,1] -> mel [B,T,out_dims]; with infer=False (the
+        train_diff.py call, diffusion/solver.py:128) -> the training loss."""
+        if not units.is_cuda:
+            raise S.SvcError("Unit2Mel needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+        if not infer:
+            if spk_mix_dict is not None:
+                raise NotImplementedError("spk_mix_dict is an inference option")
+            cond = self._condition_train(units, f0, volume, spk_id, aug_shift)
+            return self.decoder(cond.transpose(1, 2), gt_spec=gt_spec, infer=False, k_step=k_step, noise=noise)
+        with torch.no_grad():
+            return self._infer(units, f0, volume, spk_id, spk_mix_dict, aug_shift, gt_spec, infer_speedup, method, k_step,
+                               use_tqdm, noise)
+
+    def _infer(self, units, f0, volume, spk_id, spk_mix_dict, aug_shift, gt_spec, infer_speedup, method, k_step, use_tqdm, noise):
         if gt_spec is not None and k_step > self.k_step_max:
             raise Exception("The shallow diffusion k_step is greater than the maximum diffusion k_step(k_step_max)!")
         if gt_spec is None and self.k_step_max != self.timesteps:
             raise Exception("This model can only be used for shallow diffusion and can not infer alone!")
-        if not units.is_cuda:
-            raise S.SvcError("Unit2Mel needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
         cond = self._condition(units, f0, volume, spk_id, spk_mix_dict, aug_shift)
         return self.decoder(cond.transpose(1, 2), gt_spec=gt_spec, infer=True, infer_speedup=infer_speedup, method=method,
                             k_step=k_step, use_tqdm=use_tqdm, noise=noise)

@@ -19,6 +19,7 @@ from math import sqrt
 import torch
 import torch.nn as nn
 
+import svc_autograd as A
 import svc_hip as S
 
 
@@ -106,11 +107,50 @@ class WaveNet(nn.Module):
             self._cond_cache = (key, cp, cond)          # keep `cond` alive so that the pointer key stays unique
         return self._cond_cache[1]
 
-    @torch.no_grad()
+    def forward_train(self, spec, diffusion_step, cond):
+        """The same map on the autograd ops of svc_autograd.py (HIP forward + backward), for p_losses / train_diff.py.
+        All layers' conditioner projections are one stacked conv (one dgrad into `cond`, one wgrad), split into
+        contiguous per-layer chunks; the reference's sigmoid(first half) * tanh(second half) is tanh(first) * sigmoid(second)
+        on weights whose halves are swapped (pure index reshapes of the parameters)."""
+        C, L = self.n_chans, self.n_layers
+        B, _, M, T = spec.shape
+        x = A.relu(A.conv1d(spec.reshape(B, M, T).float().contiguous(), self.input_projection.weight, self.input_projection.bias))
+        emb = self.diffusion_embedding(diffusion_step.float()).view(B, C, 1)
+        h = A.mish(A.conv1d(emb, self.mlp[0].weight.unsqueeze(-1), self.mlp[0].bias))
+        step = A.conv1d(h, self.mlp[2].weight.unsqueeze(-1), self.mlp[2].bias)                       # [B, C, 1]
+        layers = self.residual_layers
+        w_cp = torch.cat([_swap_halves(l.conditioner_projection.weight) for l in layers], 0)
+        b_cp = torch.cat([_swap_halves(l.conditioner_projection.bias) for l in layers], 0)
+        cps = A.chunk_channels(A.conv1d(cond, w_cp, b_cp), L)                                        # L x [B, 2C, T]
+        w_dp = torch.cat([l.diffusion_projection.weight for l in layers], 0).unsqueeze(-1)
+        b_dp = torch.cat([l.diffusion_projection.bias for l in layers], 0)
+        dps = A.chunk_channels(A.conv1d(step, w_dp, b_dp), L)                                        # L x [B, C, 1]
+        skip = None
+        r2 = 1.0 / math.sqrt(2.0)
+        for l, layer in enumerate(layers):
+            y = A.add_bcast(x, dps[l])
+            y = A.conv1d(y, _swap_halves(layer.dilated_conv.weight), _swap_halves(layer.dilated_conv.bias),
+                         padding=layer.dilation, dilation=layer.dilation)
+            acts = A.gate(A.add(y, cps[l]))
+            wo, bo = layer.output_projection.weight, layer.output_projection.bias
+            if l < L - 1:               # the last layer's residual half feeds nothing (reference :99-100 uses the skips only)
+                x = A.add(x, A.conv1d(acts, wo[:C], bo[:C]), alpha=r2, beta=r2)
+            sk = A.conv1d(acts, wo[C:], bo[C:])
+            skip = sk if skip is None else A.add(skip, sk)
+        h = A.relu(A.conv1d(A.scale(skip, 1.0 / sqrt(L)), self.skip_projection.weight, self.skip_projection.bias))
+        out = A.conv1d(h, self.output_projection.weight, self.output_projection.bias)
+        return out[:, None, :, :]
+
     def forward(self, spec, diffusion_step, cond):
         """spec [B,1,M,T], diffusion_step [B] (or [B,1]), cond [B,n_hidden,T] -> [B,1,M,T]  (reference :81-108)."""
         if not spec.is_cuda:
             raise S.SvcError("WaveNet.forward needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+        if torch.is_grad_enabled() and (self.training or cond.requires_grad or spec.requires_grad):
+            return self.forward_train(spec, diffusion_step, cond)
+        with torch.no_grad():
+            return self._forward_infer(spec, diffusion_step, cond)
+
+    def _forward_infer(self, spec, diffusion_step, cond):
         pk = self._packs()
         C, L = self.n_chans, self.n_layers
         B, _, M, T = spec.shape

@@ -215,6 +215,36 @@ class _Gate(Function):
         return S.gate_bwd(x, d)
 
 
+class _ChunkC(Function):
+    """x [B, n*C, T] -> n contiguous [B, C, T] chunks; the backward writes the n gradients into ONE buffer (torch's own
+    slice backward would zero-fill and add a full-size tensor per chunk)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        B, Ct, T = x.shape
+        C = Ct // n
+        ctx.cfg = (n, C)
+        outs = tuple(S.copy_bct(x[:, i * C:(i + 1) * C]) for i in range(n))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, C = ctx.cfg
+        g0 = next(g for g in gs if g is not None)
+        B, _, T = g0.shape
+        dx = torch.empty((B, n * C, T), device=g0.device, dtype=torch.float32)
+        for i, g in enumerate(gs):
+            if g is None:
+                dx[:, i * C:(i + 1) * C].zero_()
+            else:
+                S.copy_bct(g, out=dx[:, i * C:(i + 1) * C])
+        return dx, None
+
+
+def chunk_channels(x, n):
+    return _ChunkC.apply(x, n)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # functional API
 # ---------------------------------------------------------------------------------------------------------------
@@ -232,6 +262,11 @@ def relu(x):
 
 def tanh(x):
     return _EwUnary.apply(x, S.EW_TANH, S.EW_TANH_BWD, 1.0, True)
+
+
+def mish(x):
+    """x * tanh(softplus(x)) (diffusion/wavenet.py:76)."""
+    return _EwUnary.apply(x, S.EW_MISH, S.EW_MISH_BWD, 0.0, False)
 
 
 def add(a, b, alpha=1.0, beta=1.0):

@@ -534,7 +534,7 @@ def device_info():
 # training-path entry points (include/svc_hip.h, "TRAINING path")
 # --------------------------------------------------------------------------------------------------------------
 (EW_ADD, EW_MUL, EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_RELU, EW_RELU_BWD, EW_EXP, EW_LOG_CLAMP,
- EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU, EW_MISH, EW_CLAMP) = range(19)
+ EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU, EW_MISH, EW_CLAMP, EW_MISH_BWD) = range(20)
 RED_SUM, RED_ABS_DIFF, RED_SQ_DIFF, RED_SQ_ONE_MINUS, RED_SQ, RED_KL = range(6)
 
 

@@ -80,3 +80,79 @@ def test_unit2mel_matches_reference_golden(dev, name, method, speedup, shallow, 
     assert mel.shape == ref.shape
     err = (mel.cpu() - ref).abs().max().item()
     assert err <= 1e-3 * max(1.0, ref.abs().max().item()), err
+
+
+# ---- training (train_diff.py / diffusion/solver.py:116-147) ------------------------------------------------------------
+def _train_golden():
+    z = np.load(os.path.join(G, "diffusion_train_small.npz"))
+    meta = json.loads(str(z["meta"]))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mkdt", os.path.join(G, "make_golden_diffusion_train.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    c = DO.small_cfg()
+    return z, meta, c, mk.make_batches(c, meta["seed"], meta["B"], meta["T"], meta["N"])
+
+
+def test_oracle_reproduces_reference_training():
+    """Oracle p_losses + AdamW loop vs the REAL Unit2Mel(infer=False) + torch.optim.AdamW/StepLR: losses, first-step
+    gradients, parameters after 4 steps."""
+    z, meta, c, batches = _train_golden()
+    sd = DO.make_state_dict(c, meta["seed"])
+    losses, g0, final = DO.train_loop(sd, c, batches, lr=meta["lr"])
+    assert np.allclose(losses, z["losses"], rtol=1e-5)
+    for k in g0:
+        ref = z["g0/" + k]
+        assert np.abs(g0[k].numpy() - ref).max() <= 1e-5 * max(1e-6, np.abs(ref).max()) + 1e-9, k
+        assert np.abs(final[k].numpy() - z["final/" + k]).max() <= 2e-6, k
+
+
+@pytest.mark.gpu
+def test_unit2mel_training_matches_reference_golden(dev):
+    """HIP forward + backward of Unit2Mel(infer=False) and FusedAdamW vs the real reference's training run.
+    Tolerances: loss 2e-5 relative; gradients 2e-3 of each tensor's max (fp32 MFMA accumulation order vs MKL through
+    3 gated layers); parameters after 4 AdamW steps at lr 2e-3: 2e-4 absolute (Adam's g/sqrt(v) amplifies relative
+    gradient error on near-zero entries)."""
+    from optim import FusedAdamW
+    z, meta, c, batches = _train_golden()
+    net = _mirror(c, meta["seed"], dev).train()
+    opt = FusedAdamW(net.parameters(), lr=meta["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    names = [k for k, _ in net.named_parameters()]
+    for i, bt in enumerate(batches):
+        d = {k: v.to(dev) for k, v in bt.items()}
+        opt.zero_grad()
+        loss = net(d["units"], d["f0"], d["volume"], d["spk_id"], aug_shift=None, gt_spec=d["gt"], infer=False,
+                   k_step=net.k_step_max, noise=dict(t=d["t"], noise=d["noise"]))
+        loss.backward()
+        assert abs(float(loss) - z["losses"][i]) <= 2e-5 * z["losses"][i], (i, float(loss), z["losses"][i])
+        if i == 0:
+            for k, p in net.named_parameters():
+                ref = z["g0/" + k]
+                assert p.grad is not None, k
+                err = np.abs(p.grad.cpu().numpy() - ref).max()
+                assert err <= 2e-3 * np.abs(ref).max() + 1e-9, (k, err, np.abs(ref).max())
+        opt.step()
+    for k, p in net.named_parameters():
+        assert np.abs(p.detach().cpu().numpy() - z["final/" + k]).max() <= 2e-4, k
+    assert len(names) == len([k for k in z.files if k.startswith("g0/")])
+
+
+@pytest.mark.gpu
+def test_diffusion_train_step_graph_equals_eager(dev):
+    """diffusion/solver.py mirror: the hipGraph-replayed iteration gives the eager iteration's losses and parameters."""
+    from diffusion import solver
+    z, meta, c, batches = _train_golden()
+    res = []
+    for graph in (False, True):
+        net = _mirror(c, meta["seed"], dev).train()
+        step = solver.TrainStep(net, solver.build_optimizer(net, lr=meta["lr"])).enable_graph(graph)
+        losses = []
+        for bt in batches:
+            d = {k: v.to(dev) for k, v in bt.items()}
+            data = dict(units=d["units"], f0=d["f0"], volume=d["volume"], spk_id=d["spk_id"], mel=d["gt"])
+            losses.append(float(step(data, noise=dict(t=d["t"], noise=d["noise"]))))
+        res.append((losses, {k: p.detach().clone() for k, p in net.named_parameters()}))
+    assert np.allclose(res[0][0], z["losses"], rtol=2e-5)
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6)
+    for k in res[0][1]:
+        assert torch.allclose(res[0][1][k], res[1][1][k], atol=1e-6), k
