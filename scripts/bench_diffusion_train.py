@@ -11,16 +11,17 @@ B, T = int(os.environ.get("B", 48)), int(os.environ.get("T", 172))
 torch.manual_seed(0)
 net = Unit2Mel(768, 1, False, 128, 20, 512, 256, 1000, 1000).to(dev).train()
 torch.nn.init.normal_(net.decoder.denoise_fn.output_projection.weight, std=0.02)
+net.decoder.denoise_fn.pack_batches = os.environ.get("PACK", "1") == "1"
 step = solver.TrainStep(net, solver.build_optimizer(net, lr=1e-4))
 data = dict(units=torch.randn(B, T, 768, device=dev), f0=200 + 100 * torch.rand(B, T, 1, device=dev),
             volume=torch.rand(B, T, 1, device=dev), spk_id=torch.zeros(B, 1, dtype=torch.long, device=dev),
             mel=-6 + 2 * torch.randn(B, T, 128, device=dev))
-for graph in (False, True):
+for graph in ((False,) if os.environ.get("EAGER_ONLY") else (False, True)):
     step.enable_graph(graph)
     for _ in range(3):
         l = step(data)
     torch.cuda.synchronize()
-    n = 10
+    n = int(os.environ.get("N", 10))
     t0 = time.perf_counter()
     for _ in range(n):
         l = step(data)

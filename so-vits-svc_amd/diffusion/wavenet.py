@@ -75,6 +75,7 @@ class WaveNet(nn.Module):
         nn.init.zeros_(self.output_projection.weight)
         self._cache = {}
         self._cond_cache = None
+        self.pack_batches = True        # training: run batches of short crops as one packed row (forward_train)
 
     # -- packed weights (rebuilt when any parameter changes) --------------------------------------------------------
     def _packs(self):
@@ -114,11 +115,16 @@ class WaveNet(nn.Module):
         on weights whose halves are swapped (pure index reshapes of the parameters)."""
         C, L = self.n_chans, self.n_layers
         B, _, M, T = spec.shape
-        x = A.relu(A.conv1d(spec.reshape(B, M, T).float().contiguous(), self.input_projection.weight, self.input_projection.bias))
+        layers = self.residual_layers
+        gap = max(l.dilation for l in layers)                   # halo of the (only) K=3 conv
+        packed = self.pack_batches and B > 1 and T % 128 != 0                         # batches of short crops: run on the packed row (see A.pack_items)
+        xin = spec.reshape(B, M, T).float().contiguous()
+        if packed:
+            xin, cond = A.pack_items(xin, gap), A.pack_items(cond, gap)
+        x = A.relu(A.conv1d(xin, self.input_projection.weight, self.input_projection.bias))
         emb = self.diffusion_embedding(diffusion_step.float()).view(B, C, 1)
         h = A.mish(A.conv1d(emb, self.mlp[0].weight.unsqueeze(-1), self.mlp[0].bias))
         step = A.conv1d(h, self.mlp[2].weight.unsqueeze(-1), self.mlp[2].bias)                       # [B, C, 1]
-        layers = self.residual_layers
         w_cp = torch.cat([_swap_halves(l.conditioner_projection.weight) for l in layers], 0)
         b_cp = torch.cat([_swap_halves(l.conditioner_projection.bias) for l in layers], 0)
         cps = A.chunk_channels(A.conv1d(cond, w_cp, b_cp), L)                                        # L x [B, 2C, T]
@@ -128,7 +134,7 @@ class WaveNet(nn.Module):
         skip = None
         r2 = 1.0 / math.sqrt(2.0)
         for l, layer in enumerate(layers):
-            y = A.add_bcast(x, dps[l])
+            y = A.packed_add_item(x, dps[l], B, T, gap) if packed else A.add_bcast(x, dps[l])
             y = A.conv1d(y, _swap_halves(layer.dilated_conv.weight), _swap_halves(layer.dilated_conv.bias),
                          padding=layer.dilation, dilation=layer.dilation)
             acts = A.gate(A.add(y, cps[l]))
@@ -139,6 +145,8 @@ class WaveNet(nn.Module):
             skip = sk if skip is None else A.add(skip, sk)
         h = A.relu(A.conv1d(A.scale(skip, 1.0 / sqrt(L)), self.skip_projection.weight, self.skip_projection.bias))
         out = A.conv1d(h, self.output_projection.weight, self.output_projection.bias)
+        if packed:
+            out = A.unpack_items(out, B, T, gap)
         return out[:, None, :, :]
 
     def forward(self, spec, diffusion_step, cond):

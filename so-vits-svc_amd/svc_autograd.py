@@ -245,6 +245,82 @@ def chunk_channels(x, n):
     return _ChunkC.apply(x, n)
 
 
+# ---- packed batches: [B, C, T] items laid end to end in ONE row of length Lp, `gap` zero columns after each item ----------
+# A stride-1 "same" conv with halo <= gap over the packed row equals the per-item zero-padded conv as long as the gap columns
+# of its INPUT are zero; its MFMA column tiles then run over B*(T+gap) columns instead of B x ceil(T/128) x 128 (short
+# items: T = 172 fills 67 % of two 128-wide tiles).  The [B, C, T] window of a packed row is a strided view, so the existing
+# strided copy / broadcast / reduction kernels do the packing and the gap masking.
+def packed_len(B, T, gap):
+    return (B * (T + gap) + 3) // 4 * 4
+
+
+def _pview(p, B, T, gap):
+    return p.as_strided((B, p.shape[1], T), (T + gap, p.shape[2], 1), p.storage_offset())
+
+
+class _Pack(Function):
+    @staticmethod
+    def forward(ctx, x, gap):
+        B, C, T = x.shape
+        ctx.cfg = (B, T, gap)
+        p = torch.zeros((1, C, packed_len(B, T, gap)), device=x.device, dtype=torch.float32)
+        S.copy_bct(x, out=_pview(p, B, T, gap))
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        B, T, gap = ctx.cfg
+        return S.copy_bct(_pview(_c(dp), B, T, gap)), None
+
+
+class _Unpack(Function):
+    @staticmethod
+    def forward(ctx, p, B, T, gap):
+        ctx.cfg = (B, T, gap, p.shape[2])
+        return S.copy_bct(_pview(_c(p), B, T, gap))
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, T, gap, Lp = ctx.cfg
+        dp = torch.zeros((1, dx.shape[1], Lp), device=dx.device, dtype=torch.float32)
+        S.copy_bct(_c(dx), out=_pview(dp, B, T, gap))
+        return dp, None, None, None
+
+
+class _PackedAddItem(Function):
+    """y = packed(x_b + side_b) with the gap columns ZERO (the mask a following conv with a halo needs); side [B, C, 1]."""
+
+    @staticmethod
+    def forward(ctx, p, side, B, T, gap):
+        ctx.cfg = (B, T, gap)
+        y = torch.zeros_like(p)
+        S.ew_bct(S.EW_ADD, _pview(_c(p), B, T, gap), side, alpha=1.0, beta=1.0, out=_pview(y, B, T, gap))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, gap = ctx.cfg
+        dyv = _pview(_c(dy), B, T, gap)
+        dp = None
+        if ctx.needs_input_grad[0]:
+            dp = torch.zeros_like(dy)
+            S.copy_bct(dyv, out=_pview(dp, B, T, gap))
+        ds = S.reduce_bct(dyv, 1) if ctx.needs_input_grad[1] else None
+        return dp, ds, None, None, None
+
+
+def pack_items(x, gap):
+    return _Pack.apply(x, gap)
+
+
+def unpack_items(p, B, T, gap):
+    return _Unpack.apply(p, B, T, gap)
+
+
+def packed_add_item(p, side, B, T, gap):
+    return _PackedAddItem.apply(p, side, B, T, gap)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # functional API
 # ---------------------------------------------------------------------------------------------------------------

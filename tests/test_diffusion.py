@@ -156,3 +156,23 @@ def test_diffusion_train_step_graph_equals_eager(dev):
     assert np.allclose(res[0][0], res[1][0], rtol=1e-6)
     for k in res[0][1]:
         assert torch.allclose(res[0][1][k], res[1][1][k], atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_wavenet_training_packed_row_equals_per_item(dev):
+    """The packed-row layout of WaveNet.forward_train (items end to end, zero gap columns) gives the per-item result:
+    loss and every gradient (fp32 summation order differs in wgrad: 2e-4 of each tensor's max)."""
+    z, meta, c, batches = _train_golden()
+    d = {k: v.to(dev) for k, v in batches[1].items()}
+    grads = []
+    for pack in (True, False):
+        net = _mirror(c, meta["seed"], dev).train()
+        net.decoder.denoise_fn.pack_batches = pack
+        loss = net(d["units"], d["f0"], d["volume"], d["spk_id"], gt_spec=d["gt"], infer=False, k_step=net.k_step_max,
+                   noise=dict(t=d["t"], noise=d["noise"]))
+        loss.backward()
+        grads.append((float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
+    for k in grads[0][1]:
+        a, b = grads[0][1][k], grads[1][1][k]
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-10, k
