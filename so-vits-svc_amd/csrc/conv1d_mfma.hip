@@ -43,7 +43,22 @@ struct ConvP {
   int xvec;       // 1: X rows are 16 B aligned -> float4 staging (selects the XVEC kernel instantiation)
   int yvec;       // 1: y / res / y2 rows are 16 B aligned and unit-stride in time -> float4 epilogue
   int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
+  int db_ni;      // DB kernels: LDS-DMA pieces (1 KiB each) per wave per chunk
+  const float* zero;  // DB kernels: 16 B of zeros in global memory (source of padding / out-of-tile pieces)
 };
+
+__device__ float4 g_zero_block[2];
+
+// One LDS-DMA piece: every lane's 16 B at `g` land at LDS byte address lds_byte + lane*16 (wave-uniform base in M0).
+// Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (svc_vmcnt0 before the barrier).
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_byte)
+               : "memory");
+}
+__device__ __forceinline__ void svc_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float acc_probe(const f32x16& a, const f32x4& b) { return a[0] + b[0]; }
 
@@ -58,7 +73,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false>
 __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
   constexpr int TS = M16 ? 16 : 32;   // MFMA tile edge
   constexpr int KPI = M16 ? 4 : 2;    // K indices consumed per MFMA
@@ -220,6 +235,164 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   const int dbg = p.dbg;
   // (tried: offsetting the chunk phase of co-resident workgroups by half a chunk — no gain, −3 %: the two workgroups
   // of a CU are not phase-locked)
+  if constexpr (DB) {
+    // ---- LDS-DMA, double-buffered chunks ---------------------------------------------------------------------
+    // A chunk's W block [BC*KS][BM] and X block [BC][XW] are one linear range of float4 slots; wave w's piece i covers
+    // slots (i*NW + w)*64 .. +63 (1 KiB, lane-linear as the DMA writes it).  Each lane keeps the global source of its
+    // slot and advances it by the chunk stride; padding (t outside the sequence, weight columns >= CoutP) and slots past
+    // the tile read a 16 B zero block with stride 0, so the issue code has no branches and the LDS image needs no
+    // fix-up.  While the MFMA loop runs on buffer i&1 the pieces of chunk i+1 are in flight into the other buffer:
+    // one vmcnt(0) + one barrier per chunk, neither on the critical path (the loads had a whole MFMA loop to land).
+    // The leaky-ReLU pre-activation moves from the staging pass to the operand read: max(x, slope*x), 0 <= slope <= 1.
+    constexpr int NI = 16;
+    static_assert(!M16 && WK == 1 && XVEC, "DB kernels: 32x32 tiles, no split-K, aligned rows");
+    const int WF4 = BC * KS * BM4, TOT = WF4 + BC * XW4;
+    const int ni = p.db_ni;
+    const int buf_f = ni * NW * 256;  // floats per buffer
+    const char* src[NI];
+    int stp[NI];  // signed: channel-flipped views have negative channel strides
+    unsigned xmask = 0;  // bit i: this lane's slot of piece i is an X slot (pre-activation applies)
+    {
+      const int wstep = BC * KS * a.CoutP * 4, xstep = (int)(BC * a.x_cs * 4);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int sl = (i * NW + wave) * 64 + lane;
+        const float* q = p.zero;
+        int st = 0;
+        if (sl < WF4) {
+          const int row = sl / BM4, c4 = sl - row * BM4;
+          if (co0 + c4 * 4 < a.CoutP) {
+            q = wph + (long long)row * a.CoutP + co0 + c4 * 4;
+            st = wstep;
+          }
+        } else if (sl < TOT) {
+          const int sx = sl - WF4;
+          const int r = sx / XW4, c4 = sx - r * XW4;
+          const int tin = tin_base + c4 * 4;
+          if (tin >= 0 && tin < a.Tin) {
+            q = xb + (long long)r * a.x_cs + tin;
+            st = xstep;
+            xmask |= 1u << i;
+          }
+        }
+        src[i] = reinterpret_cast<const char*>(q);
+        stp[i] = st;
+      }
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int buf) {
+      const unsigned d0 = lds_base + (unsigned)buf * (unsigned)buf_f * 4u + wave_u * 1024u;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i < ni) {
+          glds16(src[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(d0 + (unsigned)(i * NW) * 1024u)));
+          src[i] += stp[i];
+        }
+      }
+    };
+    // Pre-activation: each wave applies it IN PLACE to the X slots it fetched itself (its own vmcnt covers them, no
+    // barrier needed), right after the MFMA loop of the previous chunk; the barrier at the top of the loop publishes it.
+    // (For 1..3 taps the chunks are short and that pass — a dependent LDS round trip per chunk — costs more than applying
+    // the activation to each operand as it is read: 2 VALU per B operand, hidden under the MFMAs.)
+    constexpr bool ACT_ON_READ = KSC >= 1 && KSC <= 3;
+    const float ps = a.pre_slope;
+    const bool act = !ACT_ON_READ && ps != 1.f && !(dbg & 8);
+    auto activate = [&](int buf) {
+      float* d0 = smem + buf * buf_f + wave * 256 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i < ni && ((xmask >> i) & 1u)) {
+          float4* q = reinterpret_cast<float4*>(d0 + i * NW * 256);
+          float4 v = *q;
+          v.x = fmaxf(v.x, v.x * ps); v.y = fmaxf(v.y, v.y * ps); v.z = fmaxf(v.z, v.z * ps); v.w = fmaxf(v.w, v.w * ps);
+          *q = v;
+        }
+      }
+    };
+    issue(0);
+    svc_vmcnt0();
+    if (act) activate(0);
+    int it = 0;
+    for (int c0 = 0; c0 < a.Cin; c0 += BC, ++it) {
+      __syncthreads();  // chunk `it` is in LDS (landed + activated by its owners); everyone is done reading the other buffer
+      if (c0 + BC < a.Cin && !(dbg & 1)) issue((it + 1) & 1);
+      const float* wbuf = wbase + (it & 1) * buf_f;
+      const float* xbuf = xbase + (it & 1) * buf_f;
+      const int n_cc = BC / KPI;
+      if constexpr (KSC > 0) {
+        const int dil = a.dil;
+        for (int q = 0; q < n_cc; ++q) {
+          const int cl = q * KPI + lk;
+          const float* wa = wbuf + cl * (KSC * BM);
+          const float* xa = xbuf + cl * XW;
+          float av[KSC][MT], bv[KSC][NT];
+#pragma unroll
+          for (int k = 0; k < KSC; ++k) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[k][i] = wa[k * BM + i * TS];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              if constexpr (ACT_ON_READ) {
+                const float v = xa[k * dil + j * TS];
+                bv[k][j] = fmaxf(v, v * ps);
+              } else {
+                bv[k][j] = xa[k * dil + j * TS];
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < KSC; ++k)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
+          if constexpr (KSC >= 3) {
+            constexpr int DSPT = (MT + 1) / 2 + (NT + 1) / 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * DSPT, 0);
+#pragma unroll
+            for (int k = 0; k < KSC; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+              if (k + 2 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, DSPT, 0);
+            }
+          }
+        }
+      } else {
+        const int n_it = n_cc * KS;
+        const int a_step_cc = KPI * KS * BM - KS * BM;
+        const int b_step_cc = KPI * XW - KS * a.dil;
+        int a_off = (lk * KS) * BM;
+        int b_off = lk * XW;
+        int k = 0;
+        for (int itk = 0; itk < n_it; ++itk) {
+          float av[MT], bv[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) av[i] = wbuf[a_off + i * TS];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            bv[j] = xbuf[b_off + j * TS];
+          }
+          a_off += BM;
+          b_off += a.dil;
+          if (++k == KS) {
+            k = 0;
+            a_off += a_step_cc;
+            b_off += b_step_cc;
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc32[i][j], 0, 0, 0);
+        }
+      }
+      if (c0 + BC < a.Cin) {
+        svc_vmcnt0();  // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
+        if (act) activate((it + 1) & 1);
+      }
+    }
+  } else {
   const int cur = BC;
   load_chunk(0);
   for (int c0 = 0; c0 < a.Cin; c0 += cur) {
@@ -299,6 +472,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
           }
       }
     }
+  }
+
   }
 
   // ---- epilogue: accumulators -> LDS ([WK][BM][CP], the MFMA C layout has one time column per lane), then every
@@ -450,6 +625,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
 int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
+int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
 
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI = SVC_EPI_PLAIN, int KSC = 0>
 int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
@@ -508,6 +684,52 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     svc::set_error("conv1d: tile does not fit the staging registers (KS=%d dil=%d Cin=%d)", a.KS, a.dil, a.Cin);
     return SVC_ERR_UNSUPPORTED;
   }
+  p.n_t_tiles = svc::cdiv(a.Tout, BN);
+  p.n_m_tiles = svc::cdiv(a.Cout, BM);
+  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B * a.n_phase;
+
+  // ---- LDS-DMA double-buffered variant (DB): aligned rows, whole chunks, pre-activation expressible as max(x, s*x) ----
+  if constexpr (!M16 && WK == 1) {
+    const size_t epi_bytes = (size_t)BM * (BN + 4) * 4;
+    const size_t budget = std::max((size_t)64 * 1024, epi_bytes);
+    bool use_db = g_db_mode != 0 && xvec && a.pre_slope >= 0.f && a.pre_slope <= 1.f && (a.Cin % KG) == 0 &&
+                  std::llabs((long long)a.x_cs) * 4 * 64 < (1ll << 31) && (long long)a.CoutP * a.KS * 4 * 64 < (1ll << 31);
+    int bcd = 0, ni = 0;
+    if (use_db) {
+      // largest chunk (multiple of KG dividing Cin) whose two buffers fit the budget and 16 pieces per wave
+      for (int c = std::min(a.Cin, 64) / KG * KG; c >= KG; c -= KG) {
+        if (a.Cin % c) continue;
+        const int tot4 = c * (a.KS * BM + xw) / 4;
+        const int n = svc::cdiv(tot4, NWV * 64);
+        if (n <= 16 && (size_t)2 * n * NWV * 1024 <= budget) { bcd = c; ni = n; break; }
+      }
+      use_db = bcd > 0;
+    }
+    if (use_db) {
+      static const float* zero = nullptr;
+      if (!zero) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_block)) != hipSuccess) return svc::check_launch("conv1d zero block");
+        zero = static_cast<const float*>(zp);
+      }
+      p.BC = bcd;
+      p.db_ni = ni;
+      p.zero = zero;
+      p.dump_off = 0;
+      const size_t lds = std::max((size_t)2 * ni * NWV * 1024, epi_bytes);
+      auto kd = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true, true>;
+      if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          done = true;
+        }
+      }
+      hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+      return svc::check_launch("conv1d_mfma_db");
+    }
+  }
+
   size_t lds = (size_t)bc * per_c;
   lds = std::max(lds, (size_t)WK * BM * (BN + 4) * 4);   // epilogue transpose buffer
   p.dump_off = (int)(lds / 4);
@@ -516,9 +738,6 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     svc::set_error("conv1d: LDS tile too large (KS=%d dil=%d)", a.KS, a.dil);
     return SVC_ERR_UNSUPPORTED;
   }
-  p.n_t_tiles = svc::cdiv(a.Tout, BN);
-  p.n_m_tiles = svc::cdiv(a.Cout, BM);
-  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B * a.n_phase;
   auto kv = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true>;
   auto ks = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, false>;
   if (lds > 64 * 1024) {
@@ -537,11 +756,12 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
-  // cfg = dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; return SVC_OK; }
+  // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; return SVC_OK; }
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;
-  g_dbg = cfg / 1000;
+  g_dbg = (cfg / 1000) % 10;
+  g_db_mode = (cfg / 10000) ? 0 : 1;
   return SVC_OK;
 }
 
