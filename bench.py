@@ -234,6 +234,9 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if os.environ.get("SVC_CONV_CFG"):           # tuning aid (A/B of kernel variants on one box): svc_debug_set_conv_cfg code
+        import svc_hip
+        svc_hip.tlib().svc_debug_set_conv_cfg(int(os.environ["SVC_CONV_CFG"]))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
 int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
+int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
 
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI = SVC_EPI_PLAIN, int KSC = 0>
@@ -691,7 +692,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   // ---- LDS-DMA double-buffered variant (DB): aligned rows, whole chunks, pre-activation expressible as max(x, s*x) ----
   if constexpr (!M16 && WK == 1) {
     const size_t epi_bytes = (size_t)BM * (BN + 4) * 4;
-    const size_t budget = std::max((size_t)64 * 1024, epi_bytes);
+    // (tried: 80 KiB for the 128x128 tiles, two per CU, half as many chunks / barriers: no measurable change)
+    const size_t budget = std::max((size_t)(BM * BN >= 128 * 128 ? g_db_budget_kb : 64) * 1024, epi_bytes);
     bool use_db = g_db_mode != 0 && xvec && a.pre_slope >= 0.f && a.pre_slope <= 1.f && (a.Cin % KG) == 0 &&
                   std::llabs((long long)a.x_cs) * 4 * 64 < (1ll << 31) && (long long)a.CoutP * a.KS * 4 * 64 < (1ll << 31);
     int bcd = 0, ni = 0;
@@ -757,11 +759,12 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; return SVC_OK; }
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;
   g_dbg = (cfg / 1000) % 10;
-  g_db_mode = (cfg / 10000) ? 0 : 1;
+  g_db_mode = ((cfg / 10000) % 10) ? 0 : 1;
+  g_db_budget_kb = (cfg / 100000) ? 80 : 64;
   return SVC_OK;
 }
 
