@@ -110,6 +110,57 @@ def condition(sd, c, units, f0, volume, spk_id=None):
     return x
 
 
+def _interp(x, xp, yp):
+    """dpm_solver_pytorch.py:1255-1295 for one query: piecewise linear through (xp, yp), the outer segments extrapolate."""
+    K = xp.shape[0]
+    i = int(torch.searchsorted(xp, x.reshape(1), right=False))
+    i0 = 0 if i == 0 else (K - 2 if i == K else i - 1)
+    return yp[i0] + (x - xp[i0]) * (yp[i0 + 1] - yp[i0]) / (xp[i0 + 1] - xp[i0])
+
+
+def dpm_solver_multistep2(model, betas, x, steps, plus):
+    """DPM_Solver(model_wrapper(model, NoiseScheduleVP('discrete', betas), 'noise'), algorithm_type = dpmsolver / dpmsolver++)
+    .sample(x, steps, order=2, skip_type='time_uniform', method='multistep') — diffusion/dpm_solver_pytorch.py:80-166,
+    269-296, 425-449, 545-590, 793-850, 1185-1224 restated on fp32 scalars; model(x, model_time[1]) -> noise."""
+    log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+    lambs = log_alphas - 0.5 * torch.log(1. - torch.exp(2. * log_alphas))
+    idx = int(torch.searchsorted(torch.flip(lambs, [0]), torch.tensor(-5.1)))
+    if idx > 0:
+        log_alphas = log_alphas[:-idx]
+    N = log_alphas.shape[0]
+    t_arr = torch.linspace(0., 1., N + 1)[1:]
+    la = lambda t: _interp(t, t_arr, log_alphas)
+    std = lambda t: torch.sqrt(1. - torch.exp(2. * la(t)))
+    lam = lambda t: la(t) - 0.5 * torch.log(1. - torch.exp(2. * la(t)))
+    ts = torch.linspace(1., 1. / N, steps + 1)
+
+    def mfn(xc, t):
+        noise = model(xc, ((t - 1. / N) * N).reshape(1))
+        return (xc - std(t) * noise) / torch.exp(la(t)) if plus else noise
+
+    def update(xc, ms, tp, t, order):
+        h = lam(t) - lam(tp[-1])
+        if plus:
+            cx, cm = std(t) / std(tp[-1]), torch.exp(la(t)) * torch.expm1(-h)
+        else:
+            cx, cm = torch.exp(la(t) - la(tp[-1])), std(t) * torch.expm1(h)
+        xt = cx * xc - cm * ms[-1]
+        if order == 2:
+            r0 = (lam(tp[-1]) - lam(tp[-2])) / h
+            xt = xt - 0.5 * cm * ((1. / r0) * (ms[-1] - ms[-2]))
+        return xt
+    tp, ms = [ts[0]], [mfn(x, ts[0])]
+    x = update(x, ms, tp, ts[1], 1)
+    tp.append(ts[1])
+    ms.append(mfn(x, ts[1]))
+    for step in range(2, steps + 1):
+        order = min(2, steps + 1 - step) if steps < 10 else 2
+        x = update(x, ms, tp, ts[step], order)
+        tp = [tp[1], ts[step]]
+        ms = [ms[1], mfn(x, ts[step]) if step < steps else None]
+    return x
+
+
 def sample(sd, c, cond_btH, method, infer_speedup, gt_spec=None, k_step=None, x_T=None, step_noise=None, spec_min=-12., spec_max=2.):
     """GaussianDiffusion.forward(infer=True): returns mel [B,T,M]."""
     S_ = schedule(c["timesteps"])
@@ -151,6 +202,9 @@ def sample(sd, c, cond_btH, method, infer_speedup, gt_spec=None, k_step=None, x_
                     prime = (55 * n - 59 * nl[-1] + 37 * nl[-2] - 9 * nl[-3]) / 24
                 x = pred(x, prime, i)
                 nl.append(n)
+        elif method in ("dpm-solver", "dpm-solver++"):
+            x = dpm_solver_multistep2(lambda xc, t_in: wavenet(sd, c, xc, t_in.expand(b), cond), S_["betas"][:t], x,
+                                      steps=t // infer_speedup, plus=(method == "dpm-solver++"))
         else:
             raise NotImplementedError(method)
     else:

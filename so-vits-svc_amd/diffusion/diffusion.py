@@ -1,12 +1,12 @@
 """MI355X-native mirror of diffusion/diffusion.py: GaussianDiffusion (schedules, samplers) around the WaveNet denoiser
 (SURVEY.md §8f row 2).  Same constructor, buffers (`state_dict` keys) and `forward` signature as the reference.
 
-Inference samplers implemented: plain ancestral sampling (`p_sample`, :155-162), DDIM (`p_sample_ddim`, :143-153) and
-PNDM/PLMS (`p_sample_plms`, :164-199) — the ones defined in this file.  Every per-step update is a scalar-coefficient
+Inference samplers implemented: plain ancestral sampling (`p_sample`, :155-162), DDIM (`p_sample_ddim`, :143-153),
+PNDM/PLMS (`p_sample_plms`, :164-199) and DPM-Solver / DPM-Solver++ in the configuration this file calls them with
+(multistep order 2, :257-303 -> diffusion/dpm_solver_pytorch.py).  Every per-step update is a scalar-coefficient
 combination of [B,1,M,T] tensors: the coefficients come from the host copy of the schedule (all batch items share the
-step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  'dpm-solver(++)' and 'unipc' call
-into two third-party solver libraries (diffusion/dpm_solver_pytorch.py, uni_pc.py: 2000 lines) that are not mirrored;
-they raise NotImplementedError.  Training (`infer=False` -> p_losses, :210-243) runs on the autograd ops of
+step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  'unipc' calls into a third-party
+solver library (diffusion/uni_pc.py) that is not mirrored: it raises NotImplementedError.  Training (`infer=False` -> p_losses, :210-243) runs on the autograd ops of
 svc_autograd.py."""
 from collections import deque
 from functools import partial
@@ -135,6 +135,78 @@ class GaussianDiffusion(nn.Module):
         nl.append(noise_pred)
         return x_prev
 
+    # -- DPM-Solver / DPM-Solver++ (the reference's default samplers, diffusion/diffusion.py:257-303) -------------------------
+    def _sample_dpm_solver(self, x, cond, t, steps, plus):
+        """The one configuration the reference calls (diffusion.py:296-302): multistep, order 2, uniform time steps,
+        `lower_order_final`, on NoiseScheduleVP('discrete', betas[:t]) — diffusion/dpm_solver_pytorch.py:80-166 (schedule),
+        :269-296 (model time / noise model), :425-449 (data prediction), :545-590 (first update), :793-850 (second update),
+        :1185-1224 (the multistep driver).  The schedule is scalar fp32 arithmetic on the host (same formulas and operation
+        order as the library, which evaluates them on 1-element tensors); every update is a scalar-coefficient combination
+        of [B,1,M,T] tensors = svc_ew_f32 launches; the denoiser gets the library's fractional model time."""
+        if steps < 2:
+            raise ValueError("dpm-solver needs t // infer_speedup >= 2 steps (the library asserts steps >= order)")
+        f32 = np.float32
+        betas = self._host_arr("betas")[:t]
+        log_alphas = (f32(0.5) * np.log(f32(1) - betas)).astype(f32).cumsum(dtype=f32)
+        # numerical_clip_alpha (:112-123): drop the tail whose half-logSNR is below -5.1
+        lambs = log_alphas - f32(0.5) * np.log(f32(1) - np.exp(f32(2) * log_alphas))
+        idx = int(np.searchsorted(lambs[::-1], f32(-5.1)))
+        if idx > 0:
+            log_alphas = log_alphas[:-idx]
+        N = log_alphas.shape[0]
+        t_arr = torch.linspace(0., 1., N + 1)[1:].numpy()
+
+        def log_alpha(tc):                                     # interpolate_fn(:1255-1295): piecewise linear, extrapolating
+            i = int(np.searchsorted(t_arr, tc, side="left"))
+            i0 = 0 if i == 0 else (N - 2 if i == N else i - 1)
+            x0, x1, y0, y1 = t_arr[i0], t_arr[i0 + 1], log_alphas[i0], log_alphas[i0 + 1]
+            return f32(y0 + (tc - x0) * (y1 - y0) / (x1 - x0))
+        std = lambda la: f32(np.sqrt(f32(1) - np.exp(f32(2) * la)))
+        lam = lambda la: f32(la - f32(0.5) * np.log(f32(1) - np.exp(f32(2) * la)))
+        ts = torch.linspace(1., 1. / N, steps + 1).numpy()    # get_time_steps('time_uniform')
+        B = x.shape[0]
+
+        def model(xc, tc):                                     # model_fn: noise model at the library's model time, x0 for '++'
+            t_in = torch.full((B,), float((tc - f32(1. / N)) * f32(N)), device=xc.device, dtype=torch.float32)
+            noise = self.denoise_fn(xc, t_in, cond=cond)
+            if not plus:
+                return noise
+            la = log_alpha(tc)
+            a = f32(np.exp(la))
+            return _lin(f32(1) / a, xc, -std(la) / a, noise)   # (x - sigma_t * noise) / alpha_t
+
+        def update(xc, m_prev1, m_prev0, t_prev1, t_prev0, tc, order):
+            la0, lat = log_alpha(t_prev0), log_alpha(tc)
+            h = lam(lat) - lam(la0)
+            if plus:
+                c_x = std(lat) / std(la0)
+                c_m = -(f32(np.exp(lat)) * f32(np.expm1(-h)))
+            else:
+                c_x = f32(np.exp(lat - la0))
+                c_m = -(std(lat) * f32(np.expm1(h)))
+            xt = _lin(c_x, xc, c_m, m_prev0)
+            if order == 2:                                     # - 0.5 * coeff * D1_0,  D1_0 = (m0 - m1) / r0
+                r0 = (lam(la0) - lam(log_alpha(t_prev1))) / h
+                c_d = f32(0.5) * c_m * (f32(1) / r0)
+                xt = _lin(1.0, xt, 1.0, _lin(c_d, m_prev0, -c_d, m_prev1))
+            return xt
+
+        t_prev = [ts[0]]
+        m_prev = [model(x, ts[0])]
+        x = update(x, None, m_prev[0], None, ts[0], ts[1], 1)
+        t_prev.append(ts[1])
+        m_prev.append(model(x, ts[1]))
+        for step in range(2, steps + 1):
+            order = min(2, steps + 1 - step) if steps < 10 else 2
+            x = update(x, m_prev[0], m_prev[1], t_prev[0], t_prev[1], ts[step], order)
+            t_prev = [t_prev[1], ts[step]]
+            m_prev = [m_prev[1], model(x, ts[step]) if step < steps else None]
+        return x
+
+    def _host_arr(self, name):
+        self._h(name, 0)
+        return self._host[1][name]
+
     def q_sample(self, x_start, t, noise=None):
         """Reference :201-206; t python int."""
         if noise is None:
@@ -189,9 +261,12 @@ class GaussianDiffusion(nn.Module):
             norm_spec = self.norm_spec(gt_spec).transpose(1, 2)[:, None, :, :].contiguous()
             x = self.q_sample(norm_spec, t - 1, noise=noise.get("x_T"))
         if method is not None and infer_speedup > 1:
-            if method in ("dpm-solver", "dpm-solver++", "unipc"):
-                raise NotImplementedError(f"sampler '{method}' (third-party solver library) is not mirrored; use 'ddim' or 'pndm'")
-            if method == "pndm":
+            if method in ("dpm-solver", "dpm-solver++"):
+                x = self._sample_dpm_solver(x, cond, t, t // infer_speedup, plus=(method == "dpm-solver++"))
+            elif method == "unipc":
+                raise NotImplementedError("sampler 'unipc' (third-party solver library diffusion/uni_pc.py) is not mirrored; "
+                                          "use 'dpm-solver', 'dpm-solver++', 'ddim' or 'pndm'")
+            elif method == "pndm":
                 self.noise_list = deque(maxlen=4)
                 for i in reversed(range(0, t, infer_speedup)):
                     x = self.p_sample_plms(x, i, infer_speedup, cond=cond)

@@ -176,3 +176,67 @@ def test_wavenet_training_packed_row_equals_per_item(dev):
     for k in grads[0][1]:
         a, b = grads[0][1][k], grads[1][1][k]
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-10, k
+
+
+# ---- DPM-Solver / DPM-Solver++ (the reference's default samplers) -----------------------------------------------------
+DPM_CASES = [("dpm_full", "dpm-solver", 10, False, None), ("dpmpp_full", "dpm-solver++", 10, False, None),
+             ("dpm_shallow", "dpm-solver", 5, True, 40), ("dpmpp_shallow", "dpm-solver++", 5, True, 40),
+             ("dpmpp_shallow3", "dpm-solver++", 10, True, 30)]
+
+
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", DPM_CASES)
+def test_oracle_reproduces_reference_dpm_solver(name, method, speedup, shallow, k_step):
+    z, meta = _load()
+    zd = np.load(os.path.join(G, "diffusion_dpm_small.npz"))
+    c = DO.small_cfg()
+    sd = DO.make_state_dict(c, meta["seed"])
+    t = lambda k: torch.from_numpy(z[k])
+    cond = DO.condition(sd, c, t("units"), t("f0"), t("volume"), t("spk_id"))
+    with torch.no_grad():
+        mel = DO.sample(sd, c, cond, method, speedup, gt_spec=t("gt") if shallow else None, k_step=k_step, x_T=t("x_T"))
+    ref = zd["mel_" + name]
+    assert np.abs(mel.numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", DPM_CASES)
+def test_mirror_dpm_solver_host_schedule_on_cpu(name, method, speedup, shallow, k_step, monkeypatch):
+    """The mirror's host-side DPM-Solver schedule / driver (GaussianDiffusion._sample_dpm_solver), with the two device
+    calls it makes replaced by CPU stand-ins (test-only: the a*x+b*y launch and the denoiser), against the real library's
+    output: checks the coefficient arithmetic without a GPU."""
+    import diffusion.diffusion as DD
+    z, meta = _load()
+    zd = np.load(os.path.join(G, "diffusion_dpm_small.npz"))
+    c = DO.small_cfg()
+    sd = DO.make_state_dict(c, meta["seed"])
+    t = lambda k: torch.from_numpy(z[k])
+    cond = DO.condition(sd, c, t("units"), t("f0"), t("volume"), t("spk_id")).transpose(1, 2)
+    monkeypatch.setattr(DD, "_lin", lambda a, x, b, y: float(a) * x + float(b) * y)
+    gd = DD.GaussianDiffusion(lambda x, tt, cond: DO.wavenet(sd, c, x, tt, cond), out_dims=c["out_dims"],
+                              timesteps=c["timesteps"], k_step=c["k_step_max"])
+    with torch.no_grad():
+        if shallow:
+            tt = k_step
+            ns = gd.norm_spec(t("gt")).transpose(1, 2)[:, None, :, :]
+            S_ = DO.schedule(c["timesteps"])
+            x = S_["sqrt_alphas_cumprod"][tt - 1] * ns + S_["sqrt_one_minus_alphas_cumprod"][tt - 1] * t("x_T")
+        else:
+            tt = gd.k_step
+            x = t("x_T")
+        x = gd._sample_dpm_solver(x, cond, tt, tt // speedup, plus=(method == "dpm-solver++"))
+        mel = gd.denorm_spec(x.squeeze(1).transpose(1, 2))
+    ref = zd["mel_" + name]
+    assert np.abs(mel.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", DPM_CASES)
+def test_unit2mel_dpm_solver_matches_reference_golden(dev, name, method, speedup, shallow, k_step):
+    z, meta = _load()
+    zd = np.load(os.path.join(G, "diffusion_dpm_small.npz"))
+    c = DO.small_cfg()
+    net = _mirror(c, meta["seed"], dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    mel = net(t("units"), t("f0"), t("volume"), spk_id=t("spk_id"), gt_spec=t("gt") if shallow else None, infer=True,
+              infer_speedup=speedup, method=method, k_step=k_step if shallow else 300, use_tqdm=False, noise=dict(x_T=t("x_T")))
+    ref = zd["mel_" + name]
+    assert np.abs(mel.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
