@@ -102,3 +102,18 @@ def generator(sd, h, mel, f0, rand_ini, noise):
         x = acc / nk
     x = F.leaky_relu(x)
     return torch.tanh(O.conv1d(x, sd, "conv_post", padding=3))
+
+
+def get_mel(y, sr=44100, n_mels=128, n_fft=2048, win_size=2048, hop=512, fmin=40, fmax=16000, clip_val=1e-5):
+    """vdecoder/nsf_hifigan/nvSTFT.py:63-122 (keyshift 0, speed 1, center False): y [B,L] -> log-mel [B,n_mels,frames].
+    The mel basis is oracle.mel.mel_filterbank (librosa itself is absent: basis parity UNPINNED, see oracle/mel.py)."""
+    from oracle.mel import mel_filterbank
+    basis = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).float()
+    pad_left = (win_size - hop) // 2
+    pad_right = max((win_size - hop + 1) // 2, win_size - y.size(-1) - pad_left)
+    mode = "reflect" if pad_right < y.size(-1) else "constant"
+    yp = F.pad(y.unsqueeze(1), (pad_left, pad_right), mode=mode).squeeze(1)
+    spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win_size, window=torch.hann_window(win_size), center=False,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    spec = torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(basis, spec), min=clip_val))

@@ -125,14 +125,19 @@ class Unit2Mel(nn.Module):
 
 
 def load_model_vocoder(model_path, device="cuda", config_path=None):
-    """Reference :22-58 — the vocoder wrapper (diffusion/vocoder.py, nvSTFT mel extraction with librosa) is out of
-    scope: returns (model, None, args); pair the mel output with vdecoder.nsf_hifigan.models.load_model."""
+    """Reference :22-58: (model, vocoder, args) — the Unit2Mel mirror, the NSF-HiFiGAN `Vocoder` mirror
+    (diffusion/vocoder.py) named by args.vocoder, and the parsed diffusion.yaml."""
+    from .vocoder import Vocoder
     config_file = os.path.join(os.path.split(model_path)[0], "config.yaml") if config_path is None else config_path
     with open(config_file, "r") as config:
         args = DotDict(yaml.safe_load(config))
-    model = Unit2Mel(args.data.encoder_out_channels, args.model.n_spk, args.model.use_pitch_aug, 128,
+    vocoder = Vocoder(args.vocoder.type, args.vocoder.ckpt, device=device)
+    model = Unit2Mel(args.data.encoder_out_channels, args.model.n_spk, args.model.use_pitch_aug, vocoder.dimension,
                      args.model.n_layers, args.model.n_chans, args.model.n_hidden, args.model.timesteps,
                      args.model.k_step_max)
+    print(" [Loading] " + model_path)
     ckpt = torch.load(model_path, map_location="cpu")
     model.load_state_dict(ckpt["model"])
-    return model.to(device).eval(), None, args
+    model.to(device).eval()
+    print(f"Loaded diffusion model, sampler is {args.infer.method}, speedup: {args.infer.speedup} ")
+    return model, vocoder, args

@@ -2,10 +2,14 @@
 signature, attributes (`target_sample`, `hop_size`, `spk2id`, `dev`, `net_g_ms`, `hubert_model`) and `infer` /
 `slice_inference` / `clear_empty` / `unload_model` methods, with the synthesizer running on libsvc_hip.so.
 
-Scope: the I/O glue around the hot path — wav decoding, the speech-unit encoder
-(fairseq ContentVec), the f0 predictors (parselmouth/pyworld/crepe), k-means / faiss retrieval, shallow diffusion and
-the enhancer — is OUT OF SCOPE of this engine and their third-party dependencies are not in this image.  They are
-therefore *injected*: `Svc(..., front_end=FrontEnd)` (or assigning `svc.hubert_model`, `svc.f0_predictor_object`,
+Shallow diffusion (`shallow_diffusion=True` / `only_diffusion=True`, infer_tool.py:163-181,278-304) runs on the engine too:
+synthesizer -> `Vocoder.extract` (log-mel, rocFFT) -> `Unit2Mel` (WaveNet denoiser, DDIM / PNDM / DPM-Solver(++)) ->
+`Vocoder.infer` (stand-alone NSF-HiFiGAN), see diffusion/{unit2mel,vocoder}.py.
+
+Scope: the I/O glue around the hot path — wav decoding, the fairseq ContentVec unit
+encoders (the HuBERT-soft encoder IS mirrored: vencoder/HubertSoft.py), the f0 predictors (parselmouth/pyworld/crepe),
+k-means / faiss retrieval and the enhancer — is OUT OF SCOPE of this engine and their third-party dependencies are not in
+this image.  They are therefore *injected*: `Svc(..., front_end=FrontEnd)` (or assigning `svc.hubert_model`, `svc.f0_predictor_object`,
 `svc.load_wav`) supplies objects with the reference's own interfaces
     hubert_model.encoder(wav16k[T16]) -> [1, ssl_dim, T50]                 (vencoder/encoder.py:8-13)
     f0_predictor_object.compute_f0_uv(wav[T]) -> (f0[Tf], uv[Tf]) numpy     (modules/F0Predictor/F0Predictor.py:10-16)
@@ -63,14 +67,14 @@ class Svc(object):
                  nsf_hifigan_enhance=False, diffusion_model_path="logs/44k/diffusion/model_0.pt",
                  diffusion_config_path="configs/diffusion.yaml", shallow_diffusion=False, only_diffusion=False,
                  spk_mix_enable=False, feature_retrieval=False, front_end=None):
-        if shallow_diffusion or only_diffusion or nsf_hifigan_enhance:
-            raise NotImplementedError("shallow diffusion / enhancer are outside the MI355X engine's scope "
-                                      "(SURVEY.md §2 rows 20,22)")
+        if nsf_hifigan_enhance:
+            raise NotImplementedError("the NSF-HiFiGAN enhancer (modules/enhancer.py: resampling + key-shifted mel extraction) "
+                                      "is outside the MI355X engine's scope (SURVEY.md §2 row 22)")
         if feature_retrieval or (cluster_model_path and os.path.exists(cluster_model_path)):
             raise NotImplementedError("k-means / faiss feature retrieval is out of scope (SURVEY.md §2 row 19)")
         self.net_g_path = net_g_path
-        self.only_diffusion = False
-        self.shallow_diffusion = False
+        self.only_diffusion = only_diffusion
+        self.shallow_diffusion = shallow_diffusion
         self.feature_retrieval = False
         self.nsf_hifigan_enhance = False
         if device is None:
@@ -79,15 +83,36 @@ class Svc(object):
             self.dev = torch.device("cuda")
         else:
             self.dev = torch.device(device)
-        self.hps_ms = utils.get_hparams_from_file(config_path, True)
-        self.target_sample = self.hps_ms.data.sampling_rate
-        self.hop_size = self.hps_ms.data.hop_length
-        self.spk2id = self.hps_ms.spk
-        self.unit_interpolate_mode = self.hps_ms.data.unit_interpolate_mode or "left"
-        self.vol_embedding = bool(self.hps_ms.model.vol_embedding)
-        self.speech_encoder = self.hps_ms.model.speech_encoder or "vec768l12"
+        self.vol_embedding = False
         self.net_g_ms = None
-        self.load_model(spk_mix_enable)
+        if not self.only_diffusion:                                          # infer_tool.py:141-160
+            self.hps_ms = utils.get_hparams_from_file(config_path, True)
+            self.target_sample = self.hps_ms.data.sampling_rate
+            self.hop_size = self.hps_ms.data.hop_length
+            self.spk2id = self.hps_ms.spk
+            self.unit_interpolate_mode = self.hps_ms.data.unit_interpolate_mode or "left"
+            self.vol_embedding = bool(self.hps_ms.model.vol_embedding)
+            self.speech_encoder = self.hps_ms.model.speech_encoder or "vec768l12"
+        if self.shallow_diffusion or self.only_diffusion:                    # infer_tool.py:163-181
+            if os.path.exists(diffusion_model_path) and os.path.exists(diffusion_config_path):
+                from diffusion.unit2mel import load_model_vocoder
+                self.diffusion_model, self.vocoder, self.diffusion_args = load_model_vocoder(
+                    diffusion_model_path, self.dev, config_path=diffusion_config_path)
+                if self.only_diffusion:
+                    self.target_sample = self.diffusion_args.data.sampling_rate
+                    self.hop_size = self.diffusion_args.data.block_size
+                    self.spk2id = self.diffusion_args.spk
+                    self.speech_encoder = self.diffusion_args.data.encoder
+                    self.unit_interpolate_mode = self.diffusion_args.data.unit_interpolate_mode or "left"
+                if spk_mix_enable:
+                    raise NotImplementedError("speaker-mix tracks for the diffusion model (Unit2Mel.init_spkmix) are not mirrored")
+            else:
+                if self.only_diffusion:
+                    raise FileNotFoundError(f"only_diffusion needs {diffusion_model_path} and {diffusion_config_path}")
+                print("No diffusion model or config found. Shallow diffusion mode will False")
+                self.shallow_diffusion = False
+        if not self.only_diffusion:
+            self.load_model(spk_mix_enable)
         self.hubert_model = getattr(front_end, "hubert_model", None)
         self.f0_predictor_object = getattr(front_end, "f0_predictor_object", None)
         self.load_wav = getattr(front_end, "load_wav", None)
@@ -159,10 +184,28 @@ class Svc(object):
             n_frames = f0.size(1)
         start = time.time()
         vol = None
-        if self.vol_embedding:
-            vol = self.volume_extractor.extract(torch.as_tensor(wav, dtype=torch.float32).to(self.dev)[None, :])[None, :]
-        audio, f0 = self.infer_units(c, f0, uv, sid, auto_predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol)
-        audio = audio[0, 0].data.float()
+        if not self.only_diffusion:
+            if self.vol_embedding:
+                vol = self.volume_extractor.extract(torch.as_tensor(wav, dtype=torch.float32).to(self.dev)[None, :])[None, :]
+            audio, f0 = self.infer_units(c, f0, uv, sid, auto_predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol)
+            audio = audio[0, 0].data.float()
+            audio_mel = self.vocoder.extract(audio[None, :], self.target_sample) if self.shallow_diffusion else None
+        else:
+            audio = torch.as_tensor(wav, dtype=torch.float32).to(self.dev)
+            audio_mel = None
+        if self.only_diffusion or self.shallow_diffusion:                    # infer_tool.py:287-304
+            vol = self.volume_extractor.extract(audio[None, :])[None, :, None].to(self.dev) if vol is None else vol[:, :, None]
+            if self.shallow_diffusion and second_encoding:
+                audio16k = self._need("resample")(audio[None, :], self.target_sample, 16000)[0]
+                c = self._need("hubert_model").encoder(audio16k)
+                c = repeat_expand_2d(c.squeeze(0), f0.shape[1], self.unit_interpolate_mode).unsqueeze(0)
+            f0 = f0[:, :, None]
+            c = c.transpose(-1, -2)
+            with torch.no_grad():
+                audio_mel = self.diffusion_model(c, f0, vol, spk_id=sid, spk_mix_dict=None, gt_spec=audio_mel, infer=True,
+                                                 infer_speedup=self.diffusion_args.infer.speedup,
+                                                 method=self.diffusion_args.infer.method, k_step=k_step, use_tqdm=False)
+                audio = self.vocoder.infer(audio_mel, f0).squeeze()
         if loudness_envelope_adjustment != 1:
             raise NotImplementedError("loudness_envelope_adjustment != 1 (utils.change_rms, librosa) is out of scope")
         print("vits use time:{}".format(time.time() - start))

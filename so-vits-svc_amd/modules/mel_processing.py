@@ -85,7 +85,7 @@ def spectral_normalize_torch(magnitudes):
     return dynamic_range_compression_torch(magnitudes)
 
 
-def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, n_frames=None):
+def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, n_frames=None, eps=1e-6):
     """y [B, L] in [-1, 1] -> |STFT| [B, n_fft/2+1, frames] (reference :40-64).  n_frames (optional) limits the number of
     frames produced (data_utils.batch_spectrogram passes signals that already carry their right-hand extension)."""
     if center or win_size != n_fft:
@@ -97,7 +97,7 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False,
     if n_frames is not None:
         NF = min(NF, int(n_frames))
     frames = A.stft_frames(y, _window(win_size, y.device), NF, n_fft, hop_size, pad)      # [B, NF, n_fft]
-    mag = A.rfft_mag(frames, 1e-6)                     # batched rocFFT R2C + fused magnitude -> [B, NF, bins]
+    mag = A.rfft_mag(frames, eps)                     # batched rocFFT R2C + fused magnitude -> [B, NF, bins]
     return mag.transpose(1, 2)
 
 

@@ -77,3 +77,41 @@ def test_vocoder_matches_oracle(dev):
         ref = NO.generator(sd, h, mel, f0, rand_ini, noise)
     y = net(mel.to(dev), f0.to(dev), noise=dict(rand_ini=rand_ini.to(dev), sine=noise.to(dev)))
     _check(y, ref)
+
+
+# ---- nvSTFT log-mel (vdecoder/nsf_hifigan/nvSTFT.py) and the diffusion/vocoder.py wrapper -------------------------------
+def test_oracle_reproduces_reference_nvstft_mel():
+    z = np.load(os.path.join(G, "nvstft_mel.npz"))
+    mel = NO.get_mel(torch.from_numpy(z["y"]))
+    assert np.abs(mel.numpy() - z["mel"]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_nvstft_and_vocoder_wrapper_match_reference_golden(dev, tmp_path):
+    """STFT.get_mel on the rocFFT path vs the real module's output (log-mel, 2e-4 absolute: fp32 FFT + log of small
+    magnitudes), then the Vocoder wrapper: extract() layout and infer() == the generator it wraps."""
+    from vdecoder.nsf_hifigan.nvSTFT import STFT
+    from diffusion.vocoder import Vocoder
+    z = np.load(os.path.join(G, "nvstft_mel.npz"))
+    y = torch.from_numpy(z["y"]).to(dev)
+    mel = STFT(44100, 128, 2048, 2048, 512, 40, 16000).get_mel(y)
+    assert mel.shape == z["mel"].shape
+    assert np.abs(mel.cpu().numpy() - z["mel"]).max() <= 2e-4
+    h = dict(NO.small_h(), n_fft=2048, win_size=2048, hop_size=512, fmin=40, fmax=16000, num_mels=128)
+    sd = NO.make_state_dict(h, 5)
+    d = str(tmp_path)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(h, f)
+    torch.save({"generator": sd}, os.path.join(d, "model"))
+    voc = Vocoder("nsf-hifigan", os.path.join(d, "model"), device=dev)
+    assert (voc.vocoder_sample_rate, voc.vocoder_hop_size, voc.dimension) == (44100, 512, 128)
+    m2 = voc.extract(y, 44100)                                   # [B, frames, bins]
+    assert torch.equal(m2, mel.transpose(1, 2))
+    with pytest.raises(NotImplementedError):
+        voc.extract(y, 16000)
+    f0 = 220.0 + torch.zeros(2, m2.shape[1], 1, device=dev)
+    torch.manual_seed(3)
+    a = voc.infer(m2, f0)
+    torch.manual_seed(3)
+    b = voc.vocoder.model(m2.transpose(1, 2).contiguous(), f0[:, :, 0])
+    assert torch.equal(a, b) and a.shape[-1] == m2.shape[1] * 32 and torch.isfinite(a).all()

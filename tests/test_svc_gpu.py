@@ -93,3 +93,75 @@ def test_svc_infer_and_slice_inference(dev, tmp_path):
     assert abs(len(out2) - len(wav)) <= 4 * HOP and np.isfinite(out2).all()
     svc.clear_empty()
     svc.unload_model()
+
+
+def _write_diffusion(tmp_path, ssl_dim, n_mels, method="dpm-solver++", speedup=10):
+    """Vocoder checkpoint + config.json and diffusion checkpoint + yaml in the reference's layouts
+    (vdecoder/nsf_hifigan/models.py:17-35, diffusion/unit2mel.py:22-58)."""
+    import yaml
+    from oracle import diffusion_oracle as DO
+    from oracle import nsf_hifigan_oracle as NO
+    vd = os.path.join(tmp_path, "voc")
+    os.makedirs(vd, exist_ok=True)
+    h = dict(NO.small_h(), num_mels=n_mels, upsample_rates=[8, 8, 8], upsample_kernel_sizes=[16, 16, 16], n_fft=2048,
+             win_size=2048, hop_size=HOP, fmin=40, fmax=16000, sampling_rate=SR)
+    with open(os.path.join(vd, "config.json"), "w") as f:
+        json.dump(h, f)
+    torch.save({"generator": NO.make_state_dict(h, 21)}, os.path.join(vd, "model"))
+    c = dict(DO.small_cfg(), input_channel=ssl_dim, out_dims=n_mels, n_spk=2)
+    dd = os.path.join(tmp_path, "diff")
+    os.makedirs(dd, exist_ok=True)
+    from diffusion.unit2mel import Unit2Mel
+    u2m = Unit2Mel(c["input_channel"], c["n_spk"], False, c["out_dims"], c["n_layers"], c["n_chans"], c["n_hidden"],
+                   c["timesteps"], c["k_step_max"])
+    u2m.load_state_dict(DO.make_state_dict(c, 22), strict=False)      # + the schedule buffers, as a real checkpoint has them
+    torch.save({"model": u2m.state_dict()}, os.path.join(dd, "model_0.pt"))
+    args = dict(data=dict(encoder_out_channels=ssl_dim, sampling_rate=SR, block_size=HOP, encoder="stub", unit_interpolate_mode="nearest"),
+                model=dict(n_spk=c["n_spk"], use_pitch_aug=False, n_layers=c["n_layers"], n_chans=c["n_chans"],
+                           n_hidden=c["n_hidden"], timesteps=c["timesteps"], k_step_max=c["k_step_max"]),
+                vocoder=dict(type="nsf-hifigan", ckpt=os.path.join(vd, "model")), infer=dict(speedup=speedup, method=method),
+                spk={"alice": 0, "bob": 1})
+    yp = os.path.join(dd, "config.yaml")
+    with open(yp, "w") as f:
+        yaml.safe_dump(args, f)
+    return os.path.join(dd, "model_0.pt"), yp
+
+
+def test_svc_shallow_and_only_diffusion(dev, tmp_path):
+    """infer_tool.py:163-181,278-304 — synthesizer -> Vocoder.extract -> Unit2Mel (DPM-Solver++) -> Vocoder.infer wired
+    through Svc; compared with the same pipeline composed by hand from the mirror modules (each has its own parity test)."""
+    from inference.infer_tool import Svc
+    cfg = W.small_config()
+    net, ck, cj = _write_model(str(tmp_path), cfg, 9)
+    dm, dy = _write_diffusion(str(tmp_path), cfg["ssl_dim"], 16)
+    fe = _FrontEnd(cfg["ssl_dim"], dev)
+    svc = Svc(ck, cj, device="cuda:0", cluster_model_path="", front_end=fe, shallow_diffusion=True,
+              diffusion_model_path=dm, diffusion_config_path=dy)
+    assert svc.shallow_diffusion and svc.vocoder.dimension == 16 and svc.diffusion_args.infer.method == "dpm-solver++"
+    g = torch.Generator().manual_seed(1)
+    wav = (0.5 * (torch.rand(SR, generator=g) - 0.5)).numpy().astype(np.float32)          # 1 s
+    torch.manual_seed(11)
+    audio, n, n_frames = svc.infer("bob", 0, (wav, SR), k_step=30)
+    assert n == audio.shape[-1] == n_frames * HOP and torch.isfinite(audio).all()
+    # by hand
+    c, f0, uv = svc.get_unit_f0(wav, 0, 0, "bob", False, "pm")
+    sid = torch.LongTensor([[1]]).to(dev)
+    torch.manual_seed(11)
+    a0, f0o = svc.net_g_ms.infer(c, f0, uv, g=sid, noice_scale=0.4)
+    a0 = a0[0, 0].float()
+    mel0 = svc.vocoder.extract(a0[None, :], SR)
+    vol = svc.volume_extractor.extract(a0[None, :])[None, :, None].to(dev)
+    mel1 = svc.diffusion_model(c.transpose(-1, -2), f0o[:, :, None], vol, spk_id=sid, gt_spec=mel0, infer=True, infer_speedup=10,
+                               method="dpm-solver++", k_step=30, use_tqdm=False)
+    ref = svc.vocoder.infer(mel1, f0o[:, :, None]).squeeze()
+    assert torch.equal(ref, audio)
+    assert (mel1 - mel0).abs().max() > 1e-3          # the diffusion stage did change the mel
+    with pytest.raises(Exception):
+        svc.infer("bob", 0, (wav, SR), k_step=1000)  # k_step > k_step_max (diffusion/unit2mel.py:131-132)
+
+    only = Svc(None, None, device="cuda:0", cluster_model_path="", front_end=fe, only_diffusion=True,
+               diffusion_model_path=dm, diffusion_config_path=dy)
+    assert only.net_g_ms is None and only.target_sample == SR and only.hop_size == HOP and only.spk2id["bob"] == 1
+    torch.manual_seed(12)
+    a2, n2, nf2 = only.infer("alice", 0, (wav, SR))
+    assert n2 == nf2 * HOP and torch.isfinite(a2).all()
