@@ -5,10 +5,11 @@ through a GradScaler (train.py:191-213), with `ExponentialLR` per epoch (train.p
 in every checkpoint (utils.py:189-199).  The reference runs a Python loop over 751 (G) / ~180 (D) tensors per step.
 
 MI355X design: 99 M fp32 parameters are 0.4 GB — nothing next to 288 GB of HBM — so all parameters of one optimizer live
-in ONE contiguous arena (`ParamArena`): `p.data` and `p.grad` of every parameter are views into flat `param` / `grad`
-buffers, Adam moments are two more flat buffers.  Consequences:
+in ONE contiguous arena (`ParamArena`): `p.data` of every parameter is a view into the flat `param` buffer, gradients
+live in the flat `grad` buffer (as `p.grad` views when a data-parallel reducer is attached, else gathered there by one
+multi-tensor copy per step), Adam moments are two more flat buffers.  Consequences:
   * the optimizer step is ONE `svc_adamw_f32` launch over the arena (HBM-bound: 5 reads + 3 writes of 4 B / element),
-  * `zero_grad` is one memset,
+  * `zero_grad` is one memset (view mode) or free (gather mode: `p.grad = None`),
   * the data-parallel gradient all-reduce (data_parallel.py) works on contiguous slices of `grad` — buckets need no
     gather/scatter copies and the initial parameter broadcast is one collective.
 `FusedAdamW` is a `torch.optim.Optimizer` (param_groups / state_dict / lr schedulers keep working unchanged), with
@@ -49,16 +50,22 @@ class ParamArena:
         self.touched = [False] * len(params)          # gradient accumulated since the last zero_grad
         self._listeners = []                          # callables(index) fired from the post-accumulate hook
         self._hooks = []
+        # Two ways for gradients to reach `grad`:
+        #   gather (default, single process): `p.grad` is None before backward, autograd stores each produced gradient
+        #     tensor as is (no per-parameter accumulate kernel: ~1100 launches per training iteration) and step() moves
+        #     them into the arena with ONE multi-tensor copy;
+        #   views (a listener is attached: the data-parallel reducer needs each gradient in its bucket slice the moment
+        #     it is produced): `p.grad` IS the arena slice and autograd accumulates into it in place.
+        self.gather = True
+        self._gviews = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(params, self.offsets)):
                 view = self.param[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                gview = self.grad[o:o + p.numel()].view(p.shape)
+                self._gviews.append(self.grad[o:o + p.numel()].view(p.shape))
                 if p.grad is not None:
-                    gview.copy_(p.grad)
                     self.touched[i] = True
-                p.grad = gview
                 _ARENA_OF[id(p)] = (self, i)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -68,26 +75,55 @@ class ParamArena:
         return hook
 
     def _on_grad(self, i, p):
+        self.touched[i] = True
+        if self.gather:
+            return
         o = self.offsets[i]
         if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
             # someone replaced .grad (e.g. zero_grad(set_to_none=True) on the module): move it back into the arena
-            gview = self.grad[o:o + p.numel()].view(p.shape)
+            gview = self._gviews[i]
             if p.grad is not None:
                 gview.copy_(p.grad)
             p.grad = gview
-        self.touched[i] = True
         for fn in self._listeners:
             fn(i)
 
     def add_listener(self, fn):
+        """Attach a per-gradient callback (the data-parallel reducer): switches the arena to view mode."""
         self._listeners.append(fn)
+        if self.gather:
+            self.gather = False
+            with torch.no_grad():
+                for i, p in enumerate(self.params):
+                    gview = self._gviews[i]
+                    if p.grad is not None and p.grad.data_ptr() != gview.data_ptr():
+                        gview.copy_(p.grad)
+                    elif p.grad is None:
+                        gview.zero_()
+                    p.grad = gview
+
+    def collect(self):
+        """gather mode: move the gradients autograd produced into the arena — one multi-tensor copy."""
+        if not self.gather:
+            return
+        dst, src = [], []
+        for i, p in enumerate(self.params):
+            if self.touched[i] and p.grad is not None and p.grad.data_ptr() != self._gviews[i].data_ptr():
+                dst.append(self._gviews[i])
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def zero_grad(self):
-        self.grad.zero_()
         self.touched = [False] * len(self.params)
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        if self.gather:
+            for p in self.params:
+                p.grad = None
+            return
+        self.grad.zero_()
+        for i, p in enumerate(self.params):
+            if p.grad is None or p.grad.data_ptr() != self._gviews[i].data_ptr():
+                p.grad = self._gviews[i]
 
     def span(self, i):
         """(start, end) element range of parameter i including its alignment padding."""
@@ -236,6 +272,7 @@ class FusedAdamW(torch.optim.Optimizer):
         a.check_views()
         if not any(a.touched):
             return loss
+        a.collect()
         self._gstep += 1
         self._steps = [n + 1 if t else n for n, t in zip(self._steps, a.touched)]
         lags = [self._gstep - n for n in self._steps]

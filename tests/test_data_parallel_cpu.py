@@ -151,10 +151,25 @@ def test_arena_touched_runs_and_foreign_grad():
     for p, v in zip(ps, vals):
         assert torch.equal(p.detach(), v)
     assert a.offsets == [0, 64, 192] and a.numel == 256
+    # gather mode (no listener): autograd stores the produced gradients as they are; collect() moves them into the arena
+    assert a.gather and all(p.grad is None for p in ps)
     (ps[0].sum() * 2 + ps[2].sum()).backward()
     assert a.touched == [True, False, True]
     assert a.touched_runs() == [(0, 64, None), (192, 256, None)]
-    assert torch.equal(a.grad[:15], torch.full((15,), 2.0))
+    assert ps[0].grad.data_ptr() != a.grad.data_ptr() and ps[1].grad is None
+    a.collect()
+    assert torch.equal(a.grad[:15], torch.full((15,), 2.0)) and torch.equal(a.grad[192:194], torch.full((2,), 1.0))
+    a.zero_grad()
+    assert not any(a.touched) and all(p.grad is None for p in ps)
+    # view mode (a listener, i.e. the data-parallel reducer, is attached): p.grad IS the arena slice
+    seen = []
+    (ps[0].sum() * 5).backward()
+    a.add_listener(seen.append)
+    assert not a.gather and ps[0].grad.data_ptr() == a.grad.data_ptr() and torch.equal(a.grad[:15], torch.full((15,), 5.0))
+    assert a.grad[64:134].abs().max().item() == 0
+    a.zero_grad()
+    (ps[0].sum() * 2 + ps[2].sum()).backward()
+    assert sorted(seen) == [0, 2] and torch.equal(a.grad[:15], torch.full((15,), 2.0))
     # a foreign .grad (module.zero_grad(set_to_none=True)) is moved back into the arena on the next accumulate
     ps[1].grad = None
     (ps[1] * 3).sum().backward()
