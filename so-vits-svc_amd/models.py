@@ -331,6 +331,10 @@ class SynthesizerTrn(nn.Module):
     def _infer_body(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol):
         """The device work of infer(): every line is one or a few HIP kernels (no torch arithmetic)."""
         B, _, T = c.shape
+        # (tried: for T % 4 != 0 — 862 frames = 10 s — run the encoder / flow section on T rounded up to 4 with the extra
+        # frames masked off, so that every row is 16-byte aligned and the convs take their float4 / LDS-DMA paths: exact,
+        # but same-box A/B 10.46/10.57 ms without vs 10.72/10.62 ms with — those T=862 launches are latency-bound, not
+        # staging-bound, and the padding mask costs the attention kernel 6 %.)
         x_mask = torch.ones((B, 1, T), device=c.device, dtype=torch.float32)      # c_lengths == T (models.py:503)
         m = mask2d(x_mask)
         xin = self.pre.run(c, mask=m)                                               # pre(c) * mask

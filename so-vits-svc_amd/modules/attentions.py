@@ -140,13 +140,19 @@ class FFN(nn.Module):
         h = self.conv_2.forward_train(A.mul_bcast(h, x_mask), causal=self.causal, padding=(k - 1) // 2)
         return A.mul_bcast(h, x_mask)
 
-    def forward(self, x, x_mask):
+    def forward(self, x, x_mask, x_is_masked=False):
+        """`x_is_masked`: the caller already multiplied x by x_mask (the LayerNorm epilogue does); the `* x_mask` in front
+        of conv_2 (reference :341) then moves into conv_1's epilogue and neither conv needs a pre-mask on its input — which
+        is what lets them take the vectorised / LDS-DMA staging paths."""
         if training_call(self.conv_1.weight) or (torch.is_grad_enabled() and x.requires_grad):
             return self.forward_train(x, x_mask)
         k = self.kernel_size
         pad_l = 0 if k == 1 else (k - 1 if self.causal else (k - 1) // 2)
         m = mask2d(x_mask)
         T = x.shape[2]
+        if x_is_masked:
+            h = self.conv_1.run(x, pad_left=pad_l, Tout=T, post_act=S.ACT_RELU, mask=m)
+            return self.conv_2.run(h, pad_left=pad_l, Tout=T, mask=m)
         h = self.conv_1.run(x, premask=m, pad_left=pad_l, Tout=T, post_act=S.ACT_RELU)
         return self.conv_2.run(h, premask=m, pad_left=pad_l, Tout=T, mask=m)
 
@@ -185,11 +191,13 @@ class Encoder(nn.Module):
         m = mask2d(x_mask)
         x = S.copy_bct(x, mask=m)
         mode = MASK_NONE if full_mask else MASK_PADDING
+        # every LayerNorm applies x_mask in its epilogue (the reference masks only at the very end, :107: frames outside
+        # the mask never influence frames inside it, so the valid frames are unchanged) — the FFN input is then masked
         for i in range(self.n_layers):
             y = self.attn_layers[i](x, x, mask_mode=mode, mask_vec=None if full_mask else m)
-            x = self.norm_layers_1[i](x, residual=y)
-            y = self.ffn_layers[i](x, x_mask)
-            x = self.norm_layers_2[i](x, residual=y, x_mask=x_mask if i == self.n_layers - 1 else None)
+            x = self.norm_layers_1[i](x, residual=y, x_mask=x_mask)
+            y = self.ffn_layers[i](x, x_mask, x_is_masked=True)
+            x = self.norm_layers_2[i](x, residual=y, x_mask=x_mask)
         return x
 
 
@@ -260,7 +268,7 @@ class FFT(nn.Module):
         x = S.copy_bct(x, mask=m)
         for i in range(self.n_layers):
             y = self.self_attn_layers[i](x, x, mask_mode=MASK_CAUSAL)
-            x = self.norm_layers_0[i](x, residual=y)
-            y = self.ffn_layers[i](x, x_mask)
-            x = self.norm_layers_1[i](x, residual=y, x_mask=x_mask if i == self.n_layers - 1 else None)
+            x = self.norm_layers_0[i](x, residual=y, x_mask=x_mask)
+            y = self.ffn_layers[i](x, x_mask, x_is_masked=True)
+            x = self.norm_layers_1[i](x, residual=y, x_mask=x_mask)
         return x
