@@ -7,6 +7,8 @@ import svc_hip as S
 Cin, Cout, L, k, d = [int(a) for a in sys.argv[1:6]]
 n = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 dev = torch.device("cuda:0")
+if os.environ.get("SVC_CONV_CFG"):
+    S.tlib().svc_debug_set_conv_cfg(int(os.environ["SVC_CONV_CFG"]))
 x = torch.randn(1, Cin, L, device=dev)
 w = torch.randn(Cout, Cin, k, device=dev) / (Cin * k) ** 0.5
 b = torch.randn(Cout, device=dev)
