@@ -147,7 +147,10 @@ def run_train(args, dev, rank, world, dist):
     net_g.train()
     net_d.train()
     step_fn = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d)
-    use_graph = (not args.no_graph) and (world == 1 or os.environ.get("SVC_TRAIN_GRAPH") == "1")
+    # N = 1: the whole iteration is ONE hipGraph.  N > 1: two hipGraphs per iteration (D segment, G segment) with the
+    # gradient all-reduces and optimizer launches between them (train.TrainStep._call_graph_dp); SVC_TRAIN_GRAPH=0 selects the
+    # eager, bucket-overlapped path instead.
+    use_graph = (not args.no_graph) and os.environ.get("SVC_TRAIN_GRAPH", "1") != "0"
     step_fn.enable_graph(use_graph)
     items_cpu, T = make_train_items(cfg, TRAIN_B, 4321 + rank)
     items = tuple(t.to(dev) if t is not None else None for t in items_cpu)
@@ -160,6 +163,14 @@ def run_train(args, dev, rank, world, dist):
 
     steps, warm = args.train_steps, args.train_warmup
     last = None
+    if use_graph and world > 1:
+        try:                                       # first call = warm-up + capture; every rank takes the same branch
+            last = step_fn(items)
+        except Exception as e:                     # noqa: BLE001 — e.g. a collective runtime that cannot coexist with capture
+            print(f"bench.py: data-parallel hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                  file=sys.stderr)
+            use_graph = False
+            step_fn.enable_graph(False)
     for _ in range(warm):
         last = step_fn(items)
     barrier()
@@ -176,10 +187,16 @@ def run_train(args, dev, rank, world, dist):
         return None
     fams = None
     if not args.no_roofline:
+        import contextlib
         step_fn.enable_graph(False)
         S.prof_enable(True)
         S.prof_reset()
-        step_fn(items)
+        # rank 0 only: this extra (untimed) iteration must not communicate — the other ranks have already left
+        with contextlib.ExitStack() as es:
+            for net in (net_g, net_d):
+                if getattr(net, "reducer", None) is not None:
+                    es.enter_context(net.reducer.no_sync())
+            step_fn(items)
         torch.cuda.synchronize()
         rep = S.prof_report()
         S.prof_enable(False)
@@ -199,7 +216,9 @@ def run_train(args, dev, rank, world, dist):
                                      f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
                                      "4 speakers, fp32, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
                             global_batch=TRAIN_B * world, frames=T,
-                            launch="hipGraph replay of the whole iteration" if use_graph else "eager",
+                            launch=("hipGraph replay of the whole iteration" if world == 1 else
+                                    "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph
+                            else "eager",
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU"),
                 losses={k: round(float(v), 4) for k, v in last.items()},
                 families=fams, allreduce=red, cpu_baseline=cpu)

@@ -79,6 +79,8 @@ class TrainStep:
         """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
         returns a dict of 0-dim device tensors."""
         if self.use_graph:
+            if all(r is not None for r in self._reducers()):
+                return self._call_graph_dp(items, noise)
             return self._call_graph(items, noise)
         return self._step_body(items, noise)
 
@@ -121,10 +123,16 @@ class TrainStep:
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
 
     def _step_body(self, items, noise=None):
+        ctx = self._seg_d(items, noise)
+        self.optim_d.step()
+        out = self._seg_g(ctx)
+        self.optim_g.step()
+        return out
+
+    def _seg_d(self, items, noise=None):
+        """Generator forward + the discriminator step up to (and including) its backward (train.py:151-194)."""
         c, f0, spec, y, spk, lengths, uv, volume = items
         net_g, net_d = self.net_g, self.net_d
-        gmod = net_g.module if hasattr(net_g, "module") else net_g
-        dmod = net_d.module if hasattr(net_d, "module") else net_d
         seg_frames = self.segment_size // self.hop
         if spec is None:          # loader items without a cached .spec.pt / vol-augmented audio: STFT of the batch on the GPU
             from data_utils import batch_spectrogram
@@ -143,27 +151,94 @@ class TrainStep:
         loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         loss_disc.backward()
-        self.optim_d.step()
+        return dict(y=y, y_hat=y_hat, y_mel=y_mel, y_hat_mel=y_hat_mel, z_p=z_p, logs_q=logs_q, m_p=m_p, logs_p=logs_p,
+                    z_mask=z_mask, pred_lf0=pred_lf0, lf0=lf0, loss_disc=loss_disc)
 
-        # ---- generator step (:198-213): D frozen, real branch tape-free ----
+    def _seg_g(self, ctx):
+        """The generator step up to (and including) its backward (train.py:198-211): D frozen, real branch tape-free."""
+        net_g, net_d = self.net_g, self.net_d
+        gmod = net_g.module if hasattr(net_g, "module") else net_g
+        dmod = net_d.module if hasattr(net_d, "module") else net_d
+        y, y_hat, y_mel, y_hat_mel = ctx["y"], ctx["y_hat"], ctx["y_mel"], ctx["y_hat_mel"]
         with no_param_grads(dmod):
             _, y_d_hat_g, fmap_r, fmap_g = dmod.forward_gen_step(y, y_hat)
         loss_mel = A.sum_abs_diff(y_mel, y_hat_mel) / y_mel.numel() * self.c_mel                           # :202
-        loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * self.c_kl                                   # :203
+        loss_kl = kl_loss(ctx["z_p"], ctx["logs_q"], ctx["m_p"], ctx["logs_p"], ctx["z_mask"]) * self.c_kl  # :203
         loss_fm = feature_loss(fmap_r, fmap_g)
         loss_gen, _ = generator_loss(y_d_hat_g)
         if gmod.use_automatic_f0_prediction:
-            loss_lf0 = A.sum_sq_diff(pred_lf0, lf0) / lf0.numel()                                         # :206
+            loss_lf0 = A.sum_sq_diff(ctx["pred_lf0"], ctx["lf0"]) / ctx["lf0"].numel()                    # :206
         else:
             loss_lf0 = 0
         loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
         self.optim_g.zero_grad()
         loss_gen_all.backward()
-        self.optim_g.step()
+        loss_disc = ctx["loss_disc"]
         return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
                     loss_mel=loss_mel.detach(), loss_kl=loss_kl.detach(),
                     loss_lf0=loss_lf0.detach() if torch.is_tensor(loss_lf0) else loss_lf0,
                     loss_gen_all=loss_gen_all.detach())
+
+    # -- data-parallel hipGraph mode ---------------------------------------------------------------------------------------
+    def _reducers(self):
+        return getattr(self.net_g, "reducer", None), getattr(self.net_d, "reducer", None)
+
+    def _call_graph_dp(self, items, noise=None):
+        """With a process group the iteration is replayed as TWO hipGraphs (D segment, G segment) with the gradient
+        all-reduces and the two (one-launch) optimizer steps issued eagerly between them:
+            graph[G forward, D forward, D backward] -> all-reduce(D grads) -> AdamW(D)
+            -> graph[D forward (frozen), losses, G backward] -> all-reduce(G grads) -> AdamW(G)
+        Collectives are not captured (RCCL inside a graph needs capture-aware streams and watchdog handling; the two
+        all-reduces move 0.2 + 0.4 GB per iteration, a few ms over xGMI) and the Python autograd hooks that drive the
+        overlapped per-bucket path do not run in a replay, so each optimizer's gradients are reduced in one call."""
+        red_g, red_d = self._reducers()
+        nkeys = sorted(noise) if noise is not None else []
+        items = list(items) + [noise[k] for k in nkeys]
+        key = ("dp",) + tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
+        ent = self._graphs.get(key)
+        n_in = len(items) - len(nkeys)
+        if ent is None:
+            commons.DEVICE_RNG = True
+            static = [t.clone() if t is not None else None for t in items]
+            s_items = static[:n_in]
+            s_noise = dict(zip(nkeys, static[n_in:])) if nkeys else None
+            snaps = (self.optim_g.snapshot(), self.optim_d.snapshot())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                       # warm-up (real, bucket-overlapped all-reduces: every rank runs it)
+                    self._step_body(s_items, s_noise)
+            torch.cuda.current_stream().wait_stream(side)
+            self.optim_g.restore(snaps[0])               # also invalidates every packed-weight cache (version bump)
+            self.optim_d.restore(snaps[1])
+            torch.cuda.synchronize()
+            with red_g.no_sync(), red_d.no_sync():       # hooks must not launch collectives inside a capture
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    ctx = self._seg_d(s_items, s_noise)
+                touched_d = list(self.optim_d.arena.touched)
+                # what optim_d.step() does to the host view of the weights: the G segment must re-pack D's weights
+                torch.autograd.graph.increment_version(self.optim_d.arena.params)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    out = self._seg_g(ctx)
+                touched_g = list(self.optim_g.arena.touched)
+                torch.autograd.graph.increment_version(self.optim_g.arena.params)
+            ent = (g1, g2, static, out, touched_d, touched_g, ctx)
+            self._graphs[key] = ent
+        g1, g2, static, out, touched_d, touched_g, _ = ent
+        for s, t in zip(static, items):
+            if s is not None:
+                s.copy_(t, non_blocking=True)
+        g1.replay()
+        red_d.reduce_all()
+        self.optim_d.arena.touched = list(touched_d)
+        self.optim_d.step()
+        g2.replay()
+        red_g.reduce_all()
+        self.optim_g.arena.touched = list(touched_g)
+        self.optim_g.step()
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
 def init_distributed(rank, world, device):

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, graph=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -49,14 +49,16 @@ def _worker(rank, world, port, q):
         net_d.reducer.broadcast_parameters(0)
         net_g.train()
         net_d.train()
-        step = T.TrainStep(hps, net_g, net_d, og, od)
+        step = T.TrainStep(hps, net_g, net_d, og, od).enable_graph(bool(graph))
         c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
         noise = {k: v.to(dev) for k, v in cs["noise"].items()}
         sl = slice(rank, rank + 1)                          # rank r trains on item r of the 2-item batch
         items = (c[sl], f0[sl], spec[sl], y[sl], sid[sl], lengths[sl], uv[sl], None)
         nz = {k: v[sl].contiguous() for k, v in noise.items()}
-        for _ in range(2):
+        for _ in range(2 if graph is False else 3):
             out = step(items, noise=nz)
+        if graph:
+            assert any(k[0] == "dp" for k in step._graphs), "the data-parallel hipGraph path was not taken"
         flat = torch.cat([net_g.arena.param.detach(), net_d.arena.param.detach()]).cpu()
         parts = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(parts, flat)
@@ -64,26 +66,66 @@ def _worker(rank, world, port, q):
         fin = all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v))
         stats = (dict(net_g.reducer.stats), dict(net_d.reducer.stats))
         dist.destroy_process_group()
-        q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats))
+        q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats, flat if rank == 0 else None))
     except Exception:      # noqa: BLE001
         import traceback
-        q.put((rank, traceback.format_exc(), None))
+        q.put((rank, traceback.format_exc(), None, None))
 
 
-def test_two_rank_training_keeps_parameters_identical():
+def _run_two_ranks(graph):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    for rank, msg, stats in res:
+    for rank, msg, stats, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+    return res
+
+
+def test_two_rank_training_keeps_parameters_identical():
+    for rank, msg, stats, _ in _run_two_ranks(False):
         g, d = stats
         assert g["backward_passes"] == 2 and g["launches"] >= 2 and d["backward_passes"] == 2     # D: only the D steps
+
+
+def test_two_rank_training_graph_segments():
+    """train.TrainStep with a process group AND enable_graph(): two hipGraphs per iteration (D segment, G segment) with
+    whole-arena all-reduces and the AdamW launches between them.  Ranks stay bit-identical, the un-captured warm-up leaves no
+    trace (3 replayed iterations == 3 training steps: compared against 3 eager data-parallel iterations)."""
+    res_g = _run_two_ranks(True)
+    flat_g = next(f for r, _, _, f in res_g if f is not None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3_eager, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, _, _ in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+    flat_e = next(f for r, _, _, f in res if f is not None)
+    # Not bit-comparable: the weight-gradient kernels combine their time splits with fp32 atomics, and in its first steps
+    # Adam moves every element by ~lr * sign(g) — an element whose gradient is ~0 can flip direction between two runs
+    # (|difference| up to 2 * lr per step, isolated elements).  A skipped / doubled step would shift EVERY element by ~lr.
+    d = (flat_g - flat_e).abs()
+    lr, steps = 2e-4, 3
+    stats = dict(max=d.max().item(), mean=d.mean().item(), frac_gt_1e5=(d > 1e-5).float().mean().item())
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "dp_graph_vs_eager.txt"), "w") as f:
+            f.write(repr(stats) + "\n")
+    assert stats["max"] <= 2.5 * lr * steps and stats["mean"] <= 0.02 * lr and stats["frac_gt_1e5"] <= 0.02, stats
+
+
+def _worker3_eager(rank, world, port, q):
+    _worker(rank, world, port, q, graph=None)
 
 
 def _worker_diffusion(rank, world, port, q):
