@@ -24,7 +24,11 @@ class TrainStep:
             raise NotImplementedError("amp_dtype fp16/bf16 is not implemented: the MI355X engine trains in fp32")
         self.model, self.opt = model, optimizer
         self.gamma, self.decay_step = gamma, decay_step
-        self.sched_epoch = max(initial_global_step - 1, 0)         # StepLR(last_epoch = initial_global_step - 2) + its init step
+        # torch's StepLR(optimizer, step_size, gamma, last_epoch=initial_global_step - 2) (train_diff.py:60): the constructor
+        # performs one step() (last_epoch -> initial_global_step - 1), then every scheduler.step() increments
+        # last_epoch and multiplies the CURRENT lr by gamma when last_epoch is a non-zero multiple of step_size
+        self.sched_epoch = initial_global_step - 2
+        self._sched_step()                                          # the constructor's step (it CAN decay: last_epoch 3 -> 4 at step 4)
         self.use_graph = False
         self._graphs = {}
 
@@ -45,10 +49,11 @@ class TrainStep:
     def _mod(self):
         return self.model.module if isinstance(self.model, DataParallel) else self.model
 
-    def _sched_step(self):                       # lr_scheduler.StepLR.step() (solver.py:147)
+    def _sched_step(self):                       # lr_scheduler.StepLR.step() (solver.py:147), chainable form
         self.sched_epoch += 1
-        for pg in self.opt.param_groups:
-            pg["lr"] = pg["initial_lr"] * self.gamma ** (self.sched_epoch // self.decay_step)
+        if self.sched_epoch != 0 and self.sched_epoch % self.decay_step == 0:
+            for pg in self.opt.param_groups:
+                pg["lr"] = pg["lr"] * self.gamma
 
     def __call__(self, data, noise=None):
         """data: dict(units [B,T,n_unit], f0 [B,T,1], volume [B,T,1], spk_id [B,1], mel [B,T,M], aug_shift [B,1,1] | None)

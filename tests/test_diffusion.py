@@ -241,3 +241,59 @@ def test_unit2mel_dpm_solver_matches_reference_golden(dev, name, method, speedup
               infer_speedup=speedup, method=method, k_step=k_step if shallow else 300, use_tqdm=False, noise=dict(x_T=t("x_T")))
     ref = zd["mel_" + name]
     assert np.abs(mel.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("igs", [0, 1, 5, 7, 12])
+def test_solver_lr_schedule_matches_torch_steplr(igs):
+    """diffusion/solver.py mirror: lr trajectory == train_diff.py:55-60's set-up (lr pre-decayed by the global step, StepLR
+    with last_epoch = initial_global_step - 2) stepped once per iteration (solver.py:147).  CPU only: the schedule is host code."""
+    from diffusion import solver
+    lr, gamma, step = 1e-3, 0.5, 4
+
+    class _Opt:                                    # the two attributes the schedule touches
+        def __init__(self, lr0):
+            self.param_groups = [dict(lr=lr0, initial_lr=lr)]
+    lr0 = lr * gamma ** max((igs - 2) // step, 0)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.AdamW([p])
+    for pg in ref_opt.param_groups:
+        pg["initial_lr"] = lr
+        pg["lr"] = lr0
+    sched = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=step, gamma=gamma, last_epoch=igs - 2)
+    mine = solver.TrainStep(None, _Opt(lr0), gamma=gamma, decay_step=step, initial_global_step=igs)
+    for _ in range(14):
+        ref_opt.step()
+        sched.step()
+        mine._sched_step()
+        assert abs(mine.opt.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) <= 1e-12
+
+
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", CASES)
+def test_mirror_sampler_host_schedules_on_cpu(name, method, speedup, shallow, k_step, monkeypatch):
+    """GaussianDiffusion.forward (DDIM / PNDM / ancestral drivers and their host-side fp32 coefficient arithmetic) with the
+    device calls replaced by CPU stand-ins (test-only), against the REAL modules' outputs."""
+    import diffusion.diffusion as DD
+    z, meta = _load()
+    c = DO.small_cfg()
+    sd = DO.make_state_dict(c, meta["seed"])
+    t = lambda k: torch.from_numpy(z[k])
+    nb = 1 if method == "pndm" else meta["B"]
+    cond = DO.condition(sd, c, t("units"), t("f0"), t("volume"), t("spk_id"))[:nb]
+    monkeypatch.setattr(DD, "_lin", lambda a, x, b, y: float(a) * x + float(b) * y)
+
+    class _S:                                       # the one other device call of the samplers: the clamp of p_sample
+        EW_CLAMP = DD.S.EW_CLAMP
+
+        @staticmethod
+        def ew(op, x, alpha=1.0, beta=0.0):
+            assert op == DD.S.EW_CLAMP
+            return x.clamp(alpha, beta)
+    monkeypatch.setattr(DD, "S", _S)
+    gd = DD.GaussianDiffusion(lambda x, tt, cond: DO.wavenet(sd, c, x, tt, cond), out_dims=c["out_dims"],
+                              timesteps=c["timesteps"], k_step=c["k_step_max"])
+    k_step = meta["K"] if name == "naive_shallow" else k_step
+    noise = dict(x_T=t("x_T")[:nb], steps=[s[:nb] for s in t("steps")])
+    mel = gd(cond, gt_spec=t("gt")[:nb] if shallow else None, infer=True, infer_speedup=speedup, method=method,
+             k_step=k_step if shallow else 300, use_tqdm=False, noise=noise)
+    ref = z["mel_" + name]
+    assert np.abs(mel.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
