@@ -51,15 +51,7 @@ def split_list_by_n(seq, n, pre=0):
         yield seq[i - pre if i - pre >= 0 else i: i + n]
 
 
-def repeat_expand_2d(content, target_len, mode="left"):
-    """utils.repeat_expand_2d (utils.py:396-424): stretch [H, Tsrc] units to target_len frames.  'left' is the
-    reference's piecewise-constant hold; computed as one gather instead of a Python loop over frames."""
-    src_len = content.shape[-1]
-    if mode == "left":
-        edges = torch.arange(src_len + 1, dtype=torch.float32) * target_len / src_len
-        idx = torch.searchsorted(edges, torch.arange(target_len, dtype=torch.float32), right=True) - 1
-        return content[:, idx.clamp_(0, src_len - 1).to(content.device)].float()
-    return torch.nn.functional.interpolate(content[None], size=target_len, mode=mode)[0]
+repeat_expand_2d = utils.repeat_expand_2d      # utils.py:396-424 (the reference calls utils.repeat_expand_2d, infer_tool.py:240)
 
 
 class Svc(object):

@@ -157,20 +157,19 @@ def load_filepaths_and_text(filename, split="|"):
 
 
 def repeat_expand_2d(content, target_len, mode="left"):
-    """utils.py:396-424: stretch [H, Tsrc] units to target_len frames ('left' = the reference's sequential fill,
-    vectorised; other modes = F.interpolate)."""
+    """utils.py:396-424: stretch [H, Tsrc] units to target_len frames.  'left' = the reference's sequential fill: frame i
+    takes source column p(i), where p advances past column c once i >= edge[c+1] = (c+1)*target_len/src_len — but by AT
+    MOST ONE column per frame (when target_len < src_len the fill lags behind the edges; kept, it is what the reference
+    feeds the model).  p(i) = min(a(i), p(i-1)+1) with a(i) = #{edges[1:] <= i}  ==>  p(i) = i + min_{j<=i}(a(j) - j):
+    one searchsorted + one cumulative minimum instead of a Python loop over frames.  Other modes = F.interpolate."""
     if mode != "left":
         return torch.nn.functional.interpolate(content[None], size=target_len, mode=mode)[0]
     src_len = content.shape[-1]
-    edges = torch.arange(src_len + 1) * target_len / src_len
-    # frame i takes source column p(i) = number of edges[1:] that are <= i, advanced at most one per frame
-    idx = torch.zeros(target_len, dtype=torch.long)
-    cur = 0
-    for i in range(target_len):
-        if not i < edges[cur + 1]:
-            cur += 1
-        idx[i] = cur
-    return content[:, idx.to(content.device)].float()
+    edges = torch.arange(src_len + 1) * target_len / src_len                     # float32, as the reference computes it
+    i = torch.arange(target_len)
+    a = torch.searchsorted(edges[1:].contiguous(), i.to(edges.dtype), right=True)
+    idx = i + torch.cummin(a - i, dim=0).values
+    return content[:, idx.clamp_(max=src_len - 1).to(content.device)].float()
 
 
 class Volume_Extractor:

@@ -126,3 +126,27 @@ def test_batch_spectrogram_equals_per_item(dev):
         one = spectrogram_torch(wav[b, :, :n * HOP].to(dev), NFFT, SR, HOP, NFFT)[0]            # [bins, n]
         assert (spec[b, :, :n] - one).abs().max().item() <= 1e-4 * one.abs().max().item()
         assert spec[b, :, n:].abs().max().item() == 0 if n < 37 else True
+
+
+def test_repeat_expand_2d_left_is_the_reference_sequential_fill():
+    """utils.repeat_expand_2d('left') vectorised == the reference's frame loop (utils.py:402-416, restated here), including
+    target_len < src_len where the reference's fill advances at most one source column per frame."""
+    import utils as U
+
+    def ref_loop(content, target_len):
+        src_len = content.shape[-1]
+        target = torch.zeros([content.shape[0], target_len], dtype=torch.float)
+        temp = torch.arange(src_len + 1) * target_len / src_len
+        cur = 0
+        for i in range(target_len):
+            if i < temp[cur + 1]:
+                target[:, i] = content[:, cur]
+            else:
+                cur += 1
+                target[:, i] = content[:, cur]
+        return target
+    g = torch.Generator().manual_seed(0)
+    for src, tgt in [(50, 86), (499, 862), (7, 7), (1, 5), (3, 100), (100, 37), (862, 500), (10, 9), (33, 34), (250, 431)]:
+        x = torch.randn(4, src, generator=g)
+        assert torch.equal(U.repeat_expand_2d(x, tgt), ref_loop(x, tgt)), (src, tgt)
+    assert U.repeat_expand_2d(torch.randn(3, 10), 25, mode="nearest").shape == (3, 25)
