@@ -132,17 +132,37 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) bsum += brow_sum[c];
     }
+    if constexpr (NK == 1) {
+      // one tap per group (nk == 1 always): unconditional MFMAs.  With the per-tap `q < nk` guard below the accumulators
+      // are values merged across branches, and for NK = 1 hipcc kept them in VGPRs, copying all 32 into AGPRs and back
+      // around EVERY MFMA pair (64 v_accvgpr moves + an exposed MFMA latency per 2 MFMAs in the ISA).  (The same
+      // specialisation for full groups of NK >= 2 removes the per-tap branches too, but raises their VGPR count past the
+      // two-workgroups-per-CU limit: left for a measured round.)
 #pragma unroll 4
-    for (int s = 0; s < TT; s += 2) {
-      const float a0 = ap[s], a1 = ap[32 * PA + s];
-      float bv[NK];
+      for (int s = 0; s < TT; s += 2) {
+        const float a0 = ap[s], a1 = ap[32 * PA + s];
+        float bv[NK];
 #pragma unroll
-      for (int q = 0; q < NK; ++q) bv[q] = q < nk ? bp[s + q * dil] : 0.f;
+        for (int q = 0; q < NK; ++q) bv[q] = bp[s + q * dil];
 #pragma unroll
-      for (int q = 0; q < NK; ++q) {
-        if (q < nk) {
+        for (int q = 0; q < NK; ++q) {
           acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
           acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int s = 0; s < TT; s += 2) {
+        const float a0 = ap[s], a1 = ap[32 * PA + s];
+        float bv[NK];
+#pragma unroll
+        for (int q = 0; q < NK; ++q) bv[q] = q < nk ? bp[s + q * dil] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+          if (q < nk) {
+            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
+          }
         }
       }
     }
