@@ -99,6 +99,14 @@ def _worker(rank, world, port, q):
             if not n.startswith("unused"):
                 assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
 
+        # ... followed by reduce_all(): ONE all-reduce of the whole flat buffer == the full-batch gradient again (the
+        # path train.TrainStep takes between two hipGraph replays, where the per-bucket hooks do not run)
+        dp.reducer.reduce_all()
+        assert dp.reducer.stats["launches"] == before + 1
+        for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+            if not n.startswith("unused"):
+                assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
+
         # frozen-parameter pass (the D pass of the generator step): no gradients, no communication
         arena.zero_grad()
         before = dp.reducer.stats["launches"]
