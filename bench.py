@@ -44,7 +44,7 @@ HOP = 512
 
 def build_model(dev):
     import models
-    from oracle import weights as W   # deterministic synthetic checkpoint + inputs (test infrastructure data only)
+    import synthetic_data as W        # deterministic synthetic checkpoint + inputs (data generator, not the oracle)
     cfg = W.full_config()
     kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
     net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
@@ -111,9 +111,9 @@ def cpu_baseline_train(cfg, hps, items_cpu, max_items=2):
     the reference's order) on a BOUNDED sample of the workload: the first `max_items` items of the same minibatch (the
     full B=16 iteration is ~4 TFLOP — minutes on host cores).  steps/s is reported for the full batch by scaling with
     items (work is linear in the batch)."""
+    import synthetic_data as W
     from oracle import mel as OM
     from oracle import train_oracle as TO
-    from oracle import weights as W
     c, f0, spec, y, spk, lengths, uv, _ = [t[:max_items] if t is not None else None for t in items_cpu]
     T = int(lengths.max())
     c, f0, spec, uv, y = c[:, :, :T], f0[:, :T], spec[:, :, :T], uv[:, :T], y[:, :, :T * HOP]
@@ -136,8 +136,8 @@ def cpu_baseline_train(cfg, hps, items_cpu, max_items=2):
 def run_train(args, dev, rank, world, dist):
     """Time K training iterations; returns the result dict (rank 0) or None."""
     import svc_hip as S
+    import synthetic_data as W
     import train as TR
-    from oracle import weights as W
     cfg = W.full_config()
     hps = train_hps(cfg)
     torch.manual_seed(1234)

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "so-vits-svc_amd
 import torch
 import svc_hip as S
 import models
-from oracle import weights as W
+import synthetic_data as W
 
 dev = torch.device("cuda:0")
 cfg = W.full_config()

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "so-vits-svc_amd"))
 import torch
 import bench
 import train as TR
-from oracle import weights as W
+import synthetic_data as W
 from torch.profiler import profile, ProfilerActivity
 
 dev = torch.device("cuda:0")

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "so-vits-svc_amd"))
 import torch
 import bench, svc_hip as S, train as TR
-from oracle import weights as W
+import synthetic_data as W
 dev = torch.device("cuda:0")
 cfg = W.full_config(); hps = bench.train_hps(cfg)
 net_g, net_d, og, od = TR.build(hps, dev)

@@ -60,3 +60,30 @@ def test_product_modules_never_import_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_bench_and_entry_use_the_oracle_only_as_checker():
+    """bench.py may touch oracle/ only inside its cpu_baseline legs, __graft_entry__.py only inside smoke(): everything
+    they MEASURE runs on the HIP engine with data from synthetic_data.py (a generator, no reference algorithm)."""
+    import ast
+    allowed = {"bench.py": ("cpu_baseline", "cpu_baseline_train"), "__graft_entry__.py": ("smoke",)}
+    for fname, funcs in allowed.items():
+        tree = ast.parse(open(os.path.join(ROOT, fname)).read())
+        parents = {}
+        for node in ast.walk(tree):
+            for ch in ast.iter_child_nodes(node):
+                parents[ch] = node
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                mods = [node.module or ""]
+            if not any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                continue
+            fn = node
+            while fn in parents and not isinstance(fn, ast.FunctionDef):
+                fn = parents[fn]
+            assert isinstance(fn, ast.FunctionDef) and fn.name in funcs, (fname, getattr(fn, "name", None), mods)
+    s = open(os.path.join(ROOT, "synthetic_data.py")).read()
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M)
