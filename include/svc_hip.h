@@ -306,7 +306,7 @@ enum {
   SVC_EW_GELU = 16,      /* 0.5 a (1 + erf(a / sqrt 2))  (vencoder/hubert/hubert_model.py:87-93,127) */
   SVC_EW_MISH = 17,      /* a tanh(softplus(a))  (diffusion/wavenet.py:76) */
   SVC_EW_CLAMP = 18,     /* min(max(a, alpha), beta)  (diffusion/diffusion.py:139) */
-  SVC_EW_MISH_BWD = 19   /* a=dy, b=x */
+  SVC_EW_MISH_BWD = 19   /* a = dy, b = x: d/dx [x tanh(softplus x)] (backward of diffusion/wavenet.py:76, train_diff.py) */
 };
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
 /* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:
