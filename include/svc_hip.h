@@ -306,7 +306,9 @@ enum {
   SVC_EW_GELU = 16,      /* 0.5 a (1 + erf(a / sqrt 2))  (vencoder/hubert/hubert_model.py:87-93,127) */
   SVC_EW_MISH = 17,      /* a tanh(softplus(a))  (diffusion/wavenet.py:76) */
   SVC_EW_CLAMP = 18,     /* min(max(a, alpha), beta)  (diffusion/diffusion.py:139) */
-  SVC_EW_MISH_BWD = 19   /* a = dy, b = x: d/dx [x tanh(softplus x)] (backward of diffusion/wavenet.py:76, train_diff.py) */
+  SVC_EW_MISH_BWD = 19,  /* a = dy, b = x: d/dx [x tanh(softplus x)] (backward of diffusion/wavenet.py:76, train_diff.py) */
+  SVC_EW_DROPOUT = 20    /* b = uniform [0,1) draws: a * (b >= alpha ? 1/(1-alpha) : 0) — nn.Dropout(alpha) forward, and its
+                            backward with a = dy (modules/attentions.py:51,55,100,104,344) */
 };
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
 /* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:
@@ -374,11 +376,13 @@ int svc_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, c
                           float* dx, float* dgamma, float* dbeta, int B, int C, int T, void* stream);
 /* Training-time attention pieces around svc_gemm_f32 (modules/attentions.py:207-303).  S:[B*H,T,T] scores (in place ->
  * probabilities): S[i,j] += rel[i, j-i+window] inside the band, masked to -1e4 (mask_mode 1: mask[b,i]*mask[b,j]==0,
- * 2: j>i), softmax over j.  bwd: dP -> dS in place.  band gather/scatter move the (2*window+1)-wide diagonal band
+ * 2: j>i), softmax over j.  Attention-probability dropout (modules/attentions.py:232) is fused in: with drop_u != NULL
+ * (uniform [0,1) draws, [B*H,T,T]) S keeps the probabilities and Pd receives P * (u >= p_drop ? 1/(1-p_drop) : 0).
+ * bwd: dP -> dS in place (with drop_u, dP is the gradient w.r.t. Pd and is masked first).  band gather/scatter move the (2*window+1)-wide diagonal band
  * between a [rows,T] matrix (row i of every T x T block) and a [rows, 2*window+1] array. */
 int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
-                             void* stream);
-int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, void* stream);
+                             const float* drop_u, float p_drop, float* Pd, void* stream);
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop, void* stream);
 int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream);
 int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream);
 /* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of

@@ -81,7 +81,28 @@ def layer_norm_c(x, gamma, beta, eps=1e-5):  # modules/modules.py:23-35 (LN over
 # ------------------------------------------------------------------------------------------------------------
 # attention stack (modules/attentions.py)
 # ------------------------------------------------------------------------------------------------------------
-def multi_head_attention(x, sd, prefix, attn_mask, n_heads, window_size=None):
+class DropSeq:
+    """nn.Dropout(p) in training mode with the uniform draws explicit: site k keeps where us[k] >= p and scales by 1/(1-p)
+    (torch's dropout multiplies by a Bernoulli(1-p) mask pre-divided by 1-p).  `us` is consumed in call order; p == 0 or
+    us is None = identity (eval mode)."""
+
+    def __init__(self, p, us):
+        self.p = float(p)
+        self.us = list(us) if us is not None else None
+
+    def __call__(self, x):
+        if self.us is None or self.p <= 0:
+            return x
+        u = self.us.pop(0)
+        assert tuple(u.shape) == tuple(x.shape), (u.shape, x.shape)
+        keep = (u >= self.p).to(x.dtype) * (1.0 / (1.0 - self.p))
+        return x * keep
+
+
+_NO_DROP = DropSeq(0.0, None)
+
+
+def multi_head_attention(x, sd, prefix, attn_mask, n_heads, window_size=None, drop=_NO_DROP):
     """MultiHeadAttention.forward/attention, modules/attentions.py:198-239, self-attention case.
 
     The reference realises window-`w` relative positions by padding emb_rel_k/v to 2T-1 rows and skewing
@@ -93,11 +114,11 @@ def multi_head_attention(x, sd, prefix, attn_mask, n_heads, window_size=None):
     v = conv1d(x, sd, prefix + ".conv_v")
     e_k = sd[prefix + ".emb_rel_k"][0] if window_size is not None else None
     e_v = sd[prefix + ".emb_rel_v"][0] if window_size is not None else None
-    out = attention_core(q, k, v, attn_mask, n_heads, e_k, e_v, window_size)
+    out = attention_core(q, k, v, attn_mask, n_heads, e_k, e_v, window_size, drop)
     return conv1d(out, sd, prefix + ".conv_o")
 
 
-def attention_core(q, k, v, attn_mask, n_heads, e_k=None, e_v=None, window_size=None):
+def attention_core(q, k, v, attn_mask, n_heads, e_k=None, e_v=None, window_size=None, drop=_NO_DROP):
     """MultiHeadAttention.attention, modules/attentions.py:207-239, on projected q,k,v [B, H*dk, T]."""
     b, d, t = q.shape
     kc = d // n_heads
@@ -115,7 +136,7 @@ def attention_core(q, k, v, attn_mask, n_heads, e_k=None, e_v=None, window_size=
             scores[:, :, i, i + r] = scores[:, :, i, i + r] + rel[:, :, i, m]
     if attn_mask is not None:
         scores = scores.masked_fill(attn_mask == 0, -1e4)
-    p = F.softmax(scores, dim=-1)
+    p = drop(F.softmax(scores, dim=-1))          # :232 p_attn = self.drop(p_attn)
     out = torch.matmul(p, v)
     if window_size is not None:
         idx = torch.arange(t)
@@ -126,7 +147,7 @@ def attention_core(q, k, v, attn_mask, n_heads, e_k=None, e_v=None, window_size=
     return out.transpose(2, 3).contiguous().view(b, d, t)
 
 
-def ffn(x, x_mask, sd, prefix, kernel_size, causal=False):  # modules/attentions.py:337-363
+def ffn(x, x_mask, sd, prefix, kernel_size, causal=False, drop=_NO_DROP):  # modules/attentions.py:337-363
     if kernel_size == 1:
         pad = (0, 0)
     elif causal:
@@ -134,53 +155,53 @@ def ffn(x, x_mask, sd, prefix, kernel_size, causal=False):  # modules/attentions
     else:
         pad = ((kernel_size - 1) // 2, kernel_size // 2)
     h = conv1d(F.pad(x * x_mask, pad), sd, prefix + ".conv_1")
-    h = torch.relu(h)
+    h = drop(torch.relu(h))
     h = conv1d(F.pad(h * x_mask, pad), sd, prefix + ".conv_2")
     return h * x_mask
 
 
-def attn_encoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, window_size=4):
-    """attentions.Encoder.forward, modules/attentions.py:95-107 (post-LN; dropout is identity in eval)."""
+def attn_encoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, window_size=4, drop=_NO_DROP):
+    """attentions.Encoder.forward, modules/attentions.py:95-107 (post-LN; `drop`: the DropSeq of a training pass)."""
     attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     x = x * x_mask
     for i in range(n_layers):
-        y = multi_head_attention(x, sd, f"{prefix}.attn_layers.{i}", attn_mask, n_heads, window_size)
+        y = drop(multi_head_attention(x, sd, f"{prefix}.attn_layers.{i}", attn_mask, n_heads, window_size, drop))
         x = layer_norm_c(x + y, sd[f"{prefix}.norm_layers_1.{i}.gamma"], sd[f"{prefix}.norm_layers_1.{i}.beta"])
-        y = ffn(x, x_mask, sd, f"{prefix}.ffn_layers.{i}", kernel_size)
+        y = drop(ffn(x, x_mask, sd, f"{prefix}.ffn_layers.{i}", kernel_size, drop=drop))
         x = layer_norm_c(x + y, sd[f"{prefix}.norm_layers_2.{i}.gamma"], sd[f"{prefix}.norm_layers_2.{i}.beta"])
     return x * x_mask
 
 
-def fft_decoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size):
+def fft_decoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, drop=_NO_DROP):
     """attentions.FFT.forward (isflow=False), modules/attentions.py:43-70: causal self-attention, causal FFN."""
     t = x.shape[2]
     causal = torch.tril(torch.ones(t, t)).unsqueeze(0).unsqueeze(0)
     x = x * x_mask
     for i in range(n_layers):
-        y = multi_head_attention(x, sd, f"{prefix}.self_attn_layers.{i}", causal, n_heads, None)
+        y = drop(multi_head_attention(x, sd, f"{prefix}.self_attn_layers.{i}", causal, n_heads, None, drop))
         x = layer_norm_c(x + y, sd[f"{prefix}.norm_layers_0.{i}.gamma"], sd[f"{prefix}.norm_layers_0.{i}.beta"])
-        y = ffn(x, x_mask, sd, f"{prefix}.ffn_layers.{i}", kernel_size, causal=True)
+        y = drop(ffn(x, x_mask, sd, f"{prefix}.ffn_layers.{i}", kernel_size, causal=True, drop=drop))
         x = layer_norm_c(x + y, sd[f"{prefix}.norm_layers_1.{i}.gamma"], sd[f"{prefix}.norm_layers_1.{i}.beta"])
     return x * x_mask
 
 
-def text_encoder(x, x_mask, f0_coarse, sd, cfg, noise, noice_scale=1.0, prefix="enc_p"):
+def text_encoder(x, x_mask, f0_coarse, sd, cfg, noise, noice_scale=1.0, prefix="enc_p", drop=_NO_DROP):
     """TextEncoder.forward, models.py:155-162."""
     x = x + sd[prefix + ".f0_emb.weight"][f0_coarse].transpose(1, 2)
-    x = attn_encoder(x * x_mask, x_mask, sd, prefix + ".enc_", cfg["n_layers"], cfg["n_heads"], cfg["kernel_size"])
+    x = attn_encoder(x * x_mask, x_mask, sd, prefix + ".enc_", cfg["n_layers"], cfg["n_heads"], cfg["kernel_size"], drop=drop)
     stats = conv1d(x, sd, prefix + ".proj") * x_mask
     m, logs = torch.split(stats, cfg["inter_channels"], dim=1)
     z = (m + noise * torch.exp(logs) * noice_scale) * x_mask
     return z, m, logs
 
 
-def f0_decoder(x, norm_f0, x_mask, g, sd, cfg, prefix="f0_decoder"):
+def f0_decoder(x, norm_f0, x_mask, g, sd, cfg, prefix="f0_decoder", drop=_NO_DROP):
     """F0Decoder.forward, models.py:328-336."""
     x = x + conv1d(g, sd, prefix + ".cond")
     x = x + conv1d(norm_f0, sd, prefix + ".f0_prenet", padding=1)
     x = conv1d(x, sd, prefix + ".prenet", padding=1) * x_mask
     x = fft_decoder(x * x_mask, x_mask, sd, prefix + ".decoder", cfg["n_layers"], cfg["n_heads"],
-                    cfg["kernel_size"])
+                    cfg["kernel_size"], drop=drop)
     return conv1d(x, sd, prefix + ".proj") * x_mask
 
 

@@ -17,8 +17,10 @@ LRELU_SLOPE = 0.1
 
 def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise, vol=None):
     """models.py:463-493 with the random draws explicit: noise = dict(f0_factor [B,1], enc_p, enc_q [B,inter,T],
-    ids_slice [B] int64, rand_ini [B,9], sine [B, seg*hop, 9])."""
+    ids_slice [B] int64, rand_ini [B,9], sine [B, seg*hop, 9], optional dropout_u = the uniform draws of every nn.Dropout
+    site with cfg["p_dropout"] > 0, in call order: f0_decoder's layers first (models.py:476), then enc_p's (:477))."""
     B, _, T = c.shape
+    drop = O.DropSeq(cfg.get("p_dropout", 0.0), noise.get("dropout_u"))
     g = sd["emb_g.weight"][sid].transpose(1, 2)
     x_mask = O.sequence_mask(c_lengths, T).unsqueeze(1).to(c.dtype)
     x = O.conv1d(c, sd, "pre", padding=2) * x_mask + sd["emb_uv.weight"][uv.long()].transpose(1, 2)
@@ -26,8 +28,8 @@ def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise,
         x = x + F.linear(vol[:, :, None], sd["emb_vol.weight"], sd["emb_vol.bias"]).transpose(1, 2)
     lf0 = 2595. * torch.log10(1. + f0.unsqueeze(1) / 700.) / 500
     norm_lf0 = O.normalize_f0(lf0, x_mask, uv, noise["f0_factor"])
-    pred_lf0 = O.f0_decoder(x.detach(), norm_lf0, x_mask, g, sd, cfg)
-    z_ptemp, m_p, logs_p = O.text_encoder(x, x_mask, O.f0_to_coarse(f0), sd, cfg, noise["enc_p"], 1.0)
+    pred_lf0 = O.f0_decoder(x.detach(), norm_lf0, x_mask, g, sd, cfg, drop=drop)
+    z_ptemp, m_p, logs_p = O.text_encoder(x, x_mask, O.f0_to_coarse(f0), sd, cfg, noise["enc_p"], 1.0, drop=drop)
     spec_mask = O.sequence_mask(spec_lengths, spec.shape[2]).unsqueeze(1).to(spec.dtype)
     z, m_q, logs_q = O.posterior_encoder(spec, spec_mask, g, sd, cfg, noise["enc_q"])
     z_p = O.flow(z, spec_mask, g, sd, cfg, reverse=False)

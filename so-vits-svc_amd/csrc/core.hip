@@ -92,7 +92,7 @@ extern "C" {
 
 const char* svc_last_error(void) { return svc::g_err; }
 
-int svc_abi_version(void) { return 1; }
+int svc_abi_version(void) { return 2; }
 
 int svc_device_info(char* name, int len) {
   int dev = 0;

@@ -126,6 +126,7 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
       const float th = tanhf(sp);
       return a * (th + b * (1.f - th * th) * svc_sigmoid(b));
     }
+    case SVC_EW_DROPOUT: return b >= alpha ? a * (1.f / (1.f - alpha)) : 0.f;   // b = uniform draw, alpha = p
     default: return a;
   }
 }

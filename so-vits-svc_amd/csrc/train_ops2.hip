@@ -89,9 +89,14 @@ __global__ void ln_bwd_param_kernel(const float* __restrict__ x, const float* __
 // ---- attention score post-processing: S[bh,i,:] += band(rel[bh,i,:]); mask; softmax over j --------------------------
 // mask_mode 1: key/query padding mask m[b,i]*m[b,j] == 0 -> -1e4 (attentions.Encoder :96); 2: causal j > i -> -1e4
 // (attentions.FFT :52 via commons.subsequent_mask).  One wave per row.
+// Attention-probability dropout (modules/attentions.py:232, `p_attn = self.drop(p_attn)`) rides in the same pass: with
+// drop_u (uniform [0,1) draws, one per probability) the kernel keeps P in S (the softmax backward needs it) and writes
+// Pd[j] = P[j] * (u[j] >= p ? 1/(1-p) : 0) for the AV / relative-value products.
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ rel,
                                                                const float* __restrict__ mask, int H, int T, int window,
-                                                               int mask_mode, long long n_rows) {
+                                                               int mask_mode, long long n_rows,
+                                                               const float* __restrict__ drop_u, float p_drop,
+                                                               float* __restrict__ Pd) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -122,18 +127,41 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
   }
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
   const float inv = 1.f / sum;
-  for (int j = lane; j < T; j += 64) sp[j] *= inv;
+  if (drop_u) {
+    const float* up = drop_u + row * T;
+    float* dp = Pd + row * T;
+    const float ks = 1.f / (1.f - p_drop);
+    for (int j = lane; j < T; j += 64) {
+      const float pv = sp[j] * inv;
+      sp[j] = pv;
+      dp[j] = up[j] >= p_drop ? pv * ks : 0.f;
+    }
+  } else {
+    for (int j = lane; j < T; j += 64) sp[j] *= inv;
+  }
 }
-// dS = P * (dP - sum_j dP*P), in place on dP
+// dS = P * (dP - sum_j dP*P), in place on dP; with drop_u the incoming gradient is w.r.t. the dropped probabilities and
+// is first multiplied by the same keep mask
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int T,
-                                                               long long n_rows) {
+                                                               long long n_rows, const float* __restrict__ drop_u,
+                                                               float p_drop) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
   const float* pp = P + row * T;
   float* dp = dP + row * T;
   float dot = 0.f;
-  for (int j = lane; j < T; j += 64) dot += pp[j] * dp[j];
+  if (drop_u) {
+    const float* up = drop_u + row * T;
+    const float ks = 1.f / (1.f - p_drop);
+    for (int j = lane; j < T; j += 64) {
+      const float g = up[j] >= p_drop ? dp[j] * ks : 0.f;
+      dp[j] = g;
+      dot += pp[j] * g;
+    }
+  } else {
+    for (int j = lane; j < T; j += 64) dot += pp[j] * dp[j];
+  }
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
   for (int j = lane; j < T; j += 64) dp[j] = pp[j] * (dp[j] - dot);
 }
@@ -259,18 +287,20 @@ int svc_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, c
 }
 
 int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
-                             void* stream) {
+                             const float* drop_u, float p_drop, float* Pd, void* stream) {
   SVC_REQUIRE(S && B > 0 && H > 0 && T > 0 && window >= 0, "attn_softmax_fwd: bad args");
+  SVC_REQUIRE(drop_u == nullptr || (Pd != nullptr && p_drop >= 0.f && p_drop < 1.f), "attn_softmax_fwd: dropout needs Pd and 0 <= p < 1");
   const long long rows = (long long)B * H * T;
   hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rel, mask,
-                     H, T, window, mask_mode, rows);
+                     H, T, window, mask_mode, rows, drop_u, p_drop, Pd);
   return svc::check_launch("attn_softmax_fwd");
 }
 
-int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, void* stream) {
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop, void* stream) {
   SVC_REQUIRE(P && dP && B > 0 && H > 0 && T > 0, "attn_softmax_bwd: bad args");
   const long long rows = (long long)B * H * T;
-  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows);
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows,
+                     drop_u, p_drop);
   return svc::check_launch("attn_softmax_bwd");
 }
 

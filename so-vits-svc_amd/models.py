@@ -2,10 +2,10 @@
 constructor signatures, attribute names and state_dict layout (751 keys for the full template), so
 `inference/infer_tool.Svc` / `inference_main.py` can use it unchanged.  All arithmetic runs in libsvc_hip.so.
 
-Built so far: the inference graph `SynthesizerTrn.infer` (models.py:496-532 in the reference) incl. automatic f0
-prediction, with an optional hipGraph replay of the whole path.  The training graph (`forward`, enc_q, the
-discriminators) needs backward kernels that do not exist yet and raises NotImplementedError instead of silently
-running anything else.
+`SynthesizerTrn.infer` (reference models.py:496-532, incl. automatic f0 prediction, optional hipGraph replay of the whole
+path) runs the fused inference kernels; `SynthesizerTrn.forward` (:463-493), `Encoder` (enc_q) and the
+MultiPeriodDiscriminator run the training graph on svc_autograd Functions (HIP forward + HIP backward), dropout included.
+Not built (raise NotImplementedError): use_transformer_flow, spectral-norm discriminators.
 """
 import math
 
@@ -118,13 +118,13 @@ class TextEncoder(nn.Module):
         self.f0_emb = nn.Embedding(256, hidden_channels)
         self.enc_ = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
 
-    def forward(self, x, x_mask, f0=None, noice_scale=1, noise=None, x_is_embedded=False, full_mask=False):
+    def forward(self, x, x_mask, f0=None, noice_scale=1, noise=None, x_is_embedded=False, full_mask=False, dropout_u=None):
         """Reference models.py:155-162.  `f0` is the COARSE f0 index tensor (f0_to_coarse output) unless
         x_is_embedded=True, in which case `x` already is (x + f0_emb) * mask (fused by svc_prenet_embed_f32)."""
         m = mask2d(x_mask)
         if training_call(self.proj.weight):
             x = A.add(x, A.embedding_bct(f0, self.f0_emb.weight))                    # models.py:156
-            h = self.enc_.forward_train(A.mul_bcast(x, x_mask), x_mask)
+            h = self.enc_.forward_train(A.mul_bcast(x, x_mask), x_mask, dropout_u=dropout_u)
             stats = A.mul_bcast(self.proj.forward_train(h), x_mask)
             if noise is None:
                 noise = torch.randn(stats.shape[0], self.out_channels, stats.shape[2], device=stats.device)   # :160
@@ -159,7 +159,7 @@ class F0Decoder(nn.Module):
         self.f0_prenet = Conv1d(1, hidden_channels, 3, padding=1)
         self.cond = Conv1d(spk_channels, hidden_channels, 1)
 
-    def forward(self, x, norm_f0, x_mask, spk_emb=None):
+    def forward(self, x, norm_f0, x_mask, spk_emb=None, dropout_u=None):
         """Reference models.py:328-336:  x += cond(spk); x += f0_prenet(norm_f0); prenet; FFT; proj."""
         m = mask2d(x_mask)
         if training_call(self.prenet.weight):
@@ -168,7 +168,7 @@ class F0Decoder(nn.Module):
                 x = A.add_bcast(x, self.cond.forward_train(spk_emb))
             x = A.add(x, self.f0_prenet.forward_train(norm_f0))
             x = A.mul_bcast(self.prenet.forward_train(x), x_mask)
-            x = self.decoder.forward_train(A.mul_bcast(x, x_mask), x_mask)
+            x = self.decoder.forward_train(A.mul_bcast(x, x_mask), x_mask, dropout_u=dropout_u)
             return A.mul_bcast(self.proj.forward_train(x), x_mask)
         gc = self.cond(spk_emb) if spk_emb is not None else None          # [B,H,1|T]
         # x + cond(g) + f0_prenet(norm_f0): direct conv (Cin=1) with x as residual, then the speaker bias rides as
@@ -270,9 +270,11 @@ class SynthesizerTrn(nn.Module):
     def forward(self, c, f0, uv, spec, g=None, c_lengths=None, spec_lengths=None, vol=None, noise=None):
         """Training graph, reference models.py:463-493.  Every op is a svc_autograd Function (HIP forward + backward).
         `noise` (optional dict: enc_p, enc_q [B,inter,T], f0_factor [B,1], ids_slice [B], rand_ini [B,9],
-        sine [B, seg*hop, 9]) injects the random draws explicitly (parity tests); otherwise they come from torch's
-        generator in the reference's order."""
+        sine [B, seg*hop, 9], dropout_u: list of uniform draws, one per active nn.Dropout site in call order — f0_decoder's
+        6 layers x (attention probabilities [B,H,T,T], attention output, FFN hidden, FFN output), then enc_p's) injects the
+        random draws explicitly (parity tests); otherwise they come from torch's generator in the reference's order."""
         noise = noise or {}
+        du = list(noise["dropout_u"]) if noise.get("dropout_u") is not None else None
         c, f0, uv, spec = c.float(), f0.float(), uv.float(), spec.float()
         B, _, T = c.shape
         gi = g if g.dim() == 2 else g.view(B, 1)
@@ -292,10 +294,10 @@ class SynthesizerTrn(nn.Module):
                 else:
                     factor = torch.empty(B, 1).uniform_(0.8, 1.2).to(c.device)          # utils.py:39 (CPU draw)
             lf0, norm_lf0 = S.f0_norm_lf0(f0, uv, mask=x_mask, factor=factor.reshape(-1))   # :474-475 (no grad: inputs)
-            pred_lf0 = self.f0_decoder(x, norm_lf0, x_mask, spk_emb=gemb)
+            pred_lf0 = self.f0_decoder(x, norm_lf0, x_mask, spk_emb=gemb, dropout_u=du)
         else:
             lf0 = norm_lf0 = pred_lf0 = 0
-        z_ptemp, m_p, logs_p, _ = self.enc_p(x, x_mask, f0=utils.f0_to_coarse(f0), noise=noise.get("enc_p"))
+        z_ptemp, m_p, logs_p, _ = self.enc_p(x, x_mask, f0=utils.f0_to_coarse(f0), noise=noise.get("enc_p"), dropout_u=du)
         z, m_q, logs_q, spec_mask = self.enc_q(spec, spec_lengths, g=gemb, noise=noise.get("enc_q"))
         z_p = self.flow(z, spec_mask, g=gemb)
         ids = noise.get("ids_slice")

@@ -82,14 +82,20 @@ class MultiHeadAttention(nn.Module):
             return MASK_PADDING, vec
         raise NotImplementedError("attention mask is neither all-ones, causal nor an outer product of a padding mask")
 
-    def forward_train(self, x, mask_mode, mask_vec):
-        """Reference modules/attentions.py:198-239: separate q/k/v projections, attention as GEMMs + masked softmax."""
+    def forward_train(self, x, mask_mode, mask_vec, draws=None):
+        """Reference modules/attentions.py:198-239: separate q/k/v projections, attention as GEMMs + masked softmax, and
+        `p_attn = self.drop(p_attn)` (:232) fused into the softmax kernel (`draws`: the DropoutDraws of this pass;
+        without one the module draws for itself when it is in training mode with p_dropout > 0)."""
         q = self.conv_q.forward_train(x)
         k = self.conv_k.forward_train(x)
         v = self.conv_v.forward_train(x)
         win = self.window_size or 0
+        if draws is None:
+            draws = DropoutDraws(self.p_dropout, self.training)
+        B, _, T = x.shape
+        u = draws.u((B, self.n_heads, T, T), x.device) if draws.active else None
         att = A.attention(q, k, v, self.n_heads, self.emb_rel_k if win else None, self.emb_rel_v if win else None, win,
-                          mask_vec, mask_mode)
+                          mask_vec, mask_mode, drop_u=u, p_drop=draws.p)
         return self.conv_o.forward_train(att)
 
     def forward(self, x, c, attn_mask=None, mask_mode=None, mask_vec=None):
@@ -135,8 +141,9 @@ class FFN(nn.Module):
             raise NotImplementedError("even FFN kernel sizes with 'same' padding are not on the so-vits-svc path")
         h = self.conv_1.forward_train(A.mul_bcast(x, x_mask), causal=self.causal, padding=(k - 1) // 2)
         h = A.relu(h)
-        if drop is not None:
-            h = drop(h)
+        if drop is None:
+            drop = DropoutDraws(self.p_dropout, self.training)
+        h = drop(h)                                                             # :344
         h = self.conv_2.forward_train(A.mul_bcast(h, x_mask), causal=self.causal, padding=(k - 1) // 2)
         return A.mul_bcast(h, x_mask)
 
@@ -180,9 +187,11 @@ class Encoder(nn.Module):
                                        p_dropout=p_dropout))
             self.norm_layers_2.append(LayerNorm(hidden_channels))
 
-    def forward_train(self, x, x_mask):
-        """Reference modules/attentions.py:95-107."""
-        return _encoder_forward_train(self, x, x_mask, self.attn_layers, self.norm_layers_1, self.norm_layers_2, MASK_PADDING)
+    def forward_train(self, x, x_mask, dropout_u=None):
+        """Reference modules/attentions.py:95-107.  `dropout_u`: optional list of injected uniform draws, one per dropout
+        site in the reference's order (parity tests); consumed from the front."""
+        return _encoder_forward_train(self, x, x_mask, self.attn_layers, self.norm_layers_1, self.norm_layers_2, MASK_PADDING,
+                                      dropout_u)
 
     def forward(self, x, x_mask, full_mask=False):
         """`full_mask=True` promises x_mask is all ones (inference, models.py:503) and skips the padding mask."""
@@ -201,30 +210,46 @@ class Encoder(nn.Module):
         return x
 
 
-def _dropout(p, training):
-    """nn.Dropout as a mask multiply: the Bernoulli draw comes from torch's generator (as every other random tensor
-    on the path), the scaling/multiply is svc_ew_bct_f32.  None when inactive."""
-    if not training or p <= 0:
-        return None
+class DropoutDraws:
+    """The uniform draws behind every nn.Dropout site of one forward pass.  The Bernoulli keep decision is u >= p, made
+    INSIDE the consuming HIP kernel (svc_attn_softmax_fwd_f32 for the attention probabilities, SVC_EW_DROPOUT for the
+    activation sites): the only torch call is the draw itself (torch.rand on the device, like every other random tensor
+    on the path).  `injected`: a list of draws consumed from the front in the reference's call order (parity tests)."""
 
-    def drop(x):
-        keep = (torch.rand_like(x) >= p).to(x.dtype).mul_(1.0 / (1.0 - p))
-        return A.mul_bcast(x, keep)
-    return drop
+    def __init__(self, p, training, injected=None):
+        self.p = float(p) if training else 0.0
+        self.injected = injected
+
+    @property
+    def active(self):
+        return self.p > 0.0
+
+    def u(self, shape, device):
+        if self.injected is not None:
+            t = self.injected.pop(0)
+            if tuple(t.shape) != tuple(shape):
+                raise S.SvcError(f"injected dropout draw {tuple(t.shape)} does not match the site's shape {tuple(shape)}")
+            return t.to(device=device, dtype=torch.float32).contiguous()
+        return torch.rand(shape, device=device)
+
+    def __call__(self, x):
+        if not self.active:
+            return x
+        return A.dropout(x, self.u(tuple(x.shape), x.device), self.p)
 
 
-def _encoder_forward_train(self, x, x_mask, attn_layers, norm_a, norm_b, mask_mode):
+def _encoder_forward_train(self, x, x_mask, attn_layers, norm_a, norm_b, mask_mode, dropout_u=None):
+    """Encoder / FFT training forward (modules/attentions.py:43-70,95-107) with all four dropout sites of a layer in the
+    reference's order: attention probabilities (:232), attention output (:51/:100), FFN hidden (:344), FFN output."""
     m = x_mask[:, 0].contiguous() if x_mask.dim() == 3 else x_mask
-    drop = _dropout(self.p_dropout, self.training)
+    draws = DropoutDraws(self.p_dropout, self.training, dropout_u)
     x = A.mul_bcast(x, x_mask)
     for i in range(self.n_layers):
-        y = attn_layers[i].forward_train(x, mask_mode, m if mask_mode == MASK_PADDING else None)
-        if drop is not None:
-            y = drop(y)
+        y = attn_layers[i].forward_train(x, mask_mode, m if mask_mode == MASK_PADDING else None, draws=draws)
+        y = draws(y)
         x = norm_a[i](A.add(x, y))
-        y = self.ffn_layers[i].forward_train(x, x_mask, drop=drop)
-        if drop is not None:
-            y = drop(y)
+        y = self.ffn_layers[i].forward_train(x, x_mask, drop=draws)
+        y = draws(y)
         x = norm_b[i](A.add(x, y))
     return A.mul_bcast(x, x_mask)
 
@@ -256,10 +281,10 @@ class FFT(nn.Module):
                                        p_dropout=p_dropout, causal=True))
             self.norm_layers_1.append(LayerNorm(hidden_channels))
 
-    def forward_train(self, x, x_mask):
+    def forward_train(self, x, x_mask, dropout_u=None):
         """Reference modules/attentions.py:43-70 (g is None on the so-vits-svc path)."""
         return _encoder_forward_train(self, x, x_mask, self.self_attn_layers, self.norm_layers_0, self.norm_layers_1,
-                                      MASK_CAUSAL)
+                                      MASK_CAUSAL, dropout_u)
 
     def forward(self, x, x_mask, g=None):
         if training_call(self.norm_layers_0[0].gamma) or (torch.is_grad_enabled() and x.requires_grad):

@@ -449,10 +449,12 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 class _Attention(Function):
     """MultiHeadAttention.attention (modules/attentions.py:207-239) on projected q,k,v [B, H*dk, T], training form:
-    scores / probabilities are materialised per head ([B*H, T, T]) and every product runs on svc_gemm_f32."""
+    scores / probabilities are materialised per head ([B*H, T, T]) and every product runs on svc_gemm_f32.  With
+    `drop_u` (uniform draws [B,H,T,T]) the probabilities are dropped as the reference does (:232) inside the softmax
+    kernel: P (for the softmax backward) and Pd = P * keep (for the AV and relative-value products) are both kept."""
 
     @staticmethod
-    def forward(ctx, q, k, v, emb_k, emb_v, mask, n_heads, window, mask_mode):
+    def forward(ctx, q, k, v, emb_k, emb_v, mask, n_heads, window, mask_mode, drop_u, p_drop):
         q, k, v = _c(q), _c(k), _c(v)
         B, Cc, T = q.shape
         H = n_heads
@@ -466,28 +468,34 @@ class _Attention(Function):
             ek = _c(emb_k.view(-1, dk))
             ev = _c(emb_v.view(-1, dk))
             rel = S.gemm(q, ek, qs, (0, 1, dk), BH, T, 2 * window + 1, dk, alpha=sc)
-        S.attn_softmax_fwd(P, rel, mask, B, H, T, window, mask_mode)
+        if drop_u is not None:
+            drop_u = _c(drop_u)
+            if drop_u.numel() != P.numel():
+                raise S.SvcError(f"attention dropout draws {tuple(drop_u.shape)} do not match [B,H,T,T] = {(B, H, T, T)}")
+        Pd = S.attn_softmax_fwd(P, rel, mask, B, H, T, window, mask_mode, drop_u, p_drop)
         out = torch.empty_like(q)
-        S.gemm(v, P, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
+        S.gemm(v, Pd, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
         pband = None
         if window:
-            pband = S.band_gather(P, BH * T, T, window)
+            pband = S.band_gather(Pd, BH * T, T, window)
             S.gemm(ev, pband, (0, 1, dk), (T * (2 * window + 1), 1, 2 * window + 1), BH, dk, T, 2 * window + 1, out=out,
                    c_strides=(dk * T, T, 1), beta=1.0)
-        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v)
-        ctx.cfg = (B, H, dk, T, window)
+        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v, drop_u, Pd if drop_u is not None else None)
+        ctx.cfg = (B, H, dk, T, window, p_drop)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v, P, pband, emb_k, emb_v = ctx.saved_tensors
-        B, H, dk, T, window = ctx.cfg
+        q, k, v, P, pband, emb_k, emb_v, drop_u, Pd = ctx.saved_tensors
+        B, H, dk, T, window, p_drop = ctx.cfg
+        if Pd is None:
+            Pd = P
         BH = B * H
         sc = dk ** -0.5
         nrel = 2 * window + 1
         dO = _c(dO)
         dV = torch.empty_like(v)
-        S.gemm(dO, P, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=dV, c_strides=(dk * T, T, 1))
+        S.gemm(dO, Pd, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=dV, c_strides=(dk * T, T, 1))
         dP = S.gemm(dO, v, (dk * T, 1, T), (dk * T, T, 1), BH, T, T, dk)
         dEk = dEv = None
         if window:
@@ -497,7 +505,7 @@ class _Attention(Function):
             S.band_scatter_add(dP, dpband, BH * T, T, window)
             dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T)      # [BH, nrel, dk]
             dEv = S.reduce_bct(dEv_b.view(BH, nrel * dk, 1), 0).view(emb_v.shape)
-        S.attn_softmax_bwd(P, dP, B, H, T)          # dP -> dS in place
+        S.attn_softmax_bwd(P, dP, B, H, T, drop_u, p_drop)          # dP(d) -> dS in place
         dS = dP
         dQ = torch.empty_like(q)
         S.gemm(k, dS, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=dQ, c_strides=(dk * T, T, 1), alpha=sc)
@@ -509,11 +517,30 @@ class _Attention(Function):
                    beta=1.0)
             dEk_b = S.gemm(drel, q, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, alpha=sc)
             dEk = S.reduce_bct(dEk_b.view(BH, nrel * dk, 1), 0).view(emb_k.shape)
-        return dQ, dK, dV, dEk, dEv, None, None, None, None
+        return dQ, dK, dV, dEk, dEv, None, None, None, None, None, None
 
 
-def attention(q, k, v, n_heads, emb_rel_k=None, emb_rel_v=None, window=0, mask=None, mask_mode=0):
-    return _Attention.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window or 0, mask_mode)
+def attention(q, k, v, n_heads, emb_rel_k=None, emb_rel_v=None, window=0, mask=None, mask_mode=0, drop_u=None, p_drop=0.0):
+    return _Attention.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window or 0, mask_mode, drop_u, float(p_drop))
+
+
+class _Dropout(Function):
+    """nn.Dropout(p) with the uniform draws `u` explicit: y = x * (u >= p ? 1/(1-p) : 0), one svc_ew_f32 launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, u, p):
+        ctx.save_for_backward(u)
+        ctx.p = p
+        return S.ew(S.EW_DROPOUT, x, u, alpha=p)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        return S.ew(S.EW_DROPOUT, dy, u, alpha=ctx.p), None, None
+
+
+def dropout(x, u, p):
+    return _Dropout.apply(x, _c(u), float(p))
 
 
 class _Embed(Function):

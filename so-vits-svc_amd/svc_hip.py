@@ -534,7 +534,8 @@ def device_info():
 # training-path entry points (include/svc_hip.h, "TRAINING path")
 # --------------------------------------------------------------------------------------------------------------
 (EW_ADD, EW_MUL, EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_RELU, EW_RELU_BWD, EW_EXP, EW_LOG_CLAMP,
- EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU, EW_MISH, EW_CLAMP, EW_MISH_BWD) = range(20)
+ EW_LOG_CLAMP_BWD, EW_SCALE, EW_SIGMOID, EW_SQUARE, EW_SIGN_MUL, EW_DIV, EW_GELU, EW_MISH, EW_CLAMP, EW_MISH_BWD,
+ EW_DROPOUT) = range(21)
 RED_SUM, RED_ABS_DIFF, RED_SQ_DIFF, RED_SQ_ONE_MINUS, RED_SQ, RED_KL = range(6)
 
 
@@ -895,8 +896,8 @@ def t2lib():
         i, f, ll, vp = C.c_int, C.c_float, C.c_longlong, C.c_void_p
         L.svc_layernorm_fwd_f32.argtypes = [_f32p] * 6 + [i, i, i, f, vp]
         L.svc_layernorm_bwd_f32.argtypes = [_f32p] * 8 + [i, i, i, vp]
-        L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [vp]
-        L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [vp]
+        L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [_f32p, C.c_float, _f32p, vp]
+        L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, vp]
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
@@ -939,14 +940,19 @@ def layernorm_bwd(x, gamma, dy, mean, rstd):
     return dx, dg, db
 
 
-def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode):
-    check(t2lib().svc_attn_softmax_fwd_f32(ptr(S_), ptr(rel), ptr(mask), B, H, T, window, mask_mode, stream_ptr()),
-          "attn_softmax_fwd")
-    return S_
+def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode, drop_u=None, p_drop=0.0):
+    """In place scores -> probabilities; with drop_u (uniform draws, same shape) also returns the dropped
+    probabilities P * (u >= p ? 1/(1-p) : 0) (modules/attentions.py:232), else returns S_ itself."""
+    require_gpu(drop_u)
+    Pd = torch.empty_like(S_) if drop_u is not None else None
+    check(t2lib().svc_attn_softmax_fwd_f32(ptr(S_), ptr(rel), ptr(mask), B, H, T, window, mask_mode, ptr(drop_u),
+                                           float(p_drop), ptr(Pd), stream_ptr()), "attn_softmax_fwd")
+    return S_ if Pd is None else Pd
 
 
-def attn_softmax_bwd(P, dP, B, H, T):
-    check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, stream_ptr()), "attn_softmax_bwd")
+def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0):
+    check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), stream_ptr()),
+          "attn_softmax_bwd")
     return dP
 
 

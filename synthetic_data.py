@@ -346,6 +346,20 @@ def make_train_noise(cfg, B, T, lengths, seed, hop=512):
                 sine=torch.randn(B, seg * hop, 9, generator=gen))
 
 
+def make_dropout_draws(cfg, B, T, seed):
+    """Uniform [0,1) draws for every active nn.Dropout site of one SynthesizerTrn.forward, in the reference's call order
+    (models.py:476 f0_decoder, then :477 enc_p; per attention layer: attention probabilities [B,H,T,T]
+    (modules/attentions.py:232), attention output (:51/:100), FFN hidden (:344), FFN output (:55/:104))."""
+    gen = torch.Generator().manual_seed(seed)
+    H, C, Fc = cfg["n_heads"], cfg["hidden_channels"], cfg["filter_channels"]
+    out = []
+    for _stack in ("f0_decoder", "enc_p"):
+        for _ in range(cfg["n_layers"]):
+            for shape in ((B, H, T, T), (B, C, T), (B, Fc, T), (B, C, T)):
+                out.append(torch.rand(shape, generator=gen))
+    return out
+
+
 def make_train_state_dict(cfg, seed):
     """make_state_dict with the log-variance projections damped (x0.1): with O(1) random `proj` weights exp(-2*logs_p)
     in the KL term (modules/losses.py:52-54) reaches 1e6 and every other loss term / gradient drowns in it."""

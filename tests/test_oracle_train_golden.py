@@ -6,7 +6,7 @@ import torch
 from oracle import mel as OM
 from oracle import train_oracle as TO
 from oracle import weights as W
-from train_common import LOSS_KEYS, load_case
+from train_common import LOSS_KEYS, load_case, load_dropout_case
 
 
 def test_mpd_layout_matches_reference():
@@ -70,3 +70,30 @@ def test_oracle_loop_reproduces_reference_training_loop():
             assert np.abs(sg[name[8:]].numpy() - z[name]).max() <= 2e-5, name
         if name.startswith("param_d."):
             assert np.abs(sd[name[8:]].numpy() - z[name]).max() <= 2e-5, name
+
+
+def test_oracle_reproduces_reference_training_forward_with_dropout():
+    """p_dropout = 0.1 (the shipped configs' value): attention-probability / attention-output / FFN dropouts with injected
+    draws, prior statistics + pred_lf0 + loss_kl + loss_lf0 + their gradients vs the REAL reference."""
+    cs = load_dropout_case()
+    z = cs["z"]
+    sg = {k: v.clone().requires_grad_(True) for k, v in cs["sd_g"].items()}
+    c, f0, uv, spec, y, sid, lengths = cs["batch"]
+    o = TO.synth_forward(sg, cs["cfg"], c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
+    m_p, logs_p, pred = o[3][2], o[3][3], o[4]
+    assert np.abs(m_p.detach().numpy() - z["m_p"]).max() <= 2e-5 * max(1.0, np.abs(z["m_p"]).max())
+    assert np.abs(pred.detach().numpy() - z["pred_lf0"]).max() <= 2e-5 * max(1.0, np.abs(z["pred_lf0"]).max())
+    kl = TO.kl_loss(o[3][1], o[3][5], m_p, logs_p, o[2])
+    lf0 = torch.nn.functional.mse_loss(pred, o[6])
+    assert abs(float(kl) - float(z["loss_kl"])) <= 2e-5 * max(1.0, abs(float(z["loss_kl"])))
+    assert abs(float(lf0) - float(z["loss_lf0"])) <= 2e-5 * max(1.0, abs(float(z["loss_lf0"])))
+    keys = [str(k) for k in z["gnorm_keys"]]
+    gs = torch.autograd.grad(kl + lf0, [sg[k] for k in keys], allow_unused=True)
+    for k, g, n in zip(keys, gs, z["gnorm"]):
+        if g is None:
+            assert n == 0, k
+        elif not k.endswith("conv_k.bias"):
+            assert abs(g.norm().item() - n) <= 2e-4 * max(n, 1e-5), (k, g.norm().item(), n)
+    # and dropout is really active in this case: the eval-mode statistics differ
+    o0 = TO.synth_forward(cs["sd_g"], dict(cs["cfg"], p_dropout=0.0), c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
+    assert (o0[3][2] - m_p).abs().max().item() > 1e-3

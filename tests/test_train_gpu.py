@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from train_common import LOSS_KEYS, load_case
+from train_common import LOSS_KEYS, load_case, load_dropout_case
 
 pytestmark = pytest.mark.gpu
 
@@ -190,3 +190,97 @@ def test_tiny_template_training_matches_oracle(dev):
               "enc_q.enc.in_layers.5.depth_conv.weight_g", "enc_q.enc.in_layers.0.point_conv.weight_v", "enc_q.pre.weight"):
         gh, gr = named[k].grad.cpu(), sg[k].grad
         assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k
+
+
+def test_training_forward_with_dropout_matches_reference(dev):
+    """p_dropout = 0.1 (configs_template/config_template.json:49): the HIP training graph with the keep decisions made
+    inside svc_attn_softmax_fwd_f32 (attention probabilities, modules/attentions.py:232) and SVC_EW_DROPOUT (attention /
+    FFN outputs and FFN hidden activations) on injected uniform draws, against the REAL reference's vectors: prior
+    statistics, pred_lf0, loss_kl, loss_lf0 and the gradients of loss_kl + loss_lf0."""
+    import models
+    import svc_autograd as A
+    from modules.losses import kl_loss
+    cs = load_dropout_case()
+    z = cs["z"]
+    cfg = cs["cfg"]
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(cs["sd_g"], strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
+    noise = {k: ([u.to(dev) for u in v] if isinstance(v, list) else v.to(dev)) for k, v in cs["noise"].items()}
+    out = net(c, f0, uv, spec, g=sid, c_lengths=lengths, spec_lengths=lengths, noise=noise)
+    y_hat, ids_slice, z_mask, (zq, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = out
+    assert np.abs(m_p.detach().cpu().numpy() - z["m_p"]).max() <= 2e-4 * max(1.0, np.abs(z["m_p"]).max())
+    assert np.abs(logs_p.detach().cpu().numpy() - z["logs_p"]).max() <= 2e-4 * max(1.0, np.abs(z["logs_p"]).max())
+    assert np.abs(pred_lf0.detach().cpu().numpy() - z["pred_lf0"]).max() <= 2e-4 * max(1.0, np.abs(z["pred_lf0"]).max())
+    loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask)
+    loss_lf0 = A.sum_sq_diff(pred_lf0, lf0) / lf0.numel()
+    assert abs(float(loss_kl) - float(z["loss_kl"])) <= 1e-4 * max(1.0, abs(float(z["loss_kl"])))
+    assert abs(float(loss_lf0) - float(z["loss_lf0"])) <= 1e-4 * max(1.0, abs(float(z["loss_lf0"])))
+    (loss_kl + loss_lf0).backward()
+    gg = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    for k, n in zip([str(k) for k in z["gnorm_keys"]], z["gnorm"]):
+        if k.endswith("conv_k.bias"):
+            continue
+        assert k in gg, k
+        assert abs(gg[k].norm().item() - n) <= 2e-3 * max(n, 1e-5), (k, gg[k].norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad."):
+            g = gg[name[5:]].numpy()
+            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
+    # without injected draws the module draws its own masks (torch.rand on the device): the statistics differ
+    n2 = dict(noise)
+    n2.pop("dropout_u")
+    with torch.no_grad():
+        m2 = net(c, f0, uv, spec, g=sid, c_lengths=lengths, spec_lengths=lengths, noise=n2)[3][2]
+    assert (m2 - m_p).abs().max().item() > 1e-3
+
+
+def test_attention_dropout_op_matches_torch(dev):
+    """svc_autograd.attention with injected dropout draws vs a plain torch fp32 restatement of
+    modules/attentions.py:207-239 (window 4, padding mask), forward and all five gradients."""
+    import math
+    import svc_autograd as A
+    g = torch.Generator().manual_seed(3)
+    B, H, dk, T, w, p = 2, 2, 24, 37, 4, 0.25
+    q, k, v = [torch.randn(B, H * dk, T, generator=g).to(dev).requires_grad_(True) for _ in range(3)]
+    ek, ev = [(torch.randn(1, 2 * w + 1, dk, generator=g) * 0.2).to(dev).requires_grad_(True) for _ in range(2)]
+    u = torch.rand(B, H, T, T, generator=g).to(dev)
+    lens = torch.tensor([T, T - 9])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().to(dev)
+    out = A.attention(q, k, v, H, ek, ev, w, mask, 1, drop_u=u, p_drop=p)
+    go = torch.randn(B, H * dk, T, generator=g).to(dev)
+    out.backward(go)
+    got = [t.grad.clone() for t in (q, k, v, ek, ev)]
+
+    def ref(q, k, v, ek, ev):
+        qh = q.view(B, H, dk, T).transpose(2, 3) / math.sqrt(dk)
+        kh = k.view(B, H, dk, T).transpose(2, 3)
+        vh = v.view(B, H, dk, T).transpose(2, 3)
+        sc = qh @ kh.transpose(-2, -1)
+        rel = qh @ ek[0].t()                                       # [B,H,T,2w+1]
+        idx = torch.arange(T, device=dev)
+        band = idx[None, :] - idx[:, None]                        # j - i
+        inb = band.abs() <= w
+        ii = idx[:, None].expand(T, T)[inb]
+        jj = idx[None, :].expand(T, T)[inb]
+        rr = (band + w)[inb]
+        relfull = torch.zeros_like(sc)
+        relfull[:, :, ii, jj] = rel[:, :, ii, rr]
+        sc = sc + relfull
+        am = mask[:, None, :, None] * mask[:, None, None, :]
+        sc = sc.masked_fill(am == 0, -1e4)
+        pa = torch.softmax(sc, -1) * ((u >= p).float() * (1.0 / (1.0 - p)))
+        o = pa @ vh
+        pb = torch.zeros(B, H, T, 2 * w + 1, device=dev)
+        pb[:, :, ii, rr] = pa[:, :, ii, jj]
+        o = o + pb @ ev[0]
+        return o.transpose(2, 3).contiguous().view(B, H * dk, T)
+
+    rq, rk, rv, rek, rev = [t.detach().clone().requires_grad_(True) for t in (q, k, v, ek, ev)]
+    ro = ref(rq, rk, rv, rek, rev)
+    assert (out - ro).abs().max().item() <= 2e-5 * max(1.0, ro.abs().max().item())
+    ro.backward(go)
+    for a, b, name in zip(got, (rq, rk, rv, rek, rev), "q k v emb_k emb_v".split()):
+        assert (a - b.grad).abs().max().item() <= 2e-4 * max(1.0, b.grad.abs().max().item()), name

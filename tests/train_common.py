@@ -29,3 +29,16 @@ def load_case():
 
 
 LOSS_KEYS = ["loss_disc", "loss_gen", "loss_fm", "loss_mel", "loss_kl", "loss_lf0", "loss_gen_all"]
+
+
+def load_dropout_case():
+    """The p_dropout = 0.1 case of tests/golden/train_dropout_small.npz (REAL reference with injected dropout draws,
+    tests/golden/make_golden_train_dropout.py): same batch / weights / noise as load_case() plus noise["dropout_u"]."""
+    z = np.load(os.path.join(G, "train_dropout_small.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    cs = load_case()
+    cfg = dict(cs["cfg"], p_dropout=meta["p_dropout"])
+    noise = dict(cs["noise"])
+    noise["dropout_u"] = W.make_dropout_draws(cfg, meta["B"], meta["T"], meta["seed"] + 3)
+    assert len(noise["dropout_u"]) == meta["n_sites"]
+    return dict(cs, z=z, meta=meta, cfg=cfg, noise=noise)
