@@ -190,6 +190,14 @@ int svc_snake_alias_bwd_f32(const float* x, const float* dy, const float* alpha,
  * (b, c) row (biased variance, like torch).  x, y:[B,C,T] contiguous. */
 int svc_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                               float eps, int apply_gelu, void* stream);
+/* Windowed-sinc polyphase resampling, the conversion in front of the unit encoder (inference/infer_tool.py:219-222:
+ * torchaudio.transforms.Resample(target_sample, 16000); :271-274 for inputs at another rate).  orig/nw are the two rates
+ * divided by their gcd; kern:[K, nw] is the filter bank (tap-major: kern[k*nw + j] = torchaudio's kernels[j, 0, k],
+ * K = 2*width + orig), built on the host by the caller; y[b, f*nw + j] = sum_k kern[k, j] * x[b, f*orig + k - width]
+ * with x read as zero outside [0, Lin).  x:[B, Lin] (row stride x_bs), y:[B, Lout] (row stride y_bs),
+ * Lout <= ceil(Lin*nw/orig). */
+int svc_resample_sinc_f32(const float* x, const float* kern, float* y, long long x_bs, long long y_bs, int B, int Lin,
+                          int Lout, int orig, int nw, int K, int width, void* stream);
 /* SinusoidalPosEmb (diffusion/wavenet.py:16-28): out[b, i] = sin(t[b] f_i), out[b, dim/2 + i] = cos(t[b] f_i),
  * f_i = exp(-i ln(10000) / (dim/2 - 1)); t:[B] float, out:[B, dim]. */
 int svc_sinusoidal_emb_f32(const float* t, float* out, int B, int dim, void* stream);

@@ -61,8 +61,16 @@ def make_state_dict(seed=1234):
 
 
 def units(sd, wav):
-    """HubertSoft.units: wav [B, 1, n] (16 kHz) -> [B, T, 256]."""
-    x = F.pad(wav, (40, 40))
+    """HubertSoft.units (:63-68): wav [B, 1, n] (16 kHz) -> [B, T, 256]: zero-pad 40 samples each side, encode, proj."""
+    return F.linear(encode(sd, wav, pad=40), sd["proj.weight"], sd["proj.bias"])
+
+
+def encode(sd, wav, layer=None, pad=0):
+    """Hubert.encode (:37-51) in eval mode: wav [B, 1, n] -> [B, T, 768] after `layer` transformer layers (None = all 12).
+    With pad=0 this is also fairseq HubertModel.extract_features(source, padding_mask=all-False, output_layer=layer)[0],
+    the call of vencoder/ContentVec768L12.py:28-36 (layer 12) and ContentVec256L9.py:28-37 (layer 9, then final_proj = `proj`):
+    the in-tree module is a re-keyed copy of that network."""
+    x = F.pad(wav, (pad, pad))
     x = F.conv1d(x, sd["feature_extractor.conv0.weight"], None, 5)
     x = F.gelu(F.group_norm(x, 512, sd["feature_extractor.norm0.weight"], sd["feature_extractor.norm0.bias"]))
     for i in range(1, 7):
@@ -77,7 +85,7 @@ def units(sd, wav):
     x = F.layer_norm(x, (768,), sd["norm.weight"], sd["norm.bias"])
     B, T, E = x.shape
     H, dk = 12, 64
-    for l in range(12):
+    for l in range(12 if layer is None else layer):
         p_ = f"encoder.layers.{l}"
         qkv = F.linear(x, sd[p_ + ".self_attn.in_proj_weight"], sd[p_ + ".self_attn.in_proj_bias"])
         q, k, v_ = [t.view(B, T, H, dk).transpose(1, 2) for t in qkv.split(E, dim=-1)]
@@ -88,4 +96,38 @@ def units(sd, wav):
         f = F.linear(F.gelu(F.linear(x, sd[p_ + ".linear1.weight"], sd[p_ + ".linear1.bias"])),
                      sd[p_ + ".linear2.weight"], sd[p_ + ".linear2.bias"])
         x = F.layer_norm(x + f, (E,), sd[p_ + ".norm2.weight"], sd[p_ + ".norm2.bias"])
-    return F.linear(x, sd["proj.weight"], sd["proj.bias"])
+    return x
+
+
+def to_fairseq_state_dict(sd):
+    """The same tensors under fairseq HubertModel's parameter names (what `checkpoint_best_legacy_500.pt` holds): test
+    fixture for the engine's fairseq-free checkpoint loader."""
+    fs = {}
+    for k, v in sd.items():
+        p = k.split(".")
+        if k.startswith("feature_extractor.conv"):
+            fs[f"feature_extractor.conv_layers.{p[1][4:]}.0.weight"] = v
+        elif k.startswith("feature_extractor.norm0"):
+            fs[f"feature_extractor.conv_layers.0.2.{p[-1]}"] = v
+        elif k.startswith("feature_projection.norm"):
+            fs["layer_norm." + p[-1]] = v
+        elif k.startswith("feature_projection.projection"):
+            fs["post_extract_proj." + p[-1]] = v
+        elif k.startswith("positional_embedding.conv"):
+            fs["encoder.pos_conv.0." + p[-1]] = v
+        elif k.startswith("norm."):
+            fs["encoder.layer_norm." + p[-1]] = v
+        elif k.startswith("proj."):
+            fs["final_proj." + p[-1]] = v
+        elif k == "masked_spec_embed":
+            fs["mask_emb"] = v
+        elif k == "label_embedding.weight":
+            fs["label_embs_concat"] = torch.zeros(504, 256)
+        elif "in_proj_" in k:
+            for n, t in zip("qkv", v.chunk(3, 0)):
+                fs[f"encoder.layers.{p[2]}.self_attn.{n}_proj.{p[-1].split('_')[-1]}"] = t.clone()
+        else:
+            m = {"self_attn.out_proj": "self_attn.out_proj", "norm1": "self_attn_layer_norm", "linear1": "fc1",
+                 "linear2": "fc2", "norm2": "final_layer_norm"}[".".join(p[3:-1])]
+            fs[f"encoder.layers.{p[2]}.{m}.{p[-1]}"] = v
+    return fs

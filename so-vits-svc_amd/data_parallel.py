@@ -51,6 +51,16 @@ def shard_batch(items, rank, world):
     """Slice every tensor of a global minibatch [B, ...] into this rank's B/world rows (B must divide)."""
     out = []
     for t in items:
+        if t is None:                 # TextAudioCollate: volume_padded without vol_embedding (data_utils.py:186)
+            out.append(None)
+            continue
+        if not torch.is_tensor(t):    # data_utils.SpecContextBatch
+            n_all = t.ext.shape[0]
+            if n_all % world:
+                raise ValueError(f"global batch {n_all} does not divide over {world} ranks")
+            k = n_all // world
+            out.append(t.rows(rank * k, (rank + 1) * k))
+            continue
         B = t.shape[0]
         if B % world:
             raise ValueError(f"global batch {B} does not divide over {world} ranks")

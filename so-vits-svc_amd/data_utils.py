@@ -6,10 +6,13 @@ the configured rate), `x.wav.soft.pt` (torch.save, units [1, ssl_dim, T50]), `x.
 collate output `(c, f0, spec, wav, spkids, lengths, uv, volume)` sorted by decreasing length, zero padded.
 
 What is re-designed: the reference computes a missing / re-scaled (vol_aug) linear spectrogram with torch.stft INSIDE
-the DataLoader worker (:60-66,98-103).  Here the worker only does I/O; such items carry `spec=None`, the collate returns
-`spec_padded=None`, and `batch_spectrogram` computes the spectrogram of the whole padded batch on the GPU in one batched
-rocFFT call (per-item reflect padding at each item's TRUE end, so the result equals the per-item computation), which is
-what keeps 8 GPUs fed without an 8x CPU STFT load.  Everything else is host-side plumbing on torch CPU tensors.
+the DataLoader worker (:60-66,98-103).  Here the worker only does I/O; such an item carries a `SpecContext` in its `spec`
+slot — exactly the samples the reference's STFT frames of that item read: the reference transforms the WHOLE (re-scaled)
+utterance and slices frames afterwards (:105-115), so the frames at a crop edge see the real neighbouring audio and only the
+utterance's true ends are reflect-padded — the collate returns a `SpecContextBatch` instead of `spec_padded`, and
+`batch_spectrogram` turns it into the [B, bins, T] spectrogram on the GPU in one batched rocFFT call.  That keeps 8 GPUs fed
+without an 8x CPU STFT load and equals the reference's per-item result.  (The reference also writes a missing `.spec.pt`
+back to disk, :66; the engine does not.)  Everything else is host-side plumbing on torch CPU tensors.
 """
 import os
 import random
@@ -19,6 +22,49 @@ import torch
 import torch.utils.data
 
 import utils
+
+
+class SpecContext:
+    """Stands in for a linear spectrogram that still has to be computed (on the GPU).  `full` [1, L]: the utterance the
+    reference would transform; `ext` [n_frames*hop + (n_fft - hop)]: after cropping, the samples frames [start, end) of that
+    transform read (reflect padding only where the utterance really ends)."""
+
+    def __init__(self, full=None, ext=None, n_frames=None):
+        self.full, self.ext, self.n_frames = full, ext, n_frames
+
+    def crop(self, start, end, hop, n_fft, scale=1.0):
+        pad = int((n_fft - hop) / 2)
+        x = self.full * scale if scale != 1.0 else self.full
+        padded = torch.nn.functional.pad(x.unsqueeze(0), (pad, pad), mode="reflect")[0, 0]
+        need = (end - start) * hop + 2 * pad
+        ext = padded[start * hop:start * hop + need]
+        if ext.shape[0] < need:                                   # audio a few samples short of its frame count
+            ext = torch.nn.functional.pad(ext, (0, need - ext.shape[0]))
+        return SpecContext(ext=ext.contiguous(), n_frames=end - start)
+
+
+class SpecContextBatch:
+    """Collated `spec` slot of a minibatch in which at least one item still needs its spectrogram: ext [B, max_frames*hop +
+    2*pad] (zero rows for items that came with a cached spectrogram), n_frames [B] (0 for those), cached [B, bins, T]
+    (zero rows for the others; None when no item was cached).  `.cuda()` / `.to()` / `.pin_memory()` like a tensor."""
+
+    def __init__(self, ext, n_frames, cached=None):
+        self.ext, self.n_frames, self.cached = ext, n_frames, cached
+
+    def _map(self, f):
+        return SpecContextBatch(f(self.ext), self.n_frames, None if self.cached is None else f(self.cached))
+
+    def to(self, *a, **k):
+        return self._map(lambda t: t.to(*a, **k))
+
+    def cuda(self, *a, **k):
+        return self._map(lambda t: t.cuda(*a, **k))
+
+    def pin_memory(self):
+        return self._map(lambda t: t.pin_memory())
+
+    def rows(self, lo, hi):
+        return SpecContextBatch(self.ext[lo:hi], self.n_frames[lo:hi], None if self.cached is None else self.cached[lo:hi])
 
 
 class TextAudioSpeakerLoader(torch.utils.data.Dataset):
@@ -50,7 +96,8 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
                 self.sampling_rate, sampling_rate, filename))
         audio_norm = (audio / self.max_wav_value).unsqueeze(0)
         spec_filename = filename.replace(".wav", ".spec.pt")
-        spec = torch.load(spec_filename) if os.path.exists(spec_filename) else None     # None -> computed on the GPU
+        # no cached spectrogram: computed on the GPU from the utterance as the reference transforms it (:62-64)
+        spec = torch.load(spec_filename) if os.path.exists(spec_filename) else SpecContext(full=audio_norm)
         spk = filename.split("/")[-2]
         spk = torch.LongTensor([self.spk_map[spk]])
         f0, uv = np.load(filename + ".f0.npy", allow_pickle=True)
@@ -59,14 +106,17 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
         c = torch.load(filename + ".soft.pt")
         c = utils.repeat_expand_2d(c.squeeze(0), f0.shape[0], mode=self.unit_interpolate_mode)
         volume = torch.from_numpy(np.load(filename + ".vol.npy")).float() if self.vol_emb else None
-        n_spec = spec.size(-1) if spec is not None else audio_norm.shape[1] // self.hop_length
+        n_spec = spec.size(-1) if torch.is_tensor(spec) else audio_norm.shape[1] // self.hop_length
         lmin = min(c.size(-1), n_spec)
         assert abs(c.size(-1) - n_spec) < 3, (c.size(-1), n_spec, f0.shape, filename)
         assert abs(audio_norm.shape[1] - lmin * self.hop_length) < 3 * self.hop_length
         c, f0, uv = c[:, :lmin], f0[:lmin], uv[:lmin]
-        if spec is not None:
+        if torch.is_tensor(spec):
             spec = spec[:, :lmin]
+        audio_full = audio_norm
         audio_norm = audio_norm[:, :lmin * self.hop_length]
+        if not torch.is_tensor(spec):
+            spec.n_frames = lmin
         if volume is not None:
             volume = volume[:lmin]
         return c, f0, spec, audio_norm, spk, uv, volume
@@ -76,19 +126,25 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
             max_amp = float(torch.max(torch.abs(audio_norm))) + 1e-5
             max_shift = min(1, np.log10(1 / max_amp))
             log10_vol_shift = random.uniform(-1, max_shift)
-            audio_norm = audio_norm * (10 ** log10_vol_shift)
-            volume = volume * (10 ** log10_vol_shift)
-            spec = None                                 # re-scaled audio: spectrogram recomputed on the GPU
+            scale = 10 ** log10_vol_shift
+            # re-scaled audio: the reference re-transforms the whole re-scaled utterance (:105-110); done on the GPU here
+            full = spec.full * scale if isinstance(spec, SpecContext) else audio_norm * scale
+            audio_norm = audio_norm * scale
+            volume = volume * scale
+            spec = SpecContext(full=full, n_frames=c.shape[1])
         n = c.shape[1]
+        start, end = 0, n
         if n > 800:
             start = random.randint(0, n - 800)
             end = start + 790
             c, f0, uv = c[:, start:end], f0[start:end], uv[start:end]
-            if spec is not None:
+            if torch.is_tensor(spec):
                 spec = spec[:, start:end]
             audio_norm = audio_norm[:, start * self.hop_length: end * self.hop_length]
             if volume is not None:
                 volume = volume[start:end]
+        if isinstance(spec, SpecContext):
+            spec = spec.crop(start, end, self.hop_length, self.filter_length)
         return c, f0, spec, audio_norm, spk, uv, volume
 
     def __getitem__(self, index):
@@ -111,8 +167,15 @@ class TextAudioCollate:
         lengths = torch.LongTensor(n)
         c_padded = torch.zeros(n, batch[0][0].shape[0], max_c_len)
         f0_padded = torch.zeros(n, max_c_len)
-        have_spec = all(x[2] is not None for x in batch)
-        spec_padded = torch.zeros(n, batch[0][2].shape[0], max_c_len) if have_spec else None
+        have_spec = all(torch.is_tensor(x[2]) for x in batch)
+        if have_spec:
+            spec_padded = torch.zeros(n, batch[0][2].shape[0], max_c_len)
+        else:       # vol_aug re-scales a random half of the items: cached and to-be-computed spectrograms share a batch
+            ext_len = max(x[2].ext.shape[0] for x in batch if isinstance(x[2], SpecContext))
+            ext_padded = torch.zeros(n, ext_len)
+            ext_frames = torch.zeros(n, dtype=torch.long)
+            cached = [x[2] for x in batch if torch.is_tensor(x[2])]
+            spec_cached = torch.zeros(n, cached[0].shape[0], max_c_len) if cached else None
         wav_padded = torch.zeros(n, 1, max_wav_len)
         spkids = torch.LongTensor(n, 1)
         uv_padded = torch.zeros(n, max_c_len)
@@ -125,6 +188,11 @@ class TextAudioCollate:
             f0_padded[i, :row[1].size(0)] = row[1]
             if have_spec:
                 spec_padded[i, :, :row[2].size(1)] = row[2]
+            elif torch.is_tensor(row[2]):
+                spec_cached[i, :, :row[2].size(1)] = row[2]
+            else:
+                ext_padded[i, :row[2].ext.shape[0]] = row[2].ext
+                ext_frames[i] = row[2].n_frames
             wav_padded[i, :, :row[3].size(1)] = row[3]
             spkids[i, 0] = row[4]
             uv_padded[i, :row[5].size(0)] = row[5]
@@ -132,7 +200,27 @@ class TextAudioCollate:
                 volume_padded[i, :row[6].size(0)] = row[6]
             else:
                 volume_padded = None
+        if not have_spec:
+            spec_padded = SpecContextBatch(ext_padded, ext_frames, spec_cached)
         return c_padded, f0_padded, spec_padded, wav_padded, spkids, lengths, uv_padded, volume_padded
+
+
+def context_spectrogram(ctx, n_fft, sampling_rate, hop_size, win_size):
+    """SpecContextBatch (on the device) -> [B, n_fft/2+1, max frames], zero beyond each item's frame count: one batched
+    framing + rocFFT + magnitude over signals that already carry their (n_fft-hop)/2 context on both sides."""
+    from modules.mel_processing import spectrogram_torch
+    T = int(ctx.n_frames.max())
+    spec = spectrogram_torch(ctx.ext, n_fft, sampling_rate, hop_size, win_size, center=False, n_frames=T, prepadded=True)
+    dev = spec.device
+    keep = (torch.arange(T, device=dev).view(1, 1, T) < ctx.n_frames.to(dev).view(-1, 1, 1)).to(spec.dtype)
+    spec = spec * keep
+    if ctx.cached is not None:          # rows that came with a cached spectrogram have n_frames = 0 (all-zero rows above)
+        Tc = ctx.cached.shape[2]
+        if Tc > T:
+            spec = torch.nn.functional.pad(spec, (0, Tc - T))
+        spec = spec.clone()
+        spec[:, :, :Tc] += ctx.cached.to(dev)
+    return spec
 
 
 def batch_spectrogram(wav_padded, lengths, n_fft, sampling_rate, hop_size, win_size):

@@ -85,14 +85,15 @@ def spectral_normalize_torch(magnitudes):
     return dynamic_range_compression_torch(magnitudes)
 
 
-def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, n_frames=None, eps=1e-6):
+def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False, n_frames=None, eps=1e-6, prepadded=False):
     """y [B, L] in [-1, 1] -> |STFT| [B, n_fft/2+1, frames] (reference :40-64).  n_frames (optional) limits the number of
-    frames produced (data_utils.batch_spectrogram passes signals that already carry their right-hand extension)."""
+    frames produced (data_utils.batch_spectrogram passes signals that already carry their right-hand extension);
+    prepadded=True: y already holds the (n_fft-hop)/2 samples of context on both sides (no reflect padding is added)."""
     if center or win_size != n_fft:
         raise NotImplementedError("only center=False, win_size == n_fft is used by so-vits-svc")
     y = y.float()
     B, L = y.shape
-    pad = int((n_fft - hop_size) / 2)
+    pad = 0 if prepadded else int((n_fft - hop_size) / 2)
     NF = (L + 2 * pad - n_fft) // hop_size + 1
     if n_frames is not None:
         NF = min(NF, int(n_frames))

@@ -16,12 +16,24 @@ multi-tensor copy per step), Adam moments are two more flat buffers.  Consequenc
 torch.optim.AdamW's exact update rule; parameters that received no gradient since the last `zero_grad` are skipped,
 like torch does for `p.grad is None`.
 """
+import weakref
+
 import torch
 
 import svc_hip as S
 
 _ALIGN = 64          # elements: every parameter starts on a 256-byte boundary (coalesced float4 access, RCCL alignment)
-_ARENA_OF = {}       # id(param) -> (arena, index); parameters are kept alive by the arena
+_ARENA_ATTR = "_svc_arena"   # on each parameter: (weakref to its arena, index).  Weak: an arena (0.8 GB of flat buffers for G)
+                             # lives exactly as long as its optimizer / reducer hold it, and a parameter whose arena is gone
+                             # can join a new one (rebuilt optimizers in one process: test suites, notebooks, Svc reloads)
+
+
+def _arena_of(p):
+    ent = getattr(p, _ARENA_ATTR, None)
+    if ent is None:
+        return None
+    arena = ent[0]()
+    return None if arena is None or arena.released else (arena, ent[1])
 
 
 class ParamArena:
@@ -36,10 +48,11 @@ class ParamArena:
             if p.device != dev or p.dtype != torch.float32:
                 raise S.SvcError("ParamArena: all parameters must be fp32 on one device "
                                  f"(got {p.dtype} on {p.device} vs {dev})")
-            if id(p) in _ARENA_OF:
-                raise S.SvcError("ParamArena: parameter already belongs to another arena")
+            if _arena_of(p) is not None:
+                raise S.SvcError("ParamArena: parameter already belongs to another (live) arena; release() it first")
         self.params = params
         self.device = dev
+        self.released = False
         self.offsets, off = [], 0
         for p in params:
             self.offsets.append(off)
@@ -66,13 +79,35 @@ class ParamArena:
                 self._gviews.append(self.grad[o:o + p.numel()].view(p.shape))
                 if p.grad is not None:
                     self.touched[i] = True
-                _ARENA_OF[id(p)] = (self, i)
+                setattr(p, _ARENA_ATTR, (weakref.ref(self), i))
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
     def _make_hook(self, i):
+        ref = weakref.ref(self)          # the hook must not keep the arena alive through its parameters
+
         def hook(p):
-            self._on_grad(i, p)
+            arena = ref()
+            if arena is not None and not arena.released:
+                arena._on_grad(i, p)
         return hook
+
+    def release(self):
+        """Detach from the parameters: hooks removed, every parameter gets its own storage back (a copy of its current
+        value) and may join another arena.  The flat buffers are freed once the last reference to the arena goes."""
+        if self.released:
+            return
+        self.released = True
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._listeners = []
+        with torch.no_grad():
+            for p in self.params:
+                p.data = p.data.clone()
+                if p.grad is not None:
+                    p.grad = None
+                if hasattr(p, _ARENA_ATTR):
+                    delattr(p, _ARENA_ATTR)
 
     def _on_grad(self, i, p):
         self.touched[i] = True
@@ -158,7 +193,7 @@ class ParamArena:
 def arena_for(params):
     """The arena holding exactly `params` (created on first use)."""
     params = list(params)
-    hit = _ARENA_OF.get(id(params[0]))
+    hit = _arena_of(params[0])
     if hit is not None:
         arena = hit[0]
         if len(arena.params) == len(params) and all(a is b for a, b in zip(arena.params, params)):
@@ -197,6 +232,11 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         self.arena.zero_grad()
+
+    def release(self):
+        """Give the parameters their own storage back and drop the arena (call before discarding the optimizer when the
+        model lives on, e.g. to build a new optimizer over the same parameters)."""
+        self.arena.release()
 
     # -- hyper-parameters in device memory (svc_adamw_f32 reads them there: hipGraph-safe) ----------------------------
     def _host_hyper(self):

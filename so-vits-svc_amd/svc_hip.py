@@ -111,6 +111,7 @@ def lib():
         L.svc_sinusoidal_emb_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_void_p]
         L.svc_nsf_source_exact_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
         L.svc_channel_norm_gelu_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
+        L.svc_resample_sinc_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 2 + [C.c_int] * 7 + [C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
         _lib = L
@@ -122,7 +123,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
+    "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
 
@@ -309,6 +310,22 @@ def sinusoidal_emb(t, dim):
     out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
     check(lib().svc_sinusoidal_emb_f32(ptr(t), ptr(out), t.shape[0], dim, stream_ptr()), "sinusoidal_emb")
     return out
+
+
+def resample_sinc(x, kern, orig, new, width, Lout=None):
+    """x [B, Lin] -> [B, Lout] through the [K, new] filter bank `kern` (see include/svc_hip.h); orig/new already reduced."""
+    require_gpu(x, kern)
+    x = x.contiguous()
+    B, Lin = x.shape
+    K = kern.shape[0]
+    if tuple(kern.shape) != (2 * width + orig, new):
+        raise SvcError(f"resample_sinc: kernel bank {tuple(kern.shape)} != {(2 * width + orig, new)}")
+    full = -(-Lin * new // orig)
+    Lout = full if Lout is None else Lout
+    y = torch.empty((B, Lout), device=x.device, dtype=torch.float32)
+    check(lib().svc_resample_sinc_f32(ptr(x), ptr(kern.contiguous()), ptr(y), x.stride(0), y.stride(0), B, Lin, Lout, orig, new,
+                                      K, width, stream_ptr()), "resample_sinc")
+    return y
 
 
 def nsf_source_exact(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0.1, noise_std=0.003):

@@ -134,9 +134,12 @@ class TrainStep:
         c, f0, spec, y, spk, lengths, uv, volume = items
         net_g, net_d = self.net_g, self.net_d
         seg_frames = self.segment_size // self.hop
-        if spec is None:          # loader items without a cached .spec.pt / vol-augmented audio: STFT of the batch on the GPU
+        if spec is None:          # no spectrogram supplied at all: STFT of the padded batch on the GPU
             from data_utils import batch_spectrogram
             spec = batch_spectrogram(y, lengths, self.n_fft, self.sr, self.hop, self.win)
+        elif not torch.is_tensor(spec):   # loader items without a cached .spec.pt / vol-augmented audio (data_utils.SpecContextBatch)
+            from data_utils import context_spectrogram
+            spec = context_spectrogram(spec.to(y.device), self.n_fft, self.sr, self.hop, self.win)
         mel = spec_to_mel_torch(spec, self.n_fft, self.n_mels, self.sr, self.fmin, self.fmax)            # :158-164
         kw = dict(noise=noise) if noise is not None else {}
         y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(

@@ -6,8 +6,13 @@
   HParams / InferHParams / get_hparams_from_file   utils.py:353-358,514-557   (host, JSON -> attribute dict)
   load_checkpoint / save_checkpoint / latest_checkpoint_path   utils.py:155-200,238-243   (host, torch.save format)
 
-Everything outside that slice (faiss index training, speech-encoder / f0-predictor factories, matplotlib logging)
-is out of scope and deliberately absent.
+  get_speech_encoder / get_f0_predictor           utils.py:88-153   (factories `Svc` calls; engine encoders or the reference's)
+  get_hparams / get_logger / check_git_hash / summarize / clean_checkpoints / plot_*   utils.py:46-66,202-298,312-394
+                                                   (train.py's run-directory, logging and TensorBoard helpers: host only)
+  change_rms, mix_model                            utils.py:427-459
+
+Every other name of the reference's utils.py (train_index / faiss, ...) falls through to the reference checkout's own
+utils.py when one follows this package on sys.path (module __getattr__ at the bottom, svc_overlay).
 """
 import glob
 import json
@@ -19,6 +24,9 @@ import numpy as np
 import torch
 
 import svc_hip as S
+import svc_overlay
+
+svc_overlay.install()
 
 logger = logging.getLogger(__name__)
 
@@ -186,3 +194,233 @@ class Volume_Extractor:
         a2 = torch.nn.functional.pad((audio ** 2)[:, None, :], (self.hop_size // 2, (self.hop_size + 1) // 2),
                                      mode="reflect")[:, 0]
         return a2[:, :n_frames * self.hop_size].reshape(a2.shape[0], n_frames, self.hop_size).mean(-1)[0].sqrt()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# factories for the front-ends `Svc` builds (utils.py:88-153).  The encoders this engine mirrors come from this package's
+# vencoder/; every other name is imported the reference's way and resolves — through svc_overlay — to the reference
+# checkout next on sys.path, with whatever third-party packages that module needs.
+# ------------------------------------------------------------------------------------------------------------
+_F0_PREDICTORS = {"pm": "PMF0Predictor", "crepe": "CrepeF0Predictor", "harvest": "HarvestF0Predictor",
+                  "dio": "DioF0Predictor", "rmvpe": "RMVPEF0Predictor", "fcpe": "FCPEF0Predictor"}
+_SPEECH_ENCODERS = {"vec768l12": "ContentVec768L12", "vec256l9": "ContentVec256L9", "vec256l9-onnx": "ContentVec256L9_Onnx",
+                    "vec256l12-onnx": "ContentVec256L12_Onnx", "vec768l9-onnx": "ContentVec768L9_Onnx",
+                    "vec768l12-onnx": "ContentVec768L12_Onnx", "hubertsoft-onnx": "HubertSoft_Onnx", "hubertsoft": "HubertSoft",
+                    "whisper-ppg": "WhisperPPG", "cnhubertlarge": "CNHubertLarge", "dphubert": "DPHubert",
+                    "whisper-ppg-large": "WhisperPPGLarge", "wavlmbase+": "WavLMBasePlus"}
+
+
+def get_f0_predictor(f0_predictor, hop_length, sampling_rate, **kargs):
+    """utils.py:88-109: name -> modules.F0Predictor.<Class>(hop_length, sampling_rate[, dtype, device, threshold])."""
+    import importlib
+    cls_name = _F0_PREDICTORS.get(f0_predictor)
+    if cls_name is None:
+        raise Exception("Unknown f0 predictor")
+    cls = getattr(importlib.import_module("modules.F0Predictor." + cls_name), cls_name)
+    kw = dict(hop_length=hop_length, sampling_rate=sampling_rate)
+    if f0_predictor in ("crepe", "rmvpe", "fcpe"):
+        kw.update(device=kargs["device"], threshold=kargs["threshold"])
+    if f0_predictor in ("rmvpe", "fcpe"):
+        kw.update(dtype=torch.float32)
+    return cls(**kw)
+
+
+def get_speech_encoder(speech_encoder, device=None, **kargs):
+    """utils.py:111-153: name -> vencoder.<Class>(device=device)."""
+    import importlib
+    cls_name = _SPEECH_ENCODERS.get(speech_encoder)
+    if cls_name is None:
+        raise Exception("Unknown speech encoder")
+    return getattr(importlib.import_module("vencoder." + cls_name), cls_name)(device=device)
+
+
+def get_content(cmodel, y):
+    """utils.py:82-86."""
+    with torch.no_grad():
+        c = cmodel.extract_features(y.squeeze(1))[0]
+    return c.transpose(1, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# run directory / logging helpers of train.py (utils.py:202-236,312-394): host-side bookkeeping, no device work
+# ------------------------------------------------------------------------------------------------------------
+def get_hparams(init=True):
+    """`-c config.json -m model_name` -> HParams with .model_dir = ./logs/<model>; the config is copied there on a fresh
+    start and read back from there otherwise (utils.py:312-339)."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-c", "--config", type=str, default="./configs/config.json", help="JSON file for configuration")
+    parser.add_argument("-m", "--model", type=str, required=True, help="Model name")
+    args = parser.parse_args()
+    model_dir = os.path.join("./logs", args.model)
+    os.makedirs(model_dir, exist_ok=True)
+    saved = os.path.join(model_dir, "config.json")
+    if init:
+        with open(args.config, "r") as f:
+            text = f.read()
+        with open(saved, "w") as f:
+            f.write(text)
+    else:
+        with open(saved, "r") as f:
+            text = f.read()
+    hparams = HParams(**json.loads(text))
+    hparams.model_dir = model_dir
+    return hparams
+
+
+def get_hparams_from_dir(model_dir):
+    hparams = get_hparams_from_file(os.path.join(model_dir, "config.json"))
+    hparams.model_dir = model_dir
+    return hparams
+
+
+def check_git_hash(model_dir):
+    """Warn when the run directory was started from another commit of the SOURCE tree (utils.py:361-378)."""
+    import subprocess
+    source_dir = os.path.dirname(os.path.realpath(__file__))
+    if not os.path.exists(os.path.join(source_dir, ".git")):
+        logger.warning("%s is not a git repository, therefore hash value comparison will be ignored.", source_dir)
+        return
+    cur_hash = subprocess.getoutput("git rev-parse HEAD")
+    path = os.path.join(model_dir, "githash")
+    if os.path.exists(path):
+        with open(path) as f:
+            saved_hash = f.read()
+        if saved_hash != cur_hash:
+            logger.warning("git hash values are different. %s(saved) != %s(current)", saved_hash[:8], cur_hash[:8])
+    else:
+        with open(path, "w") as f:
+            f.write(cur_hash)
+
+
+def get_logger(model_dir, filename="train.log"):
+    global logger
+    logger = logging.getLogger(os.path.basename(model_dir))
+    logger.setLevel(logging.DEBUG)
+    os.makedirs(model_dir, exist_ok=True)
+    h = logging.FileHandler(os.path.join(model_dir, filename))
+    h.setLevel(logging.DEBUG)
+    h.setFormatter(logging.Formatter("%(asctime)s\t%(name)s\t%(levelname)s\t%(message)s"))
+    logger.addHandler(h)
+    return logger
+
+
+def clean_checkpoints(path_to_models="logs/44k/", n_ckpts_to_keep=2, sort_by_time=True):
+    """Delete all but the newest `n_ckpts_to_keep` G_*/D_* checkpoints (G_0 / D_0 always stay), utils.py:202-225."""
+    files = [f for f in os.listdir(path_to_models) if os.path.isfile(os.path.join(path_to_models, f))]
+    if sort_by_time:
+        key = lambda f: os.path.getmtime(os.path.join(path_to_models, f))          # noqa: E731
+    else:
+        key = lambda f: int(re.compile("._(\\d+)\\.pth").match(f).group(1))       # noqa: E731
+    for prefix in ("G", "D"):
+        ordered = sorted([f for f in files if f.startswith(prefix) and not f.endswith("_0.pth")], key=key)
+        for f in ordered[:-n_ckpts_to_keep]:
+            os.remove(os.path.join(path_to_models, f))
+            logger.info(".. Free up space by deleting ckpt %s", os.path.join(path_to_models, f))
+
+
+def summarize(writer, global_step, scalars={}, histograms={}, images={}, audios={}, audio_sampling_rate=22050):
+    """TensorBoard fan-out (utils.py:227-235); `writer` is whatever SummaryWriter-like object the caller built."""
+    for k, v in scalars.items():
+        writer.add_scalar(k, v, global_step)
+    for k, v in histograms.items():
+        writer.add_histogram(k, v, global_step)
+    for k, v in images.items():
+        writer.add_image(k, v, global_step, dataformats="HWC")
+    for k, v in audios.items():
+        writer.add_audio(k, v, global_step, audio_sampling_rate)
+
+
+def _figure_to_numpy(fig):
+    fig.canvas.draw()
+    data = np.frombuffer(fig.canvas.buffer_rgba(), dtype=np.uint8).reshape(fig.canvas.get_width_height()[::-1] + (4,))
+    return np.ascontiguousarray(data[:, :, :3])
+
+
+def _pyplot():
+    import matplotlib
+    matplotlib.use("Agg")
+    logging.getLogger("matplotlib").setLevel(logging.WARNING)
+    import matplotlib.pylab as plt
+    return plt
+
+
+def plot_spectrogram_to_numpy(spectrogram):
+    """utils.py:246-269: [bins, frames] -> RGB image array for TensorBoard."""
+    plt = _pyplot()
+    fig, ax = plt.subplots(figsize=(10, 2))
+    im = ax.imshow(spectrogram, aspect="auto", origin="lower", interpolation="none")
+    plt.colorbar(im, ax=ax)
+    plt.xlabel("Frames")
+    plt.ylabel("Channels")
+    plt.tight_layout()
+    data = _figure_to_numpy(fig)
+    plt.close()
+    return data
+
+
+def plot_data_to_numpy(x, y):
+    """utils.py:46-66: two curves on one axis -> RGB image array."""
+    plt = _pyplot()
+    fig, ax = plt.subplots(figsize=(10, 2))
+    plt.plot(x)
+    plt.plot(y)
+    plt.tight_layout()
+    data = _figure_to_numpy(fig)
+    plt.close()
+    return data
+
+
+def plot_alignment_to_numpy(alignment, info=None):
+    """utils.py:272-298."""
+    plt = _pyplot()
+    fig, ax = plt.subplots(figsize=(6, 4))
+    im = ax.imshow(alignment.transpose(), aspect="auto", origin="lower", interpolation="none")
+    fig.colorbar(im, ax=ax)
+    plt.xlabel("Decoder timestep" + ("\n\n" + info if info is not None else ""))
+    plt.ylabel("Encoder timestep")
+    plt.tight_layout()
+    data = _figure_to_numpy(fig)
+    plt.close()
+    return data
+
+
+def change_rms(data1, sr1, data2, sr2, rate):
+    """utils.py:440-459 (loudness-envelope transfer, `-lea`): data2 *= rms1^(1-rate) * rms2^(rate-1) with the half-second
+    RMS envelopes of the input (data1, numpy) and the output (data2, device tensor) linearly interpolated to data2's length."""
+    import svc_audio
+    F = torch.nn.functional
+    rms1 = svc_audio.frame_rms(np.asarray(data1), sr1 // 2 * 2, sr1 // 2)[None, :]
+    rms2 = svc_audio.frame_rms(data2.detach().cpu().numpy(), sr2 // 2 * 2, sr2 // 2)[None, :]
+    rms1 = F.interpolate(torch.from_numpy(rms1).to(data2.device).unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = F.interpolate(torch.from_numpy(rms2).to(data2.device).unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = torch.max(rms2, torch.zeros_like(rms2) + 1e-6)
+    data2 *= torch.pow(rms1, torch.tensor(1 - rate)) * torch.pow(rms2, torch.tensor(rate - 1))
+    return data2
+
+
+def mix_model(model_paths, mix_rate, mode):
+    """utils.py:427-438: weighted average of checkpoints (mode 0: softmax of the rates)."""
+    rate = torch.FloatTensor(mix_rate) / 100
+    base = torch.load(model_paths[0], map_location="cpu")
+    models = [torch.load(path, map_location="cpu")["model"] for path in model_paths]
+    if mode == 0:
+        rate = torch.softmax(rate, dim=0)
+    for k in base["model"].keys():
+        base["model"][k] = sum(m[k] * rate[i] for i, m in enumerate(models))
+    out = os.path.join(os.path.curdir, "output.pth")
+    torch.save(base, out)
+    return out
+
+
+def __getattr__(name):
+    """Names of the reference's utils.py that this engine does not restate (train_index / faiss, ...) resolve to the
+    reference checkout's own utils.py when one is on sys.path behind this package (svc_overlay)."""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    import svc_overlay
+    ref = svc_overlay.load_reference_module("utils", "_svc_reference_utils")
+    if ref is not None and hasattr(ref, name):
+        return getattr(ref, name)
+    raise AttributeError(f"module 'utils' (MI355X engine mirror) has no attribute {name!r}"
+                         + ("" if ref is not None else " and no reference checkout is on sys.path to take it from"))

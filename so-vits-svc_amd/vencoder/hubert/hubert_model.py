@@ -15,9 +15,12 @@ LayerNorms there, so the two `transpose(1, 2)` of :42,:124-127 never materialise
                               out_proj, add+LayerNorm, FFN 768->3072 (GELU epilogue) ->768, add+LayerNorm
   proj (:26,:68)              Linear(768,256)                    1x1 MFMA conv
 
-The fairseq ContentVec encoders (vencoder/ContentVec768L12.py etc.) are the same architecture under different
-parameter names (q_proj/k_proj/v_proj, fc1/fc2, post_extract_proj, ...); fairseq and its checkpoint are absent here, so
-only this in-tree variant is parity-pinned (tests/golden/hubert_soft_1s.npz from the real module).  Inference only.
+The fairseq ContentVec encoders (vencoder/ContentVec768L12.py, ContentVec256L9.py: fairseq `HubertModel`,
+`extract_features(source, padding_mask, output_layer=L)`) are the same network under fairseq's parameter names;
+`hubert_from_fairseq_state_dict` / `load_fairseq_hubert` below map a `checkpoint_best_legacy_500.pt` onto this module
+(q_proj|k_proj|v_proj -> in_proj, fc1/fc2 -> linear1/2, post_extract_proj -> feature_projection.projection, ...) without
+importing fairseq.  fairseq and its checkpoint are absent from this image, so that mapping is UNPINNED against fairseq itself;
+the arithmetic is pinned through this in-tree variant (tests/golden/hubert_soft_1s.npz from the real module).  Inference only.
 """
 import copy
 from typing import Optional
@@ -70,6 +73,11 @@ class Hubert(nn.Module):
             x = self.encoder(x, self, output_layer=layer)
         return x, None
 
+    def project(self, x):
+        """`proj` / fairseq `final_proj` on channel-major features: [B, 768, T] -> [B, P, T] (1x1 MFMA conv)."""
+        wp = self._packed("proj", lambda: _pack(self.proj.weight.unsqueeze(-1)))
+        return S.conv1d(x, wp, self.proj.out_features, 1, bias=self.proj.bias)
+
     def logits(self, x):
         raise NotImplementedError("label logits are a training-time head of HuBERT (out of scope)")
 
@@ -85,9 +93,7 @@ class HubertSoft(Hubert):
     def units(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B, 1, n] -> soft units [B, T, 256] (reference :63-68: zero-pad 40 samples each side, encode, proj)."""
         x, _ = self._encode_padded(wav)
-        wp = self._packed("proj", lambda: _pack(self.proj.weight.unsqueeze(-1)))
-        u = S.conv1d(x, wp, 256, 1, bias=self.proj.bias)
-        return u.transpose(1, 2)
+        return self.project(x).transpose(1, 2)
 
     def _encode_padded(self, wav):
         self.feature_extractor.pad = (400 - 320) // 2
@@ -207,3 +213,100 @@ def hubert_soft(path: str) -> HubertSoft:
     hubert.load_state_dict(checkpoint)
     hubert.eval()
     return hubert
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fairseq HubertModel checkpoints (vencoder/ContentVec768L12.py:12-15: checkpoint_utils.load_model_ensemble_and_task)
+# ------------------------------------------------------------------------------------------------------------
+_FAIRSEQ_DIRECT = {
+    "feature_extractor.conv_layers.0.2.weight": "feature_extractor.norm0.weight",
+    "feature_extractor.conv_layers.0.2.bias": "feature_extractor.norm0.bias",
+    "layer_norm.weight": "feature_projection.norm.weight", "layer_norm.bias": "feature_projection.norm.bias",
+    "post_extract_proj.weight": "feature_projection.projection.weight",
+    "post_extract_proj.bias": "feature_projection.projection.bias",
+    "encoder.pos_conv.0.bias": "positional_embedding.conv.bias",
+    "encoder.pos_conv.0.weight_g": "positional_embedding.conv.weight_g",
+    "encoder.pos_conv.0.weight_v": "positional_embedding.conv.weight_v",
+    "encoder.layer_norm.weight": "norm.weight", "encoder.layer_norm.bias": "norm.bias",
+    "final_proj.weight": "proj.weight", "final_proj.bias": "proj.bias", "mask_emb": "masked_spec_embed",
+}
+_FAIRSEQ_LAYER = {"self_attn.out_proj": "self_attn.out_proj", "self_attn_layer_norm": "norm1", "fc1": "linear1",
+                  "fc2": "linear2", "final_layer_norm": "norm2"}
+
+
+def hubert_from_fairseq_state_dict(fsd):
+    """fairseq `HubertModel.state_dict()` (HuBERT-base: extractor_mode 'default', conv_bias False, layer_norm_first False)
+    -> the key layout of `Hubert` above.  Tensors are re-used, q/k/v projections are concatenated into in_proj_*;
+    `label_embs_concat` (training head) is dropped."""
+    out = {}
+    for k, v in fsd.items():
+        if k in _FAIRSEQ_DIRECT:
+            out[_FAIRSEQ_DIRECT[k]] = v
+            continue
+        parts = k.split(".")
+        if k.startswith("feature_extractor.conv_layers.") and parts[3] == "0" and parts[4] == "weight":
+            out[f"feature_extractor.conv{parts[2]}.weight"] = v
+            continue
+        if k.startswith("encoder.layers."):
+            li, rest = parts[2], ".".join(parts[3:-1])
+            leaf = parts[-1]
+            if rest in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"):
+                continue                                          # gathered below
+            if rest in _FAIRSEQ_LAYER:
+                out[f"encoder.layers.{li}.{_FAIRSEQ_LAYER[rest]}.{leaf}"] = v
+                continue
+        if k == "label_embs_concat":
+            continue
+        raise KeyError(f"unexpected key in a fairseq HuBERT checkpoint: {k}")
+    n_layers = 1 + max(int(k.split(".")[2]) for k in fsd if k.startswith("encoder.layers."))
+    for li in range(n_layers):
+        for leaf in ("weight", "bias"):
+            out[f"encoder.layers.{li}.self_attn.in_proj_{leaf}"] = torch.cat(
+                [fsd[f"encoder.layers.{li}.self_attn.{p}_proj.{leaf}"] for p in "qkv"], 0)
+    return out
+
+
+def _load_fairseq_pickle(path):
+    """torch.load of a fairseq checkpoint without fairseq installed: its `cfg` / `args` entries pickle fairseq / omegaconf
+    classes, which are replaced by inert placeholders (only the `model` tensors are used)."""
+    import pickle
+    import types
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            self.__dict__["state"] = state
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return type(name, (_Stub,), {"__module__": module})
+
+    shim = types.ModuleType("svc_fairseq_pickle")
+    shim.Unpickler = _Unpickler
+    shim.load = lambda f, **kw: _Unpickler(f, **kw).load()
+    shim.__name__ = "pickle"
+    for attr in ("PickleError", "UnpicklingError", "dump", "dumps", "loads", "HIGHEST_PROTOCOL"):
+        setattr(shim, attr, getattr(pickle, attr))
+    return torch.load(path, map_location="cpu", pickle_module=shim, weights_only=False)
+
+
+def load_fairseq_hubert(path, num_label_embeddings=100):
+    """`checkpoint_best_legacy_500.pt` (ContentVec, fairseq format) -> `Hubert` in eval mode."""
+    ckpt = _load_fairseq_pickle(path)
+    fsd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    sd = hubert_from_fairseq_state_dict(fsd)
+    model = Hubert(num_label_embeddings=num_label_embeddings)
+    own = model.state_dict()
+    if "proj.weight" in sd and tuple(sd["proj.weight"].shape) != tuple(own["proj.weight"].shape):
+        model.proj = nn.Linear(sd["proj.weight"].shape[1], sd["proj.weight"].shape[0])
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    allowed = {"label_embedding.weight", "masked_spec_embed", "proj.weight", "proj.bias"}
+    bad = [k for k in missing if k not in allowed]
+    if bad or unexpected:
+        raise RuntimeError(f"fairseq HuBERT checkpoint does not fit the HuBERT-base layout: missing {bad}, unexpected {unexpected}")
+    return model.eval()

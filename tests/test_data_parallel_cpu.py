@@ -184,3 +184,30 @@ def test_arena_touched_runs_and_foreign_grad():
     assert ps[1].grad.data_ptr() == a.grad.data_ptr() + 4 * 64 and torch.equal(a.grad[64:134], torch.full((70,), 3.0))
     a.zero_grad()
     assert not any(a.touched) and a.grad.abs().max().item() == 0
+
+
+def test_param_arena_is_released_with_its_optimizer():
+    """the id(param) -> arena registry kept every arena (flat param / grad / Adam buffers) alive for the life
+    of the process and made a parameter un-registrable once its optimizer was gone."""
+    import gc
+    import weakref
+    import optim
+    lin = torch.nn.Linear(8, 8)
+    a1 = optim.ParamArena(lin.parameters())
+    assert optim.arena_for(lin.parameters()) is a1
+    with pytest.raises(Exception):
+        optim.ParamArena(lin.parameters())              # still owned by a live arena
+    w = lin.weight.detach().clone()
+    ref = weakref.ref(a1)
+    a1.release()
+    assert torch.equal(lin.weight, w) and lin.weight.data_ptr() != a1.param.data_ptr()
+    del a1
+    gc.collect()
+    assert ref() is None                                 # nothing else holds the flat buffers
+    a2 = optim.ParamArena(lin.parameters())              # the parameters can join a new arena
+    ref2 = weakref.ref(a2)
+    del a2                                               # dropped WITHOUT release(): must not stay reachable either
+    gc.collect()
+    assert ref2() is None
+    a3 = optim.ParamArena(lin.parameters())
+    assert optim.arena_for(lin.parameters()) is a3

@@ -65,7 +65,10 @@ def test_loader_and_collate_invariants(tmp_path):
     for c, f0, spec, wav, spk, uv, vol in items:
         T = c.shape[1]
         assert c.shape[0] == SSL and f0.shape == (T,) and uv.shape == (T,) and wav.shape == (1, T * HOP) and vol.shape == (T,)
-        assert spec is None or spec.shape == (NFFT // 2 + 1, T)
+        if torch.is_tensor(spec):
+            assert spec.shape == (NFFT // 2 + 1, T)
+        else:       # vol-augmented item: the samples its T frames read, context included
+            assert spec.n_frames == T and spec.ext.shape == (T * HOP + (NFFT - HOP),)
         assert wav.abs().max() <= 1.0 * 10 and int(spk) in (0, 1)
     c_p, f0_p, spec_p, wav_p, spk_p, lengths, uv_p, vol_p = collate(items)
     assert list(lengths) == sorted(lengths.tolist(), reverse=True) and c_p.shape == (5, SSL, int(lengths[0]))
@@ -73,7 +76,16 @@ def test_loader_and_collate_invariants(tmp_path):
     for i in range(5):
         L = int(lengths[i])
         assert c_p[i, :, L:].abs().sum() == 0 and f0_p[i, L:].abs().sum() == 0 and wav_p[i, 0, L * HOP:].abs().sum() == 0
-    assert spec_p is None or spec_p.shape == (5, NFFT // 2 + 1, int(lengths[0]))
+    if torch.is_tensor(spec_p):
+        assert spec_p.shape == (5, NFFT // 2 + 1, int(lengths[0]))
+    else:
+        n_ctx = sum(1 for it in items if not torch.is_tensor(it[2]))
+        assert 0 < n_ctx and int((spec_p.n_frames > 0).sum()) == n_ctx
+        assert spec_p.ext.shape == (5, int(spec_p.n_frames.max()) * HOP + (NFFT - HOP))
+        assert (spec_p.cached is None) == (n_ctx == 5)
+        import data_parallel
+        half = data_parallel.shard_batch([c_p[:4], None, spec_p.rows(0, 4)], 1, 2)
+        assert half[1] is None and half[0].shape[0] == 2 and half[2].ext.shape[0] == 2
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only mounted in the build container")
@@ -126,6 +138,57 @@ def test_batch_spectrogram_equals_per_item(dev):
         one = spectrogram_torch(wav[b, :, :n * HOP].to(dev), NFFT, SR, HOP, NFFT)[0]            # [bins, n]
         assert (spec[b, :, :n] - one).abs().max().item() <= 1e-4 * one.abs().max().item()
         assert spec[b, :, n:].abs().max().item() == 0 if n < 37 else True
+
+
+@pytest.mark.gpu
+def test_context_spectrogram_equals_reference_per_item_transform(dev, tmp_path):
+    """Items without a cached .spec.pt and vol-augmented items: the reference transforms the WHOLE (re-scaled) utterance in
+    the loader worker and slices frames afterwards (data_utils.py:62-66,105-115); the engine ships the samples those frames
+    read and transforms them on the GPU.  Checked against the oracle's torch.stft restatement applied the reference's way."""
+    import data_utils
+    import utils
+    from oracle import train_oracle as TO
+    fl, cj = _make_dataset(str(tmp_path), n_items=4, with_spec=False, with_vol=True)
+    # make two utterances long enough to be cropped (> 800 frames)
+    from scipy.io.wavfile import write
+    g = torch.Generator().manual_seed(9)
+    for i, p in enumerate(open(fl).read().split()[:2]):
+        T = 900 + 20 * i
+        write(p, SR, ((torch.rand(T * HOP + 37, generator=g) - 0.5) * 20000).to(torch.int16).numpy())
+        torch.save(torch.randn(1, SSL, T // 2 + 1, generator=g), p + ".soft.pt")
+        f0 = (100 + 200 * torch.rand(T, generator=g)).numpy()
+        np.save(p + ".f0.npy", np.asanyarray((f0, (f0 > 0).astype(float)), dtype=object), allow_pickle=True)
+        np.save(p + ".vol.npy", torch.rand(T, generator=g).numpy())
+    hps = utils.get_hparams_from_file(cj)
+    ds = data_utils.TextAudioSpeakerLoader(fl, hps)
+    random.seed(3)
+    items = [ds[i] for i in range(len(ds))]
+    assert all(isinstance(it[2], data_utils.SpecContext) for it in items)
+    c_p, f0_p, spec_p, wav_p, spk_p, lengths, uv_p, vol_p = data_utils.TextAudioCollate()(items)
+    spec = data_utils.context_spectrogram(spec_p.cuda(), NFFT, SR, HOP, NFFT)
+    assert spec.shape == (4, NFFT // 2 + 1, int(lengths[0]))
+    # reference semantics, item by item, from the files: same RNG stream -> same vol shifts / crops
+    random.seed(3)
+    order = torch.sort(torch.LongTensor([it[0].shape[1] for it in items]), descending=True)[1].tolist()
+    refs = []
+    for i in range(len(ds)):
+        c, f0, sp, audio, spk, uv, vol = ds.get_audio(ds.audiopaths[i][0])
+        full = sp.full
+        T = c.shape[1]
+        if random.choice([True, False]) and ds.vol_aug and vol is not None:
+            max_amp = float(torch.max(torch.abs(audio))) + 1e-5
+            full = full * (10 ** random.uniform(-1, min(1, np.log10(1 / max_amp))))
+        ref = TO.spectrogram(full, NFFT, HOP, NFFT)[0][:, :T]
+        if T > 800:
+            s0 = random.randint(0, T - 800)
+            ref = ref[:, s0:s0 + 790]
+        refs.append(ref)
+    for row, i in enumerate(order):
+        n = refs[i].shape[1]
+        assert n == int(lengths[row])
+        err = (spec[row, :, :n].cpu() - refs[i]).abs().max().item()
+        assert err <= 2e-4 * refs[i].abs().max().item(), (row, err)
+        assert spec[row, :, n:].abs().max().item() == 0 if n < spec.shape[2] else True
 
 
 def test_repeat_expand_2d_left_is_the_reference_sequential_fill():
