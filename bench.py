@@ -53,8 +53,10 @@ def build_model(dev):
     return net, cfg, W
 
 
-def cpu_baseline(cfg, W, inputs, max_seconds=30.0):
-    """Time the CPU oracle on the same 10 s clip (bounded: 1 warm-up + up to 3 timed runs within ~max_seconds)."""
+def cpu_baseline(cfg, W, inputs, max_seconds=45.0, runs=5):
+    """Time the CPU oracle on the same 10 s clip (bounded: 1 warm-up + `runs` timed runs, fewer only if ~max_seconds of
+    host time would be exceeded; the sample string says how many were taken).  The unmodified reference cannot be timed
+    on the GPU box (no /root/reference there): kind = "port"."""
     from oracle import svc_oracle as O
     c, f0, uv, sid = inputs
     sd = W.make_state_dict(cfg, 1234)
@@ -65,7 +67,7 @@ def cpu_baseline(cfg, W, inputs, max_seconds=30.0):
         warm = time.perf_counter() - t0
         times = []
         budget = max_seconds - warm
-        while len(times) < 3 and (not times or sum(times) + times[-1] < budget):
+        while len(times) < runs and (not times or sum(times) + times[-1] < budget):
             t0 = time.perf_counter()
             O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
             times.append(time.perf_counter() - t0)
@@ -106,7 +108,7 @@ def make_train_items(cfg, B, seed):
     return (c, f0, spec, y, spk, lengths, uv, None), T
 
 
-def cpu_baseline_train(cfg, hps, items_cpu, max_items=2):
+def cpu_baseline_train(cfg, hps, items_cpu, max_items=4):
     """One iteration of the CPU oracle's training loop (oracle.train_oracle.gan_train_loop: torch-CPU autograd + AdamW in
     the reference's order) on a BOUNDED sample of the workload: the first `max_items` items of the same minibatch (the
     full B=16 iteration is ~4 TFLOP — minutes on host cores).  steps/s is reported for the full batch by scaling with
@@ -120,10 +122,11 @@ def cpu_baseline_train(cfg, hps, items_cpu, max_items=2):
     d = hps["data"]
     data = dict(n_fft=d["filter_length"], hop=d["hop_length"], win=d["win_length"], n_mels=d["n_mel_channels"],
                 sr=d["sampling_rate"], fmin=d["mel_fmin"], fmax=d["mel_fmax"])
-    ocfg = dict(cfg, p_dropout=0.0)
+    ocfg = dict(cfg)                      # p_dropout 0.1 active, like the timed HIP iteration
     sd_g = W.make_train_state_dict(cfg, 1234)
     sd_d = W.make_mpd_state_dict(1235)
     noise = W.make_train_noise(ocfg, max_items, T, lengths, 7, hop=HOP)
+    noise["dropout_u"] = W.make_dropout_draws(ocfg, max_items, T, 8)
     mb = torch.from_numpy(OM.mel_filterbank(data["sr"], data["n_fft"], data["n_mels"], data["fmin"], data["fmax"]))
     t0 = time.perf_counter()
     TO.gan_train_loop(sd_g, sd_d, ocfg, data, (c, f0, uv, spec, y, spk, lengths), noise, mb, 1)
@@ -219,7 +222,8 @@ def run_train(args, dev, rank, world, dist):
                             launch=("hipGraph replay of the whole iteration" if world == 1 else
                                     "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph
                             else "eager",
-                            parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU"),
+                            parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU",
+                            p_dropout=cfg["p_dropout"]),
                 losses={k: round(float(v), 4) for k, v in last.items()},
                 families=fams, allreduce=red, cpu_baseline=cpu)
 
@@ -241,8 +245,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run, exactly the
+        # command line the driver uses; rank 0's JSON line is the child's stdout
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the MI355X engine has no CPU fallback", file=sys.stderr)
@@ -326,15 +342,22 @@ def main():
         fam = max(rep.items(), key=lambda kv: kv[1]["ms"])
         name, r = fam
         achieved = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-        traffic = None
+        # HBM traffic needs rocprofv3 --pmc passes around the process (MI355X_MICROARCH.md): it cannot be measured from
+        # inside this run.  The figure below is read from the committed PMC summary of an EARLIER builder-side run of this
+        # same command and is labelled as such; null when that file is missing.
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv1d_mfma.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_conv1d_mfma.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the builder's "
+                                  f"box ({pj.get('source', 'see profiles/')}), NOT collected in this run")
             except Exception:
                 traffic = None
         roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    traffic_source=traffic_source,
                     launches_per_step=r["calls"] / nprof, avg_launch_us=round(1e3 * r["ms"] / r["calls"], 2),
                     flop_per_launch=r["flop"] / r["calls"],
                     families={k: dict(ms_per_step=round(v["ms"] / nprof, 4), calls=v["calls"] // nprof,

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-2 GPU call A: full GPU parity suite, default bench line, kernel-trace stats (infer eager + train).
+set -x
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --timeout=600 -rf --maxfail=20 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -40 gpurun_out/pytest_gpu.log
+timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
+cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
+rm -rf gpurun_out/prof_stats gpurun_out/prof_train
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-graph > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err; echo "rocprof rc=$?"
+DB=$(find gpurun_out/prof_stats -name '*.db' | head -1); python scripts/prof_summary.py $DB > gpurun_out/kernel_stats.txt 2>&1; head -40 gpurun_out/kernel_stats.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/bench_train_prof.json 2> gpurun_out/bench_train_prof.err; echo "rocprof train rc=$?"
+DB=$(find gpurun_out/prof_train -name '*.db' | head -1); python scripts/prof_summary.py $DB > gpurun_out/kernel_stats_train.txt 2>&1; head -50 gpurun_out/kernel_stats_train.txt
+find gpurun_out -name '*.db' -size +30M -delete
+du -sh gpurun_out

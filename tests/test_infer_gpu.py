@@ -58,6 +58,47 @@ def test_infer_matches_reference_golden(dev, name, cfgname):
         _check(o, torch.from_numpy(z["o"]))
 
 
+def test_infer_matches_oracle_at_the_benchmarked_shape(dev):
+    """BASELINE configs[1] exactly as bench.py runs it: full template, B = 1, T = 862 frames (10.01 s, 441,344 samples;
+    862 % 4 = 2, so every encoder / flow conv takes the unaligned staging path and the decoder the 128x224 LDS-DMA tiles),
+    bench.py's own input generator and seed, eager launches and the hipGraph replay, against the CPU oracle."""
+    import bench
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    B, T = 1, bench.T_FRAMES
+    assert T == 862
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=1234)          # bench.py: make_inputs(cfg, B, T_FRAMES, seed=1234 + rank)
+    noise = W.make_noise(cfg, B, T, seed=99)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    assert ref.shape == (1, 1, 441344)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    _check(o, ref)
+    net.enable_graph(True)
+    o2, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    o3, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert torch.equal(o2, o) and torch.equal(o3, o)
+    _check(o3, ref)
+
+
+def test_snake_long_form_matches_oracle_on_full_clips(dev):
+    """BASELINE configs[3] at its real length: nsf-snake-hifigan, T = 2584 frames (30.0 s, 1,323,008 samples), B = 2 full
+    clips against the CPU oracle (the B = 8 run of the same config is covered by the batch-consistency test below)."""
+    cfg = W.full_config()
+    cfg["vocoder_name"] = "nsf-snake-hifigan"
+    net, sd = _build(cfg, 77, dev)
+    B, T = 2, 2584
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=21)
+    noise = W.make_noise(cfg, B, T, seed=22)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4,
+                     noise={k: v.to(dev) for k, v in noise.items()})
+    assert o.shape == ref.shape == (B, 1, T * 512)
+    _check(o, ref)
+
+
 @pytest.mark.parametrize("B,T", [(1, 97), (2, 33)])
 def test_infer_matches_oracle_full_config(dev, B, T):
     cfg = W.full_config()

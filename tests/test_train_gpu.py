@@ -284,3 +284,85 @@ def test_attention_dropout_op_matches_torch(dev):
     ro.backward(go)
     for a, b, name in zip(got, (rq, rk, rv, rek, rev), "q k v emb_k emb_v".split()):
         assert (a - b.grad).abs().max().item() <= 2e-4 * max(1.0, b.grad.abs().max().item()), name
+
+
+def test_training_step_at_the_benchmarked_shapes(dev):
+    """BASELINE configs[2] shapes as bench.py builds them — full template (p_dropout 0.1 ACTIVE), segment_size 8192, hop 512,
+    n_fft 2048, 80 mels, items of 300..790 frames from bench.make_train_items — on the first FOUR items of the benchmark's
+    minibatch (the CPU oracle needs ~10 s per item for one step; the losses are batch means, so the comparison has to run on
+    the same items): the seven losses, y_hat and the gradient norms of a parameter sample against the oracle's CPU autograd,
+    every random draw (incl. the 48 dropout sites) injected."""
+    import bench
+    import models
+    import svc_autograd as A
+    import modules.commons as commons
+    from modules.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
+    from modules.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
+    from oracle import mel as OM
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    cfg = W.full_config()
+    assert cfg["p_dropout"] == 0.1
+    hps = bench.train_hps(cfg)
+    (c, f0, spec, y, spk, lengths, uv, _), _ = bench.make_train_items(cfg, bench.TRAIN_B, 4321)
+    n = 4
+    lengths = lengths[:n]
+    T = int(lengths.max())
+    c, f0, spec, uv, y, spk = c[:n, :, :T], f0[:n, :T], spec[:n, :, :T], uv[:n, :T], y[:n, :, :T * bench.HOP], spk[:n]
+    assert T >= 600
+    d = hps["data"]
+    data = dict(n_fft=d["filter_length"], hop=d["hop_length"], win=d["win_length"], n_mels=d["n_mel_channels"],
+                sr=d["sampling_rate"], fmin=d["mel_fmin"], fmax=d["mel_fmax"])
+    sd_g = W.make_train_state_dict(cfg, 1234)
+    sd_d = W.make_mpd_state_dict(1235)
+    noise = W.make_train_noise(cfg, n, T, lengths, 7, hop=bench.HOP)
+    noise["dropout_u"] = W.make_dropout_draws(cfg, n, T, 8)
+    mb = torch.from_numpy(OM.mel_filterbank(data["sr"], data["n_fft"], data["n_mels"], data["fmin"], data["fmax"]))
+    probe_g = ["pre.weight", "enc_p.enc_.attn_layers.3.conv_q.weight", "enc_p.enc_.ffn_layers.5.conv_2.weight",
+               "f0_decoder.decoder.self_attn_layers.2.conv_v.weight", "flow.flows.2.enc.in_layers.1.weight_v",
+               "dec.ups.1.weight_v", "dec.resblocks.7.convs1.1.weight_v", "dec.conv_post.weight_v", "enc_q.enc.in_layers.9.weight_v"]
+    probe_d = ["discriminators.0.convs.3.weight_v", "discriminators.2.convs.4.weight_v", "discriminators.5.convs.2.weight_v"]
+    sg = {k: v.clone().requires_grad_(k in probe_g) for k, v in sd_g.items()}
+    sdd = {k: v.clone().requires_grad_(k in probe_d) for k, v in sd_d.items()}
+    ref = TO.gan_step_losses(sg, sdd, cfg, data, (c, f0, uv, spec, y, spk, lengths), noise, mb)
+    rg_d = torch.autograd.grad(ref["loss_disc"], [sdd[k] for k in probe_d], retain_graph=True)
+    rg_g = torch.autograd.grad(ref["loss_gen_all"], [sg[k] for k in probe_g])
+
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net_g = models.SynthesizerTrn(cfg["spec_channels"], hps["train"]["segment_size"] // bench.HOP, **kw)
+    net_g.load_state_dict(sd_g, strict=True)
+    net_d = models.MultiPeriodDiscriminator()
+    net_d.load_state_dict(sd_d, strict=True)
+    net_g, net_d = net_g.to(dev).train(), net_d.to(dev).train()
+    nz = {k: ([u.to(dev) for u in v] if isinstance(v, list) else v.to(dev)) for k, v in noise.items()}
+    cD, f0D, uvD, specD, yD, spkD, lenD = [t.to(dev) for t in (c, f0, uv, spec, y, spk, lengths)]
+    seg, hop = cfg["segment_size"], bench.HOP
+    mel = spec_to_mel_torch(specD, data["n_fft"], data["n_mels"], data["sr"], data["fmin"], data["fmax"])
+    y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
+        cD, f0D, uvD, specD, g=spkD, c_lengths=lenD, spec_lengths=lenD, noise=nz)
+    y_mel = commons.slice_segments(mel, ids_slice, seg)
+    y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), data["n_fft"], data["n_mels"], data["sr"], hop, data["win"], data["fmin"], data["fmax"])
+    y_seg = commons.slice_segments(yD, ids_slice * hop, seg * hop)
+    rs, gs, _, _ = net_d(y_seg, y_hat.detach())
+    loss_disc, _, _ = discriminator_loss(rs, gs)
+    rs, gs, fr, fg = net_d(y_seg, y_hat)
+    out = dict(loss_disc=loss_disc, loss_mel=A.sum_abs_diff(y_mel, y_hat_mel) / y_mel.numel() * 45.0,
+               loss_kl=kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * 1.0, loss_fm=feature_loss(fr, fg),
+               loss_gen=generator_loss(gs)[0], loss_lf0=A.sum_sq_diff(pred_lf0, lf0) / lf0.numel())
+    out["loss_gen_all"] = out["loss_gen"] + out["loss_fm"] + out["loss_mel"] + out["loss_kl"] + out["loss_lf0"]
+    assert y_hat.shape == (n, 1, 8192)
+    yr = ref["y_hat"].detach()
+    assert (y_hat.detach().cpu() - yr).abs().max().item() <= 2e-4 * max(1.0, yr.abs().max().item())
+    assert (y_hat.detach().cpu() - yr).pow(2).mean().item() < 1e-4
+    for k in LOSS_KEYS:
+        r = float(ref[k])
+        assert abs(float(out[k]) - r) <= 2e-4 * max(1.0, abs(r)), (k, float(out[k]), r)
+    out["loss_disc"].backward(retain_graph=True)
+    pd = dict(net_d.named_parameters())
+    for k, g in zip(probe_d, rg_d):
+        assert abs(pd[k].grad.norm().item() - g.norm().item()) <= 2e-3 * max(g.norm().item(), 1e-6), ("D", k)
+    net_d.zero_grad()
+    out["loss_gen_all"].backward()
+    pg = dict(net_g.named_parameters())
+    for k, g in zip(probe_g, rg_g):
+        assert abs(pg[k].grad.norm().item() - g.norm().item()) <= 2e-3 * max(g.norm().item(), 1e-6), ("G", k, pg[k].grad.norm().item(), g.norm().item())
