@@ -386,11 +386,13 @@ int svc_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, c
  * probabilities): S[i,j] += rel[i, j-i+window] inside the band, masked to -1e4 (mask_mode 1: mask[b,i]*mask[b,j]==0,
  * 2: j>i), softmax over j.  Attention-probability dropout (modules/attentions.py:232) is fused in: with drop_u != NULL
  * (uniform [0,1) draws, [B*H,T,T]) S keeps the probabilities and Pd receives P * (u >= p_drop ? 1/(1-p_drop) : 0).
- * bwd: dP -> dS in place (with drop_u, dP is the gradient w.r.t. Pd and is masked first).  band gather/scatter move the (2*window+1)-wide diagonal band
+ * bwd: dP -> dS in place (with drop_u, dP is the gradient w.r.t. Pd and is masked first); dS is zero at the masked score
+ * positions (masked_fill passes no gradient; same mask / mask_mode as the forward).  band gather/scatter move the (2*window+1)-wide diagonal band
  * between a [rows,T] matrix (row i of every T x T block) and a [rows, 2*window+1] array. */
 int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
                              const float* drop_u, float p_drop, float* Pd, void* stream);
-int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop, void* stream);
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop,
+                             const float* mask, int mask_mode, void* stream);
 int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream);
 int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream);
 /* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of

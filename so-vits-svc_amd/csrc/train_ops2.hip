@@ -142,12 +142,18 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
 }
 // dS = P * (dP - sum_j dP*P), in place on dP; with drop_u the incoming gradient is w.r.t. the dropped probabilities and
 // is first multiplied by the same keep mask
+// Masked score positions were overwritten by the constant -1e4 in the forward (masked_fill, modules/attentions.py:231): no
+// gradient reaches the scores there (matters only for fully masked query rows, whose probabilities are uniform, not 0).
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int T,
                                                                long long n_rows, const float* __restrict__ drop_u,
-                                                               float p_drop) {
+                                                               float p_drop, const float* __restrict__ mask, int H,
+                                                               int mask_mode) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
+  const int qi = (int)(row % T);
+  const float* mp = (mask_mode == 1 && mask) ? mask + (row / T / H) * T : nullptr;
+  const float mi = mp ? mp[qi] : 1.f;
   const float* pp = P + row * T;
   float* dp = dP + row * T;
   float dot = 0.f;
@@ -163,7 +169,10 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     for (int j = lane; j < T; j += 64) dot += pp[j] * dp[j];
   }
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-  for (int j = lane; j < T; j += 64) dp[j] = pp[j] * (dp[j] - dot);
+  for (int j = lane; j < T; j += 64) {
+    const bool masked = (mp && mi * mp[j] == 0.f) || (mask_mode == 2 && j > qi);
+    dp[j] = masked ? 0.f : pp[j] * (dp[j] - dot);
+  }
 }
 // band[row, r] = M[row, i + r - window] (0 outside);   scatter: M[row, i + r - window] += band[row, r]
 __global__ void band_gather_kernel(const float* __restrict__ M, float* __restrict__ band, int T, int window,
@@ -296,11 +305,12 @@ int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int 
   return svc::check_launch("attn_softmax_fwd");
 }
 
-int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop, void* stream) {
+int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop,
+                             const float* mask, int mask_mode, void* stream) {
   SVC_REQUIRE(P && dP && B > 0 && H > 0 && T > 0, "attn_softmax_bwd: bad args");
   const long long rows = (long long)B * H * T;
   hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows,
-                     drop_u, p_drop);
+                     drop_u, p_drop, mask, H, mask_mode);
   return svc::check_launch("attn_softmax_bwd");
 }
 

@@ -480,14 +480,14 @@ class _Attention(Function):
             pband = S.band_gather(Pd, BH * T, T, window)
             S.gemm(ev, pband, (0, 1, dk), (T * (2 * window + 1), 1, 2 * window + 1), BH, dk, T, 2 * window + 1, out=out,
                    c_strides=(dk * T, T, 1), beta=1.0)
-        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v, drop_u, Pd if drop_u is not None else None)
-        ctx.cfg = (B, H, dk, T, window, p_drop)
+        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v, drop_u, Pd if drop_u is not None else None, mask)
+        ctx.cfg = (B, H, dk, T, window, p_drop, mask_mode)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v, P, pband, emb_k, emb_v, drop_u, Pd = ctx.saved_tensors
-        B, H, dk, T, window, p_drop = ctx.cfg
+        q, k, v, P, pband, emb_k, emb_v, drop_u, Pd, mask = ctx.saved_tensors
+        B, H, dk, T, window, p_drop, mask_mode = ctx.cfg
         if Pd is None:
             Pd = P
         BH = B * H
@@ -505,7 +505,7 @@ class _Attention(Function):
             S.band_scatter_add(dP, dpband, BH * T, T, window)
             dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T)      # [BH, nrel, dk]
             dEv = S.reduce_bct(dEv_b.view(BH, nrel * dk, 1), 0).view(emb_v.shape)
-        S.attn_softmax_bwd(P, dP, B, H, T, drop_u, p_drop)          # dP(d) -> dS in place
+        S.attn_softmax_bwd(P, dP, B, H, T, drop_u, p_drop, mask, mask_mode)          # dP(d) -> dS in place
         dS = dP
         dQ = torch.empty_like(q)
         S.gemm(k, dS, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=dQ, c_strides=(dk * T, T, 1), alpha=sc)

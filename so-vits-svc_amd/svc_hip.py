@@ -914,7 +914,7 @@ def t2lib():
         L.svc_layernorm_fwd_f32.argtypes = [_f32p] * 6 + [i, i, i, f, vp]
         L.svc_layernorm_bwd_f32.argtypes = [_f32p] * 8 + [i, i, i, vp]
         L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [_f32p, C.c_float, _f32p, vp]
-        L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, vp]
+        L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, _f32p, i, vp]
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
@@ -967,9 +967,9 @@ def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode, drop_u=None, p_d
     return S_ if Pd is None else Pd
 
 
-def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0):
-    check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), stream_ptr()),
-          "attn_softmax_bwd")
+def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0, mask=None, mask_mode=0):
+    check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), ptr(mask), mask_mode,
+                                           stream_ptr()), "attn_softmax_bwd")
     return dP
 
 
