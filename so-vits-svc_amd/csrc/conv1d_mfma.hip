@@ -72,6 +72,138 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+// ---- shared epilogue: the WK partial tiles of a workgroup sit in LDS as [WK][BM][BN + 4]; every thread owns 4 consecutive
+// time steps of one output row: 16 B residual loads / stores, full cache lines per row.  Split-K partial tiles are summed
+// here (fixed order wk = 0..WK-1: deterministic).
+template <int BM, int BN, int NTHR, int WK, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem, int tid, int b, int ph, int t0, int co0) {
+  const svc_conv1d_args& a = p.a;
+  constexpr int CP = BN + 4;
+  const float* maskb = a.mask ? a.mask + (long long)b * a.mask_bs : nullptr;
+  const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
+  const float* resb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+  float* yb = a.y + (long long)b * a.y_bs;
+  const float* biasp = a.bias;
+  const long long cond_cs = a.cond_cs, cond_ts = a.cond_ts;
+  constexpr int BN4 = BN / 4;
+  constexpr int OUT_ROWS = EPI == SVC_EPI_GATE ? BM / 2 : BM;
+  const bool yvec = p.yvec != 0;
+  const int H = a.Cout >> 1;
+
+  auto tile4 = [&](int prow, int c4) -> float4 {
+    float4 q = *reinterpret_cast<const float4*>(smem + prow * CP + c4 * 4);
+#pragma unroll
+    for (int w = 1; w < WK; ++w) {
+      const float4 q2 = *reinterpret_cast<const float4*>(smem + (w * BM + prow) * CP + c4 * 4);
+      q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+    }
+    return q;
+  };
+  auto tout = [&](int tq, int e) { return (tq + e) * a.y_ts + a.y_t0 + ph; };
+  auto tvalid = [&](int tq, int e) {
+    const int t = tout(tq, e);
+    return tq + e < a.Tout && t >= 0 && t < a.y_len;
+  };
+  auto tclamp = [&](int tq, int e) { return min(max(tout(tq, e), 0), a.y_len - 1); };
+  // 4 values of an output-shaped row at time steps tq..tq+3 (vector when aligned, else element-wise with bounds)
+  auto load4 = [&](const float* rowp, int tq) -> float4 {
+    if (yvec && tq + 3 < a.Tout) return *reinterpret_cast<const float4*>(rowp + tq);
+    float4 r;
+    r.x = tvalid(tq, 0) ? rowp[tclamp(tq, 0)] : 0.f;
+    r.y = tvalid(tq, 1) ? rowp[tclamp(tq, 1)] : 0.f;
+    r.z = tvalid(tq, 2) ? rowp[tclamp(tq, 2)] : 0.f;
+    r.w = tvalid(tq, 3) ? rowp[tclamp(tq, 3)] : 0.f;
+    return r;
+  };
+  auto store4 = [&](float* rowp, int tq, float4 v) {
+    if (yvec && tq + 3 < a.Tout) {
+      *reinterpret_cast<float4*>(rowp + tq) = v;
+    } else {
+      if (tvalid(tq, 0)) rowp[tout(tq, 0)] = v.x;
+      if (tvalid(tq, 1)) rowp[tout(tq, 1)] = v.y;
+      if (tvalid(tq, 2)) rowp[tout(tq, 2)] = v.z;
+      if (tvalid(tq, 3)) rowp[tout(tq, 3)] = v.w;
+    }
+  };
+  auto side4 = [&](const float* base, long long ts, int tq) -> float4 {   // base[t*ts] for the 4 (clamped) steps
+    return make_float4(base[(long long)tclamp(tq, 0) * ts], base[(long long)tclamp(tq, 1) * ts],
+                       base[(long long)tclamp(tq, 2) * ts], base[(long long)tclamp(tq, 3) * ts]);
+  };
+#define SVC_F4_MAP(dst, expr)            \
+  {                                      \
+    { const int e = 0; (dst).x = (expr); } \
+    { const int e = 1; (dst).y = (expr); } \
+    { const int e = 2; (dst).z = (expr); } \
+    { const int e = 3; (dst).w = (expr); } \
+  }
+#define F4C(q) (e == 0 ? (q).x : e == 1 ? (q).y : e == 2 ? (q).z : (q).w)
+
+  for (int idx = tid; idx < OUT_ROWS * BN4; idx += NTHR) {
+    const int row = idx / BN4, c4 = idx - row * BN4;
+    const int tq = t0 + c4 * 4;
+    if (tq >= a.Tout) continue;
+    const float4 mk = maskb ? side4(maskb, 1, tq) : make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (EPI == SVC_EPI_GATE) {
+      static_assert(EPI != SVC_EPI_GATE || (BM % 64) == 0, "gate epilogue needs tile pairs");
+      const int prow = (row >> 5) * 64 + (row & 31);  // packed tanh row inside the tile; +32 = its sigmoid row
+      const int c = (co0 >> 1) + row;
+      if (c >= H) continue;
+      const float4 vt = tile4(prow, c4), vs = tile4(prow + 32, c4);
+      const float bt = biasp ? biasp[c] : 0.f, bs = biasp ? biasp[H + c] : 0.f;
+      float4 ct = make_float4(0.f, 0.f, 0.f, 0.f), cs = ct;
+      if (condb) {
+        ct = side4(condb + c * cond_cs, cond_ts, tq);
+        cs = side4(condb + (H + c) * cond_cs, cond_ts, tq);
+      }
+      float4 o;
+      SVC_F4_MAP(o, tanhf(F4C(vt) + bt + F4C(ct)) * svc_sigmoid(F4C(vs) + bs + F4C(cs)));
+      store4(yb + (long long)c * a.y_cs, tq, o);
+    } else {
+      const int co = co0 + row;
+      if (co >= a.Cout) continue;
+      float4 v = tile4(row, c4);
+      const float bb = biasp ? biasp[co] : 0.f;
+      float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (condb) cc = side4(condb + co * cond_cs, cond_ts, tq);
+      SVC_F4_MAP(v, F4C(v) + bb + F4C(cc));
+      if constexpr (EPI == SVC_EPI_RES_SKIP) {
+        if (co < a.skip_from) {
+          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
+          SVC_F4_MAP(v, (F4C(r) + F4C(v)) * F4C(mk));
+          store4(yb + (long long)co * a.y_cs, tq, v);
+        } else {
+          float* y2p = a.y2 + (long long)b * a.y2_bs + (long long)(co - a.skip_from) * a.y2_cs;
+          if (a.beta != 0.f) {
+            const float4 r = load4(y2p, tq);
+            SVC_F4_MAP(v, F4C(v) + a.beta * F4C(r));
+          }
+          if (a.res_mode == 1) {  // last WN layer: `output * x_mask` (modules/modules.py:138)
+            SVC_F4_MAP(v, F4C(v) * F4C(mk));
+          }
+          store4(y2p, tq, v);
+        }
+      } else {
+        float* yp = yb + (long long)co * a.y_cs;
+        SVC_F4_MAP(v, apply_act(F4C(v), a.post_act, a.post_slope) * F4C(mk));
+        if (a.res_mode != 0) {
+          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
+          if (a.res_mode == 1) { SVC_F4_MAP(v, F4C(v) + F4C(r)); }
+          else if (a.res_mode == 2) { SVC_F4_MAP(v, (F4C(r) - F4C(v)) * F4C(mk)); }
+          else { SVC_F4_MAP(v, F4C(v) + F4C(r) * F4C(mk)); }
+        }
+        if (a.beta != 0.f) {
+          const float4 yo = load4(yp, tq);
+          SVC_F4_MAP(v, F4C(v) + a.beta * F4C(yo));
+        }
+        if (a.out_div != 1.f) { SVC_F4_MAP(v, F4C(v) / a.out_div); }
+        store4(yp, tq, v);
+      }
+    }
+  }
+#undef SVC_F4_MAP
+#undef F4C
+}
+
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false>
 __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
@@ -497,129 +629,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   }
   __syncthreads();
 
-  const float* maskb = a.mask ? a.mask + (long long)b * a.mask_bs : nullptr;
-  const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
-  const float* resb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-  float* yb = a.y + (long long)b * a.y_bs;
-  const float* biasp = a.bias;
-  const long long cond_cs = a.cond_cs, cond_ts = a.cond_ts;
-  constexpr int BN4 = BN / 4;
-  constexpr int OUT_ROWS = EPI == SVC_EPI_GATE ? BM / 2 : BM;
-  const bool yvec = p.yvec != 0;
-  const int H = a.Cout >> 1;
-
-  auto tile4 = [&](int prow, int c4) -> float4 {
-    float4 q = *reinterpret_cast<const float4*>(smem + prow * CP + c4 * 4);
-#pragma unroll
-    for (int w = 1; w < WK; ++w) {
-      const float4 q2 = *reinterpret_cast<const float4*>(smem + (w * BM + prow) * CP + c4 * 4);
-      q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
-    }
-    return q;
-  };
-  auto tout = [&](int tq, int e) { return (tq + e) * a.y_ts + a.y_t0 + ph; };
-  auto tvalid = [&](int tq, int e) {
-    const int t = tout(tq, e);
-    return tq + e < a.Tout && t >= 0 && t < a.y_len;
-  };
-  auto tclamp = [&](int tq, int e) { return min(max(tout(tq, e), 0), a.y_len - 1); };
-  // 4 values of an output-shaped row at time steps tq..tq+3 (vector when aligned, else element-wise with bounds)
-  auto load4 = [&](const float* rowp, int tq) -> float4 {
-    if (yvec && tq + 3 < a.Tout) return *reinterpret_cast<const float4*>(rowp + tq);
-    float4 r;
-    r.x = tvalid(tq, 0) ? rowp[tclamp(tq, 0)] : 0.f;
-    r.y = tvalid(tq, 1) ? rowp[tclamp(tq, 1)] : 0.f;
-    r.z = tvalid(tq, 2) ? rowp[tclamp(tq, 2)] : 0.f;
-    r.w = tvalid(tq, 3) ? rowp[tclamp(tq, 3)] : 0.f;
-    return r;
-  };
-  auto store4 = [&](float* rowp, int tq, float4 v) {
-    if (yvec && tq + 3 < a.Tout) {
-      *reinterpret_cast<float4*>(rowp + tq) = v;
-    } else {
-      if (tvalid(tq, 0)) rowp[tout(tq, 0)] = v.x;
-      if (tvalid(tq, 1)) rowp[tout(tq, 1)] = v.y;
-      if (tvalid(tq, 2)) rowp[tout(tq, 2)] = v.z;
-      if (tvalid(tq, 3)) rowp[tout(tq, 3)] = v.w;
-    }
-  };
-  auto side4 = [&](const float* base, long long ts, int tq) -> float4 {   // base[t*ts] for the 4 (clamped) steps
-    return make_float4(base[(long long)tclamp(tq, 0) * ts], base[(long long)tclamp(tq, 1) * ts],
-                       base[(long long)tclamp(tq, 2) * ts], base[(long long)tclamp(tq, 3) * ts]);
-  };
-#define SVC_F4_MAP(dst, expr)            \
-  {                                      \
-    { const int e = 0; (dst).x = (expr); } \
-    { const int e = 1; (dst).y = (expr); } \
-    { const int e = 2; (dst).z = (expr); } \
-    { const int e = 3; (dst).w = (expr); } \
-  }
-#define F4C(q) (e == 0 ? (q).x : e == 1 ? (q).y : e == 2 ? (q).z : (q).w)
-
-  for (int idx = tid; idx < OUT_ROWS * BN4; idx += NTHR) {
-    const int row = idx / BN4, c4 = idx - row * BN4;
-    const int tq = t0 + c4 * 4;
-    if (tq >= a.Tout) continue;
-    const float4 mk = maskb ? side4(maskb, 1, tq) : make_float4(1.f, 1.f, 1.f, 1.f);
-    if constexpr (EPI == SVC_EPI_GATE) {
-      static_assert(EPI != SVC_EPI_GATE || ((MT % 2) == 0 && !M16), "gate epilogue needs tile pairs");
-      const int prow = (row >> 5) * 64 + (row & 31);  // packed tanh row inside the tile; +32 = its sigmoid row
-      const int c = (co0 >> 1) + row;
-      if (c >= H) continue;
-      const float4 vt = tile4(prow, c4), vs = tile4(prow + 32, c4);
-      const float bt = biasp ? biasp[c] : 0.f, bs = biasp ? biasp[H + c] : 0.f;
-      float4 ct = make_float4(0.f, 0.f, 0.f, 0.f), cs = ct;
-      if (condb) {
-        ct = side4(condb + c * cond_cs, cond_ts, tq);
-        cs = side4(condb + (H + c) * cond_cs, cond_ts, tq);
-      }
-      float4 o;
-      SVC_F4_MAP(o, tanhf(F4C(vt) + bt + F4C(ct)) * svc_sigmoid(F4C(vs) + bs + F4C(cs)));
-      store4(yb + (long long)c * a.y_cs, tq, o);
-    } else {
-      const int co = co0 + row;
-      if (co >= a.Cout) continue;
-      float4 v = tile4(row, c4);
-      const float bb = biasp ? biasp[co] : 0.f;
-      float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (condb) cc = side4(condb + co * cond_cs, cond_ts, tq);
-      SVC_F4_MAP(v, F4C(v) + bb + F4C(cc));
-      if constexpr (EPI == SVC_EPI_RES_SKIP) {
-        if (co < a.skip_from) {
-          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
-          SVC_F4_MAP(v, (F4C(r) + F4C(v)) * F4C(mk));
-          store4(yb + (long long)co * a.y_cs, tq, v);
-        } else {
-          float* y2p = a.y2 + (long long)b * a.y2_bs + (long long)(co - a.skip_from) * a.y2_cs;
-          if (a.beta != 0.f) {
-            const float4 r = load4(y2p, tq);
-            SVC_F4_MAP(v, F4C(v) + a.beta * F4C(r));
-          }
-          if (a.res_mode == 1) {  // last WN layer: `output * x_mask` (modules/modules.py:138)
-            SVC_F4_MAP(v, F4C(v) * F4C(mk));
-          }
-          store4(y2p, tq, v);
-        }
-      } else {
-        float* yp = yb + (long long)co * a.y_cs;
-        SVC_F4_MAP(v, apply_act(F4C(v), a.post_act, a.post_slope) * F4C(mk));
-        if (a.res_mode != 0) {
-          const float4 r = load4(resb + (long long)co * a.res_cs, tq);
-          if (a.res_mode == 1) { SVC_F4_MAP(v, F4C(v) + F4C(r)); }
-          else if (a.res_mode == 2) { SVC_F4_MAP(v, (F4C(r) - F4C(v)) * F4C(mk)); }
-          else { SVC_F4_MAP(v, F4C(v) + F4C(r) * F4C(mk)); }
-        }
-        if (a.beta != 0.f) {
-          const float4 yo = load4(yp, tq);
-          SVC_F4_MAP(v, F4C(v) + a.beta * F4C(yo));
-        }
-        if (a.out_div != 1.f) { SVC_F4_MAP(v, F4C(v) / a.out_div); }
-        store4(yp, tq, v);
-      }
-    }
-  }
-#undef SVC_F4_MAP
-#undef F4C
+  conv_epilogue<BM, BN, NTHR, WK, EPI>(p, smem, tid, b, ph, t0, co0);
 }
 
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
@@ -627,6 +637,7 @@ int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
 int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
+int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
 
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI = SVC_EPI_PLAIN, int KSC = 0>
 int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
@@ -755,16 +766,184 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   return svc::check_launch("conv1d_mfma");
 }
 
+
+// ---- short-sequence kernel: operands straight from global memory / L2 into registers --------------------------------------
+// The encoder / flow convs of a single 10 s utterance have only B*T = 862 columns and 192..768 rows: at most a few hundred
+// 32x32 tiles, each with a long reduction (Cin*KS up to 2304).  The LDS-staged kernels above are built for thousands of
+// columns; here their per-chunk staging passes (sized for 128-wide tiles) and two barriers per chunk cost more than the
+// MFMAs of the chunk (8 chunks x ~3.5 us for a 768 -> 192 k3 conv = 30 us for 2 us of matrix work).  This kernel has NO
+// staging and NO barrier in its main loop: a workgroup owns a (32*MT) x 32 output tile, its 4 waves split the reduction
+// (input channels), and every wave feeds its MFMAs from its own registers:
+//     A (weights): packed [Cin][KS][CoutP] -> lane ln reads row (c, k), column co0 + ln: 128 contiguous bytes per half wave
+//     B (input)  : lane ln reads x[c][t0 + ln + k*dil - pad]: 128 contiguous bytes per half wave, any alignment
+// (c = the lane's channel of the pair the instruction consumes).  Loads run DEPTH reduction steps ahead of the MFMAs that
+// use them (two register banks, straight-line code), so L2 latency is hidden by the wave itself; zero padding, the channel
+// tail and the leaky-ReLU / pre-mask prologue are applied to the B value in registers.  The partial tiles meet in LDS once,
+// in the shared epilogue.
+template <int MT, int EPI, int KSC>
+__global__ __launch_bounds__(256) void conv1d_mfma_direct_kernel(ConvP p) {
+  static_assert(KSC >= 1 && KSC <= 7, "direct kernel: compile-time tap count");
+  // PR channel pairs x KSC taps = one register bank (12..16 reduction steps, 36..48 loads in flight per wave)
+  constexpr int PR = KSC == 1 ? 8 : (KSC <= 3 ? 5 : (KSC <= 5 ? 3 : 2));
+  constexpr int NS = PR * KSC;
+  constexpr int WK = 4, BM = MT * 32, BN = 32, NTHR = 256, CP = BN + 4;
+  const svc_conv1d_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything derived from it stays scalar
+  const int ln = lane & 31, lk = lane >> 5;
+  int bid = blockIdx.x;
+  const int tt = bid % p.n_t_tiles;
+  bid /= p.n_t_tiles;
+  const int mtile = bid % p.n_m_tiles;
+  const int b = bid / p.n_m_tiles;
+  const int t0 = tt * BN, co0 = mtile * BM;
+  const float ps = a.pre_slope;
+
+  // this wave's slice of the channel pairs (Cin is even: checked by the launcher)
+  const int npairs = a.Cin >> 1;
+  const int ppw = (npairs + WK - 1) / WK;
+  const int pr0 = wk * ppw;
+  const int my_pairs = max(0, min(ppw, npairs - pr0));
+  const int n_it = (my_pairs + PR - 1) / PR;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // Addressing: ALL per-step address arithmetic is scalar.  A load is  (wave-uniform base in SGPRs) + (per-lane 32-bit byte
+  // offset in a VGPR that never changes): the lane offsets below are computed once, the bases advance with s_add per step.
+  //   weights  w[((2*pr + lk)*KS + k)*CoutP + col]  = base_w(pr, k) + [lk*KS*CoutP + col]
+  //   input    x[chan(2*pr + lk)*xcs + clamp(t)]    = base_x(pr)    + [lk'*xcs + clamp(t0 + ln + k*dil - pad)]
+  // (a channel-flipped view — negative channel stride — is re-based on its lowest address, channels mirrored: lk' = 1 - lk).
+  const bool xflip = a.x_cs < 0;
+  const unsigned xcs = (unsigned)(xflip ? -a.x_cs : a.x_cs);
+  const char* xlo = reinterpret_cast<const char*>(a.x + (long long)b * a.x_bs + (xflip ? (long long)(a.Cin - 1) * a.x_cs : 0ll));
+  const char* wlo = reinterpret_cast<const char*>(a.w);
+  unsigned vw[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) vw[i] = 4u * ((unsigned)(lk * KSC * a.CoutP) + (unsigned)min(co0 + i * 32 + ln, a.CoutP - 1));
+  unsigned vx[KSC];
+  float okt[KSC];   // zero padding as a multiply by 0 / 1 (a select on the loaded value would let the compiler sink the load
+                    // under a branch, and a load under a branch costs an s_waitcnt vmcnt(0) at every step)
+#pragma unroll
+  for (int k = 0; k < KSC; ++k) {
+    const int tin = t0 + ln - a.pad_left + k * a.dil;
+    vx[k] = 4u * ((unsigned)(xflip ? 1 - lk : lk) * xcs + (unsigned)min(max(tin, 0), a.Tin - 1));
+    okt[k] = (tin >= 0 && tin < a.Tin) ? 1.f : 0.f;
+  }
+
+  // register banks: raw loads only — nothing in load_bank may USE a loaded value (that would put an s_waitcnt inside the
+  // load block); zero padding and the leaky-ReLU prologue are applied in mfma_bank, right before the MFMA
+  float av[2][NS][MT], bx[2][NS];
+  auto load_bank = [&](int it, float (&A_)[NS][MT], float (&X_)[NS]) {
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+      const int pr = pr0 + min(it * PR + j, my_pairs - 1);            // scalar; pairs past the slice re-read the last one
+      const char* wb = wlo + 4ull * (unsigned)(2 * pr * KSC * a.CoutP);
+      const char* xbp = xlo + 4ull * ((unsigned)(xflip ? a.Cin - 2 - 2 * pr : 2 * pr) * xcs);
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          A_[j * KSC + k][i] = *reinterpret_cast<const float*>(wb + 4ull * (unsigned)(k * a.CoutP) + vw[i]);
+        X_[j * KSC + k] = *reinterpret_cast<const float*>(xbp + vx[k]);
+      }
+    }
+  };
+  auto mfma_bank = [&](int it, const float (&A_)[NS][MT], const float (&X_)[NS]) {
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+      const float live = it * PR + j < my_pairs ? 1.f : 0.f;           // scalar
+#pragma unroll
+      for (int k = 0; k < KSC; ++k) {
+        const float xv = X_[j * KSC + k];
+        const float bvu = fmaxf(xv, xv * ps) * (okt[k] * live);        // leaky-ReLU for 0 <= slope <= 1 (launcher checks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[j * KSC + k][i], bvu, acc[i], 0, 0, 0);
+      }
+    }
+  };
+  // Every load_bank is UNCONDITIONAL (banks past the slice re-read the last pair and are not consumed): a load issued under
+  // a branch would make the compiler's vmcnt bookkeeping wait for ALL outstanding loads before the next MFMAs, i.e.
+  // serialise L2 latency with the matrix work.  The sched_barriers pin the order [loads of bank i+1][MFMAs of bank i]: left
+  // alone, the scheduler sinks every load next to its MFMA to save registers (vmcnt(2) in front of each MFMA).
+  if (n_it > 0) {
+    load_bank(0, av[0], bx[0]);
+    for (int it = 0; it < n_it; it += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(it + 1, av[1], bx[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_bank(it, av[0], bx[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(it + 2, av[0], bx[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < n_it) mfma_bank(it + 1, av[1], bx[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  {
+    float* cw = smem + wk * BM * CP + ln;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CP] = acc[i][r];
+  }
+  __syncthreads();
+  conv_epilogue<BM, BN, NTHR, WK, EPI>(p, smem, tid, b, 0, t0, co0);
+}
+
+// shapes the register-fed kernel takes: dense (one phase), no pre-mask, 1 / 3 / 5 / 7 taps, an even channel count, a
+// pre-activation expressible as max(x, slope*x), and 32-bit byte offsets inside one batch row of x and inside the weights
+static bool direct_ok(const svc_conv1d_args& a) {
+  return a.n_phase == 1 && a.premask == nullptr && (a.KS == 1 || a.KS == 3 || a.KS == 5 || a.KS == 7) && (a.Cin % 2) == 0 &&
+         a.pre_slope >= 0.f && a.pre_slope <= 1.f && (long long)a.Cin * a.KS * a.CoutP < (1ll << 29) &&
+         std::llabs((long long)a.x_cs) * a.Cin + a.Tin < (1ll << 29);
+}
+
+template <int MT, int EPI, int KSC>
+int launch_direct(const svc_conv1d_args& a, hipStream_t s) {
+  constexpr int BM = MT * 32, BN = 32, WK = 4;
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.a = a;
+  auto al4 = [](const void* ptr, long long bs, long long cs) {
+    return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 4) == 0 && (cs % 4) == 0);
+  };
+  p.yvec = (a.n_phase == 1 && a.y_ts == 1 && a.y_t0 == 0 && al4(a.y, a.y_bs, a.y_cs) && al4(a.res, a.res_bs, a.res_cs) &&
+            al4(a.y2, a.y2_bs, a.y2_cs)) ? 1 : 0;
+  p.n_t_tiles = svc::cdiv(a.Tout, BN);
+  p.n_m_tiles = svc::cdiv(a.Cout, BM);
+  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
+  const size_t lds = (size_t)WK * BM * (BN + 4) * 4;
+  hipLaunchKernelGGL((conv1d_mfma_direct_kernel<MT, EPI, KSC>), dim3((unsigned)nblk), dim3(256), lds, s, p);
+  return svc::check_launch("conv1d_mfma_direct");
+}
+
+template <int MT, int EPI>
+int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
+  switch (a.KS) {
+    case 1: return launch_direct<MT, EPI, 1>(a, s);
+    case 3: return launch_direct<MT, EPI, 3>(a, s);
+    case 5: return launch_direct<MT, EPI, 5>(a, s);
+    default: return launch_direct<MT, EPI, 7>(a, s);
+  }
+}
+
 }  // namespace
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; return SVC_OK; }
+  g_direct_mode = ((cfg / 1000000) % 10) ? 0 : 1;
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;
   g_dbg = (cfg / 1000) % 10;
   g_db_mode = ((cfg / 10000) % 10) ? 0 : 1;
-  g_db_budget_kb = (cfg / 100000) ? 80 : 64;
+  g_db_budget_kb = ((cfg / 100000) % 10) ? 80 : 64;
   return SVC_OK;
 }
 
@@ -846,6 +1025,12 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
                     (a.epi != SVC_EPI_GATE && g_force_cfg <= 7 && g_force_cfg >= 1);
     if (ok) cfg = g_force_cfg;
+  }
+  if ((cfg == 5 || cfg == 6 || (a.epi == SVC_EPI_GATE && cfg != 3 && cfg != 4)) && direct_ok(a) && g_direct_mode) {
+    const bool two = cfg == 5 || a.epi == SVC_EPI_GATE;
+    if (a.epi == SVC_EPI_GATE) return launch_direct_ks<2, SVC_EPI_GATE>(a, s);
+    if (a.epi == SVC_EPI_RES_SKIP) return two ? launch_direct_ks<2, SVC_EPI_RES_SKIP>(a, s) : launch_direct_ks<1, SVC_EPI_RES_SKIP>(a, s);
+    return two ? launch_direct_ks<2, SVC_EPI_PLAIN>(a, s) : launch_direct_ks<1, SVC_EPI_PLAIN>(a, s);
   }
   if (a.epi == SVC_EPI_GATE) {
     switch (cfg) {
