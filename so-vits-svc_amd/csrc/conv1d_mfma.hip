@@ -44,6 +44,7 @@ struct ConvP {
   int yvec;       // 1: y / res / y2 rows are 16 B aligned and unit-stride in time -> float4 epilogue
   int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
   int db_ni;      // DB kernels: LDS-DMA pieces (1 KiB each) per wave per chunk
+  int fast_epi;   // DB kernels: 1 = plain epilogue with all residual / accumulate loads issued up front (conv_epilogue<BATCH>)
   const float* zero;  // DB kernels: 16 B of zeros in global memory (source of padding / out-of-tile pieces)
 };
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // ---- shared epilogue: the WK partial tiles of a workgroup sit in LDS as [WK][BM][BN + 4]; every thread owns 4 consecutive
 // time steps of one output row: 16 B residual loads / stores, full cache lines per row.  Split-K partial tiles are summed
 // here (fixed order wk = 0..WK-1: deterministic).
-template <int BM, int BN, int NTHR, int WK, int EPI>
+template <int BM, int BN, int NTHR, int WK, int EPI, bool BATCH = false>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem, int tid, int b, int ph, int t0, int co0) {
   const svc_conv1d_args& a = p.a;
   constexpr int CP = BN + 4;
@@ -138,6 +139,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem,
   }
 #define F4C(q) (e == 0 ? (q).x : e == 1 ? (q).y : e == 2 ? (q).z : (q).w)
 
+  if constexpr (BATCH && EPI == SVC_EPI_PLAIN && (BM * BN4) % NTHR == 0) {
+    // Big tiles of the MRF ResBlock convs (p.fast_epi: aligned rows, residual add or none, no mask / time-varying cond):
+    // ALL residual (and accumulate) loads of the thread are issued first, then the trips compute and store.  Measured on the
+    // 128-channel k=11 stage (128 x 224 tile, 28 trips per thread): the epilogue is 27 of 192 us when every trip waits for
+    // its own 16-byte load (one L2 / HBM round trip per trip); nothing else can hide that latency in a kernel that runs
+    // one tile per CU with the whole chip in the same phase.  Same arithmetic, same order: bit-identical results.
+    if (p.fast_epi) {
+      constexpr int NIT = BM * BN4 / NTHR;
+      float4 rr[NIT], yy[NIT];
+      const bool has_res = a.res_mode != 0, has_acc = a.beta != 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int row = idx / BN4, c4 = idx - row * BN4;
+        const int co = min(co0 + row, a.Cout - 1);
+        const int tq = min(t0 + c4 * 4, a.Tout - 4);
+        rr[it] = has_res ? *reinterpret_cast<const float4*>(resb + (long long)co * a.res_cs + tq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        yy[it] = has_acc ? *reinterpret_cast<const float4*>(yb + (long long)co * a.y_cs + tq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int row = idx / BN4, c4 = idx - row * BN4;
+        const int co = co0 + row, tq = t0 + c4 * 4;
+        if (co >= a.Cout || tq >= a.Tout) continue;
+        float4 v = tile4(row, c4);
+        const float bb = biasp ? biasp[co] : 0.f;
+        const float cc = condb ? condb[co * cond_cs] : 0.f;
+        SVC_F4_MAP(v, F4C(v) + bb + cc);
+        SVC_F4_MAP(v, apply_act(F4C(v), a.post_act, a.post_slope) * 1.f);
+        if (has_res) { SVC_F4_MAP(v, F4C(v) + F4C(rr[it])); }
+        if (has_acc) { SVC_F4_MAP(v, F4C(v) + a.beta * F4C(yy[it])); }
+        if (a.out_div != 1.f) { SVC_F4_MAP(v, F4C(v) / a.out_div); }
+        *reinterpret_cast<float4*>(yb + (long long)co * a.y_cs + tq) = v;
+      }
+      return;
+    }
+  }
   for (int idx = tid; idx < OUT_ROWS * BN4; idx += NTHR) {
     const int row = idx / BN4, c4 = idx - row * BN4;
     const int tq = t0 + c4 * 4;
@@ -629,7 +668,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 
   }
   __syncthreads();
 
-  conv_epilogue<BM, BN, NTHR, WK, EPI>(p, smem, tid, b, ph, t0, co0);
+  // (batched epilogue loads: -4..5 us per launch on the 64x128 / 64x256 / 32x512 / 128x128 tiles, +3..5 us on 128x224 where the
+  // extra live registers push the kernel to the 256-VGPR line and the main loop's allocation suffers: not used there)
+  conv_epilogue<BM, BN, NTHR, WK, EPI, DB && NT != 7>(p, smem, tid, b, ph, t0, co0);
 }
 
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
@@ -637,6 +678,7 @@ int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
 int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
+int g_fast_epi = 1;    // 1: DB kernels batch the epilogue's residual loads (svc_debug_set_conv_cfg: +10000000 disables)
 int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
 
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI = SVC_EPI_PLAIN, int KSC = 0>
@@ -727,6 +769,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       }
       p.BC = bcd;
       p.db_ni = ni;
+      p.fast_epi = (g_fast_epi && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
+                    (a.cond == nullptr || a.cond_ts == 0) && p.yvec && (a.Tout % 4) == 0 && a.Tout >= 4) ? 1 : 0;
       p.zero = zero;
       p.dump_off = 0;
       const size_t lds = std::max((size_t)2 * ni * NWV * 1024, epi_bytes);
@@ -937,7 +981,8 @@ int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; return SVC_OK; }
+  g_fast_epi = ((cfg / 10000000) % 10) ? 0 : 1;
   g_direct_mode = ((cfg / 1000000) % 10) ? 0 : 1;
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;

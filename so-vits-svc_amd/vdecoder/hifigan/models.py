@@ -26,6 +26,7 @@ from .env import AttrDict  # noqa: F401
 from .utils import get_padding, init_weights
 
 LRELU_SLOPE = 0.1
+_POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
 
 
 class ResBlock1(nn.Module):
@@ -53,14 +54,21 @@ class ResBlock1(nn.Module):
         cur = x
         bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
         xt, ping, pong = bufs
+        # the second leaky_relu of a pair (:64) is applied ONCE, in the epilogue of the conv that produces xt, instead of to
+        # every operand the next conv stages (xt has no other consumer): max(v, 0.1 v) == (v > 0 ? v : 0.1 v) bit for bit
         for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
-            c1.run(cur, pre_slope=LRELU_SLOPE, out=xt)
+            if _POSTACT:
+                c1.run(cur, pre_slope=LRELU_SLOPE, post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE, out=xt)
+                ps2 = 1.0
+            else:
+                c1.run(cur, pre_slope=LRELU_SLOPE, out=xt)
+                ps2 = LRELU_SLOPE
             if j == n - 1:
                 dst = out if out is not None else (ping if cur is not ping else pong)
-                c2.run(xt, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
+                c2.run(xt, pre_slope=ps2, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
                 return dst
             dst = ping if cur is not ping else pong
-            c2.run(xt, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst)
+            c2.run(xt, pre_slope=ps2, res=cur, res_mode=1, out=dst)
             cur = dst
 
     def remove_weight_norm(self):
