@@ -154,6 +154,29 @@ typedef struct svc_conv1d_direct_args {
 int svc_conv1d_direct_f32(const svc_conv1d_direct_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One ResBlock1 pair of the NARROW decoder stages in one launch (vdecoder/hifigan/models.py:60-67, one iteration of the
+ * loop over dilations):   y = conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2 + x
+ * conv1 = Conv1d(C, C, KS, dilation dil1, padding dil1*(KS-1)/2), conv2 = Conv1d(C, C, KS, dilation 1, padding (KS-1)/2),
+ * lrelu slope `slope` (0.1).  Built for C in {16, 32} (the last two upsample stages, HBM-bound as separate launches) and
+ * KS in {3, 7, 11}; wider stages use svc_conv1d_f32.  x, y: [B, C, T] views (time contiguous, x != y); w1, w2: packed
+ * [C][KS][CP] weights (svc_pack_conv1d_weight); b1, b2: [C] or NULL.  Epilogue options of the MRF sum: y = (pair(x) +
+ * beta * y_old) / out_div.  Results are bit-identical to the two svc_conv1d_f32 launches it replaces.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svc_resblock_pair_args {
+  const float* x;
+  const float* w1;
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  float* y;
+  long long x_bs, x_cs, y_bs, y_cs;
+  int B, C, T, KS, dil1, CP;
+  float slope, beta, out_div;
+} svc_resblock_pair_args;
+
+int svc_resblock_pair_f32(const svc_resblock_pair_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * NSF harmonic source: nearest x`upp` f0 upsample (vdecoder/hifigan/models.py:369), SineGen (:138-166,
  * :250-271) and SourceModuleHnNSF (:307-320: Linear(H->1) + tanh), evaluated in closed form per frame
  * (see csrc/nsf_source.hip).  f0:[B,T]  rand_ini:[B,H] (column 0 ignored)  noise:[B,T*upp,H]

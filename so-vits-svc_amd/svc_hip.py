@@ -61,6 +61,13 @@ class Conv1dDirectArgs(C.Structure):
     ]
 
 
+class ResblockPairArgs(C.Structure):
+    _fields_ = [("x", _f32p), ("w1", _f32p), ("b1", _f32p), ("w2", _f32p), ("b2", _f32p), ("y", _f32p),
+                ("x_bs", C.c_longlong), ("x_cs", C.c_longlong), ("y_bs", C.c_longlong), ("y_cs", C.c_longlong),
+                ("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("KS", C.c_int), ("dil1", C.c_int), ("CP", C.c_int),
+                ("slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
+
+
 class AttentionArgs(C.Structure):
     _fields_ = [
         ("q", _f32p), ("k", _f32p), ("v", _f32p), ("emb_rel_k", _f32p), ("emb_rel_v", _f32p), ("mask", _f32p),
@@ -96,6 +103,7 @@ def lib():
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
+        L.svc_resblock_pair_f32.argtypes = [C.POINTER(ResblockPairArgs), C.c_void_p]
         L.svc_nsf_source_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.svc_nsf_source_scratch_bytes.restype = C.c_longlong
         L.svc_nsf_source_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
@@ -121,7 +129,7 @@ def lib():
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
-    "svc_conv1d_direct_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
+    "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
@@ -280,6 +288,33 @@ def conv1d_direct(x, wp, Cout, KS, *, bias=None, stride=1, dil=1, pad_left=0, To
     a.KS, a.dil, a.stride, a.pad_left, a.CoutP, a.post_act = KS, dil, stride, pad_left, wp.shape[2], post_act
     a.pre_slope, a.post_slope = pre_slope, post_slope
     check(lib().svc_conv1d_direct_f32(C.byref(a), stream_ptr()), "conv1d_direct")
+    return out
+
+
+RESBLOCK_PAIR_BUILT = (16, 32)          # channel counts svc_resblock_pair_f32 is instantiated for
+# ... and the ones the decoder routes to it: measured on MI355X (profiles/r02_f_resblock_pair_fused_vs_two_launches.txt) the
+# fused pair wins at C = 16 (HBM-bound stage: 50/69/88 us vs 68/82/99 us for K = 3/7/11) and still loses at C = 32, where the
+# two-launch path already runs at 67-83 TFLOP/s and the fused kernel's column tiles do not fill its 8 waves (52-58 TFLOP/s)
+RESBLOCK_PAIR_CHANNELS = (16,)
+RESBLOCK_PAIR_KERNELS = (3, 7, 11)
+
+
+def resblock_pair(x, w1p, b1, w2p, b2, KS, dil1, *, slope=0.1, out=None, beta=0.0, out_div=1.0):
+    """y = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x in one launch (C in RESBLOCK_PAIR_CHANNELS, see include/svc_hip.h);
+    w1p / w2p: packed weights of the two convs."""
+    require_gpu(x, w1p, b1, w2p, b2, out)
+    B, Cc, T = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    a = ResblockPairArgs()
+    a.x, a.w1, a.b1, a.w2, a.b2, a.y = ptr(x), ptr(w1p), ptr(b1), ptr(w2p), ptr(b2), ptr(out)
+    a.x_bs, a.x_cs = _bct_strides(x)
+    a.y_bs, a.y_cs = _bct_strides(out)
+    if tuple(w1p.shape) != tuple(w2p.shape) or w1p.shape[0] != Cc or w1p.shape[1] != KS:
+        raise SvcError(f"resblock_pair: packed weights {tuple(w1p.shape)} / {tuple(w2p.shape)} do not match C={Cc} KS={KS}")
+    a.B, a.C, a.T, a.KS, a.dil1, a.CP = B, Cc, T, KS, dil1, w1p.shape[2]
+    a.slope, a.beta, a.out_div = slope, beta, out_div
+    check(lib().svc_resblock_pair_f32(C.byref(a), stream_ptr()), "resblock_pair")
     return out
 
 

@@ -27,6 +27,7 @@ from .utils import get_padding, init_weights
 
 LRELU_SLOPE = 0.1
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
+_FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
 
 
 class ResBlock1(nn.Module):
@@ -54,6 +55,18 @@ class ResBlock1(nn.Module):
         cur = x
         bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
         xt, ping, pong = bufs
+        C = x.shape[1]
+        fused = (_FUSE_PAIR and C in S.RESBLOCK_PAIR_CHANNELS and self.convs1[0].kernel_size in S.RESBLOCK_PAIR_KERNELS
+                 and not isinstance(x, S.FlipView))
+        if fused:
+            # narrow stages (HBM-bound as separate launches): one kernel per pair, intermediate + residual stay in LDS
+            for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+                lastp = j == n - 1
+                dst = (out if out is not None else (ping if cur is not ping else pong)) if lastp else (ping if cur is not ping else pong)
+                S.resblock_pair(cur, c1.packed(), c1.bias, c2.packed(), c2.bias, c1.kernel_size, c1.dilation, slope=LRELU_SLOPE,
+                                out=dst, beta=beta if lastp else 0.0, out_div=out_div if lastp else 1.0)
+                cur = dst
+            return cur
         # the second leaky_relu of a pair (:64) is applied ONCE, in the epilogue of the conv that produces xt, instead of to
         # every operand the next conv stages (xt has no other consumer): max(v, 0.1 v) == (v > 0 ? v : 0.1 v) bit for bit
         for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):

@@ -118,3 +118,35 @@ def test_conv1d_flipped_views(dev):
     wp = S.pack_conv1d_weight(w.to(dev))
     y = S.conv1d(S.flip_view(xd).narrow_c(0, C), wp, 192, 1, bias=b.to(dev))
     assert _rel(y.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("C,K,d,B,T", [(16, 3, 1, 2, 1000), (16, 7, 3, 1, 517), (16, 11, 5, 2, 2049), (32, 3, 5, 1, 777),
+                                       (32, 7, 1, 2, 1500), (32, 11, 5, 1, 640), (32, 11, 3, 2, 131), (16, 11, 1, 1, 7)])
+def test_resblock_pair_equals_two_conv_launches(dev, C, K, d, B, T):
+    """svc_resblock_pair_f32 (narrow MRF stages: conv1 -> lrelu -> conv2 -> + x in one kernel, intermediate and residual in
+    LDS) against the two svc_conv1d_f32 launches it replaces — same reduction order, so equal to fp32 round-off — and against
+    a plain torch fp32 restatement of vdecoder/hifigan/models.py:62-66; incl. ragged lengths, sequences shorter than a
+    tile / the halo, and the MRF-sum epilogue (beta, out_div)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(C * 100 + K * 10 + d)
+    x = torch.randn(B, C, T, generator=g).to(dev)
+    w1 = (torch.randn(C, C, K, generator=g) / (C * K) ** 0.5).to(dev)
+    w2 = (torch.randn(C, C, K, generator=g) / (C * K) ** 0.5).to(dev)
+    b1, b2 = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    prev = torch.randn(B, C, T, generator=g).to(dev)
+    w1p, w2p = S.pack_conv1d_weight(w1), S.pack_conv1d_weight(w2)
+    F = torch.nn.functional
+    ref = F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w1, b1, padding=d * (K - 1) // 2, dilation=d), 0.1), w2, b2,
+                   padding=(K - 1) // 2) + x
+    for beta, div in ((0.0, 1.0), (1.0, 3.0)):
+        xt = S.conv1d(x, w1p, C, K, bias=b1, dil=d, pad_left=d * (K - 1) // 2, pre_slope=0.1, post_act=S.ACT_LRELU, post_slope=0.1)
+        two = prev.clone()
+        S.conv1d(xt, w2p, C, K, bias=b2, pad_left=(K - 1) // 2, res=x, res_mode=1, out=two, beta=beta, out_div=div)
+        one = prev.clone()
+        S.resblock_pair(x, w1p, b1, w2p, b2, K, d, slope=0.1, out=one, beta=beta, out_div=div)
+        want = (ref + beta * prev) / div
+        scale = max(1.0, want.abs().max().item())
+        assert (one - two).abs().max().item() <= 2e-6 * scale, (beta, (one - two).abs().max().item())
+        assert (one - want).abs().max().item() <= 2e-5 * scale
+    with pytest.raises(S.SvcError):
+        S.resblock_pair(x, w1p, b1, w2p, b2, K, d, out=x)              # in-place is refused
