@@ -208,7 +208,16 @@ def run_train(args, dev, rank, world, dist):
                         tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
                 for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
         fams["_kernel_ms_total"] = round(tot, 3)
-    red = net_g.reducer.stats if getattr(net_g, "reducer", None) is not None else None
+    red = None
+    if getattr(net_g, "reducer", None) is not None:
+        rg, rd = net_g.reducer, net_d.reducer
+        n_it = steps + warm + (1 if use_graph else 0)
+        red = dict(backend=rg.backend, ranks=world,
+                   mode=getattr(step_fn, "dp_mode", "eager launches, per-bucket all-reduce overlapped with backward (autograd hooks)"),
+                   bytes_per_iter=(rg.stats["reduced_bytes"] + rd.stats["reduced_bytes"]) / max(n_it, 1),
+                   launches_per_iter=(rg.stats["launches"] + rd.stats["launches"]) / max(n_it, 1),
+                   buckets=dict(g=len(rg.buckets), d=len(rd.buckets)),
+                   exposed_ms_per_iter=(rg.exposed_ms() + rd.exposed_ms()) / max(n_it, 1))
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)

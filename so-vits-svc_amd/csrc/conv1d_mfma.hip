@@ -245,7 +245,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem,
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
 template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false>
-__global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
+// (scalar-staging instantiations — unaligned rows, e.g. DiscriminatorP's period layout — keep 48 X + 64 W staging registers
+// in flight next to the accumulators: at two workgroups per CU they spilled 92..296 B/lane of scratch into the chunk loop
+// and ran 3.7x slower than their aligned twins; they get the whole register file of a SIMD instead)
+__global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (XVEC || WK > 1) ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
   constexpr int TS = M16 ? 16 : 32;   // MFMA tile edge
   constexpr int KPI = M16 ? 4 : 2;    // K indices consumed per MFMA
   constexpr int NACC = M16 ? 4 : 16;  // accumulator regs per tile

@@ -112,6 +112,7 @@ class GradReducer:
         self._works = []
         self._launched = None
         self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0)
+        self._exposed = []          # (start, end) event pairs around reduce_all on the compute stream
         arena.add_listener(self._on_grad)
 
     # -- construction-time parameter sync ----------------------------------------------------------------------
@@ -165,22 +166,43 @@ class GradReducer:
         self._works = []
         self._pending = None
 
-    def reduce_all(self):
-        """ONE all-reduce (mean) over the whole flat gradient buffer, ordered after the work already queued on the current
-        stream.  This is the reduction used between hipGraph replays (train.TrainStep with a process group): the
-        per-bucket, backward-overlapped path above is driven by Python autograd hooks, which do not run when a captured
-        backward is replayed; at 0.6 GB of gradients per iteration the un-overlapped ring all-reduce costs a few ms over
-        xGMI, the eager launch path it replaces ~100 ms of host time."""
+    def reduce_all(self, time_it=True):
+        """All-reduce (mean) of the whole flat gradient buffer, ordered after the work already queued on the current stream:
+        the reduction used BETWEEN hipGraph replays (train.TrainStep with a process group) — the per-bucket path above is
+        driven by Python autograd hooks, which do not run when a captured backward is replayed.  The same contiguous buckets
+        are issued back to back as asynchronous collectives (RCCL pipelines them on its stream), then the compute stream
+        waits for all of them.  Nothing overlaps with compute here, so the time between the two events recorded on the
+        compute stream IS the exposed communication time of the iteration (`exposed_ms()`); at 0.6 GB of gradients per
+        iteration that is a few ms over xGMI — the eager launch path it replaces costs ~100 ms of host time."""
         if self.world == 1:
             return
-        buf = self.arena.grad
-        if self.backend == "nccl":
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
-            buf.mul_(1.0 / self.world)
-        self.stats["reduced_bytes"] += buf.numel() * 4
-        self.stats["launches"] += 1
+        ev = None
+        if time_it and self.arena.grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        works = []
+        for bk in self.buckets:
+            buf = self.arena.grad[bk["start"]:bk["end"]]
+            op = dist.ReduceOp.AVG if self.backend == "nccl" else dist.ReduceOp.SUM
+            works.append((dist.all_reduce(buf, op=op, group=self.pg, async_op=True), buf))
+            self.stats["reduced_bytes"] += buf.numel() * 4
+            self.stats["launches"] += 1
+        for w, buf in works:
+            w.wait()
+            if self.backend != "nccl":
+                buf.mul_(1.0 / self.world)
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+
+    def exposed_ms(self):
+        """Total time the compute stream spent inside reduce_all since the last call (synchronises the device)."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._exposed)
+        self._exposed = []
+        return total
 
     @contextlib.contextmanager
     def no_sync(self):

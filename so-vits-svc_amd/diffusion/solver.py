@@ -6,6 +6,7 @@ Out of scope: Saver / TensorBoard / validation audio (:13-90,174-200), fp16/bf16
 import torch
 
 from data_parallel import DataParallel
+import svc_hip as S
 from optim import FusedAdamW
 
 
@@ -39,11 +40,14 @@ class TrainStep:
         return self
 
     def _body(self, data, noise):
+        S.wgrad_slab.active = True       # weight / bias gradients of the iteration accumulate into one pre-zeroed slab
+        S.wgrad_slab.reset()
         self.opt.zero_grad()
         loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
                           gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
         loss.backward()
         self.opt.step()
+        S.wgrad_slab.active = False
         return loss.detach()
 
     def _mod(self):

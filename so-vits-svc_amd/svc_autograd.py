@@ -51,7 +51,9 @@ class _Conv1dDense(Function):
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:      # bias gradient from the dy tiles the wgrad kernel stages anyway
-                db = torch.empty(Cout, device=dy.device, dtype=torch.float32)
+                db, zeroed = S.wgrad_zeros((Cout,), dy.device)
+                if not zeroed and S.wgrad_slab.active:
+                    db.zero_()
             dw = S.conv1d_wgrad(dy, x, KS, dil, pad, dbias=db)
         elif want_db:
             db = S.reduce_bct(dy, 0)

@@ -733,14 +733,63 @@ def pack_conv1d_weight_T(w):
     return dst
 
 
+class ZeroSlab:
+    """Pre-zeroed storage for the atomically accumulated outputs of one training iteration (weight / bias gradients of
+    svc_conv1d_wgrad_f32): `take` hands out zero-filled views, `reset` re-zeroes what was handed out with ONE memset per
+    chunk.  Replaces one hipMemsetAsync per gradient tensor (585 per iteration of the B=16 GAN step, 2.9 ms of 5 us
+    launches, profiles/r01_k_train_aten_op_census.txt).  Off unless a training loop turns it on (train.TrainStep): a view
+    stays valid only until the next reset, i.e. until the optimizer has consumed the gradients of the iteration."""
+
+    CHUNK = 96 * 1024 * 1024     # floats per chunk (384 MB: the 99 M parameters of G + D fit in two)
+
+    def __init__(self):
+        self.chunks, self.used, self.cur, self.active = [], [], 0, False
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        need = (n + 63) // 64 * 64
+        while True:
+            if self.cur < len(self.chunks):
+                c = self.chunks[self.cur]
+                if c.device == torch.device(device) and self.used[self.cur] + need <= c.numel():
+                    o = self.used[self.cur]
+                    self.used[self.cur] = o + need
+                    return c[o:o + n].view(*shape)
+                self.cur += 1
+                continue
+            self.chunks.append(torch.zeros(max(need, self.CHUNK), device=device, dtype=torch.float32))
+            self.used.append(0)
+
+    def reset(self):
+        for c, u in zip(self.chunks, self.used):
+            if u:
+                c[:u].zero_()
+        self.used = [0] * len(self.chunks)
+        self.cur = 0
+
+
+wgrad_slab = ZeroSlab()
+
+
+def wgrad_zeros(shape, device):
+    """Zero-initialised gradient buffer: a slab view when the slab is active (then no per-tensor memset is needed)."""
+    if wgrad_slab.active:
+        return wgrad_slab.take(shape, device), True
+    return torch.empty(tuple(shape), device=device, dtype=torch.float32), False
+
+
 def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None):
     """G[ca,cb,k] = sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad]; dbias (optional [Ca] buffer) also receives
-    sum_{b,t} A[b,ca,t]."""
+    sum_{b,t} A[b,ca,t].  Without `out` the result lands in the pre-zeroed gradient slab when that is active; a dbias
+    passed together with a slab-backed output must itself be zero-initialised (wgrad_zeros)."""
     require_gpu(A, Bm, out, dbias)
     B, Ca, TA = A.shape
     _, Cb, TB = Bm.shape
     if out is None:
-        out = torch.empty((Ca, Cb, KS), device=A.device, dtype=torch.float32)
+        out, zeroed = wgrad_zeros((Ca, Cb, KS), A.device)
+        accumulate = accumulate or zeroed
     a = WgradArgs()
     a.A, a.Bm, a.G = ptr(A), ptr(Bm), ptr(out)
     a.a_bs, a.a_cs = _bct_strides(A)

@@ -14,9 +14,12 @@ fp16/bf16 autocast (`fp16_run`) is not implemented — the engine computes in fp
 import torch
 import torch.distributed as dist
 
+import os
+
 import models
 import modules.commons as commons
 import svc_autograd as A
+import svc_hip as S
 from data_parallel import DataParallel, no_param_grads
 from modules.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
 from modules.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
@@ -127,10 +130,14 @@ class TrainStep:
         self.optim_d.step()
         out = self._seg_g(ctx)
         self.optim_g.step()
+        S.wgrad_slab.active = False      # gradients consumed: later backward passes outside this loop allocate normally
         return out
 
     def _seg_d(self, items, noise=None):
         """Generator forward + the discriminator step up to (and including) its backward (train.py:151-194)."""
+        # weight / bias gradients of this iteration accumulate into one pre-zeroed slab (one memset instead of ~585)
+        S.wgrad_slab.active = True
+        S.wgrad_slab.reset()
         c, f0, spec, y, spk, lengths, uv, volume = items
         net_g, net_d = self.net_g, self.net_d
         seg_frames = self.segment_size // self.hop
@@ -215,7 +222,17 @@ class TrainStep:
             self.optim_g.restore(snaps[0])               # also invalidates every packed-weight cache (version bump)
             self.optim_d.restore(snaps[1])
             torch.cuda.synchronize()
-            with red_g.no_sync(), red_d.no_sync():       # hooks must not launch collectives inside a capture
+            # SVC_DP_CAPTURE_COLLECTIVES=1 (opt-in, RCCL only): let the autograd hooks fire DURING capture, so the per-bucket
+            # all-reduces are recorded on RCCL's stream inside the two graphs and overlap the rest of the captured backward
+            # (north_star's schedule, replayed without host work).  Not the default: collectives inside hipGraphs have never run
+            # on this code base's hardware (single-GPU boxes only), and a mis-captured collective hangs instead of raising.
+            captured = os.environ.get("SVC_DP_CAPTURE_COLLECTIVES", "0") == "1" and red_g.backend == "nccl"
+            import contextlib
+            guard = contextlib.ExitStack()
+            if not captured:
+                guard.enter_context(red_g.no_sync())     # hooks must not launch collectives inside a capture
+                guard.enter_context(red_d.no_sync())
+            with guard:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     ctx = self._seg_d(s_items, s_noise)
@@ -227,20 +244,25 @@ class TrainStep:
                     out = self._seg_g(ctx)
                 touched_g = list(self.optim_g.arena.touched)
                 torch.autograd.graph.increment_version(self.optim_g.arena.params)
-            ent = (g1, g2, static, out, touched_d, touched_g, ctx)
+            ent = (g1, g2, static, out, touched_d, touched_g, ctx, captured)
             self._graphs[key] = ent
-        g1, g2, static, out, touched_d, touched_g, _ = ent
+            self.dp_mode = "collectives captured in the graphs (bucket-overlapped)" if captured else \
+                "two graphs, bucketed all-reduce between them (exposed)"
+        g1, g2, static, out, touched_d, touched_g, _, captured = ent
         for s, t in zip(static, items):
             if s is not None:
                 s.copy_(t, non_blocking=True)
         g1.replay()
-        red_d.reduce_all()
+        if not captured:
+            red_d.reduce_all()
         self.optim_d.arena.touched = list(touched_d)
         self.optim_d.step()
         g2.replay()
-        red_g.reduce_all()
+        if not captured:
+            red_g.reduce_all()
         self.optim_g.arena.touched = list(touched_g)
         self.optim_g.step()
+        S.wgrad_slab.active = False
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 

@@ -99,10 +99,10 @@ def _worker(rank, world, port, q):
             if not n.startswith("unused"):
                 assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
 
-        # ... followed by reduce_all(): ONE all-reduce of the whole flat buffer == the full-batch gradient again (the
-        # path train.TrainStep takes between two hipGraph replays, where the per-bucket hooks do not run)
+        # ... followed by reduce_all(): every bucket of the flat buffer all-reduced back to back == the full-batch gradient
+        # again (the path train.TrainStep takes between two hipGraph replays, where the per-bucket hooks do not run)
         dp.reducer.reduce_all()
-        assert dp.reducer.stats["launches"] == before + 1
+        assert dp.reducer.stats["launches"] == before + len(dp.reducer.buckets)
         for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
             if not n.startswith("unused"):
                 assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
