@@ -1030,7 +1030,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     cfg = cols >= 16384 ? 3 : (wg64x128 >= 200 && m64 ? 4 : (m64 && wg64x32 >= 200 ? 5 : 6));
   } else {
     SVC_REQUIRE(a.epi == SVC_EPI_PLAIN, "conv1d: unknown epilogue %d", a.epi);
-    if (a.Cout <= 16) cfg = 0;
+    if (a.Cout <= 16) cfg = cols >= 16384 ? 0 : 6;   // few columns (DiscriminatorP's 1024 -> 1 conv_post): split the reduction instead
     else if (a.Cout <= 32) cfg = cols >= 16384 ? 1 : 6;
     else if (cols >= 16384) cfg = a.Cout <= 64 ? 2 : 3;
     else if (m64 && wg64x128 >= 128) cfg = 4;   // measured (768 -> 2304/3072, T=500): 64x128 at 144..192 workgroups beats
