@@ -681,6 +681,7 @@ int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
 int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
+int g_no224 = 0;       // debug: 1 keeps the 128x224 tile out of the selection (svc_debug_set_conv_cfg: +100000000)
 int g_fast_epi = 1;    // 1: DB kernels batch the epilogue's residual loads (svc_debug_set_conv_cfg: +10000000 disables)
 int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
 
@@ -984,8 +985,9 @@ int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; g_no224 = 0; return SVC_OK; }
   g_fast_epi = ((cfg / 10000000) % 10) ? 0 : 1;
+  g_no224 = ((cfg / 100000000) % 10) ? 1 : 0;
   g_direct_mode = ((cfg / 1000000) % 10) ? 0 : 1;
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;
@@ -1053,7 +1055,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
         const double t64 = std::ceil(n64 / 256.0) * 64 * 128 * 1.05;
         if (t64 < best) { best = t64; cfg = 4; }
       }
-      if (a.KS >= 7 && n224 >= 200) {
+      if (a.KS >= 7 && n224 >= 200 && !g_no224) {
         const double t224 = std::ceil(n224 / 256.0) * 128 * 224 * 1.04;
         if (t224 < best) { best = t224; cfg = 7; }
       }

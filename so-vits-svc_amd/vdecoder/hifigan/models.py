@@ -27,6 +27,7 @@ from .utils import get_padding, init_weights
 
 LRELU_SLOPE = 0.1
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
+_MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
 
 
@@ -49,8 +50,9 @@ class ResBlock1(nn.Module):
             x = A.add(xt, x)
         return x
 
-    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
-        """out (+)= resblock(x); the optional epilogue arguments let Generator accumulate the MRF mean in place."""
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
+        """out (+)= resblock(x); the optional epilogue arguments let Generator accumulate the MRF mean in place.
+        `before_last()` (optional) is called right before the launch that touches `out` (stream ordering hook)."""
         n = len(self.convs1)
         cur = x
         bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
@@ -63,6 +65,8 @@ class ResBlock1(nn.Module):
             for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
                 lastp = j == n - 1
                 dst = (out if out is not None else (ping if cur is not ping else pong)) if lastp else (ping if cur is not ping else pong)
+                if lastp and before_last is not None:
+                    before_last()
                 S.resblock_pair(cur, c1.packed(), c1.bias, c2.packed(), c2.bias, c1.kernel_size, c1.dilation, slope=LRELU_SLOPE,
                                 out=dst, beta=beta if lastp else 0.0, out_div=out_div if lastp else 1.0)
                 cur = dst
@@ -78,6 +82,8 @@ class ResBlock1(nn.Module):
                 ps2 = LRELU_SLOPE
             if j == n - 1:
                 dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
                 c2.run(xt, pre_slope=ps2, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
                 return dst
             dst = ping if cur is not ping else pong
@@ -238,6 +244,9 @@ class Generator(nn.Module):
             xs = self.noise_convs[i](har)                              # (:379)
             x = self.ups[i].run(x, pre_slope=LRELU_SLOPE, res=xs)      # lrelu + ConvT + add (:377-381)
             acc = xs                                                   # reuse the noise-conv buffer as MRF accumulator
+            if _MRF_STREAMS and self.num_kernels > 1 and x.is_cuda:
+                x = self._mrf_concurrent(i, x, acc)
+                continue
             tmp = [torch.empty_like(x) for _ in range(3)]
             for j in range(self.num_kernels):
                 last = j == self.num_kernels - 1
@@ -246,6 +255,38 @@ class Generator(nn.Module):
             x = acc
         # F.leaky_relu default slope 0.01 (:390), conv_post, tanh
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
+
+    def _mrf_concurrent(self, i, x, acc):
+        """The num_kernels ResBlocks of a stage are independent chains over the same input (`xs += resblocks[j](x)`,
+        vdecoder/hifigan/models.py:382-388); only their LAST launch touches the shared accumulator.  Each chain runs on its own
+        HIP stream (fork after the upsample, ordered accumulation through events, join before the next stage), so the memory
+        phase of one chain's tiles (epilogue: residual read + store, 14 % of a 128-channel k=11 launch with every CU in the
+        same phase) and its last partial round of tiles overlap another chain's matrix work.  Same launches, same
+        accumulation order (k = 3, then 7, then 11): bit-identical output.  Capturable (torch.cuda.graph follows the fork/join)."""
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_mrf_streams", {})
+        key = (x.device.index, self.num_kernels)
+        if key not in side:
+            side[key] = [torch.cuda.Stream(device=x.device) for _ in range(self.num_kernels - 1)]
+        streams = [main] + side[key]
+        # scratch of every chain comes from the MAIN stream's allocator: main joins all chains below before anything is freed
+        tmps = [[torch.empty_like(x) for _ in range(3)] for _ in range(self.num_kernels)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        done = [torch.cuda.Event() for _ in range(self.num_kernels)]
+        for j in range(self.num_kernels):
+            last = j == self.num_kernels - 1
+            st = streams[j]
+            with torch.cuda.stream(st):
+                if j:
+                    st.wait_event(fork)
+                hook = (lambda jj=j, ss=st: ss.wait_event(done[jj - 1])) if j else None
+                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
+                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmps[j],
+                                                         before_last=hook)
+                done[j].record(st)
+        main.wait_event(done[-1])      # chain j's last launch waited for chain j-1's: the last event covers all of them
+        return acc
 
     def remove_weight_norm(self):
         for l in self.ups:
