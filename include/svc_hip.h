@@ -267,6 +267,8 @@ typedef struct svc_attention_args {
 } svc_attention_args;
 
 int svc_attention_f32(const svc_attention_args* a, void* stream);
+/* Tuning aid (A/B on one box): force the 8- or 16-wave workgroup variant of svc_attention_f32; 0 = automatic. */
+int svc_debug_set_attention_waves(int nw);
 
 
 /* ================================================================================================

@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int NW = 8;        // waves per workgroup (they split the key tiles)
 constexpr int MAXREL = 17;   // 2*window+1 <= 17
 
 struct AttnP {
@@ -29,18 +28,27 @@ struct AttnP {
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int NDT>  // dk = 32 * NDT
+// NDT: dk = 32 * NDT.  NW: waves per workgroup — they split the key tiles.  A 10 s utterance has 27 key tiles and only
+// 27 x heads query tiles: with 8 waves a workgroup walks 4 key tiles per wave on 54 of 256 CUs (88 us per layer); 16 waves
+// halve the walk (2 key tiles per wave, 4 waves per SIMD hiding each other's load latency).  To fit 16 waves in LDS the V
+// operand is staged 32 channel rows at a time (4.2 KB per wave instead of 12.7) and the per-wave output tiles are folded
+// 16 -> 8 before the final combine.
+template <int NDT, int NW>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
   constexpr int DK = 32 * NDT;
   constexpr int VP = 33;  // V tile pitch
+  constexpr int VROWS = NW > 8 ? 32 : DK;      // channel rows of V staged per wave at a time
+  constexpr int NWC = NW > 8 ? NW / 2 : NW;    // output tiles that meet in LDS for the final combine
   const svc_attention_args& a = p.a;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // carve
-  float* Vl = lds;                                  // [NW][DK][VP]   (aliased by Ol [NW][DK][32] after the loop)
-  float* Rk = Vl + NW * DK * VP;                    // [MAXREL][32]  relative-key logits of this query tile
+  constexpr int SLAB = (NW * VROWS * VP > NWC * DK * 32) ? NW * VROWS * VP : NWC * DK * 32;
+  float* Vl = lds;                                  // [NW][VROWS][VP]   (aliased by Ol [NWC][DK][32] after the loop)
+  float* Rk = Vl + SLAB;                            // [MAXREL][32]  relative-key logits of this query tile
   float* Pl = Rk + MAXREL * 32;                     // [MAXREL][32]  normalised band probabilities
   float* Ml = Pl + MAXREL * 32;                     // [NW][32]
   float* Ll = Ml + NW * 32;                         // [NW][32]
+  float* Ql = Ll + NW * 32;                         // NW > 8: [DK/2][64] the Q fragment, shared by all waves (lane-linear)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
@@ -55,12 +63,21 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
   const float* vb = a.v + (long long)b * a.v_bs + (long long)h * DK * a.v_cs;
   const float* mq = a.mask ? a.mask + (long long)b * a.mask_bs : nullptr;
 
-  // Q fragment (B operand of S^T = K Q^T): lane (half, li) holds q[d = 2s + half][i] / sqrt(dk)
-  float qreg[DK / 2];
+  // Q fragment (B operand of S^T = K Q^T): lane (half, li) holds q[d = 2s + half][i] / sqrt(dk).  It is the same for every
+  // wave of the workgroup: the 16-wave variant (128 VGPRs per wave) keeps it in LDS instead of DK/2 registers per lane.
+  float qreg[NW > 8 ? 1 : DK / 2];
+  if constexpr (NW > 8) {
+    for (int idx = tid; idx < (DK / 2) * 64; idx += NW * 64) {
+      const int s = idx >> 6, l = idx & 63;
+      const int d = 2 * s + (l >> 5), iq = i0 + (l & 31);
+      Ql[idx] = iq < T ? qb[(long long)d * a.q_cs + iq] / sqrtk : 0.f;
+    }
+  } else {
 #pragma unroll
-  for (int s = 0; s < DK / 2; ++s) {
-    const int d = 2 * s + half;
-    qreg[s] = i < T ? qb[(long long)d * a.q_cs + i] / sqrtk : 0.f;
+    for (int s = 0; s < DK / 2; ++s) {
+      const int d = 2 * s + half;
+      qreg[s] = i < T ? qb[(long long)d * a.q_cs + i] / sqrtk : 0.f;
+    }
   }
   // relative-key logits for this query tile: Rk[m][ii] = sum_d q[d][i0+ii]/sqrt(dk) * E_k[m][d]
   for (int idx = tid; idx < nrel * 32; idx += NW * 64) {
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float* Vw = Vl + w * DK * VP;
+  float* Vw = Vl + w * VROWS * VP;
   for (int it = 0; it < n_iter; ++it) {
     const int jt = it * NW + w;
     const int j0 = jt * 32;
@@ -105,8 +122,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) kv[u] = (kb + (long long)(2 * (c * 16 + u)) * a.k_cs)[koff];   // uniform row + lane offset
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jok ? kv[u] : 0.f, qreg[c * 16 + u], acc, 0, 0, 0);
+      for (int u = 0; u < 16; ++u) {
+        const float qv = NW > 8 ? Ql[(c * 16 + u) * 64 + lane] : qreg[NW > 8 ? 0 : c * 16 + u];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jok ? kv[u] : 0.f, qv, acc, 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     float sc[16];
@@ -142,30 +161,51 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[dt][r] *= resc;
-    // ---- stage V (pitch 33: the A-operand fetch below has its 32 lanes on 32 different d rows) ----
+    // ---- stage V (pitch 33: the A-operand fetch below has its 32 lanes on 32 different d rows) and O^T += V^T P^T ----
+    if constexpr (NW > 8) {
 #pragma unroll
-    for (int c = 0; c < DK / 32; ++c) {
-      float vv[16];
+      for (int dt = 0; dt < NDT; ++dt) {
+        float vv[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) vv[u] = (vb + (long long)(2 * (c * 16 + u)) * a.v_cs)[voff];
+        for (int u = 0; u < 16; ++u) vv[u] = (vb + (long long)(dt * 32 + 2 * u) * a.v_cs)[voff];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) Vw[(2 * (c * 16 + u) + half) * VP + li] = jok ? vv[u] : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // the slab is private to this wave: LDS ops of one wave complete in order, no workgroup barrier needed
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int u = 0; u < 16; ++u) Vw[(2 * u + half) * VP + li] = jok ? vv[u] : 0.f;
+        // the slab is private to this wave: LDS ops of one wave complete in order, no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float av = Vw[(dt * 32 + li) * VP + crow(r, half)];
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const float av = Vw[li * VP + crow(r, half)];
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
+    } else {
+#pragma unroll
+      for (int c = 0; c < DK / 32; ++c) {
+        float vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vv[u] = (vb + (long long)(2 * (c * 16 + u)) * a.v_cs)[voff];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) Vw[(2 * (c * 16 + u) + half) * VP + li] = jok ? vv[u] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float av = Vw[(dt * 32 + li) * VP + crow(r, half)];
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pr[r], oacc[dt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 
   // ---------------- combine the waves: M = max m_w, L = sum l_w e^{m_w - M}, O = sum O_w e^{m_w - M} / L ----------------
@@ -211,11 +251,31 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
     Pl[idx] = pv;
   }
   __syncthreads();   // every wave is past its V slab; Pl complete
-  float* Ol = Vl;  // [NW][DK][32]
+  float* Ol = Vl;  // [NWC][DK][32]
+  if constexpr (NW > 8) {
+    // fold 16 -> 8: the upper half of the waves parks its (already weighted) tile, its partner adds it in registers
+    if (w >= NWC) {
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ol[(w * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r] * wsc;
+        for (int r = 0; r < 16; ++r) Ol[((w - NWC) * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r] * wsc;
+    }
+    __syncthreads();
+    if (w < NWC) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = Ol + (w * DK + dt * 32 + crow(r, half)) * 32 + li;
+          *q = oacc[dt][r] * wsc + *q;
+        }
+    }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ol[(w * DK + dt * 32 + crow(r, half)) * 32 + li] = oacc[dt][r] * wsc;
+  }
   __syncthreads();
   float* ob = a.out + (long long)b * a.o_bs + (long long)h * DK * a.o_cs;
   for (int idx = tid; idx < DK * 32; idx += NW * 64) {
@@ -223,21 +283,25 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnP p) {
     if (i0 + ii >= T) continue;
     float v = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) v += Ol[(ww * DK + d) * 32 + ii];
+    for (int ww = 0; ww < NWC; ++ww) v += Ol[(ww * DK + d) * 32 + ii];
     for (int m = 0; m < nrel; ++m) v = fmaf(Pl[m * 32 + ii], a.emb_rel_v[m * DK + d], v);
     ob[(long long)d * a.o_cs + i0 + ii] = v;
   }
 }
 
-template <int NDT>
+int g_attn_nw = 0;   // debug: force 8 or 16 waves (svc_debug_set_attention_waves)
+
+template <int NDT, int NW>
 int launch(const svc_attention_args& a, hipStream_t s) {
   constexpr int DK = 32 * NDT;
+  constexpr int VROWS = NW > 8 ? 32 : DK, NWC = NW > 8 ? NW / 2 : NW;
+  constexpr int SLAB = (NW * VROWS * 33 > NWC * DK * 32) ? NW * VROWS * 33 : NWC * DK * 32;
   AttnP p;
   p.a = a;
   p.nJ = svc::cdiv(a.T, 32);
   p.inv_unused = 0.f;
-  const size_t lds = (size_t)(NW * DK * 33 + 2 * MAXREL * 32 + 2 * NW * 32) * 4;
-  auto kern = attention_kernel<NDT>;
+  const size_t lds = (size_t)(SLAB + 2 * MAXREL * 32 + 2 * NW * 32 + (NW > 8 ? (DK / 2) * 64 : 0)) * 4;
+  auto kern = attention_kernel<NDT, NW>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -264,10 +328,28 @@ extern "C" int svc_attention_f32(const svc_attention_args* ap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const double flop = 4.0 * a.B * a.H * (double)a.T * a.T * a.dk;
   svc::ProfScope prof(s, "attention", flop, 16.0 * a.B * a.H * a.dk * a.T);
-  switch (a.dk / 32) {
-    case 1: return launch<1>(a, s);
-    case 2: return launch<2>(a, s);
-    case 3: return launch<3>(a, s);
-    default: return launch<4>(a, s);
+  // 16 waves per workgroup when the key walk is long enough to give every wave work and the query tiles alone cannot fill
+  // the chip (one utterance: 27 x heads workgroups); many short rows (batched training-size inputs) keep 8
+  const int nJ = svc::cdiv(a.T, 32);
+  const long long wgs = (long long)nJ * a.H * a.B;
+  const bool wide = (g_attn_nw ? g_attn_nw == 16 : (nJ >= 16 && wgs < 512)) && a.dk <= 96;   // dk = 128 would spill at 128 VGPRs
+  if (wide) {
+    switch (a.dk / 32) {
+      case 1: return launch<1, 16>(a, s);
+      case 2: return launch<2, 16>(a, s);
+      case 3: return launch<3, 16>(a, s);
+      default: return launch<4, 16>(a, s);
+    }
   }
+  switch (a.dk / 32) {
+    case 1: return launch<1, 8>(a, s);
+    case 2: return launch<2, 8>(a, s);
+    case 3: return launch<3, 8>(a, s);
+    default: return launch<4, 8>(a, s);
+  }
+}
+
+extern "C" int svc_debug_set_attention_waves(int nw) {
+  g_attn_nw = (nw == 8 || nw == 16) ? nw : 0;
+  return SVC_OK;
 }

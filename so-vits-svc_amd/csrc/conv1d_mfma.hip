@@ -681,7 +681,11 @@ int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
 int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
-int g_no224 = 0;       // debug: 1 keeps the 128x224 tile out of the selection (svc_debug_set_conv_cfg: +100000000)
+int g_no224 = 1;       // 1: the 128x224 one-workgroup-per-CU tile stays out of the selection (svc_debug_set_conv_cfg: +100000000
+                       // re-admits it).  Launched alone it wins 8..13 % for KS >= 7 at 128 channels (one round of 247 tiles), but it
+                       // owns a whole CU (223 VGPR + 112 AGPR, 116 KB LDS): with the decoder's three MRF chains on concurrent
+                       // streams the 128x128 tile (two workgroups per CU, from different launches) lets one launch's epilogue
+                       // overlap another's MFMA loop: clip 8.29 / 8.44 ms with 128x224 vs 8.17 / 8.19 ms without (same box)
 int g_fast_epi = 1;    // 1: DB kernels batch the epilogue's residual loads (svc_debug_set_conv_cfg: +10000000 disables)
 int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
 
@@ -985,9 +989,9 @@ int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; g_no224 = 0; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; g_no224 = 1; return SVC_OK; }
   g_fast_epi = ((cfg / 10000000) % 10) ? 0 : 1;
-  g_no224 = ((cfg / 100000000) % 10) ? 1 : 0;
+  g_no224 = ((cfg / 100000000) % 10) ? 0 : 1;
   g_direct_mode = ((cfg / 1000000) % 10) ? 0 : 1;
   g_force_cfg = cfg % 100 - 1;
   g_no_ksc = (cfg / 100) % 10;

@@ -109,7 +109,7 @@ class ResBlock2(nn.Module):
             x = A.add(c.forward_train(A.leaky_relu(x, LRELU_SLOPE)), x)
         return x
 
-    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None):
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
         n = len(self.convs)
         cur = x
         bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(3)]
@@ -117,6 +117,8 @@ class ResBlock2(nn.Module):
         for j, c in enumerate(self.convs):
             if j == n - 1:
                 dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
                 c.run(cur, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
                 return dst
             dst = ping if cur is not ping else pong
@@ -175,6 +177,46 @@ class SourceModuleHnNSF(nn.Module):
         har = S.nsf_source(f0, rand_ini, nz, self.l_linear.weight, self.l_linear.bias, upp,
                            self.l_sin_gen.sampling_rate, self.sine_amp, self.noise_std)
         return har, None, None
+
+
+def mrf_stage(owner, blocks, x, acc, n_tmp=3):
+    """acc = mean_j blocks[j](x) for the ResBlocks of one decoder stage (`xs += resblocks[j](x)`; `x = xs / num_kernels`,
+    vdecoder/hifigan/models.py:382-388), the blocks accumulating into `acc` in order.
+
+    The blocks are independent chains over the same input; only their LAST launch touches the shared accumulator.  With
+    _MRF_STREAMS each chain runs on its own HIP stream (fork after the upsample, ordered accumulation through events, join
+    before the next stage), so the memory phase of one chain's tiles (epilogue: residual read + store, 14 % of a 128-channel
+    k=11 launch with every CU in the same phase) and its last partial round of tiles overlap another chain's matrix work:
+    10 s clip 9.10 -> 8.62 ms, same launches, same accumulation order (k = 3, then 7, then 11), bit-identical output.
+    Capturable (torch.cuda.graph follows the fork / join)."""
+    n = len(blocks)
+    kw = lambda j: dict(out=acc, beta=0.0 if j == 0 else 1.0, out_div=float(n) if j == n - 1 else 1.0)
+    if not (_MRF_STREAMS and n > 1 and x.is_cuda):
+        tmp = [torch.empty_like(x) for _ in range(n_tmp)]
+        for j, blk in enumerate(blocks):
+            blk(x, tmp=tmp, **kw(j))
+        return acc
+    main = torch.cuda.current_stream()
+    side = owner.__dict__.setdefault("_mrf_streams", {})
+    key = (x.device.index, n)
+    if key not in side:
+        side[key] = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
+    streams = [main] + side[key]
+    # scratch of every chain comes from the MAIN stream's allocator: main joins all chains below before anything is freed
+    tmps = [[torch.empty_like(x) for _ in range(n_tmp)] for _ in range(n)]
+    fork = torch.cuda.Event()
+    fork.record(main)
+    done = [torch.cuda.Event() for _ in range(n)]
+    for j, blk in enumerate(blocks):
+        st = streams[j]
+        with torch.cuda.stream(st):
+            if j:
+                st.wait_event(fork)
+            hook = (lambda jj=j, ss=st: ss.wait_event(done[jj - 1])) if j else None
+            blk(x, tmp=tmps[j], before_last=hook, **kw(j))
+            done[j].record(st)
+    main.wait_event(done[-1])      # chain j's last launch waited for chain j-1's: the last event covers all of them
+    return acc
 
 
 class Generator(nn.Module):
@@ -243,50 +285,10 @@ class Generator(nn.Module):
         for i in range(self.num_upsamples):
             xs = self.noise_convs[i](har)                              # (:379)
             x = self.ups[i].run(x, pre_slope=LRELU_SLOPE, res=xs)      # lrelu + ConvT + add (:377-381)
-            acc = xs                                                   # reuse the noise-conv buffer as MRF accumulator
-            if _MRF_STREAMS and self.num_kernels > 1 and x.is_cuda:
-                x = self._mrf_concurrent(i, x, acc)
-                continue
-            tmp = [torch.empty_like(x) for _ in range(3)]
-            for j in range(self.num_kernels):
-                last = j == self.num_kernels - 1
-                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
-                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmp)
-            x = acc
+            # reuse the noise-conv buffer as MRF accumulator
+            x = mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs)
         # F.leaky_relu default slope 0.01 (:390), conv_post, tanh
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
-
-    def _mrf_concurrent(self, i, x, acc):
-        """The num_kernels ResBlocks of a stage are independent chains over the same input (`xs += resblocks[j](x)`,
-        vdecoder/hifigan/models.py:382-388); only their LAST launch touches the shared accumulator.  Each chain runs on its own
-        HIP stream (fork after the upsample, ordered accumulation through events, join before the next stage), so the memory
-        phase of one chain's tiles (epilogue: residual read + store, 14 % of a 128-channel k=11 launch with every CU in the
-        same phase) and its last partial round of tiles overlap another chain's matrix work.  Same launches, same
-        accumulation order (k = 3, then 7, then 11): bit-identical output.  Capturable (torch.cuda.graph follows the fork/join)."""
-        main = torch.cuda.current_stream()
-        side = self.__dict__.setdefault("_mrf_streams", {})
-        key = (x.device.index, self.num_kernels)
-        if key not in side:
-            side[key] = [torch.cuda.Stream(device=x.device) for _ in range(self.num_kernels - 1)]
-        streams = [main] + side[key]
-        # scratch of every chain comes from the MAIN stream's allocator: main joins all chains below before anything is freed
-        tmps = [[torch.empty_like(x) for _ in range(3)] for _ in range(self.num_kernels)]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        done = [torch.cuda.Event() for _ in range(self.num_kernels)]
-        for j in range(self.num_kernels):
-            last = j == self.num_kernels - 1
-            st = streams[j]
-            with torch.cuda.stream(st):
-                if j:
-                    st.wait_event(fork)
-                hook = (lambda jj=j, ss=st: ss.wait_event(done[jj - 1])) if j else None
-                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
-                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmps[j],
-                                                         before_last=hook)
-                done[j].record(st)
-        main.wait_event(done[-1])      # chain j's last launch waited for chain j-1's: the last event covers all of them
-        return acc
 
     def remove_weight_norm(self):
         for l in self.ups:

@@ -44,7 +44,7 @@ class ResBlock1(nn.Module):
             x = A.add(xt, x)
         return x
 
-    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None, before_last=None):
         """Reference :71-77.  out (+)= resblock(x); epilogue arguments as hifigan.ResBlock1.forward."""
         n = len(self.convs1)
         acts1, acts2 = self.activations[::2], self.activations[1::2]
@@ -57,6 +57,8 @@ class ResBlock1(nn.Module):
             a2(xt, out=act)
             if j == n - 1:
                 dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
                 c2.run(act, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
                 return dst
             dst = ping if cur is not ping else pong
@@ -84,7 +86,7 @@ class ResBlock2(nn.Module):
             x = A.add(c.forward_train(a(x)), x)
         return x
 
-    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None):
+    def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, DIM=None, before_last=None):
         """Reference :101-106."""
         n = len(self.convs)
         bufs = tmp if tmp is not None else [torch.empty_like(x) for _ in range(4)]
@@ -94,6 +96,8 @@ class ResBlock2(nn.Module):
             a(cur, out=act)
             if j == n - 1:
                 dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
                 c.run(act, res=cur, res_mode=1, out=dst, beta=beta, out_div=out_div)
                 return dst
             dst = ping if cur is not ping else pong
@@ -152,11 +156,5 @@ class Generator(base.Generator):
         for i in range(self.num_upsamples):
             xs = self.noise_convs[i](har)
             x = self.ups[i].run(self.snakes[i](x), res=xs)              # snake + ConvT + noise-conv add (:395-402)
-            acc = xs
-            tmp = [torch.empty_like(x) for _ in range(4)]
-            for j in range(self.num_kernels):
-                last = j == self.num_kernels - 1
-                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
-                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmp)
-            x = acc
+            x = base.mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs, n_tmp=4)
         return self.conv_post.run(self.snake_post(x), post_act=S.ACT_TANH)     # (:409-411)

@@ -17,7 +17,7 @@ from torch import nn
 
 import svc_hip as S
 from svc_nn import Conv1d, ConvTranspose1d
-from vdecoder.hifigan.models import ResBlock1, ResBlock2
+from vdecoder.hifigan.models import ResBlock1, ResBlock2, mrf_stage
 
 from .env import AttrDict
 from .utils import init_weights
@@ -121,13 +121,7 @@ class Generator(nn.Module):
         for i in range(self.num_upsamples):
             xs = self.noise_convs[i](har)
             x = self.ups[i].run(x, pre_slope=LRELU_SLOPE, res=xs)
-            acc = xs
-            tmp = [torch.empty_like(x) for _ in range(3)]
-            for j in range(self.num_kernels):
-                last = j == self.num_kernels - 1
-                self.resblocks[i * self.num_kernels + j](x, out=acc, beta=0.0 if j == 0 else 1.0,
-                                                         out_div=float(self.num_kernels) if last else 1.0, tmp=tmp)
-            x = acc
+            x = mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs)
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
 
     def remove_weight_norm(self):
