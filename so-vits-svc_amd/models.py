@@ -339,6 +339,10 @@ class SynthesizerTrn(nn.Module):
         # staging-bound, and the padding mask costs the attention kernel 6 %.)
         x_mask = torch.ones((B, 1, T), device=c.device, dtype=torch.float32)      # c_lengths == T (models.py:503)
         m = mask2d(x_mask)
+        # the decoder's harmonic source + noise convs only need f0: start them now, underneath the encoder and the flow
+        src_noise = noise if "sine" in noise else None
+        early = not (self.use_automatic_f0_prediction and predict_f0) and hasattr(self.dec, "start_source")
+        source = self.dec.start_source(f0, src_noise) if early else None
         xin = self.pre.run(c, mask=m)                                               # pre(c) * mask
         volv = vol if (vol is not None and self.vol_embedding) else None
         x, x_enc = S.prenet_embed(xin, uv, f0, self.emb_uv.weight, self.enc_p.f0_emb.weight, mask=m, vol=volv,
@@ -355,7 +359,10 @@ class SynthesizerTrn(nn.Module):
                                          x_is_embedded=True, full_mask=True)
         z = self.flow(z_p, x_mask, g=g, reverse=True)
         # `z * c_mask` (models.py:531) is the identity here: the flow's last update already multiplies by the mask
-        o = self.dec(z, f0, g=g, noise=noise if "sine" in noise else None)
+        if source is not None:
+            o = self.dec(z, f0, g=g, noise=src_noise, source=source)
+        else:
+            o = self.dec(z, f0, g=g, noise=src_noise)
         return o, f0
 
     @torch.no_grad()

@@ -274,16 +274,50 @@ class Generator(nn.Module):
         x = self.conv_post.forward_train(x)
         return A.tanh(x)
 
-    def forward(self, x, f0, g=None, noise=None):
-        """x [B,inter,T] (tensor or channel-strided view), f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]."""
+    def start_source(self, f0, noise):
+        """The harmonic source and the five noise convs (:368-370,379) depend on f0 only.  Launched on a side stream as soon as
+        f0 is known, they run underneath the encoder / flow instead of in front of the decoder (0.35 ms of a 10 s clip:
+        the frame scan of the source is a short serial kernel, the noise convs are HBM-bound).  Returns (per-stage noise-conv
+        outputs, event to wait for); every output buffer comes from the CALLER's stream allocator."""
+        if not (_MRF_STREAMS and f0.is_cuda) or noise is None:
+            return None
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_src_stream", {})
+        if f0.device.index not in side:
+            side[f0.device.index] = torch.cuda.Stream(device=f0.device)
+        st = side[f0.device.index]
+        B, T = f0.shape
+        L = T * self.upp
+        har = torch.empty((B, 1, L), device=f0.device, dtype=torch.float32)
+        outs, Li = [], T
+        for i, nc in enumerate(self.noise_convs):
+            Li *= self.h["upsample_rates"][i]
+            outs.append(torch.empty((B, nc.out_channels, Li), device=f0.device, dtype=torch.float32))
+        fork, done = torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(st):
+            st.wait_event(fork)
+            S.nsf_source(f0, noise["rand_ini"], noise["sine"], self.m_source.l_linear.weight, self.m_source.l_linear.bias,
+                         self.upp, self.m_source.l_sin_gen.sampling_rate, self.m_source.sine_amp, self.m_source.noise_std, out=har)
+            for nc, o in zip(self.noise_convs, outs):
+                nc.run(har, out=o)
+            done.record(st)
+        return outs, done, har
+
+    def forward(self, x, f0, g=None, noise=None, source=None):
+        """x [B,inter,T] (tensor or channel-strided view), f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp].  `source`: the handle of an
+        earlier start_source(f0, noise) call (same f0 / noise), else the source is computed here."""
         if training_call(self.conv_post.bias) or (torch.is_grad_enabled() and getattr(x, "requires_grad", False)):
             return self.forward_train(x, f0, g=g, noise=noise)
         _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
-        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        if source is None:
+            har, _, _ = self.m_source(f0, self.upp, noise=noise)
         gc = self.cond(g) if g is not None else None                  # [B, C0, 1|T]  (:374)
         x = self.conv_pre.run(x, cond=gc)                              # (:373-374)
+        if source is not None:
+            torch.cuda.current_stream().wait_event(source[1])
         for i in range(self.num_upsamples):
-            xs = self.noise_convs[i](har)                              # (:379)
+            xs = source[0][i] if source is not None else self.noise_convs[i](har)     # (:379)
             x = self.ups[i].run(x, pre_slope=LRELU_SLOPE, res=xs)      # lrelu + ConvT + add (:377-381)
             # reuse the noise-conv buffer as MRF accumulator
             x = mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs)

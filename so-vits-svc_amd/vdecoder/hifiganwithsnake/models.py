@@ -145,16 +145,19 @@ class Generator(base.Generator):
         x = self.conv_post.forward_train(x)
         return A.tanh(x)
 
-    def forward(self, x, f0, g=None, noise=None):
-        """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413)."""
+    def forward(self, x, f0, g=None, noise=None, source=None):
+        """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413); `source`: see base.Generator.forward."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.conv_post.parameters()):
             return self.forward_train(x, f0, g=g, noise=noise)
         _no_grad_guard()
-        har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        if source is None:
+            har, _, _ = self.m_source(f0, self.upp, noise=noise)
         gc = self.cond(g) if g is not None else None
         x = self.conv_pre.run(x, cond=gc)
+        if source is not None:
+            torch.cuda.current_stream().wait_event(source[1])
         for i in range(self.num_upsamples):
-            xs = self.noise_convs[i](har)
+            xs = source[0][i] if source is not None else self.noise_convs[i](har)
             x = self.ups[i].run(self.snakes[i](x), res=xs)              # snake + ConvT + noise-conv add (:395-402)
             x = base.mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs, n_tmp=4)
         return self.conv_post.run(self.snake_post(x), post_act=S.ACT_TANH)     # (:409-411)
