@@ -142,6 +142,8 @@ def run_train(args, dev, rank, world, dist):
     import synthetic_data as W
     import train as TR
     cfg = W.full_config()
+    if os.environ.get("SVC_BENCH_PDROP") is not None:      # determinism experiments only
+        cfg["p_dropout"] = float(os.environ["SVC_BENCH_PDROP"])
     hps = train_hps(cfg)
     torch.manual_seed(1234)
     net_g, net_d, optim_g, optim_d = TR.build(hps, dev)
@@ -174,14 +176,22 @@ def run_train(args, dev, rank, world, dist):
                   file=sys.stderr)
             use_graph = False
             step_fn.enable_graph(False)
+    trace = [] if os.environ.get("SVC_BENCH_TRACE") else None      # determinism experiments: per-iteration losses
     for _ in range(warm):
         last = step_fn(items)
+        if trace is not None:
+            trace.append(last)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         last = step_fn(items)
+        if trace is not None:
+            trace.append(last)
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        print("TRACE " + " ".join(f"{float(l['loss_disc']):.4f}/{float(l['loss_kl']):.3f}/{float(l['loss_mel']):.3f}" for l in trace),
+              file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -21,22 +21,6 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _time_aligned(x):
-    """Rows whose length is not a multiple of 4 floats (DiscriminatorP's period layout: T = H * p) send svc_conv1d_f32 down
-    its scalar-staging path — 3-4x slower than the LDS-DMA path on the 512 / 1024-channel layers (profiles/
-    r02_g_train_B16_kernel_stats.txt: 510 vs 162 us for the same k=5 shape).  One strided copy into a zero-tailed buffer
-    of the next multiple of 4 puts the conv back on the fast path; the extra columns are zeros, i.e. exactly the zero
-    padding the conv applies past the end anyway.  Small tensors are left alone (the copy would cost more than it saves)."""
-    B, Cc, T = x.shape
-    if T % 4 == 0 or B * Cc * T < (1 << 20):
-        return x
-    Tp = (T + 3) // 4 * 4
-    buf = torch.empty((B, Cc, Tp), device=x.device, dtype=torch.float32)
-    buf[:, :, T:].zero_()
-    S.copy_bct(x, out=buf[:, :, :T])
-    return buf
-
-
 class _Conv1dDense(Function):
     """y = conv1d(x, w, bias, stride=1, padding=pad, dilation=dil)[..., :tout]; w is the explicit [Cout,Cin,KS] weight."""
 
@@ -49,7 +33,7 @@ class _Conv1dDense(Function):
         if tout is not None:
             Tout = min(Tout, tout)
         wp = S.pack_conv1d_weight(w.detach())
-        y = S.conv1d(_time_aligned(x), wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
+        y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
         ctx.save_for_backward(x, w)
         ctx.cfg = (pad, dil, bias is not None)
         return y
@@ -63,7 +47,7 @@ class _Conv1dDense(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = S.pack_conv1d_weight_T(w)
-            dx = S.conv1d(_time_aligned(dy), wt, Cin, KS, dil=dil, pad_left=dil * (KS - 1) - pad, Tout=x.shape[2])
+            dx = S.conv1d(dy, wt, Cin, KS, dil=dil, pad_left=dil * (KS - 1) - pad, Tout=x.shape[2])
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:      # bias gradient from the dy tiles the wgrad kernel stages anyway

@@ -773,9 +773,12 @@ class ZeroSlab:
 wgrad_slab = ZeroSlab()
 
 
+_SLAB_ON = os.environ.get("SVC_WGRAD_SLAB", "1") != "0"
+
+
 def wgrad_zeros(shape, device):
     """Zero-initialised gradient buffer: a slab view when the slab is active (then no per-tensor memset is needed)."""
-    if wgrad_slab.active:
+    if wgrad_slab.active and _SLAB_ON:
         return wgrad_slab.take(shape, device), True
     return torch.empty(tuple(shape), device=device, dtype=torch.float32), False
 

@@ -115,6 +115,7 @@ class TrainStep:
             ent = (graph, static, out)
             self._graphs[key] = ent
         graph, static, out = ent
+        self._serialize_replays()
         for s, t in zip(static, items):
             if s is not None:
                 s.copy_(t, non_blocking=True)
@@ -123,7 +124,26 @@ class TrainStep:
         graph.replay()
         self.optim_d.note_replayed_step()
         self.optim_g.note_replayed_step()
-        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        self._mark_replay()
+        return res
+
+    def _serialize_replays(self):
+        """Wait (on the host) for the previous replay of the iteration graph before enqueueing the next one.
+        Measured on MI355X / ROCm 7.2 (profiles/r02_o_train_replay_after_sync_determinism.txt): when a replay is enqueued
+        right behind another one that started on an idle GPU — i.e. the second replay after any host synchronisation — the
+        iteration it produces is wrong (losses off from the next step on, sometimes diverging to NaN), while replays
+        separated by a host wait, and eager iterations, reproduce each other to fp32 round-off run after run.  The training
+        iteration is ~140 ms of GPU work and the host has nothing else to do, so the wait costs one launch latency."""
+        ev = self.__dict__.get("_replay_done")
+        if ev is not None:
+            ev.synchronize()
+
+    def _mark_replay(self):
+        ev = self.__dict__.get("_replay_done")
+        if ev is None:
+            ev = self.__dict__["_replay_done"] = torch.cuda.Event()
+        ev.record()
 
     def _step_body(self, items, noise=None):
         ctx = self._seg_d(items, noise)
@@ -249,6 +269,7 @@ class TrainStep:
             self.dp_mode = "collectives captured in the graphs (bucket-overlapped)" if captured else \
                 "two graphs, bucketed all-reduce between them (exposed)"
         g1, g2, static, out, touched_d, touched_g, _, captured = ent
+        self._serialize_replays()
         for s, t in zip(static, items):
             if s is not None:
                 s.copy_(t, non_blocking=True)
@@ -263,7 +284,9 @@ class TrainStep:
         self.optim_g.arena.touched = list(touched_g)
         self.optim_g.step()
         S.wgrad_slab.active = False
-        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        self._mark_replay()
+        return res
 
 
 def init_distributed(rank, world, device):

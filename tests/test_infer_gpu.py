@@ -209,3 +209,34 @@ def test_infer_very_short_inputs(dev, B, T):
     o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4,
                      noise={k: v.to(dev) for k, v in noise.items()})
     _check(o, ref)
+
+
+def test_graph_replays_back_to_back_equal_eager(dev):
+    """hipGraph replays enqueued back to back (no host synchronisation in between, different inputs each time, and a host
+    sync in the middle of the sequence — the pattern that exposed mis-ordered training-graph replays on ROCm 7.2, see
+    train.TrainStep._serialize_replays) must each reproduce the eager result for their own input."""
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    B, T = 1, 200
+    ins = []
+    for i in range(6):
+        c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=100 + i)
+        noise = W.make_noise(cfg, B, T, seed=200 + i)
+        ins.append(([t.to(dev) for t in (c, f0, uv, sid)], {k: v.to(dev) for k, v in noise.items()}))
+    eager = []
+    for (c, f0, uv, sid), nz in ins:
+        o, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=nz)
+        eager.append(o.clone())
+    net.enable_graph(True)
+    (c, f0, uv, sid), nz = ins[0]
+    net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=nz)              # capture
+    torch.cuda.synchronize()
+    outs = []
+    for i, ((c, f0, uv, sid), nz) in enumerate(ins):
+        o, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=nz)
+        outs.append(o)
+        if i == 2:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(outs, eager)):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
