@@ -416,9 +416,6 @@ class SynthesizerTrn(nn.Module):
         return out[0].clone(), out[1].clone()
 
 
-_D_STREAMS = __import__("os").environ.get("SVC_D_STREAMS", "1") != "0"      # A/B switch: one HIP stream per sub-discriminator
-
-
 class _NormConv(nn.Module):
     """weight_norm(Conv1d / Conv2d((k,1))) parameter holder of the discriminators; `weight_v` keeps the REFERENCE shape
     ([Cout,Cin,K] for Conv1d, [Cout,Cin,K,1] for Conv2d) so checkpoints (D_*.pth) load key-for-key."""
@@ -508,40 +505,14 @@ class MultiPeriodDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm=use_spectral_norm)] +
                                             [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods])
 
-    def _fan_out(self, fn, tensors_of):
-        """[fn(d) for d in the six sub-discriminators].  They are independent networks over the same input (models.py:244-251);
-        each launch in them is small (5-600 us) and the chain inside one discriminator is strictly sequential, so with
-        _D_STREAMS every discriminator gets its own HIP stream: forward launches of different discriminators overlap, and so
-        do their backward launches (autograd replays a node on the stream its forward ran on).  Fork / join on events;
-        `tensors_of(result)` lists the tensors handed to the caller's stream (record_stream) before use."""
-        if not (_D_STREAMS and torch.cuda.is_available()):
-            return [fn(d) for d in self.discriminators]
-        main = torch.cuda.current_stream()
-        pool = self.__dict__.setdefault("_d_streams", {})
-        dev = main.device_index
-        if dev not in pool:
-            pool[dev] = [torch.cuda.Stream(device=dev) for _ in range(len(self.discriminators) - 1)]
-        streams = [main] + pool[dev]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        outs = []
-        for d, st in zip(self.discriminators, streams):
-            with torch.cuda.stream(st):
-                if st is not main:
-                    st.wait_event(fork)
-                outs.append(fn(d))
-        for res, st in zip(outs, streams):
-            if st is not main:
-                main.wait_stream(st)
-                for t in tensors_of(res):
-                    t.record_stream(main)
-        return outs
-
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
         n = y.shape[0]
         yy = torch.cat([y, y_hat], 0)      # one pass over both signals (same weights): halves the launches
-        for out, fmap in self._fan_out(lambda d: d(yy), lambda r: [r[0]] + list(r[1])):
+        # (tried: one HIP stream per sub-discriminator — forward and, through autograd's stream bookkeeping, backward launches
+        # of the six independent networks overlapping: 150 vs 140 ms per iteration on the same box, the extra event traffic costs
+        # more than the overlap of these launch-bound kernels gains inside an already captured graph)
+        for out, fmap in (d(yy) for d in self.discriminators):
             y_d_rs.append(out[:n])
             y_d_gs.append(out[n:])
             fmap_rs.append([f[:n] for f in fmap])
@@ -554,14 +525,10 @@ class MultiPeriodDiscriminator(nn.Module):
         without an autograd tape, so the generator step back-propagates through half the batch only."""
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
 
-        def both(d):
+        for d in self.discriminators:
             with torch.no_grad():
                 out_r, fmap_r = d(y)
             out_g, fmap_g = d(y_hat)
-            return (out_r, out_g), (fmap_r, fmap_g)
-
-        res = self._fan_out(both, lambda r: [r[0][0], r[0][1]] + list(r[1][0]) + list(r[1][1]))
-        for (out_r, out_g), (fmap_r, fmap_g) in res:
             y_d_rs.append(out_r)
             y_d_gs.append(out_g)
             fmap_rs.append(fmap_r)
