@@ -172,12 +172,20 @@ def attn_encoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, window_s
     return x * x_mask
 
 
-def fft_decoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, drop=_NO_DROP):
-    """attentions.FFT.forward (isflow=False), modules/attentions.py:43-70: causal self-attention, causal FFN."""
+def fft_decoder(x, x_mask, sd, prefix, n_layers, n_heads, kernel_size, drop=_NO_DROP, g=None):
+    """attentions.FFT.forward, modules/attentions.py:43-70: causal self-attention, causal FFN.  With `g` (isflow=True,
+    :24-28,49-61): g -> weight-normed cond_layer once, and in front of every layer the SHARED 1x1 `cond_pre` (H -> 2H)
+    followed by fused_add_tanh_sigmoid_multiply with that layer's 2H slice of the conditioning."""
     t = x.shape[2]
     causal = torch.tril(torch.ones(t, t)).unsqueeze(0).unsqueeze(0)
+    if g is not None:
+        g = conv1d(g, sd, prefix + ".cond_layer")
     x = x * x_mask
     for i in range(n_layers):
+        if g is not None:
+            hidden = x.shape[1]
+            x_in = conv1d(x, sd, prefix + ".cond_pre") + g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :]
+            x = torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:])        # modules/commons.py:129-136
         y = drop(multi_head_attention(x, sd, f"{prefix}.self_attn_layers.{i}", causal, n_heads, None, drop))
         x = layer_norm_c(x + y, sd[f"{prefix}.norm_layers_0.{i}.gamma"], sd[f"{prefix}.norm_layers_0.{i}.beta"])
         y = drop(ffn(x, x_mask, sd, f"{prefix}.ffn_layers.{i}", kernel_size, causal=True, drop=drop))
@@ -252,22 +260,44 @@ def coupling_layer(x, x_mask, g, sd, prefix, wn_prefix, cfg, reverse):
     return torch.cat([x0, x1], 1)
 
 
-def flow(x, x_mask, g, sd, cfg, reverse, prefix="flow"):
-    """ResidualCouplingBlock.forward, models.py:45-52: flows = [coupling, Flip] * n_flows (n_flows = n_flow_layer,
-    models.py:445), Flip = torch.flip over channels (modules/modules.py:232-239).  Note models.py:445 passes
-    n_flow_layer as BOTH the WN depth (positional n_layers) and... n_flows stays at its default 4."""
-    n_flows = 4
+def transformer_coupling_layer(x, x_mask, g, sd, prefix, enc_prefix, cfg, reverse, drop=_NO_DROP):
+    """TransformerCouplingLayer.forward with mean_only=True, modules/modules.py:337-356: the coupling network is the
+    conditioned FFT (attentions.FFT(isflow=True)) instead of WN."""
+    half = cfg["inter_channels"] // 2
+    x0, x1 = torch.split(x, [half, half], 1)
+    h = conv1d(x0, sd, prefix + ".pre") * x_mask
+    h = fft_decoder(h, x_mask, sd, enc_prefix, cfg.get("n_layers_trans_flow", 3), cfg["n_heads"], 5, drop=drop, g=g)
+    m = conv1d(h, sd, prefix + ".post") * x_mask
+    if not reverse:
+        x1 = m + x1 * x_mask
+    else:
+        x1 = (x1 - m) * x_mask
+    return torch.cat([x0, x1], 1)
+
+
+def flow(x, x_mask, g, sd, cfg, reverse, prefix="flow", drop=_NO_DROP):
+    """ResidualCouplingBlock.forward, models.py:45-52: flows = [coupling, Flip] * n_flows, Flip = torch.flip over
+    channels (modules/modules.py:232-239).  Note models.py:441 passes n_flow_layer as the WN depth (positional n_layers);
+    n_flows stays at its default 4.  With use_transformer_flow (models.py:438-439, TransformerCouplingBlock :54-92) the
+    couplings are TransformerCouplingLayers, n_flow_layer IS the number of flows, and the shared network (if any) is
+    `flow.wn` as well."""
+    trans = cfg.get("use_transformer_flow", False)
+    n_flows = cfg.get("n_flow_layer", 4) if trans else 4
     share = cfg.get("flow_share_parameter", False)
     order = range(n_flows) if not reverse else reversed(range(n_flows))
+
+    def couple(x, cp, rev):
+        enc_prefix = f"{prefix}.wn" if share else cp + ".enc"
+        if trans:
+            return transformer_coupling_layer(x, x_mask, g, sd, cp, enc_prefix, cfg, rev, drop)
+        return coupling_layer(x, x_mask, g, sd, cp, enc_prefix, cfg, rev)
+
     for i in order:
         cp = f"{prefix}.flows.{2 * i}"
-        wn_prefix = f"{prefix}.wn" if share else cp + ".enc"
         if not reverse:
-            x = coupling_layer(x, x_mask, g, sd, cp, wn_prefix, cfg, False)
-            x = torch.flip(x, [1])
+            x = torch.flip(couple(x, cp, False), [1])
         else:
-            x = torch.flip(x, [1])
-            x = coupling_layer(x, x_mask, g, sd, cp, wn_prefix, cfg, True)
+            x = couple(torch.flip(x, [1]), cp, True)
     return x
 
 

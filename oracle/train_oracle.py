@@ -18,7 +18,8 @@ LRELU_SLOPE = 0.1
 def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise, vol=None):
     """models.py:463-493 with the random draws explicit: noise = dict(f0_factor [B,1], enc_p, enc_q [B,inter,T],
     ids_slice [B] int64, rand_ini [B,9], sine [B, seg*hop, 9], optional dropout_u = the uniform draws of every nn.Dropout
-    site with cfg["p_dropout"] > 0, in call order: f0_decoder's layers first (models.py:476), then enc_p's (:477))."""
+    site with cfg["p_dropout"] > 0, in call order: f0_decoder's layers first (models.py:476), then enc_p's (:477), then — with use_transformer_flow — the
+    flow's FFT layers (:482))."""
     B, _, T = c.shape
     drop = O.DropSeq(cfg.get("p_dropout", 0.0), noise.get("dropout_u"))
     g = sd["emb_g.weight"][sid].transpose(1, 2)
@@ -32,7 +33,7 @@ def synth_forward(sd, cfg, c, f0, uv, spec, sid, c_lengths, spec_lengths, noise,
     z_ptemp, m_p, logs_p = O.text_encoder(x, x_mask, O.f0_to_coarse(f0), sd, cfg, noise["enc_p"], 1.0, drop=drop)
     spec_mask = O.sequence_mask(spec_lengths, spec.shape[2]).unsqueeze(1).to(spec.dtype)
     z, m_q, logs_q = O.posterior_encoder(spec, spec_mask, g, sd, cfg, noise["enc_q"])
-    z_p = O.flow(z, spec_mask, g, sd, cfg, reverse=False)
+    z_p = O.flow(z, spec_mask, g, sd, cfg, reverse=False, drop=drop)      # transformer flow: its dropout sites come last
     seg = cfg["segment_size"]
     ids = noise["ids_slice"]
     z_slice = torch.stack([z[i, :, ids[i]:ids[i] + seg] for i in range(B)])

@@ -5,7 +5,8 @@ constructor signatures, attribute names and state_dict layout (751 keys for the 
 `SynthesizerTrn.infer` (reference models.py:496-532, incl. automatic f0 prediction, optional hipGraph replay of the whole
 path) runs the fused inference kernels; `SynthesizerTrn.forward` (:463-493), `Encoder` (enc_q) and the
 MultiPeriodDiscriminator run the training graph on svc_autograd Functions (HIP forward + HIP backward), dropout included.
-Not built (raise NotImplementedError): use_transformer_flow, spectral-norm discriminators.
+`use_transformer_flow` (TransformerCouplingBlock) included.  Not built (raise NotImplementedError): spectral-norm
+discriminators.
 """
 import math
 
@@ -52,6 +53,9 @@ class ResidualCouplingBlock(nn.Module):
                 for flow in reversed(self.flows):
                     x = flow(x, x_mask, g=g, reverse=True)
             return x
+        return self._run_inplace(x, x_mask, g, reverse)
+
+    def _run_inplace(self, x, x_mask, g, reverse):
         buf = S.copy_bct(x)
         flipped = False
         couplings = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
@@ -66,6 +70,48 @@ class ResidualCouplingBlock(nn.Module):
         if flipped:
             buf = S.copy_bct(S.flip_view(buf))
         return buf
+
+
+class TransformerCouplingBlock(ResidualCouplingBlock):
+    """Reference models.py:54-92 (`use_transformer_flow`): n_flows mean-only couplings whose network is a conditioned
+    causal FFT stack (modules.TransformerCouplingLayer), optionally ONE stack shared by all couplings and registered as
+    `flow.wn` too.  Inference runs the same in-place / flip-view schedule as the WaveNet flow; in training every FFT layer
+    is a dropout site (`dropout_u`: injected draws, consumed in call order)."""
+
+    def __init__(self, channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, n_flows=4,
+                 gin_channels=0, share_parameter=False):
+        nn.Module.__init__(self)
+        self.channels = channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.n_layers = n_layers
+        self.n_flows = n_flows
+        self.gin_channels = gin_channels
+        self.flows = nn.ModuleList()
+        self.wn = attentions.FFT(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, isflow=True,
+                                 gin_channels=gin_channels) if share_parameter else None
+        for _ in range(n_flows):
+            self.flows.append(modules.TransformerCouplingLayer(channels, hidden_channels, kernel_size, n_layers, n_heads,
+                                                               p_dropout, filter_channels, mean_only=True,
+                                                               wn_sharing_parameter=self.wn, gin_channels=gin_channels))
+            self.flows.append(modules.Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False, dropout_u=None):
+        if training_call(self.flows[0].pre.weight) or (torch.is_grad_enabled() and x.requires_grad):
+            if not reverse:
+                for flow in self.flows:
+                    if isinstance(flow, modules.Flip):
+                        x, _ = flow(x, x_mask, g=g, reverse=False)
+                    else:
+                        x, _ = flow(x, x_mask, g=g, reverse=False, dropout_u=dropout_u)
+            else:
+                for flow in reversed(self.flows):
+                    if isinstance(flow, modules.Flip):
+                        x = flow(x, x_mask, g=g, reverse=True)
+                    else:
+                        x = flow(x, x_mask, g=g, reverse=True, dropout_u=dropout_u)
+            return x
+        return self._run_inplace(x, x_mask, g, reverse)
 
 
 class Encoder(nn.Module):
@@ -229,6 +275,7 @@ class SynthesizerTrn(nn.Module):
         self.use_depthwise_conv = use_depthwise_conv
         self.use_automatic_f0_prediction = use_automatic_f0_prediction
         self.n_layers_trans_flow = n_layers_trans_flow
+        self.use_transformer_flow = use_transformer_flow
         if vol_embedding:
             self.emb_vol = nn.Linear(1, hidden_channels)
         self.pre = Conv1d(ssl_dim, hidden_channels, kernel_size=5, padding=2)
@@ -248,10 +295,13 @@ class SynthesizerTrn(nn.Module):
             from vdecoder.hifigan.models import Generator
         self.dec = Generator(h=hps)
         self.enc_q = Encoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
-        if use_transformer_flow:
-            raise NotImplementedError("use_transformer_flow has no HIP path yet")
-        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, n_flow_layer,
-                                          gin_channels=gin_channels, share_parameter=flow_share_parameter)
+        if use_transformer_flow:            # models.py:438-439
+            self.flow = TransformerCouplingBlock(inter_channels, hidden_channels, filter_channels, n_heads,
+                                                 n_layers_trans_flow, 5, p_dropout, n_flow_layer, gin_channels=gin_channels,
+                                                 share_parameter=flow_share_parameter)
+        else:
+            self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, n_flow_layer,
+                                              gin_channels=gin_channels, share_parameter=flow_share_parameter)
         if self.use_automatic_f0_prediction:
             self.f0_decoder = F0Decoder(1, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
                                         spk_channels=gin_channels)
@@ -271,7 +321,8 @@ class SynthesizerTrn(nn.Module):
         """Training graph, reference models.py:463-493.  Every op is a svc_autograd Function (HIP forward + backward).
         `noise` (optional dict: enc_p, enc_q [B,inter,T], f0_factor [B,1], ids_slice [B], rand_ini [B,9],
         sine [B, seg*hop, 9], dropout_u: list of uniform draws, one per active nn.Dropout site in call order — f0_decoder's
-        6 layers x (attention probabilities [B,H,T,T], attention output, FFN hidden, FFN output), then enc_p's) injects the
+        6 layers x (attention probabilities [B,H,T,T], attention output, FFN hidden, FFN output), then enc_p's, then the
+        transformer flow's) injects the
         random draws explicitly (parity tests); otherwise they come from torch's generator in the reference's order."""
         noise = noise or {}
         du = list(noise["dropout_u"]) if noise.get("dropout_u") is not None else None
@@ -299,7 +350,7 @@ class SynthesizerTrn(nn.Module):
             lf0 = norm_lf0 = pred_lf0 = 0
         z_ptemp, m_p, logs_p, _ = self.enc_p(x, x_mask, f0=utils.f0_to_coarse(f0), noise=noise.get("enc_p"), dropout_u=du)
         z, m_q, logs_q, spec_mask = self.enc_q(spec, spec_lengths, g=gemb, noise=noise.get("enc_q"))
-        z_p = self.flow(z, spec_mask, g=gemb)
+        z_p = self.flow(z, spec_mask, g=gemb, dropout_u=du) if self.use_transformer_flow else self.flow(z, spec_mask, g=gemb)
         ids = noise.get("ids_slice")
         if ids is None:
             z_slice, pitch_slice, ids_slice = commons.rand_slice_segments_with_pitch(z, f0, spec_lengths, self.segment_size)

@@ -238,13 +238,16 @@ class DropoutDraws:
         return A.dropout(x, self.u(tuple(x.shape), x.device), self.p)
 
 
-def _encoder_forward_train(self, x, x_mask, attn_layers, norm_a, norm_b, mask_mode, dropout_u=None):
+def _encoder_forward_train(self, x, x_mask, attn_layers, norm_a, norm_b, mask_mode, dropout_u=None, pre_layer=None):
     """Encoder / FFT training forward (modules/attentions.py:43-70,95-107) with all four dropout sites of a layer in the
-    reference's order: attention probabilities (:232), attention output (:51/:100), FFN hidden (:344), FFN output."""
+    reference's order: attention probabilities (:232), attention output (:51/:100), FFN hidden (:344), FFN output.
+    `pre_layer(i, x)`: the conditioning gate in front of each layer of a flow FFT (:49-56)."""
     m = x_mask[:, 0].contiguous() if x_mask.dim() == 3 else x_mask
     draws = DropoutDraws(self.p_dropout, self.training, dropout_u)
     x = A.mul_bcast(x, x_mask)
     for i in range(self.n_layers):
+        if pre_layer is not None:
+            x = pre_layer(i, x)
         y = attn_layers[i].forward_train(x, mask_mode, m if mask_mode == MASK_PADDING else None, draws=draws)
         y = draws(y)
         x = norm_a[i](A.add(x, y))
@@ -266,8 +269,14 @@ class FFT(nn.Module):
         self.p_dropout = p_dropout
         self.proximal_bias = proximal_bias
         self.proximal_init = proximal_init
+        self.isflow = isflow
         if isflow:
-            raise NotImplementedError("use_transformer_flow (FFT as a coupling network) has no HIP path yet")
+            # modules/attentions.py:24-28: conditioning of a coupling network (use_transformer_flow): the speaker embedding
+            # goes through a weight-normed 1x1 `cond_layer` once, and ONE shared 1x1 `cond_pre` (H -> 2H) runs in front of
+            # every layer, gated by that layer's slice of the conditioning (fused_add_tanh_sigmoid_multiply)
+            self.gin_channels = kwargs["gin_channels"]
+            self.cond_pre = Conv1d(hidden_channels, 2 * hidden_channels, 1)
+            self.cond_layer = Conv1d(self.gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
         self.self_attn_layers = nn.ModuleList()
         self.norm_layers_0 = nn.ModuleList()
         self.ffn_layers = nn.ModuleList()
@@ -281,17 +290,32 @@ class FFT(nn.Module):
                                        p_dropout=p_dropout, causal=True))
             self.norm_layers_1.append(LayerNorm(hidden_channels))
 
-    def forward_train(self, x, x_mask, dropout_u=None):
-        """Reference modules/attentions.py:43-70 (g is None on the so-vits-svc path)."""
-        return _encoder_forward_train(self, x, x_mask, self.self_attn_layers, self.norm_layers_0, self.norm_layers_1,
-                                      MASK_CAUSAL, dropout_u)
+    def _check_g(self, g):
+        if (g is not None) != self.isflow:
+            raise S.SvcError("FFT: the conditioning `g` is given exactly when the module was built with isflow=True")
 
-    def forward(self, x, x_mask, g=None):
+    def forward_train(self, x, x_mask, dropout_u=None, g=None):
+        """Reference modules/attentions.py:43-70; with `g` the per-layer conditioning gate of :49-56."""
+        self._check_g(g)
+        pre = None
+        if g is not None:
+            H = self.hidden_channels
+            gc = self.cond_layer.forward_train(g)                                   # [B, 2H*L, 1]
+            pre = lambda i, x: A.gate(A.add_bcast(self.cond_pre.forward_train(x), gc[:, i * 2 * H:(i + 1) * 2 * H]))
+        return _encoder_forward_train(self, x, x_mask, self.self_attn_layers, self.norm_layers_0, self.norm_layers_1,
+                                      MASK_CAUSAL, dropout_u, pre_layer=pre)
+
+    def forward(self, x, x_mask, g=None, dropout_u=None):
         if training_call(self.norm_layers_0[0].gamma) or (torch.is_grad_enabled() and x.requires_grad):
-            return self.forward_train(x, x_mask)
+            return self.forward_train(x, x_mask, dropout_u=dropout_u, g=g)
+        self._check_g(g)
         m = mask2d(x_mask)
         x = S.copy_bct(x, mask=m)
+        H = self.hidden_channels
+        gc = self.cond_layer(g) if g is not None else None
         for i in range(self.n_layers):
+            if gc is not None:      # cond_pre + conditioning + tanh*sigmoid gate: one MFMA conv with the gate epilogue
+                x = self.cond_pre.run(x, cond=gc[:, i * 2 * H:(i + 1) * 2 * H], epi=S.EPI_GATE)
             y = self.self_attn_layers[i](x, x, mask_mode=MASK_CAUSAL)
             x = self.norm_layers_0[i](x, residual=y, x_mask=x_mask)
             y = self.ffn_layers[i](x, x_mask, x_is_masked=True)

@@ -177,12 +177,16 @@ class ResidualCouplingLayer(nn.Module):
         # stats = post(h) * mask ; reverse: x1 = (x1 - stats) * mask ; forward: x1 = stats + x1 * mask   (logs == 0)
         self.post.run(h, mask=m, res=x1, res_mode=2 if reverse else 3, out=x1)
 
-    def forward_train(self, x, x_mask, g=None, reverse=False):
-        """Reference modules/modules.py:288-307 with mean_only=True (logs == 0)."""
+    def forward_train(self, x, x_mask, g=None, reverse=False, dropout_u=None):
+        """Reference modules/modules.py:288-307 with mean_only=True (logs == 0).  `dropout_u`: injected dropout draws for
+        a transformer coupling network (WN has no dropout on this path)."""
         half = self.half_channels
         x0, x1 = x[:, :half], x[:, half:]
         h = A.mul_bcast(self.pre.forward_train(x0), x_mask)
-        h = self.enc.forward_train(h, x_mask, g=g)
+        if dropout_u is not None:
+            h = self.enc.forward_train(h, x_mask, g=g, dropout_u=dropout_u)
+        else:
+            h = self.enc.forward_train(h, x_mask, g=g)
         m = A.mul_bcast(self.post.forward_train(h), x_mask)
         if not reverse:
             x1n = A.add(m, A.mul_bcast(x1, x_mask))
@@ -190,14 +194,41 @@ class ResidualCouplingLayer(nn.Module):
         x1n = A.mul_bcast(A.add(x1, m, 1.0, -1.0), x_mask)
         return torch.cat([x0, x1n], 1)
 
-    def forward(self, x, x_mask, g=None, reverse=False):
+    def forward(self, x, x_mask, g=None, reverse=False, dropout_u=None):
         if training_call(self.pre.weight) or (torch.is_grad_enabled() and x.requires_grad):
-            return self.forward_train(x, x_mask, g=g, reverse=reverse)
+            return self.forward_train(x, x_mask, g=g, reverse=reverse, dropout_u=dropout_u)
         y = S.copy_bct(x)
         self.apply_inplace(y, x_mask, g=g, reverse=reverse)
         if not reverse:
             return y, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)  # logdet = sum(logs) = 0
         return y
+
+
+class TransformerCouplingLayer(ResidualCouplingLayer):
+    """Reference modules/modules.py:309-356 (use_transformer_flow): the same mean-only coupling with the conditioned FFT
+    (attentions.FFT(isflow=True)) as the coupling network; the in-place update, the Flip views and the autograd form are
+    ResidualCouplingLayer's."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, n_layers, n_heads, p_dropout=0, filter_channels=0,
+                 mean_only=False, wn_sharing_parameter=None, gin_channels=0):
+        assert channels % 2 == 0, "channels should be divisible by 2"
+        nn.Module.__init__(self)
+        from modules import attentions
+        self.channels = channels
+        self.hidden_channels = hidden_channels
+        self.kernel_size = kernel_size
+        self.n_layers = n_layers
+        self.half_channels = channels // 2
+        self.mean_only = mean_only
+        if not mean_only:
+            raise NotImplementedError("only mean_only=True couplings exist on the so-vits-svc path (models.py:82)")
+        self.pre = Conv1d(self.half_channels, hidden_channels, 1)
+        self.enc = attentions.FFT(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, isflow=True,
+                                  gin_channels=gin_channels) if wn_sharing_parameter is None else wn_sharing_parameter
+        self.post = Conv1d(hidden_channels, self.half_channels * (2 - mean_only), 1)
+        with torch.no_grad():
+            self.post.weight.zero_()
+            self.post.bias.zero_()
 
 
 class ResBlock1(nn.Module):

@@ -76,8 +76,8 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
         else:
             P[name + ".weight"] = shape
 
-    def attn_stack(prefix, attn_name, norm_a, norm_b, window):
-        for i in range(nl):
+    def attn_stack(prefix, attn_name, norm_a, norm_b, window, n_layers=None, k=k):
+        for i in range(nl if n_layers is None else n_layers):
             a = f"{prefix}.{attn_name}.{i}"
             if window:
                 P[a + ".emb_rel_k"] = (1, 9, kc)
@@ -158,12 +158,24 @@ def param_shapes(cfg, include_enc_q=True, include_f0_decoder=True):
         conv("enc_q.proj", 2 * inter, h, 1)
 
     nfl = cfg.get("n_flow_layer", 4)
+    if cfg.get("use_transformer_flow"):
+        # TransformerCouplingBlock (models.py:54-92, built at :438-439): n_flow_layer couplings, each a conditioned FFT
+        # (attentions.FFT(isflow=True), modules/attentions.py:24-28) of n_layers_trans_flow layers, kernel size 5
+        ntf = cfg.get("n_layers_trans_flow", 3)
+
+        def flow_net(prefix, _):
+            conv(prefix + ".cond_pre", 2 * h, h, 1)
+            conv(prefix + ".cond_layer", 2 * h * ntf, gin, 1, wn=True)
+            attn_stack(prefix, "self_attn_layers", "norm_layers_0", "norm_layers_1", window=False, n_layers=ntf, k=5)
+        n_flows = nfl
+    else:
+        flow_net, n_flows = wn_block, 4
     if cfg.get("flow_share_parameter"):
-        wn_block("flow.wn", nfl)
-    for f in range(4):
+        flow_net("flow.wn", nfl)
+    for f in range(n_flows):
         fp = f"flow.flows.{2 * f}"
         conv(fp + ".pre", h, inter // 2, 1)
-        wn_block(fp + ".enc", nfl)      # with flow_share_parameter these keys alias flow.wn.* (same module registered twice)
+        flow_net(fp + ".enc", nfl)      # with flow_share_parameter these keys alias flow.wn.* (same module registered twice)
         conv(fp + ".post", inter // 2, h, 1)
 
     if include_f0_decoder and cfg.get("use_automatic_f0_prediction", True):
@@ -353,9 +365,14 @@ def make_dropout_draws(cfg, B, T, seed):
     gen = torch.Generator().manual_seed(seed)
     H, C, Fc = cfg["n_heads"], cfg["hidden_channels"], cfg["filter_channels"]
     out = []
+    sites = ((B, H, T, T), (B, C, T), (B, Fc, T), (B, C, T))
     for _stack in ("f0_decoder", "enc_p"):
         for _ in range(cfg["n_layers"]):
-            for shape in ((B, H, T, T), (B, C, T), (B, Fc, T), (B, C, T)):
+            for shape in sites:
+                out.append(torch.rand(shape, generator=gen))
+    if cfg.get("use_transformer_flow"):       # models.py:482: the flow's FFT stacks come last (spec frames == unit frames)
+        for _ in range(cfg.get("n_flow_layer", 4) * cfg.get("n_layers_trans_flow", 3)):
+            for shape in sites:
                 out.append(torch.rand(shape, generator=gen))
     return out
 

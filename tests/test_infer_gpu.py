@@ -10,6 +10,7 @@ import torch
 
 from oracle import svc_oracle as O
 from oracle import weights as W
+from variants import INFER_GOLDENS, variant_config
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -34,15 +35,11 @@ def _check(o, ref, tol_rel=2e-4):
     return mse, mx
 
 
-@pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake"),
-                                          ("infer_tiny_T40.npz", "tiny")])
+@pytest.mark.parametrize("name,cfgname", INFER_GOLDENS)
 def test_infer_matches_reference_golden(dev, name, cfgname):
     z = np.load(os.path.join(G, name))
     meta = json.loads(str(z["meta"]))
-    cfg = W.full_config() if cfgname == "full" else (W.small_tiny_config() if cfgname == "tiny" else W.small_config())
-    if cfgname == "snake":
-        cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
+    cfg = variant_config(cfgname)
     net, _ = _build(cfg, meta["seed"], dev)
     t = lambda k: torch.from_numpy(z[k]).to(dev)
     noise = dict(enc_p=t("noise_enc_p"), rand_ini=t("noise_rand_ini"), sine=t("noise_sine"))

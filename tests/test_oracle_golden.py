@@ -9,6 +9,7 @@ import torch
 
 from oracle import svc_oracle as O
 from oracle import weights as W
+from variants import INFER_GOLDENS, variant_config
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -37,15 +38,11 @@ def test_f0_to_coarse_bit_exact():
     assert (z["coarse"][z["f0"] > 1110] == 0).all()
 
 
-@pytest.mark.parametrize("name,cfgname", [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"),
-                                          ("infer_full_T24.npz", "full"), ("infer_snake_T40.npz", "snake"),
-                                          ("infer_tiny_T40.npz", "tiny")])
+@pytest.mark.parametrize("name,cfgname", INFER_GOLDENS)
 def test_oracle_reproduces_reference_infer(name, cfgname):
     z = _load(name)
     meta = z["meta"]
-    cfg = W.full_config() if cfgname == "full" else (W.small_tiny_config() if cfgname == "tiny" else W.small_config())
-    if cfgname == "snake":
-        cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
+    cfg = variant_config(cfgname)
     sd = W.make_state_dict(cfg, meta["seed"])
     noise = dict(enc_p=z["noise_enc_p"], rand_ini=z["noise_rand_ini"], sine=z["noise_sine"])
     with torch.no_grad():

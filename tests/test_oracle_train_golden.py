@@ -6,7 +6,7 @@ import torch
 from oracle import mel as OM
 from oracle import train_oracle as TO
 from oracle import weights as W
-from train_common import LOSS_KEYS, load_case, load_dropout_case
+from train_common import LOSS_KEYS, load_case, load_dropout_case, load_transflow_case
 
 
 def test_mpd_layout_matches_reference():
@@ -97,3 +97,32 @@ def test_oracle_reproduces_reference_training_forward_with_dropout():
     # and dropout is really active in this case: the eval-mode statistics differ
     o0 = TO.synth_forward(cs["sd_g"], dict(cs["cfg"], p_dropout=0.0), c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
     assert (o0[3][2] - m_p).abs().max().item() > 1e-3
+
+
+def test_oracle_reproduces_reference_transformer_flow_training():
+    """use_transformer_flow (models.py:438-439) in train() mode with p_dropout = 0.1: z_p = flow(z), the losses that depend
+    on it and their gradients (incl. the flow's cond_pre / cond_layer / FFT parameters) vs the REAL reference."""
+    cs = load_transflow_case()
+    z = cs["z"]
+    sg = {k: v.clone().requires_grad_(True) for k, v in cs["sd_g"].items()}
+    c, f0, uv, spec, y, sid, lengths = cs["batch"]
+    o = TO.synth_forward(sg, cs["cfg"], c, f0, uv, spec, sid, lengths, lengths, cs["noise"])
+    z_p, m_p, pred = o[3][1], o[3][2], o[4]
+    assert np.abs(z_p.detach().numpy() - z["z_p"]).max() <= 2e-5 * max(1.0, np.abs(z["z_p"]).max())
+    assert np.abs(m_p.detach().numpy() - z["m_p"]).max() <= 2e-5 * max(1.0, np.abs(z["m_p"]).max())
+    kl = TO.kl_loss(z_p, o[3][5], m_p, o[3][3], o[2])
+    lf0 = torch.nn.functional.mse_loss(pred, o[6])
+    assert abs(float(kl) - float(z["loss_kl"])) <= 2e-5 * max(1.0, abs(float(z["loss_kl"])))
+    assert abs(float(lf0) - float(z["loss_lf0"])) <= 2e-5 * max(1.0, abs(float(z["loss_lf0"])))
+    keys = [str(k) for k in z["gnorm_keys"]]
+    assert any(k.startswith("flow.flows.0.enc.cond_pre") for k in keys)
+    gs = dict(zip(keys, torch.autograd.grad(kl + lf0, [sg[k] for k in keys], allow_unused=True)))
+    for k, n in zip(keys, z["gnorm"]):
+        if gs[k] is None:
+            assert n == 0, k
+        elif not k.endswith("conv_k.bias"):
+            assert abs(gs[k].norm().item() - n) <= 2e-4 * max(n, 1e-5), (k, gs[k].norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad."):
+            g = gs[name[5:]].numpy()
+            assert np.abs(g - z[name]).max() <= 1e-4 * max(np.abs(z[name]).max(), 1e-6), name

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from train_common import LOSS_KEYS, load_case, load_dropout_case
+from train_common import LOSS_KEYS, load_case, load_dropout_case, load_transflow_case
 
 pytestmark = pytest.mark.gpu
 
@@ -235,6 +235,44 @@ def test_training_forward_with_dropout_matches_reference(dev):
     with torch.no_grad():
         m2 = net(c, f0, uv, spec, g=sid, c_lengths=lengths, spec_lengths=lengths, noise=n2)[3][2]
     assert (m2 - m_p).abs().max().item() > 1e-3
+
+
+def test_transformer_flow_training_matches_reference(dev):
+    """use_transformer_flow = True (models.py:438-439: TransformerCouplingBlock, FFT(isflow=True) coupling networks) in the
+    HIP training graph with p_dropout = 0.1 and injected draws, against the REAL reference's vectors: z_p = flow(z), the
+    prior statistics, loss_kl + loss_lf0 and their gradients (norms of all, the flow's cond_pre / cond_layer / attention /
+    FFN parameters in full)."""
+    import models
+    import svc_autograd as A
+    from modules.losses import kl_loss
+    cs = load_transflow_case()
+    z = cs["z"]
+    cfg = cs["cfg"]
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(cs["sd_g"], strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
+    noise = {k: ([u.to(dev) for u in v] if isinstance(v, list) else v.to(dev)) for k, v in cs["noise"].items()}
+    out = net(c, f0, uv, spec, g=sid, c_lengths=lengths, spec_lengths=lengths, noise=noise)
+    y_hat, ids_slice, z_mask, (zq, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = out
+    assert np.abs(z_p.detach().cpu().numpy() - z["z_p"]).max() <= 2e-4 * max(1.0, np.abs(z["z_p"]).max())
+    assert np.abs(m_p.detach().cpu().numpy() - z["m_p"]).max() <= 2e-4 * max(1.0, np.abs(z["m_p"]).max())
+    loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask)
+    loss_lf0 = A.sum_sq_diff(pred_lf0, lf0) / lf0.numel()
+    assert abs(float(loss_kl) - float(z["loss_kl"])) <= 1e-4 * max(1.0, abs(float(z["loss_kl"])))
+    assert abs(float(loss_lf0) - float(z["loss_lf0"])) <= 1e-4 * max(1.0, abs(float(z["loss_lf0"])))
+    (loss_kl + loss_lf0).backward()
+    gg = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    for k, n in zip([str(k) for k in z["gnorm_keys"]], z["gnorm"]):
+        if k.endswith("conv_k.bias"):
+            continue
+        assert k in gg, k
+        assert abs(gg[k].norm().item() - n) <= 2e-3 * max(n, 1e-5), (k, gg[k].norm().item(), n)
+    for name in z.files:
+        if name.startswith("grad."):
+            g = gg[name[5:]].numpy()
+            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
 
 
 def test_attention_dropout_op_matches_torch(dev):
