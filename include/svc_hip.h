@@ -418,6 +418,12 @@ int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int 
                              const float* drop_u, float p_drop, float* Pd, void* stream);
 int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop,
                              const float* mask, int mask_mode, void* stream);
+/* Leaky ReLU over rows with a padded tail (DiscriminatorP's feature maps, models.py:190-193: F.leaky_relu(l(x), 0.1) on the
+ * [B,C,H,p] maps, kept here as [rows, P] with P % 4 == 0 and the first L columns meaningful): y = lrelu(x) for t < L, 0 for
+ * L <= t < P; bwd: dx = dy * (y > 0 ? 1 : slope) for t < L, 0 on the tail.  slope = 1: tail mask only. */
+int svc_lrelu_tail_fwd_f32(const float* x, float* y, long long rows, int P, int L, float slope, void* stream);
+int svc_lrelu_tail_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int P, int L, float slope,
+                           void* stream);
 int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream);
 int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream);
 /* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of

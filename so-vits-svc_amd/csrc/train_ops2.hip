@@ -465,6 +465,38 @@ __global__ void cmag_bwd_kernel(const float* __restrict__ re, const float* __res
   }
 }
 
+// ---- leaky ReLU on rows with a padded tail -----------------------------------------------------------------------
+// DiscriminatorP's feature maps are kept as [rows, P] with P = the row length rounded up so that every row starts on a
+// 16-byte boundary (P % 4 == 0) and only the first L columns meaningful.  y = lrelu(x) on t < L and 0 on the tail;
+// dx = dy * (y > 0 ? 1 : slope) on t < L and 0 on the tail.  The zero tail is what lets the neighbouring convolutions
+// (forward, dgrad and wgrad) run over the PHYSICAL row length with the float4 / LDS-DMA staging paths: zeros beyond L are
+// exactly the implicit zero padding of the logical signal.  slope = 1 gives the plain tail mask (after conv_post).
+__global__ void lrelu_tail_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, long long n4, int P4, int L,
+                                      float slope) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % P4) * 4;
+    float4 v = x[i];
+    v.x = t + 0 < L ? (v.x > 0.f ? v.x : slope * v.x) : 0.f;
+    v.y = t + 1 < L ? (v.y > 0.f ? v.y : slope * v.y) : 0.f;
+    v.z = t + 2 < L ? (v.z > 0.f ? v.z : slope * v.z) : 0.f;
+    v.w = t + 3 < L ? (v.w > 0.f ? v.w : slope * v.w) : 0.f;
+    y[i] = v;
+  }
+}
+__global__ void lrelu_tail_bwd_kernel(const float4* __restrict__ y, const float4* __restrict__ dy, float4* __restrict__ dx,
+                                      long long n4, int P4, int L, float slope) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % P4) * 4;
+    const float4 o = y[i];
+    float4 g = dy[i];
+    g.x = t + 0 < L ? (o.x > 0.f ? g.x : slope * g.x) : 0.f;
+    g.y = t + 1 < L ? (o.y > 0.f ? g.y : slope * g.y) : 0.f;
+    g.z = t + 2 < L ? (o.z > 0.f ? g.z : slope * g.z) : 0.f;
+    g.w = t + 3 < L ? (o.w > 0.f ? g.w : slope * g.w) : 0.f;
+    dx[i] = g;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -526,6 +558,27 @@ int svc_cmag_bwd_f32(const float* re, const float* im, const float* mag, const f
   hipLaunchKernelGGL(cmag_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0,
                      (hipStream_t)stream, re, im, mag, dmag, dre, dim, n);
   return svc::check_launch("cmag_bwd");
+}
+
+int svc_lrelu_tail_fwd_f32(const float* x, float* y, long long rows, int P, int L, float slope, void* stream) {
+  SVC_REQUIRE(x && y && rows > 0 && P > 0 && (P % 4) == 0 && L >= 0 && L <= P, "lrelu_tail_fwd: bad args (P % 4 == 0, L <= P)");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "lrelu_tail_fwd: 16 B alignment");
+  const long long n4 = rows * (P / 4);
+  hipLaunchKernelGGL(lrelu_tail_fwd_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n4, P / 4, L, slope);
+  return svc::check_launch("lrelu_tail_fwd");
+}
+
+int svc_lrelu_tail_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int P, int L, float slope,
+                           void* stream) {
+  SVC_REQUIRE(y && dy && dx && rows > 0 && P > 0 && (P % 4) == 0 && L >= 0 && L <= P, "lrelu_tail_bwd: bad args");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+              "lrelu_tail_bwd: 16 B alignment");
+  const long long n4 = rows * (P / 4);
+  hipLaunchKernelGGL(lrelu_tail_bwd_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dy),
+                     reinterpret_cast<float4*>(dx), n4, P / 4, L, slope);
+  return svc::check_launch("lrelu_tail_bwd");
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@ MultiPeriodDiscriminator run the training graph on svc_autograd Functions (HIP f
 discriminators.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -467,6 +468,9 @@ class SynthesizerTrn(nn.Module):
         return out[0].clone(), out[1].clone()
 
 
+_DISCP_PAD_ROWS = os.environ.get("SVC_DISCP_PAD", "1") != "0"
+
+
 class _NormConv(nn.Module):
     """weight_norm(Conv1d / Conv2d((k,1))) parameter holder of the discriminators; `weight_v` keeps the REFERENCE shape
     ([Cout,Cin,K] for Conv1d, [Cout,Cin,K,1] for Conv2d) so checkpoints (D_*.pth) load key-for-key."""
@@ -482,9 +486,28 @@ class _NormConv(nn.Module):
         self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, *([1] * (w.dim() - 1))).clone())
         self.weight_v = nn.Parameter(w)
 
-    def forward(self, x, inner=1, lp=None):
+    def forward(self, x, inner=1, lp=None, out_blocks=None):
         w = A.weight_norm(self.weight_v, self.weight_g).view(self.cout, self.cin // self.groups, self.k)
-        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups, inner=inner, lp=lp)
+        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups, inner=inner, lp=lp, out_blocks=out_blocks)
+
+
+def _padded_map_view(h, b, Hp, H, p):
+    """[b, C, Hp*p] padded feature map -> the reference's [b, C, H, p] map as a view; `_svc_padded` keeps the padded buffer
+    (zero tail) for consumers that only reduce over the map (modules.losses.feature_loss): same sums, no gather copy."""
+    v = h.view(b, h.shape[1], Hp, p)
+    if Hp != H:
+        v = v[:, :, :H]
+        v._svc_padded = h
+    return v
+
+
+def _split_map(f, n):
+    """Real / generated halves of a feature map computed on cat([y, y_hat]) (keeps the padded-buffer link)."""
+    r, g = f[:n], f[n:]
+    full = getattr(f, "_svc_padded", None)
+    if full is not None:
+        r._svc_padded, g._svc_padded = full[:n], full[n:]
+    return r, g
 
 
 class DiscriminatorP(nn.Module):
@@ -494,7 +517,15 @@ class DiscriminatorP(nn.Module):
     block decimation (svc_decimate_f32, w = p, which also folds in the reflect padding of :185-189) followed by a
     dense dilation-p Conv1d.  Every layer therefore sees T = H*p >= ~100 columns per batch row on the MFMA N axis
     (turning the columns into batch rows instead leaves 9-30 columns per row in the 1024-channel layers), and the
-    feature maps come out in the reference's [B,C,H,p] layout as plain views."""
+    feature maps come out in the reference's [B,C,H,p] layout as plain views.
+
+    Row alignment: H*p is rarely a multiple of 4 floats (segment 8192, period 3: 2731, 911, 304, 102 blocks), and rows that
+    do not start on 16-byte boundaries push the 1024-channel convolutions — forward, dgrad and wgrad — onto the
+    scalar-staging kernel instantiations (2.5-3.6x the time of the float4 / LDS-DMA ones on the same shape, 23 ms of a 144 ms
+    iteration, profiles/r02_final_train_B16_kernel_stats.txt).  Every map is therefore stored with H rounded up to H' so that
+    H'*p % 4 == 0, the H' - H tail blocks zero: the convolutions run over the physical rows (zeros past the logical end ARE
+    the convolution's implicit padding), `leaky_relu_tail` restores the zero tail after each of them in the forward and in
+    the backward direction, and the returned feature maps are the [:, :, :H] views of the padded buffers."""
 
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
         super().__init__()
@@ -515,12 +546,21 @@ class DiscriminatorP(nn.Module):
         fmap = []
         h = x
         lp = t + n_pad
-        for l in self.convs:
-            h = A.leaky_relu(l(h, inner=p, lp=lp), modules.LRELU_SLOPE)
+        H = lp // p                                             # logical number of blocks (rows of the [T/p, p] view)
+        for l in list(self.convs) + [self.conv_post]:
+            H = (H + 2 * l.padding - l.k) // l.stride + 1
+            Hp = A.align_blocks(H, p) if _DISCP_PAD_ROWS else H
+            if not _DISCP_PAD_ROWS:         # SVC_DISCP_PAD=0: the unpadded layout (A/B switch)
+                y = l(h, inner=p, lp=lp)
+                h = A.leaky_relu(y, modules.LRELU_SLOPE) if l is not self.conv_post else y
+                lp = None
+                fmap.append(h.view(b, h.shape[1], -1, p))
+                continue
+            y = l(h, inner=p, lp=lp, out_blocks=Hp)             # [b, C, Hp*p]; blocks >= H are don't-care
+            # models.py:190-193 lrelu(0.1) after every conv but conv_post (slope 1: tail mask only)
+            h = A.leaky_relu_tail(y, modules.LRELU_SLOPE if l is not self.conv_post else 1.0, H * p)
             lp = None
-            fmap.append(h.view(b, h.shape[1], -1, p))
-        h = self.conv_post(h, inner=p)
-        fmap.append(h.view(b, h.shape[1], -1, p))
+            fmap.append(_padded_map_view(h, b, Hp, H, p))
         return torch.flatten(fmap[-1], 1, -1), fmap
 
 
@@ -566,8 +606,9 @@ class MultiPeriodDiscriminator(nn.Module):
         for out, fmap in (d(yy) for d in self.discriminators):
             y_d_rs.append(out[:n])
             y_d_gs.append(out[n:])
-            fmap_rs.append([f[:n] for f in fmap])
-            fmap_gs.append([f[n:] for f in fmap])
+            halves = [_split_map(f, n) for f in fmap]
+            fmap_rs.append([r for r, _ in halves])
+            fmap_gs.append([g for _, g in halves])
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
     def forward_gen_step(self, y, y_hat):

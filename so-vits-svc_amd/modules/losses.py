@@ -11,7 +11,11 @@ def feature_loss(fmap_r, fmap_g):
     loss = 0
     for dr, dg in zip(fmap_r, fmap_g):
         for rl, gl in zip(dr, dg):
-            loss = loss + A.sum_abs_diff(rl.float().detach(), gl.float()) / gl.numel()
+            n = gl.numel()
+            rp, gp = getattr(rl, "_svc_padded", None), getattr(gl, "_svc_padded", None)
+            if rp is not None and gp is not None and rp.shape == gp.shape:
+                rl, gl = rp, gp         # DiscriminatorP's padded buffers: zero tails on both sides, same sum, no gather copy
+            loss = loss + A.sum_abs_diff(rl.float().detach(), gl.float()) / n
     return loss * 2
 
 

@@ -11,6 +11,8 @@ models.py:165-227, modules/*, vdecoder/hifigan/models.py):
   Conv2d((k,1),(s,1)) on [B,C,T/p,p] -> decimate by p (columns -> batch) then the strided conv above
   grouped conv (DiscriminatorS) -> svc_gconv1d_{fwd,dgrad,wgrad}
 """
+import math
+
 import torch
 from torch.autograd import Function
 
@@ -22,16 +24,18 @@ def _c(t):
 
 
 class _Conv1dDense(Function):
-    """y = conv1d(x, w, bias, stride=1, padding=pad, dilation=dil)[..., :tout]; w is the explicit [Cout,Cin,KS] weight."""
+    """y = conv1d(x, w, bias, stride=1, padding=pad, dilation=dil)[..., :tout]; w is the explicit [Cout,Cin,KS] weight.
+    `exact`: produce exactly `tout` columns even beyond the natural output length (x counts as zero-extended) — the padded
+    row layout of DiscriminatorP, where the columns past the logical length are don't-care and get masked by the caller."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, pad, dil, tout=None):
+    def forward(ctx, x, w, bias, pad, dil, tout=None, exact=False):
         x = _c(x)
         Cout, Cin, KS = w.shape
         Tin = x.shape[2]
         Tout = Tin + 2 * pad - dil * (KS - 1)
         if tout is not None:
-            Tout = min(Tout, tout)
+            Tout = tout if exact else min(Tout, tout)
         wp = S.pack_conv1d_weight(w.detach())
         y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
         ctx.save_for_backward(x, w)
@@ -57,7 +61,7 @@ class _Conv1dDense(Function):
             dw = S.conv1d_wgrad(dy, x, KS, dil, pad, dbias=db)
         elif want_db:
             db = S.reduce_bct(dy, 0)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _Decimate(Function):
@@ -334,6 +338,28 @@ def leaky_relu(x, slope):
     return _EwUnary.apply(x, S.EW_LRELU, S.EW_LRELU_BWD, float(slope), False)
 
 
+class _LReluTail(Function):
+    """leaky_relu on the first `valid` columns of every row and zero on the padded tail, in both directions
+    (svc_lrelu_tail_{fwd,bwd}_f32); the saved tensor is the OUTPUT (sign(y) == sign(x) for slope > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, slope, valid):
+        y = S.lrelu_tail_fwd(_c(x), valid, slope)
+        ctx.save_for_backward(y)
+        ctx.cfg = (slope, valid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        slope, valid = ctx.cfg
+        return S.lrelu_tail_bwd(y, dy, valid, slope), None, None
+
+
+def leaky_relu_tail(x, slope, valid):
+    return _LReluTail.apply(x, slope, valid)
+
+
 def relu(x):
     return _EwUnary.apply(x, S.EW_RELU, S.EW_RELU_BWD, 0.0, False)
 
@@ -378,19 +404,30 @@ def gate(x):
     return _Gate.apply(x)
 
 
-def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, lp=None):
+def align_blocks(h, inner):
+    """Smallest block count >= h whose row length h*inner is a multiple of 4 floats (16-byte rows)."""
+    m = 4 // math.gcd(inner, 4)
+    return (h + m - 1) // m * m
+
+
+def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, lp=None, out_blocks=None):
     """F.conv1d semantics on [B,Cin,T] with an explicit weight [Cout, Cin/groups, KS].
     inner > 1: x is [B, Cin, H*inner] — H blocks of `inner` time-contiguous samples — and the convolution runs over the
     BLOCK index (this is Conv2d((KS,1),(stride,1)) on the [B,Cin,H,inner] view, models.py:171-177); stride/padding are
-    in blocks.  lp: length the input is (virtually) reflect-padded to on the right (models.py:185-189)."""
+    in blocks.  lp: length the input is (virtually) reflect-padded to on the right (models.py:185-189).
+    out_blocks: produce exactly this many output blocks (>= the logical count; x counts as zero-extended) and decimate to
+    a 16-byte-aligned row length — the padded row layout of DiscriminatorP: with zero tails on x the first logical-count
+    blocks are the convolution's result and the rest is don't-care (the caller masks it, svc_autograd.leaky_relu_tail)."""
     Cout, Cg, KS = w.shape
     if groups != 1:
-        if dilation != 1 or inner != 1:
+        if dilation != 1 or inner != 1 or out_blocks is not None:
             raise S.SvcError("grouped conv with dilation is not on the so-vits-svc path")
         return _GConv1d.apply(x, w, bias, stride, padding, groups)
     if stride == 1:
         if lp is not None and lp != x.shape[2]:
             raise S.SvcError("reflect padding is folded into the decimation of a strided conv only")
+        if out_blocks is not None:
+            return _Conv1dDense.apply(x, w, bias, padding * inner, dilation * inner, out_blocks * inner, True)
         return _Conv1dDense.apply(x, w, bias, padding * inner, dilation * inner)
     if dilation != 1:
         raise S.SvcError("strided conv with dilation is not on the so-vits-svc path")
@@ -405,6 +442,11 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, 
     wpad = torch.nn.functional.pad(w, (shift, s * KSd - KS - shift))
     wd = wpad.view(Cout, Cg, KSd, s).permute(0, 3, 1, 2).reshape(Cout, s * Cg, KSd)   # index reshapes only
     Q = (Tin + s - 1) // s
+    if out_blocks is not None:
+        # blocks past the signal decimate to zeros (svc_decimate_f32 zero-fills beyond lp), so rounding Q up only appends a
+        # zero tail; the adjoint never reads it
+        xd = _Decimate.apply(x, s, 0, align_blocks(Q, inner), lp, inner)
+        return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, out_blocks * inner, True)
     xd = _Decimate.apply(x, s, 0, Q, lp, inner)
     # dense conv (dilation `inner`) over the Q blocks; only the first Tout blocks are produced
     return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, Tout * inner)

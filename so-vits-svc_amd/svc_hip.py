@@ -988,6 +988,7 @@ TRAIN_EXPORTS2 = [
     "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",
     "svc_nsf_source_train_f32", "svc_nsf_linear_fwd_f32", "svc_nsf_linear_bwd_f32", "svc_kl_fwd_f64", "svc_kl_bwd_f32",
     "svc_stft_frame_f32", "svc_stft_frame_bwd_f32", "svc_dft_basis_f32", "svc_cmag_f32", "svc_cmag_bwd_f32",
+    "svc_lrelu_tail_fwd_f32", "svc_lrelu_tail_bwd_f32",
 ]
 EXPORTS += TRAIN_EXPORTS2
 _train2_bound = False
@@ -1003,6 +1004,8 @@ def t2lib():
         L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [_f32p, C.c_float, _f32p, vp]
         L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, _f32p, i, vp]
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
+        L.svc_lrelu_tail_fwd_f32.argtypes = [_f32p, _f32p, ll, i, i, f, vp]
+        L.svc_lrelu_tail_bwd_f32.argtypes = [_f32p, _f32p, _f32p, ll, i, i, f, vp]
         L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
         L.svc_embed_bwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, i, vp]
@@ -1058,6 +1061,31 @@ def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0, mask=None, mask_mo
     check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), ptr(mask), mask_mode,
                                            stream_ptr()), "attn_softmax_bwd")
     return dP
+
+
+def _tail_rows(x):
+    if not x.is_contiguous() or x.shape[-1] % 4 or x.data_ptr() % 16:
+        raise SvcError("lrelu_tail: needs a contiguous tensor whose last dimension is a multiple of 4 (16-byte rows)")
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def lrelu_tail_fwd(x, valid, slope):
+    """y = leaky_relu(x, slope) on the first `valid` columns of every row, 0 on the rest (rows = all leading dims)."""
+    require_gpu(x)
+    rows, P = _tail_rows(x)
+    y = torch.empty_like(x)
+    check(t2lib().svc_lrelu_tail_fwd_f32(ptr(x), ptr(y), rows, P, int(valid), float(slope), stream_ptr()), "lrelu_tail_fwd")
+    return y
+
+
+def lrelu_tail_bwd(y, dy, valid, slope):
+    require_gpu(y, dy)
+    dy = dy.contiguous()
+    rows, P = _tail_rows(y)
+    dx = torch.empty_like(y)
+    check(t2lib().svc_lrelu_tail_bwd_f32(ptr(y), ptr(dy), ptr(dx), rows, P, int(valid), float(slope), stream_ptr()),
+          "lrelu_tail_bwd")
+    return dx
 
 
 def band_gather(M, n_rows, T, window):

@@ -187,3 +187,74 @@ def test_snake_alias_fwd_bwd(dev, B, C, T):
         return O.snake_alias(x, sd, "s")
 
     _run_pair(lambda x, alpha, beta: A.snake_alias(x, alpha, beta, taps), ref, t, dev, tol=5e-5)
+
+
+@pytest.mark.parametrize("rows,P,L,slope", [((3, 5), 12, 9, 0.1), ((2, 7), 8, 8, 0.1), ((4,), 104, 102, 1.0), ((1, 2), 4, 0, 0.1)])
+def test_lrelu_tail_fwd_bwd(dev, rows, P, L, slope):
+    """svc_lrelu_tail_{fwd,bwd}_f32: leaky_relu on the first L columns of every row, zero on the padded tail, in both
+    directions (the tail of the incoming gradient is garbage by contract: it must not leak)."""
+    import svc_autograd as A
+    torch.manual_seed(5)
+    x = torch.randn(*rows, P)
+    go = torch.randn(*rows, P)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(xr[..., :L], slope)
+    yr.backward(go[..., :L])
+    xh = x.clone().to(dev).requires_grad_(True)
+    yh = A.leaky_relu_tail(xh, slope, L)
+    yh.backward(go.to(dev))
+    assert torch.equal(yh[..., :L].detach().cpu(), yr.detach())
+    assert torch.equal(xh.grad.cpu()[..., :L], xr.grad[..., :L])
+    if L < P:
+        assert yh[..., L:].abs().max().item() == 0 and xh.grad[..., L:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("period,T", [(2, 8192), (3, 8192), (5, 8192), (7, 8192), (11, 8192), (3, 1000), (5, 96)])
+def test_discriminator_p_padded_rows(dev, period, T):
+    """models.DiscriminatorP keeps its feature maps in rows padded to 16-byte multiples (zero tail blocks) so that the
+    1024-channel convolutions take the aligned kernels: logits, every feature map, the feature-matching loss computed on the
+    padded buffers, and the gradients with respect to the input and to weight_v / weight_g / bias of three layers must equal
+    the plain Conv2d((5,1),(3,1)) stack of the reference (models.py:165-199, restated in oracle/train_oracle.disc_p)."""
+    import models
+    from modules.losses import feature_loss
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    torch.manual_seed(period)
+    sd_all = W.make_mpd_state_dict(77)
+    idx = [None, 2, 3, 5, 7, 11].index(period)
+    prefix = f"discriminators.{idx}"
+    sd = {k[len(prefix) + 1:]: v for k, v in sd_all.items() if k.startswith(prefix + ".")}
+    net = models.DiscriminatorP(period)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    B = 2
+    y, y_hat = torch.randn(B, 1, T) * 0.5, torch.randn(B, 1, T) * 0.5
+    probe = ["convs.1.weight_v", "convs.3.weight_g", "convs.4.weight_v", "convs.4.bias", "conv_post.weight_v"]
+    # reference
+    sr = {prefix + "." + k: v.clone().requires_grad_(k in probe) for k, v in sd.items()}
+    yh_r = y_hat.clone().requires_grad_(True)
+    lr_, fr = TO.disc_p(y, sr, prefix, period)
+    lg_, fg = TO.disc_p(yh_r, sr, prefix, period)
+    fm_r = sum((a.detach() - b).abs().mean() for a, b in zip(fr, fg)) * 2
+    loss_r = fm_r + ((1 - lg_) ** 2).mean() + (lr_ ** 2).mean()
+    loss_r.backward()
+    # engine: one pass over cat([y, y_hat]) as MultiPeriodDiscriminator.forward does
+    yh_h = y_hat.clone().to(dev).requires_grad_(True)
+    out, fmap = net(torch.cat([y.to(dev), yh_h], 0))
+    halves = [models._split_map(f, B) for f in fmap]
+    for (a, b), ra, rb in zip(halves, fr, fg):
+        assert a.shape == ra.shape and b.shape == rb.shape
+        assert (a.detach().cpu() - ra.detach()).abs().max().item() <= 2e-5 * max(1.0, ra.abs().max().item())
+        assert (b.detach().cpu() - rb.detach()).abs().max().item() <= 2e-5 * max(1.0, rb.abs().max().item())
+    fm_h = feature_loss([[a for a, _ in halves]], [[b for _, b in halves]])
+    assert abs(float(fm_h) - float(fm_r)) <= 2e-5 * max(1.0, abs(float(fm_r)))
+    import svc_autograd as A
+    loss_h = fm_h + A.sum_sq_one_minus(out[B:]) / out[B:].numel() + A.sum_sq(out[:B]) / out[:B].numel()
+    assert abs(float(loss_h) - float(loss_r)) <= 2e-5 * max(1.0, abs(float(loss_r)))
+    loss_h.backward()
+    gr = yh_r.grad
+    assert (yh_h.grad.cpu() - gr).abs().max().item() <= 2e-4 * max(gr.abs().max().item(), 1e-8)
+    named = dict(net.named_parameters())
+    for k in probe:
+        g, r = named[k].grad.cpu(), sr[prefix + "." + k].grad
+        assert (g - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-8), k
