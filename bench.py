@@ -168,7 +168,7 @@ def run_train(args, dev, rank, world, dist):
 
     steps, warm = args.train_steps, args.train_warmup
     last = None
-    if use_graph and world > 1:
+    if use_graph and dist is not None:
         try:                                       # first call = warm-up + capture; every rank takes the same branch
             last = step_fn(items)
         except Exception as e:                     # noqa: BLE001 — e.g. a collective runtime that cannot coexist with capture
@@ -292,9 +292,12 @@ def main():
         import svc_hip
         svc_hip.tlib().svc_debug_set_conv_cfg(int(os.environ["SVC_CONV_CFG"]))
     dist = None
-    if world > 1:
+    # SVC_DP_FORCE=1 at N=1: initialise the process group anyway so the data-parallel code path (reducer, two-graph iteration,
+    # RCCL all-reduces between the replays) runs against the real collective library on a single GPU — functional dry run only
+    if world > 1 or os.environ.get("SVC_DP_FORCE", "0") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

@@ -22,6 +22,7 @@ DistributedSampler, every rank trains on the SAME minibatch.  Both
 The same code runs over `gloo` on CPU tensors (tests/test_data_parallel_cpu.py, world_size 2).
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -226,7 +227,10 @@ class DataParallel(nn.Module):
         params = [p for p in module.parameters() if p.requires_grad]
         self.arena = arena_for(params)
         self.reducer = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        # SVC_DP_FORCE=1: build the reducer at world size 1 too — a functional dry run of the multi-rank path (RCCL calls between
+        # the graph replays, bucket events) on a single-GPU box
+        force = os.environ.get("SVC_DP_FORCE", "0") == "1"
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force):
             self.reducer = GradReducer(self.arena, process_group, bucket_bytes, first_bucket_bytes)
             if broadcast:
                 self.reducer.broadcast_parameters(0)
