@@ -91,6 +91,8 @@ class GradReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
+        # world size 1 normally short-circuits every collective; SVC_DP_FORCE=1 issues them anyway (dry run of the RCCL calls)
+        self.single = self.world == 1 and os.environ.get("SVC_DP_FORCE", "0") != "1"
         n = len(arena.params)
         # walk parameters in reverse (≈ gradient production order); a bucket is a contiguous [start,end) of the arena
         self.buckets = []           # dicts(start, end, members)
@@ -130,7 +132,7 @@ class GradReducer:
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _on_grad(self, i):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or self.single:
             return
         if self._pending is None:
             self._begin()
@@ -175,7 +177,7 @@ class GradReducer:
         waits for all of them.  Nothing overlaps with compute here, so the time between the two events recorded on the
         compute stream IS the exposed communication time of the iteration (`exposed_ms()`); at 0.6 GB of gradients per
         iteration that is a few ms over xGMI — the eager launch path it replaces costs ~100 ms of host time."""
-        if self.world == 1:
+        if self.single:
             return
         ev = None
         if time_it and self.arena.grad.is_cuda:

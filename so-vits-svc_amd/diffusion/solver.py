@@ -85,7 +85,7 @@ class TrainStep:
             self.opt.restore(snap)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with S.graph_capture(graph):
                 out = self._body(sdata, snoise)
             self.opt.restore(snap, device=False)
             ent = (graph, static, out)

@@ -457,7 +457,7 @@ class SynthesizerTrn(nn.Module):
                 run()                                   # warm-up: packs weights, sets kernel attributes
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with S.graph_capture(graph):
                 out = run()
             ent = (graph, static, out)
             self._graphs[key] = ent

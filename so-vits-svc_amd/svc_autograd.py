@@ -452,6 +452,12 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, 
     return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, Tout * inner)
 
 
+def conv1d_causal(x, w, bias=None, dilation=1):
+    """F.conv1d(F.pad(x, ((K-1)*dilation, 0)), w, bias, dilation=dilation): output length == input length."""
+    KS = w.shape[2]
+    return _Conv1dDense.apply(x, w, bias, (KS - 1) * dilation, dilation, x.shape[2])
+
+
 def conv_transpose1d(x, w, bias=None, stride=1, padding=0):
     """F.conv_transpose1d semantics; w [Cin, Cout, KS]."""
     Cin, Cout, KS = w.shape

@@ -1069,6 +1069,18 @@ def _tail_rows(x):
     return x.numel() // x.shape[-1], x.shape[-1]
 
 
+def graph_capture(graph, pool=None):
+    """torch.cuda.graph(...) for this engine's captures.  With a process group initialised, ProcessGroupNCCL's watchdog thread
+    polls the events of earlier collectives (hipEventQuery) from ITS thread; under the default "global" capture mode that
+    call is illegal while ANY stream captures and aborts the process ("operation not permitted when stream is capturing",
+    seen on MI355X / ROCm 7 with RCCL 2.26).  "thread_local" restricts the check to the capturing thread."""
+    kw = {} if pool is None else {"pool": pool}
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        kw["capture_error_mode"] = "thread_local"
+    return torch.cuda.graph(graph, **kw)
+
+
 def lrelu_tail_fwd(x, valid, slope):
     """y = leaky_relu(x, slope) on the first `valid` columns of every row, 0 on the rest (rows = all leading dims)."""
     require_gpu(x)

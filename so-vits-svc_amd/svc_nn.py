@@ -107,9 +107,11 @@ class Conv1d(nn.Module, _PackedMixin):
         if padding is not None and not causal:
             return A.conv1d(x, self.effective_weight(), self.bias, self.stride, padding, self.dilation)
         if causal and self.kernel_size > 1:
-            T = x.shape[2]
-            y = A.conv1d(x, self.effective_weight(), self.bias, self.stride, self.kernel_size - 1, self.dilation)
-            return y[:, :, :T]
+            # left padding only (modules/attentions.py:353-360): symmetric padding K-1 with the output cut at T — no T+K-1 wide
+            # intermediate, no slice copy, and dy keeps the (16-byte aligned) row length of x in the backward convolutions
+            if self.stride != 1:
+                raise NotImplementedError("causal padding with a stride is not on the so-vits-svc path")
+            return A.conv1d_causal(x, self.effective_weight(), self.bias, self.dilation)
         return A.conv1d(x, self.effective_weight(), self.bias, self.stride, self.padding, self.dilation)
 
     def forward(self, x, **kw):

@@ -108,7 +108,7 @@ class TrainStep:
             self.optim_d.restore(snaps[1])
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with S.graph_capture(graph):
                 out = run()
             self.optim_g.restore(snaps[0], device=False)   # capture ran the host bookkeeping but no kernels
             self.optim_d.restore(snaps[1], device=False)
@@ -254,13 +254,13 @@ class TrainStep:
                 guard.enter_context(red_d.no_sync())
             with guard:
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with S.graph_capture(g1):
                     ctx = self._seg_d(s_items, s_noise)
                 touched_d = list(self.optim_d.arena.touched)
                 # what optim_d.step() does to the host view of the weights: the G segment must re-pack D's weights
                 torch.autograd.graph.increment_version(self.optim_d.arena.params)
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with S.graph_capture(g2, pool=g1.pool()):
                     out = self._seg_g(ctx)
                 touched_g = list(self.optim_g.arena.touched)
                 torch.autograd.graph.increment_version(self.optim_g.arena.params)

@@ -252,9 +252,19 @@ def test_discriminator_p_padded_rows(dev, period, T):
     loss_h = fm_h + A.sum_sq_one_minus(out[B:]) / out[B:].numel() + A.sum_sq(out[:B]) / out[:B].numel()
     assert abs(float(loss_h) - float(loss_r)) <= 2e-5 * max(1.0, abs(float(loss_r)))
     loss_h.backward()
-    gr = yh_r.grad
-    assert (yh_h.grad.cpu() - gr).abs().max().item() <= 2e-4 * max(gr.abs().max().item(), 1e-8)
+    # gradients: the graph has non-smooth points (|r - g| of the feature loss, leaky_relu at 0); an element that sits within fp32
+    # round-off of one takes the other branch in the other implementation and shifts a handful of gradient entries by up to a
+    # percent of the tensor's maximum (measured: identical in the padded and the unpadded layout, absent between torch fp32 and
+    # fp64 — profiles/r02_q_discp_padded_vs_unpadded_vs_fp64.txt).  So: relative L2 error 1e-3 and at most 0.5 % outliers
+    # beyond 1e-3 of the maximum, none beyond 3 %.
+    def close(g, r, what):
+        d = (g - r).abs()
+        m = max(r.abs().max().item(), 1e-12)
+        assert d.max().item() <= 3e-2 * m, (what, d.max().item(), m)
+        assert (d > 1e-3 * m).float().mean().item() <= 5e-3, (what, int((d > 1e-3 * m).sum()))
+        assert (g - r).norm().item() <= 1e-3 * max(r.norm().item(), 1e-12), what
+
+    close(yh_h.grad.cpu(), yh_r.grad, "input")
     named = dict(net.named_parameters())
     for k in probe:
-        g, r = named[k].grad.cpu(), sr[prefix + "." + k].grad
-        assert (g - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-8), k
+        close(named[k].grad.cpu(), sr[prefix + "." + k].grad, k)
