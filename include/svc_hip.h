@@ -284,6 +284,27 @@ int svc_weight_norm_bwd_f32(const float* v, const float* g, const float* norm, c
 /* dgrad weight of a Conv1d: w:[Cout][Cin][KS] -> dst:[Cout][KS][CinP], dst[co][KS-1-k][ci] = w[co][ci][k]; feeding it
  * to svc_conv1d_f32 with x = dy, pad_left = dil*(KS-1) - pad computes dx (autograd of F.conv1d). */
 int svc_pack_conv1d_weight_T(const float* w, float* dst, int Cout, int Cin, int KS, int CinP, void* stream);
+/* One-launch weight preparation of a training convolution, and its adjoint.  Every nn.Conv1d / Conv2d((k,1),(s,1)) /
+ * ConvTranspose1d of the training graph (models.py:165-227, modules/*, vdecoder/hifigan/models.py:335-355) runs as a dense
+ * stride-1 convolution whose weight wd[Od][Id][Kd] is an index map of the parameter v [R][C2][K], scaled per row by the
+ * weight-norm factor g[r]/||v[r]|| when g != NULL (torch.nn.utils.weight_norm, dim 0):
+ *   kind 0 dense        wd[r][c][k] = w[r][c][k]                                           (Od=R, Id=C2, Kd=K)
+ *   kind 1 strided      wd[r][q*C2 + c][m] = w[r][c][k],  k + shift = s*m + q              (Od=R, Id=s*C2)
+ *   kind 2 transposed   wd[ph*C2 + c][r][Kd-1-mm] = w[r][c][k],  k = ph + mm*s  (v = [Cin][Cout][K], s = stride, Kd = ceil(K/s))
+ * prep writes wp[(i*Kd+m)*OdP + o] (the layout svc_conv1d_f32 reads) and, when wt != NULL, the dgrad operand
+ * wt[(o*Kd + Kd-1-m)*IdP + i], and norm[r] = ||v[r]||.  Entries that no (r,c,k) maps to are NOT written: wp / wt must be
+ * zero-filled once by the caller.  grad maps dwd [Od][Id][Kd] (svc_conv1d_wgrad_f32's output) back to dv [R][C2][K] and
+ * dg [R] (dv = dw without g). */
+typedef struct {
+  const float* v;
+  const float* g;
+  float* wp;
+  float* wt;
+  float* norm;
+  int kind, R, C2, K, Od, Id, Kd, OdP, IdP, s, shift;
+} svc_conv_weight_args;
+int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream);
+int svc_conv_weight_grad_f32(const svc_conv_weight_args* args, const float* dwd, float* dv, float* dg, void* stream);
 
 /* Weight gradient (and any "correlate two [B,C,T] signals over time" product):
  *   G[ca,cb,k] (+)= sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad],  t in [0,TA), Bm index in [0,TB), KS <= 16.

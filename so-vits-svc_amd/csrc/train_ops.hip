@@ -69,6 +69,90 @@ __global__ void pack_conv1d_T_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+// ---- one-launch weight preparation of a training convolution --------------------------------------------------------
+// Every convolution of the training graph is lowered to a dense stride-1 MFMA convolution whose weight wd[o][i][m] is an
+// index map of the parameter v[r][c][k] (times the weight-norm scale g[r]/||v[r]||):
+//   kind 0 dense       wd[r][c][k]                        = w[r][c][k]
+//   kind 1 strided(s)  wd[r][q*C2 + c][m], s*m + q = k+shift  (svc_decimate_f32 turns the s phases into channels)
+//   kind 2 transposed  wd[ph*C2 + c][r][M-1-mm], k = ph + mm*u  (v is [Cin][Cout][K]; the u output phases become channels)
+// This kernel writes the forward operand wp[(i*Kd + m)*OdP + o] (svc_pack_conv1d_weight's layout) AND the dgrad operand
+// wt[(o*Kd + Kd-1-m)*IdP + i] (svc_pack_conv1d_weight_T's) straight from v: one launch instead of weight_norm_fwd +
+// (pad, permute, copy) + pack in the forward and pack_T in the backward.  Entries no (r,c,k) maps to — the OdP / IdP padding
+// and the taps past K of a strided / transposed layout — are never written: the caller allocates wp / wt zero-filled ONCE.
+struct WMap {
+  int kind, R, C2, K, Od, Id, Kd, OdP, IdP, s, shift;
+};
+__device__ __forceinline__ void wmap_index(const WMap& p, int r, int c, int k, int& o, int& i, int& m) {
+  if (p.kind == 0) {
+    o = r; i = c; m = k;
+  } else if (p.kind == 1) {
+    const int kk = k + p.shift;
+    m = kk / p.s;
+    o = r;
+    i = (kk - m * p.s) * p.C2 + c;
+  } else {
+    const int mm = k / p.s, ph = k - mm * p.s;
+    o = ph * p.C2 + c;
+    i = r;
+    m = p.Kd - 1 - mm;
+  }
+}
+__global__ void conv_weight_prep_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ wp,
+                                        float* __restrict__ wt, float* __restrict__ norm, WMap p) {
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  const int n = p.C2 * p.K;
+  const float* vr = v + (long long)r * n;
+  float sc = 1.f;
+  if (g) {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const double x = vr[j];
+      acc += x * x;
+    }
+    const float nr = (float)sqrt(block_sum_d(acc, sh));
+    if (threadIdx.x == 0 && norm) norm[r] = nr;
+    sc = g[r] / nr;
+  }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int c = j / p.K, k = j - c * p.K;
+    int o, i, m;
+    wmap_index(p, r, c, k, o, i, m);
+    const float val = vr[j] * sc;
+    wp[((long long)i * p.Kd + m) * p.OdP + o] = val;
+    if (wt) wt[((long long)o * p.Kd + (p.Kd - 1 - m)) * p.IdP + i] = val;
+  }
+}
+// adjoint: dwd [Od][Id][Kd] (svc_conv1d_wgrad_f32's output) -> dv (and dg): dw[r][c][k] = dwd[o][i][m],
+// dg[r] = <dw, v> / ||v||,  dv = (g/||v||) (dw - v <dw,v>/||v||^2);  without g: dv = dw.
+__global__ void conv_weight_grad_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                        const float* __restrict__ norm, const float* __restrict__ dwd,
+                                        float* __restrict__ dv, float* __restrict__ dg, WMap p) {
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  const int n = p.C2 * p.K;
+  const float* vr = v + (long long)r * n;
+  auto dw_at = [&](int j) {
+    const int c = j / p.K, k = j - c * p.K;
+    int o, i, m;
+    wmap_index(p, r, c, k, o, i, m);
+    return dwd[((long long)o * p.Id + i) * p.Kd + m];
+  };
+  if (!g) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) dv[(long long)r * n + j] = dw_at(j);
+    return;
+  }
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) acc += (double)dw_at(j) * (double)vr[j];
+  const double dot = block_sum_d(acc, sh);
+  const double nr = norm[r];
+  if (threadIdx.x == 0) dg[r] = (float)(dot / nr);
+  const double sc = (double)g[r] / nr;
+  const double kq = dot / (nr * nr);
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    dv[(long long)r * n + j] = (float)(sc * ((double)dw_at(j) - (double)vr[j] * kq));
+}
+
 // ---- reductions of [B,C,T] -----------------------------------------------------------------------------------
 // mode 0: out[c] = sum_{b,t}   (bias grads)     one block per c
 // mode 1: out[b,c] = sum_t     (grad of a [B,C,1] broadcast)   one block per (b,c)
@@ -351,6 +435,47 @@ int svc_pack_conv1d_weight_T(const float* w, float* dst, int Cout, int Cin, int 
   const long long n = (long long)Cout * KS * CinP;
   hipLaunchKernelGGL(pack_conv1d_T_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin, KS, CinP);
   return svc::check_launch("pack_conv1d_T");
+}
+
+static int wmap_from(const svc_conv_weight_args& a, WMap& p) {
+  p.kind = a.kind; p.R = a.R; p.C2 = a.C2; p.K = a.K; p.Od = a.Od; p.Id = a.Id; p.Kd = a.Kd; p.OdP = a.OdP; p.IdP = a.IdP;
+  p.s = a.s; p.shift = a.shift;
+  SVC_REQUIRE(a.R > 0 && a.C2 > 0 && a.K > 0 && a.Od > 0 && a.Id > 0 && a.Kd > 0 && a.OdP >= a.Od && a.IdP >= a.Id,
+              "conv_weight: bad shape");
+  if (a.kind == 0) {
+    SVC_REQUIRE(a.Od == a.R && a.Id == a.C2 && a.Kd == a.K, "conv_weight: dense map needs Od=R, Id=C2, Kd=K");
+  } else if (a.kind == 1) {
+    SVC_REQUIRE(a.s >= 1 && a.shift >= 0 && a.Od == a.R && a.Id == a.s * a.C2 && (a.K - 1 + a.shift) / a.s < a.Kd,
+                "conv_weight: strided map needs Od=R, Id=s*C2, (K-1+shift)/s < Kd");
+  } else if (a.kind == 2) {
+    SVC_REQUIRE(a.s >= 1 && a.Od == a.s * a.C2 && a.Id == a.R && a.Kd == (a.K + a.s - 1) / a.s,
+                "conv_weight: transposed map needs Od=u*C2, Id=R, Kd=ceil(K/u)");
+  } else {
+    SVC_REQUIRE(false, "conv_weight: kind must be 0 (dense), 1 (strided) or 2 (transposed)");
+  }
+  return SVC_OK;
+}
+
+int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream) {
+  SVC_REQUIRE(args && args->v && args->wp, "conv_weight_prep: null tensor");
+  SVC_REQUIRE(!args->g || args->norm, "conv_weight_prep: weight-normed weights need the norm output");
+  WMap p;
+  const int rc = wmap_from(*args, p);
+  if (rc != SVC_OK) return rc;
+  hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(p.R), dim3(256), 0, (hipStream_t)stream, args->v, args->g, args->wp,
+                     args->wt, args->norm, p);
+  return svc::check_launch("conv_weight_prep");
+}
+
+int svc_conv_weight_grad_f32(const svc_conv_weight_args* args, const float* dwd, float* dv, float* dg, void* stream) {
+  SVC_REQUIRE(args && args->v && dwd && dv, "conv_weight_grad: null tensor");
+  SVC_REQUIRE(!args->g || (args->norm && dg), "conv_weight_grad: weight-normed weights need norm and dg");
+  WMap p;
+  const int rc = wmap_from(*args, p);
+  if (rc != SVC_OK) return rc;
+  hipLaunchKernelGGL(conv_weight_grad_kernel, dim3(p.R), dim3(256), 0, (hipStream_t)stream, args->v, args->g, args->norm,
+                     dwd, dv, dg, p);
+  return svc::check_launch("conv_weight_grad");
 }
 
 int svc_reduce_bct_f32(const float* x, float* out, long long x_bs, long long x_cs, int B, int C, int T, int mode,

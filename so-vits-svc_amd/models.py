@@ -19,6 +19,7 @@ import modules.commons as commons
 import modules.modules as modules
 import svc_autograd as A
 import svc_hip as S
+import svc_nn
 import utils
 from svc_nn import Conv1d, mask2d, training_call
 
@@ -487,6 +488,13 @@ class _NormConv(nn.Module):
         self.weight_v = nn.Parameter(w)
 
     def forward(self, x, inner=1, lp=None, out_blocks=None):
+        if svc_nn.WEIGHT_PLANS and self.groups == 1:
+            plan = self.__dict__.get("_svc_plan")
+            if plan is None:
+                plan = A.conv_plan((self.cout, self.cin, self.k), self.stride, self.padding)
+                self.__dict__["_svc_plan"] = plan
+            return A.conv1d_planned(x, plan, self.weight_v, self.weight_g, self.bias, self.stride, self.padding, 1,
+                                    inner=inner, lp=lp, out_blocks=out_blocks)
         w = A.weight_norm(self.weight_v, self.weight_g).view(self.cout, self.cin // self.groups, self.k)
         return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups, inner=inner, lp=lp, out_blocks=out_blocks)
 

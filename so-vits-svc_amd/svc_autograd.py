@@ -64,6 +64,55 @@ class _Conv1dDense(Function):
         return dx, dw, db, None, None, None, None
 
 
+class _ConvPlanned(Function):
+    """_Conv1dDense with the weight side folded in: the inputs are the PARAMETERS (v and, for weight-normed layers, g) and a
+    svc_hip.ConvWeightPlan that maps them to the dense-conv operands.  Forward = plan.prepare (one launch: weight-norm scale,
+    index map of a strided / transposed layout, forward AND dgrad packing) + the MFMA conv; backward = dgrad on the operand
+    prepared in the forward, wgrad in the dense layout, plan.grad (one launch back to dv, dg).  Replaces weight_norm_fwd +
+    F.pad / permute / copy + pack (+ pack_T, the adjoint copies and weight_norm_bwd in the backward): 4-9 launches -> 2."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, plan, pad, dil, tout, exact):
+        x = _c(x)
+        vd = v.detach()
+        gd = g.detach().reshape(-1) if g is not None else None
+        wp, _ = plan.prepare(vd, gd)
+        Tin = x.shape[2]
+        Tout = Tin + 2 * pad - dil * (plan.Kd - 1)
+        if tout is not None:
+            Tout = tout if exact else min(Tout, tout)
+        y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
+        ctx.save_for_backward(x, v, g)
+        ctx.plan = plan
+        ctx.cfg = (pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, v, g = ctx.saved_tensors
+        plan = ctx.plan
+        pad, dil, has_bias = ctx.cfg
+        dy = _c(dy)
+        dx = dv = dg = db = None
+        if ctx.needs_input_grad[0]:
+            dx = S.conv1d(dy, plan.wt, plan.Id, plan.Kd, dil=dil, pad_left=dil * (plan.Kd - 1) - pad, Tout=x.shape[2])
+        want_db = has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[1]:
+            if want_db:
+                db, zeroed = S.wgrad_zeros((plan.Od,), dy.device)
+                if not zeroed and S.wgrad_slab.active:
+                    db.zero_()
+            dwd = S.conv1d_wgrad(dy, x, plan.Kd, dil, pad, dbias=db)
+            gd = g.detach().reshape(-1) if g is not None else None
+            dv, dgf = plan.grad(v.detach(), gd, dwd)
+            dv = dv.view(v.shape)
+            if g is not None:
+                dg = dgf.view(g.shape)
+        elif want_db:
+            db = S.reduce_bct(dy, 0)
+        return dx, dv, dg, db, None, None, None, None, None
+
+
 class _Decimate(Function):
     @staticmethod
     def forward(ctx, x, s, off, Q, lp, inner=1):
@@ -423,33 +472,92 @@ def conv1d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1, inner=1, 
         if dilation != 1 or inner != 1 or out_blocks is not None:
             raise S.SvcError("grouped conv with dilation is not on the so-vits-svc path")
         return _GConv1d.apply(x, w, bias, stride, padding, groups)
+
+    def dense(xx, pad, dil, tout=None, exact=False, strided=None):
+        if strided is None:
+            return _Conv1dDense.apply(xx, w, bias, pad, dil, tout, exact)
+        KSd, shift = strided
+        wpad = torch.nn.functional.pad(w, (shift, stride * KSd - KS - shift))
+        wd = wpad.view(Cout, Cg, KSd, stride).permute(0, 3, 1, 2).reshape(Cout, stride * Cg, KSd)   # index reshapes only
+        return _Conv1dDense.apply(xx, wd, bias, pad, dil, tout, exact)
+
+    return _conv1d_lowered(dense, x, KS, stride, padding, dilation, inner, lp, out_blocks)
+
+
+def strided_geometry(KS, s, padding):
+    """Stride-s conv as a dense conv over the s input phases: input position t*s + k - pad = (t + m)*s + r with
+    k - pad = s*m + r, r in [0,s).  -> (KSd taps of the dense conv, shift: zeros in front of the kernel so that
+    k + shift = s*(m - m_min) + r, m_min)."""
+    m_min = (0 - padding) // s
+    m_max = (KS - 1 - padding) // s
+    return m_max - m_min + 1, -(s * m_min + padding), m_min
+
+
+def _conv1d_lowered(dense, x, KS, stride, padding, dilation, inner, lp, out_blocks):
+    """The activation side shared by conv1d() and conv1d_planned(): `dense(x, pad, dil, tout, exact, strided)` runs the dense
+    stride-1 convolution (strided = (KSd, shift) when the weight has to take the phase-decimated layout)."""
     if stride == 1:
         if lp is not None and lp != x.shape[2]:
             raise S.SvcError("reflect padding is folded into the decimation of a strided conv only")
         if out_blocks is not None:
-            return _Conv1dDense.apply(x, w, bias, padding * inner, dilation * inner, out_blocks * inner, True)
-        return _Conv1dDense.apply(x, w, bias, padding * inner, dilation * inner)
+            return dense(x, padding * inner, dilation * inner, out_blocks * inner, True)
+        return dense(x, padding * inner, dilation * inner)
     if dilation != 1:
         raise S.SvcError("strided conv with dilation is not on the so-vits-svc path")
-    # stride-s conv: input position t*s + k - pad = (t + m)*s + r with k - pad = s*m + r, r in [0,s)
     s = stride
     Tin = (x.shape[2] if lp is None else lp) // inner          # in blocks
     Tout = (Tin + 2 * padding - KS) // s + 1
-    m_min = (0 - padding) // s
-    m_max = (KS - 1 - padding) // s
-    KSd = m_max - m_min + 1
-    shift = -(s * m_min + padding)               # >= 0: zeros in front so that k + shift = s*(m - m_min) + r
-    wpad = torch.nn.functional.pad(w, (shift, s * KSd - KS - shift))
-    wd = wpad.view(Cout, Cg, KSd, s).permute(0, 3, 1, 2).reshape(Cout, s * Cg, KSd)   # index reshapes only
+    KSd, shift, m_min = strided_geometry(KS, s, padding)
     Q = (Tin + s - 1) // s
     if out_blocks is not None:
         # blocks past the signal decimate to zeros (svc_decimate_f32 zero-fills beyond lp), so rounding Q up only appends a
         # zero tail; the adjoint never reads it
         xd = _Decimate.apply(x, s, 0, align_blocks(Q, inner), lp, inner)
-        return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, out_blocks * inner, True)
+        return dense(xd, -m_min * inner, inner, out_blocks * inner, True, (KSd, shift))
     xd = _Decimate.apply(x, s, 0, Q, lp, inner)
     # dense conv (dilation `inner`) over the Q blocks; only the first Tout blocks are produced
-    return _Conv1dDense.apply(xd, wd, bias, -m_min * inner, inner, Tout * inner)
+    return dense(xd, -m_min * inner, inner, Tout * inner, False, (KSd, shift))
+
+
+def conv_plan(weight_shape, stride=1, padding=0, transposed=False):
+    """svc_hip.ConvWeightPlan for a module's convolution: weight [Cout, Cin, KS(,1)] (nn.Conv1d / Conv2d((k,1))) or, with
+    transposed=True, [Cin, Cout, KS] (nn.ConvTranspose1d)."""
+    R, C2, KS = weight_shape[0], weight_shape[1], weight_shape[2]
+    P = S.ConvWeightPlan
+    if transposed:
+        return P(P.TRANSPOSED, R, C2, KS, s=stride)
+    if stride == 1:
+        return P(P.DENSE, R, C2, KS)
+    KSd, shift, _ = strided_geometry(KS, stride, padding)
+    return P(P.STRIDED, R, C2, KS, s=stride, shift=shift, Kd=KSd)
+
+
+def conv1d_planned(x, plan, v, g=None, bias=None, stride=1, padding=0, dilation=1, inner=1, lp=None, out_blocks=None,
+                   causal=False):
+    """conv1d() on a module's parameters through its ConvWeightPlan (groups == 1): v is weight / weight_v, g weight_g or
+    None.  causal: left padding (K-1)*dilation only, output length == input length."""
+    KS = plan.K
+    if causal:
+        if stride != 1 or inner != 1:
+            raise S.SvcError("causal padding with a stride is not on the so-vits-svc path")
+        return _ConvPlanned.apply(x, v, g, bias, plan, (KS - 1) * dilation, dilation, x.shape[2], False)
+
+    def dense(xx, pad, dil, tout=None, exact=False, strided=None):
+        return _ConvPlanned.apply(xx, v, g, bias, plan, pad, dil, tout, exact)
+
+    return _conv1d_lowered(dense, x, KS, stride, padding, dilation, inner, lp, out_blocks)
+
+
+def conv_transpose1d_planned(x, plan, v, g=None, bias=None, stride=1, padding=0):
+    """conv_transpose1d() on a module's parameters through its (TRANSPOSED) ConvWeightPlan; v [Cin, Cout, KS]."""
+    Cin, Cout, KS = plan.R, plan.C2, plan.K
+    M = plan.Kd
+    Lout = (x.shape[2] - 1) * stride - 2 * padding + KS
+    yq = _ConvPlanned.apply(x, v, g, None, plan, M - 1, 1, None, False)          # [B, u*Cout, Tin + M - 1]
+    y = _Interleave.apply(yq, Cout, Lout, stride, -padding)
+    if bias is not None:
+        y = add_bcast(y, bias.view(1, -1, 1))
+    return y
 
 
 def conv1d_causal(x, w, bias=None, dilation=1):

@@ -607,7 +607,13 @@ class GemmArgs(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_float)]
 
 
+class ConvWeightArgs(C.Structure):
+    _fields_ = [("v", _f32p), ("g", _f32p), ("wp", _f32p), ("wt", _f32p), ("norm", _f32p)] + \
+               [(n, C.c_int) for n in ("kind", "R", "C2", "K", "Od", "Id", "Kd", "OdP", "IdP", "s", "shift")]
+
+
 TRAIN_EXPORTS = [
+    "svc_conv_weight_prep_f32", "svc_conv_weight_grad_f32",
     "svc_weight_norm_fwd_f32", "svc_weight_norm_bwd_f32", "svc_pack_conv1d_weight_T", "svc_conv1d_wgrad_f32",
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
@@ -627,6 +633,8 @@ def tlib():
         L.svc_weight_norm_bwd_f32.argtypes = [_f32p] * 6 + [i, i, vp]
         L.svc_pack_conv1d_weight_T.argtypes = [_f32p, _f32p, i, i, i, i, vp]
         L.svc_conv1d_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]
+        L.svc_conv_weight_prep_f32.argtypes = [C.POINTER(ConvWeightArgs), vp]
+        L.svc_conv_weight_grad_f32.argtypes = [C.POINTER(ConvWeightArgs), _f32p, _f32p, _f32p, vp]
         L.svc_gemm_f32.argtypes = [C.POINTER(GemmArgs), vp]
         L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
         L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
@@ -731,6 +739,65 @@ def pack_conv1d_weight_T(w):
     dst = torch.empty((Cout, KS, CinP), device=w.device, dtype=torch.float32)
     check(tlib().svc_pack_conv1d_weight_T(ptr(w), ptr(dst), Cout, Cin, KS, CinP, stream_ptr()), "pack_conv1d_T")
     return dst
+
+
+class ConvWeightPlan:
+    """The weight side of one training convolution: the index map parameter -> dense-conv weight (svc_conv_weight_args in
+    include/svc_hip.h) and the two persistent operand buffers it fills.  `prepare(v, g)` is ONE launch producing the forward
+    operand, the dgrad operand and the weight-norm row norms; `grad(v, g, dwd)` ONE launch mapping the dense-layout weight
+    gradient back to (dv, dg).  The buffers are allocated zero-filled on first use and only their mapped entries are ever
+    rewritten, so they are valid hipGraph operands (fixed addresses) and the padding stays zero."""
+
+    DENSE, STRIDED, TRANSPOSED = 0, 1, 2
+
+    def __init__(self, kind, R, C2, K, s=1, shift=0, Kd=None):
+        self.kind, self.R, self.C2, self.K, self.s, self.shift = kind, R, C2, K, s, shift
+        if kind == self.DENSE:
+            self.Od, self.Id, self.Kd = R, C2, K
+        elif kind == self.STRIDED:
+            self.Od, self.Id, self.Kd = R, s * C2, Kd
+        else:
+            self.Od, self.Id, self.Kd = s * C2, R, (K + s - 1) // s
+        self.OdP, self.IdP = round_up(self.Od, 32), round_up(self.Id, 32)
+        self.wp = self.wt = self.norm = None
+
+    def _args(self, v, g):
+        a = ConvWeightArgs()
+        a.v, a.g, a.wp, a.wt, a.norm = ptr(v), ptr(g), ptr(self.wp), ptr(self.wt), ptr(self.norm if g is not None else None)
+        a.kind, a.R, a.C2, a.K, a.s, a.shift = self.kind, self.R, self.C2, self.K, self.s, self.shift
+        a.Od, a.Id, a.Kd, a.OdP, a.IdP = self.Od, self.Id, self.Kd, self.OdP, self.IdP
+        return a
+
+    def _check(self, v, g):
+        require_gpu(v, g)
+        if v.numel() != self.R * self.C2 * self.K or not v.is_contiguous():
+            raise SvcError(f"ConvWeightPlan: parameter {tuple(v.shape)} does not match the plan [{self.R},{self.C2},{self.K}]")
+        if g is not None and (g.numel() != self.R or not g.is_contiguous()):
+            raise SvcError("ConvWeightPlan: weight_g must hold one contiguous value per row")
+
+    def prepare(self, v, g=None):
+        """-> (wp [Id,Kd,OdP], wt [Od,Kd,IdP]) for v (and g) as they are now."""
+        self._check(v, g)
+        if self.wp is None or self.wp.device != v.device:
+            self.wp = torch.zeros((self.Id, self.Kd, self.OdP), device=v.device, dtype=torch.float32)
+            self.wt = torch.zeros((self.Od, self.Kd, self.IdP), device=v.device, dtype=torch.float32)
+            self.norm = torch.empty((self.R,), device=v.device, dtype=torch.float32)
+        check(tlib().svc_conv_weight_prep_f32(C.byref(self._args(v, g)), stream_ptr()), "conv_weight_prep")
+        return self.wp, self.wt
+
+    def grad(self, v, g, dwd):
+        """dwd [Od,Id,Kd] -> (dv like v, dg like g or None); uses the row norms of the last prepare()."""
+        self._check(v, g)
+        require_gpu(dwd)
+        if tuple(dwd.shape) != (self.Od, self.Id, self.Kd) or not dwd.is_contiguous():
+            raise SvcError(f"ConvWeightPlan.grad: dwd {tuple(dwd.shape)} is not contiguous [{self.Od},{self.Id},{self.Kd}]")
+        if g is None and self.kind == self.DENSE:
+            return dwd.view(v.shape), None
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g) if g is not None else None
+        check(tlib().svc_conv_weight_grad_f32(C.byref(self._args(v, g)), ptr(dwd), ptr(dv), ptr(dg), stream_ptr()),
+              "conv_weight_grad")
+        return dv, dg
 
 
 class ZeroSlab:

@@ -11,12 +11,17 @@ autograd form built from svc_autograd Functions (every forward and backward kern
 fused inference epilogues (`run(...)`) are inference-only and raise under grad mode.
 """
 import math
+import os
 
 import torch
 from torch import nn
 
 import svc_hip as S
 import svc_autograd as A
+
+
+# SVC_WEIGHT_PLAN=0: the unfused weight path (weight_norm op, torch index reshapes, separate packs) — A/B switch
+WEIGHT_PLANS = os.environ.get("SVC_WEIGHT_PLAN", "1") != "0"
 
 
 def training_call(*params):
@@ -102,8 +107,20 @@ class Conv1d(nn.Module, _PackedMixin):
         """The [Cout,Cin,KS] weight on the autograd tape (weight-norm folded by svc_weight_norm_fwd_f32)."""
         return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
 
+    def _plan(self):
+        """The layer's svc_hip.ConvWeightPlan (index map + persistent operand buffers), built on first use."""
+        plan = self.__dict__.get("_svc_plan")
+        if plan is None:
+            plan = A.conv_plan((self.out_channels, self.in_channels, self.kernel_size), self.stride, self.padding)
+            self.__dict__["_svc_plan"] = plan
+        return plan
+
     def forward_train(self, x, causal=False, padding=None):
         """Autograd form of the plain convolution (no fused prologue/epilogue); `padding` overrides self.padding."""
+        if WEIGHT_PLANS and (padding is None or self.stride == 1):
+            v, g = (self.weight_v, self.weight_g) if self.is_weight_norm else (self.weight, None)
+            return A.conv1d_planned(x, self._plan(), v, g, self.bias, self.stride,
+                                    self.padding if padding is None else padding, self.dilation, causal=causal)
         if padding is not None and not causal:
             return A.conv1d(x, self.effective_weight(), self.bias, self.stride, padding, self.dilation)
         if causal and self.kernel_size > 1:
@@ -264,6 +281,13 @@ class ConvTranspose1d(nn.Module, _PackedMixin):
         return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
 
     def forward_train(self, x):
+        if WEIGHT_PLANS:
+            plan = self.__dict__.get("_svc_plan")
+            if plan is None:
+                plan = A.conv_plan((self.in_channels, self.out_channels, self.kernel_size), self.stride, transposed=True)
+                self.__dict__["_svc_plan"] = plan
+            v, g = (self.weight_v, self.weight_g) if self.is_weight_norm else (self.weight, None)
+            return A.conv_transpose1d_planned(x, plan, v, g, self.bias, self.stride, self.padding)
         return A.conv_transpose1d(x, self.effective_weight(), self.bias, self.stride, self.padding)
 
     def forward(self, x, **kw):

@@ -268,3 +268,73 @@ def test_discriminator_p_padded_rows(dev, period, T):
     named = dict(net.named_parameters())
     for k in probe:
         close(named[k].grad.cpu(), sr[prefix + "." + k].grad, k)
+
+
+def _wn(v, g):
+    return v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,dil,wn,causal,T", [
+    (16, 24, 3, 1, 1, 1, True, False, 200), (32, 32, 11, 1, 25, 5, True, False, 333), (192, 384, 5, 1, 2, 1, False, False, 77),
+    (64, 48, 3, 1, 0, 1, False, True, 128), (1, 16, 16, 8, 4, 1, False, False, 1024), (1, 32, 128, 64, 32, 1, False, False, 4096),
+    (12, 20, 5, 3, 2, 1, True, False, 301), (1024, 1, 3, 1, 1, 1, True, False, 40), (40, 1, 1, 1, 0, 1, False, False, 50)])
+def test_conv1d_module_weight_plan(dev, Cin, Cout, K, stride, pad, dil, wn, causal, T):
+    """svc_nn.Conv1d.forward_train through its ConvWeightPlan (svc_conv_weight_prep_f32 / svc_conv_weight_grad_f32: weight
+    norm, strided index map, both operand packings in one launch; one launch back to dv / dg) against torch's conv1d on
+    the weight-normed weight: output and the gradients of x, weight(_v), weight_g, bias.  Two passes with changed parameters:
+    the plan's persistent operand buffers must follow the parameters."""
+    import svc_nn
+    torch.manual_seed(11)
+    m = svc_nn.Conv1d(Cin, Cout, K, stride=stride, padding=pad, dilation=dil, weight_norm=wn).to(dev)
+    assert svc_nn.WEIGHT_PLANS
+    for it in range(2):
+        x = torch.randn(2, Cin, T)
+        go = None
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.0 + 0.3 * it).add_(0.01 * it)
+        ps = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in m.named_parameters()}
+        xr = x.clone().requires_grad_(True)
+        w = _wn(ps["weight_v"], ps["weight_g"]) if wn else ps["weight"]
+        if causal:
+            yr = F.conv1d(F.pad(xr, ((K - 1) * dil, 0)), w, ps["bias"], stride, 0, dil)
+        else:
+            yr = F.conv1d(xr, w, ps["bias"], stride, pad, dil)
+        xh = x.clone().to(dev).requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        yh = m.forward_train(xh, causal=causal)
+        _close(yh, yr, 2e-5, "forward")
+        go = torch.randn_like(yr)
+        yr.backward(go)
+        yh.backward(go.to(dev))
+        _close(xh.grad, xr.grad, 2e-5, "grad x")
+        for k, p in m.named_parameters():
+            _close(p.grad, ps[k].grad, 5e-5, f"grad {k} (pass {it})")
+
+
+@pytest.mark.parametrize("Cin,Cout,K,u,pad,wn,T", [(32, 16, 16, 8, 4, True, 50), (16, 8, 4, 2, 1, True, 300), (6, 5, 5, 2, 1, False, 64),
+                                                   (8, 8, 7, 3, 2, True, 33)])
+def test_conv_transpose1d_module_weight_plan(dev, Cin, Cout, K, u, pad, wn, T):
+    """svc_nn.ConvTranspose1d.forward_train through its (transposed) ConvWeightPlan against torch's conv_transpose1d."""
+    import svc_nn
+    torch.manual_seed(12)
+    m = svc_nn.ConvTranspose1d(Cin, Cout, K, stride=u, padding=pad, weight_norm=wn).to(dev)
+    for it in range(2):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.0 + 0.3 * it)
+        x = torch.randn(2, Cin, T)
+        ps = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in m.named_parameters()}
+        xr = x.clone().requires_grad_(True)
+        w = _wn(ps["weight_v"], ps["weight_g"]) if wn else ps["weight"]
+        yr = F.conv_transpose1d(xr, w, ps["bias"], u, pad)
+        xh = x.clone().to(dev).requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        yh = m.forward_train(xh)
+        _close(yh, yr, 2e-5, "forward")
+        go = torch.randn_like(yr)
+        yr.backward(go)
+        yh.backward(go.to(dev))
+        _close(xh.grad, xr.grad, 2e-5, "grad x")
+        for k, p in m.named_parameters():
+            _close(p.grad, ps[k].grad, 5e-5, f"grad {k} (pass {it})")
