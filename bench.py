@@ -347,6 +347,26 @@ def main():
     samples_per_step = B * T_FRAMES * HOP
     value = world * samples_per_step * args.steps / elapsed
 
+    # ---- PCIe-inclusive rate (reported beside `value`, never as it): units / f0 / uv start in pinned host memory and the
+    # waveform ends in pinned host memory, one clip at a time, synchronised per clip (what a caller holding host buffers sees) --
+    host_io = None
+    if rank == 0:
+        hin = [t.pin_memory() for t in cpu_in[:3]]
+        o0, _ = step()
+        oh = torch.empty(o0.shape, dtype=o0.dtype).pin_memory()
+        nio = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nio):
+            ch, fh, uh = [t.to(dev, non_blocking=True) for t in hin]
+            o, _ = net.infer(ch, fh, uh, g=sid, noice_scale=0.4)
+            oh.copy_(o, non_blocking=True)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / nio
+        host_io = dict(ms_per_step=round(1e3 * dt, 4), samples_per_s=samples_per_step / dt,
+                       h2d_bytes=int(sum(t.numel() * t.element_size() for t in hin)), d2h_bytes=int(oh.numel() * oh.element_size()),
+                       note="pinned host -> HBM -> pinned host around every clip, synchronised per clip")
+
     # ---- roofline: per-launch hipEvent durations of every kernel family, eager pass over the same step ----
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -413,7 +433,7 @@ def main():
                                batch=B, frames=T_FRAMES, samples_per_step=samples_per_step,
                                launch="hipGraph replay" if not args.no_graph else "eager",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU"),
-                   roofline=roof, cpu_baseline=cpu, train=train_res)
+                   roofline=roof, cpu_baseline=cpu, host_io=host_io, train=train_res)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
