@@ -221,13 +221,17 @@ def run_train(args, dev, rank, world, dist):
     red = None
     if getattr(net_g, "reducer", None) is not None:
         rg, rd = net_g.reducer, net_d.reducer
-        n_it = steps + warm + (1 if use_graph else 0)
+        # every iteration reduces each network's gradients once: per-iteration figures = totals / number of reductions
+        # (reduce_all calls between graph replays, or hooked backward passes in the eager mode; warm-up iterations included)
+        def per_it(r, key):
+            return r.stats[key] / max(r.stats["reduce_all_calls"] or r.stats["backward_passes"], 1)
+        n_red = max(rg.stats["reduce_all_calls"] or rg.stats["backward_passes"], 1)
         red = dict(backend=rg.backend, ranks=world,
                    mode=getattr(step_fn, "dp_mode", "eager launches, per-bucket all-reduce overlapped with backward (autograd hooks)"),
-                   bytes_per_iter=(rg.stats["reduced_bytes"] + rd.stats["reduced_bytes"]) / max(n_it, 1),
-                   launches_per_iter=(rg.stats["launches"] + rd.stats["launches"]) / max(n_it, 1),
+                   bytes_per_iter=per_it(rg, "reduced_bytes") + per_it(rd, "reduced_bytes"),
+                   launches_per_iter=per_it(rg, "launches") + per_it(rd, "launches"),
                    buckets=dict(g=len(rg.buckets), d=len(rd.buckets)),
-                   exposed_ms_per_iter=(rg.exposed_ms() + rd.exposed_ms()) / max(n_it, 1))
+                   exposed_ms_per_iter=(rg.exposed_ms() + rd.exposed_ms()) / n_red)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)

@@ -5,7 +5,7 @@ set -x
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_train_ops_gpu.py tests/test_boundary_gpu.py -m gpu -q --timeout=600 -rf > gpurun_out/f2_pytest_subset.log 2>&1; echo "pytest rc=$?" >> gpurun_out/f2_pytest_subset.log
+timeout 600 python -m pytest tests/test_train_ops_gpu.py tests/test_train_gpu.py tests/test_train_loop_gpu.py tests/test_data_parallel_gpu.py tests/test_boundary_gpu.py -m gpu -q --timeout=600 -rf > gpurun_out/f2_pytest_subset.log 2>&1; echo "pytest rc=$?" >> gpurun_out/f2_pytest_subset.log
 tail -4 gpurun_out/f2_pytest_subset.log | cut -c1-300
 timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/f2_bench.json 2> gpurun_out/f2_bench.err; echo "bench rc=$?"
 cat gpurun_out/f2_bench.json; tail -3 gpurun_out/f2_bench.err

@@ -114,7 +114,7 @@ class GradReducer:
         self._pending = None        # per-bucket count of members still waiting for a gradient in this backward
         self._works = []
         self._launched = None
-        self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0)
+        self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0, reduce_all_calls=0)
         self._exposed = []          # (start, end) event pairs around reduce_all on the compute stream
         arena.add_listener(self._on_grad)
 
@@ -179,6 +179,7 @@ class GradReducer:
         iteration that is a few ms over xGMI — the eager launch path it replaces costs ~100 ms of host time."""
         if self.single:
             return
+        self.stats["reduce_all_calls"] += 1
         ev = None
         if time_it and self.arena.grad.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -4,44 +4,38 @@ plain scalar arithmetic, as train.py itself does with the returned losses."""
 import torch
 
 import svc_autograd as A
+import svc_hip as S
 
 
 def feature_loss(fmap_r, fmap_g):
-    """Reference modules/losses.py:4-12: 2 * sum over discriminators/layers of mean|r - g| (r detached)."""
-    loss = 0
+    """Reference modules/losses.py:4-12: 2 * sum over discriminators/layers of mean|r - g| (r detached) — all 41 terms
+    accumulate into one device scalar (svc_autograd.weighted_sums)."""
+    terms = []
     for dr, dg in zip(fmap_r, fmap_g):
         for rl, gl in zip(dr, dg):
             n = gl.numel()
             rp, gp = getattr(rl, "_svc_padded", None), getattr(gl, "_svc_padded", None)
             if rp is not None and gp is not None and rp.shape == gp.shape:
                 rl, gl = rp, gp         # DiscriminatorP's padded buffers: zero tails on both sides, same sum, no gather copy
-            loss = loss + A.sum_abs_diff(rl.float().detach(), gl.float()) / n
-    return loss * 2
+            terms.append((S.RED_ABS_DIFF, 2.0 / n, rl.float().detach(), gl.float()))
+    return A.weighted_sums(terms)
 
 
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
     """Reference :15-28.  r_losses / g_losses are returned as device scalars (the reference calls .item() on each of
     the 12 terms — a host sync per term)."""
-    loss = 0
-    r_losses, g_losses = [], []
+    terms = []
     for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
-        r_loss = A.sum_sq_one_minus(dr.float()) / dr.numel()
-        g_loss = A.sum_sq(dg.float()) / dg.numel()
-        loss = loss + (r_loss + g_loss)
-        r_losses.append(r_loss.detach())
-        g_losses.append(g_loss.detach())
-    return loss, r_losses, g_losses
+        terms.append((S.RED_SQ_ONE_MINUS, 1.0 / dr.numel(), dr.float()))
+        terms.append((S.RED_SQ, 1.0 / dg.numel(), dg.float()))
+    loss, vals = A.weighted_sums(terms, per_term=True)
+    return loss, list(vals[0::2].unbind(0)), list(vals[1::2].unbind(0))
 
 
 def generator_loss(disc_outputs):
     """Reference :31-40."""
-    loss = 0
-    gen_losses = []
-    for dg in disc_outputs:
-        l = A.sum_sq_one_minus(dg.float()) / dg.numel()
-        gen_losses.append(l)
-        loss = loss + l
-    return loss, gen_losses
+    loss, vals = A.weighted_sums([(S.RED_SQ_ONE_MINUS, 1.0 / dg.numel(), dg.float()) for dg in disc_outputs], per_term=True)
+    return loss, list(vals.unbind(0))
 
 
 def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):

@@ -827,6 +827,78 @@ class _KLSums(Function):
         return dz, dlq, dm, dlp, None
 
 
+class _WeightedSums(Function):
+    """total = sum_i w_i * red_i(a_i[, b_i]) for a list of reduction terms (ops of svc_reduce_scalar_f64), accumulated on the
+    device into ONE float64 cell (per_term=False) or one cell per term plus the total (per_term=True: the second output holds
+    the weighted terms, for logging; it carries no gradient).  One zero-fill + one reduction launch per term + one or three
+    conversions, instead of (zero-fill, reduce, convert, divide, add) per term in the caller's scalar arithmetic — the
+    feature-matching loss alone has 41 terms (modules/losses.py:4-12)."""
+
+    @staticmethod
+    def forward(ctx, spec, per_term, *tensors):
+        n = len(spec)
+        ts, k = [], 0
+        for op, w, nin in spec:
+            ts.append(tuple(_c(t) for t in tensors[k:k + nin]))
+            k += nin
+        dev = tensors[0].device
+        acc = torch.zeros(n + 1 if per_term else 1, device=dev, dtype=torch.float64)
+        for i, ((op, w, nin), tt) in enumerate(zip(spec, ts)):
+            S.reduce_scalar(op, tt[0], tt[1] if nin > 1 else None, scale=w, acc=acc[i + 1:i + 2] if per_term else acc)
+        ctx.spec = spec
+        ctx.save_for_backward(*[t for tt in ts for t in tt])
+        if not per_term:
+            vals = torch.empty(0, device=dev)
+            total = S.f64_to_f32(acc).view(())
+        else:
+            vals = S.f64_to_f32(acc[1:])
+            S.reduce_scalar(S.RED_SUM, vals, acc=acc[0:1])
+            total = S.f64_to_f32(acc[0:1]).view(())
+        ctx.mark_non_differentiable(vals)
+        return total, vals
+
+    @staticmethod
+    def backward(ctx, g, _gv):
+        saved = ctx.saved_tensors
+        grads, k = [], 0
+        for j, (op, w, nin) in enumerate(ctx.spec):
+            a = saved[k]
+            b = saved[k + 1] if nin > 1 else None
+            need_a = ctx.needs_input_grad[2 + k]
+            need_b = nin > 1 and ctx.needs_input_grad[3 + k]
+            da = db = None
+            if need_a or need_b:
+                if op == S.RED_ABS_DIFF:
+                    d = S.ew(S.EW_SIGN_MUL, S.ew(S.EW_ADD, a, b, alpha=1.0, beta=-1.0), alpha=w)
+                elif op == S.RED_SQ_DIFF:
+                    d = S.ew(S.EW_ADD, a, b, alpha=2.0 * w, beta=-2.0 * w)
+                elif op == S.RED_SQ:
+                    d = S.ew(S.EW_SCALE, a, alpha=2.0 * w)
+                elif op == S.RED_SQ_ONE_MINUS:
+                    d = S.ew(S.EW_SCALE, a, alpha=2.0 * w, beta=-2.0 * w)
+                else:
+                    raise S.SvcError(f"weighted_sums: no gradient for reduction op {op}")
+                da = _bscale(d, g)
+                if need_b:
+                    db = S.ew(S.EW_SCALE, da, alpha=-1.0)
+                if not need_a:
+                    da = None
+            grads.append(da)
+            if nin > 1:
+                grads.append(db)
+            k += nin
+        return (None, None) + tuple(grads)
+
+
+def weighted_sums(terms, per_term=False):
+    """terms: [(op, weight, a[, b])] with op one of S.RED_ABS_DIFF / RED_SQ_DIFF / RED_SQ / RED_SQ_ONE_MINUS.
+    -> total (0-dim) or, with per_term, (total, [N] weighted terms without gradient)."""
+    spec = tuple((t[0], float(t[1]), len(t) - 2) for t in terms)
+    flat = [x for t in terms for x in t[2:]]
+    total, vals = _WeightedSums.apply(spec, per_term, *flat)
+    return (total, vals) if per_term else total
+
+
 def sum_abs_diff(a, b):
     return _SumAbsDiff.apply(a, b)
 
