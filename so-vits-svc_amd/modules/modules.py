@@ -88,8 +88,8 @@ class WN(nn.Module):
             acts = A.gate(x_in)
             rs = self.res_skip_layers[i].forward_train(acts)
             if i < self.n_layers - 1:
-                x = A.mul_bcast(A.add(x, rs[:, :H]), x_mask)
-                skip = rs[:, H:]
+                res, skip = A.chunk_channels(rs, 2)     # one gradient buffer in the backward (no zero-fill + add per half)
+                x = A.mul_bcast(A.add(x, res), x_mask)
             else:
                 skip = rs
             output = skip if output is None else A.add(output, skip)
