@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=None)
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -354,7 +355,7 @@ def main():
     # ---- PCIe-inclusive rate (reported beside `value`, never as it): units / f0 / uv start in pinned host memory and the
     # waveform ends in pinned host memory, one clip at a time, synchronised per clip (what a caller holding host buffers sees) --
     host_io = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_io:
         hin = [t.pin_memory() for t in cpu_in[:3]]
         o0, _ = step()
         oh = torch.empty(o0.shape, dtype=o0.dtype).pin_memory()

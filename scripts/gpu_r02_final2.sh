@@ -16,8 +16,8 @@ SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/pro
 DB=$(find gpurun_out/prof_stats -name '*.db' | head -1); python scripts/prof_summary.py $DB > gpurun_out/f2_kernel_stats.txt 2>&1; head -12 gpurun_out/f2_kernel_stats.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/f2_bench_train_prof.json 2> gpurun_out/f2_bench_train_prof.err; echo "rocprof train rc=$?"
 DB=$(find gpurun_out/prof_train -name '*.db' | head -1); python scripts/prof_summary.py $DB > gpurun_out/f2_kernel_stats_train.txt 2>&1; head -30 gpurun_out/f2_kernel_stats_train.txt
-SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > gpurun_out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
-SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > gpurun_out/pmc_write.log 2>&1; echo "pmc write rc=$?"
+SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-host-io > gpurun_out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-host-io > gpurun_out/pmc_write.log 2>&1; echo "pmc write rc=$?"
 python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write 4 gpurun_out/f2_pmc_conv1d_mfma.json > gpurun_out/f2_pmc_summary.txt 2>&1; cat gpurun_out/f2_pmc_summary.txt
 find gpurun_out -name '*.db' -size +30M -delete
 find gpurun_out -name '*counter_collection.csv' -size +20M -delete
