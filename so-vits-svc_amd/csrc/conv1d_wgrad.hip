@@ -132,38 +132,24 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) bsum += brow_sum[c];
     }
-    if constexpr (NK == 1) {
-      // one tap per group (nk == 1 always): unconditional MFMAs.  With the per-tap `q < nk` guard below the accumulators
-      // are values merged across branches, and for NK = 1 hipcc kept them in VGPRs, copying all 32 into AGPRs and back
-      // around EVERY MFMA pair (64 v_accvgpr moves + an exposed MFMA latency per 2 MFMAs in the ISA).  (The same
-      // specialisation for full groups of NK >= 2 removes the per-tap branches too, but raises their VGPR count past the
-      // two-workgroups-per-CU limit: left for a measured round.)
+    // Straight-line MFMA loop, NO per-tap `q < nk` guards: a partial tap group (the 3-tap tail of KS = 7 = 4+3 or
+    // 11 = 4+4+3) runs its NK - nk surplus taps on whatever the Bs rows hold past the staged width — finite or not, those
+    // accumulators are never written out (the epilogue keeps its guard) — at the price of 14 % / 9 % surplus MFMAs in that
+    // group only.  With the guards hipcc turned every tap into its own basic block: a branch, a ds_read and an
+    // `s_waitcnt lgkmcnt(0)` in front of EVERY MFMA pair (LDS latency fully exposed at one wave per SIMD), and the
+    // branch-merged accumulators were copied between AGPRs and VGPRs inside the loop (16 v_accvgpr moves per MFMA pair in
+    // the NK = 5 ISA).  Unguarded, the loop body is 2 + NK ds_reads feeding 2*NK back-to-back MFMAs, software-pipelined
+    // over the 4x unroll.
 #pragma unroll 4
-      for (int s = 0; s < TT; s += 2) {
-        const float a0 = ap[s], a1 = ap[32 * PA + s];
-        float bv[NK];
+    for (int s = 0; s < TT; s += 2) {
+      const float a0 = ap[s], a1 = ap[32 * PA + s];
+      float bv[NK];
 #pragma unroll
-        for (int q = 0; q < NK; ++q) bv[q] = bp[s + q * dil];
+      for (int q = 0; q < NK; ++q) bv[q] = bp[s + q * dil];
 #pragma unroll
-        for (int q = 0; q < NK; ++q) {
-          acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
-          acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int s = 0; s < TT; s += 2) {
-        const float a0 = ap[s], a1 = ap[32 * PA + s];
-        float bv[NK];
-#pragma unroll
-        for (int q = 0; q < NK; ++q) bv[q] = q < nk ? bp[s + q * dil] : 0.f;
-#pragma unroll
-        for (int q = 0; q < NK; ++q) {
-          if (q < nk) {
-            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
-          }
-        }
+      for (int q = 0; q < NK; ++q) {
+        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
+        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
       }
     }
   }
@@ -291,15 +277,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_small_kernel(WgSP p) {
       float av[MA];
 #pragma unroll
       for (int i = 0; i < MA; ++i) av[i] = ap[i * 16 * SPA + s];
+      // no `q < nk` guard (see conv1d_wgrad_kernel): the surplus taps of a partial group read past the staged width inside
+      // the row pitch (PB covers NKS taps) into accumulators that are never written out
 #pragma unroll
       for (int q = 0; q < NKS; ++q) {
-        if (q < nk) {
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const float bv = bp[j * 16 * PB + s + q * dil];
+        for (int j = 0; j < NB; ++j) {
+          const float bv = bp[j * 16 * PB + s + q * dil];
 #pragma unroll
-            for (int i = 0; i < MA; ++i) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i][j], 0, 0, 0);
-          }
+          for (int i = 0; i < MA; ++i) acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i][j], 0, 0, 0);
         }
       }
     }
@@ -422,7 +408,7 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
     splits = std::min(splits, q.n_tiles);
     q.tiles_per_wg = svc::cdiv(q.n_tiles, splits);
     q.splits = svc::cdiv(q.n_tiles, q.tiles_per_wg);
-    int pb = STT + (std::min(nks, a.KS) - 1) * a.dil;
+    int pb = STT + (nks - 1) * a.dil;      // row pitch covers all NKS taps of the instantiation (unguarded MFMA loop)
     if ((pb & 1) == 0) ++pb;
     q.PB = pb;
     size_t lds = sizeof(float) * ((size_t)16 * MA * SPA + (size_t)16 * NB * pb);
