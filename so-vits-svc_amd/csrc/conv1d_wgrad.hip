@@ -19,6 +19,8 @@
 
 namespace {
 
+int g_wgrad_target = 512;   // workgroups a 3..5-tap launch is split into (svc_debug_set_wgrad_target)
+
 constexpr int TT = 64;      // time steps per staged tile
 constexpr int CA_T = 128;   // rows of A per workgroup (2 x 2 MFMA tiles)
 constexpr int CB_T = 64;    // rows of Bm per workgroup (2 MFMA tiles)
@@ -362,6 +364,12 @@ void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int svc_debug_set_wgrad_target(int workgroups) {
+  if (workgroups < 1) return SVC_ERR_BAD_ARG;
+  g_wgrad_target = workgroups;
+  return SVC_OK;
+}
+
 extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   SVC_REQUIRE(ap != nullptr, "wgrad: null args");
   const svc_wgrad_args& a = *ap;
@@ -441,9 +449,11 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   p.tiles_per_b = svc::cdiv(a.TA, TT);
   p.n_tiles = p.tiles_per_b * a.B;
   const int n_ca = svc::cdiv(a.Ca, CA_T), n_cb = svc::cdiv(a.Cb, CB_T);
-  // enough time-splits to fill the chip (~512 workgroups = 2 rounds at one workgroup per CU; every split costs one
-  // atomic pass over G), at least 2 tiles each so the prefetch has something to hide
-  int splits = std::max(1, 512 / (n_ca * n_cb * p.n_kgroups));
+  // enough time-splits to fill the chip (every split costs one prologue and one atomic pass over G), at least 2 tiles each so
+  // the prefetch has something to hide.  The 1- and 2-tap instantiations fit two workgroups per CU (512 resident), the 3..5-tap
+  // ones (96-160 accumulator registers) one: their target is tunable (svc_debug_set_wgrad_target)
+  const int target = nk >= 3 ? g_wgrad_target : 512;
+  int splits = std::max(1, target / (n_ca * n_cb * p.n_kgroups));
   splits = std::min(splits, std::max(1, p.n_tiles / 2));
   p.tiles_per_wg = svc::cdiv(p.n_tiles, splits);
   splits = svc::cdiv(p.n_tiles, p.tiles_per_wg);
