@@ -19,7 +19,11 @@
 
 namespace {
 
-int g_wgrad_target = 512;   // workgroups a 3..5-tap launch is split into (svc_debug_set_wgrad_target)
+// Workgroups a 3..5-tap launch is split into.  256 = one workgroup per CU in ONE round: measured on the B=16 training step
+// (profiles/r02_u_wgrad_split_target_sweep.txt) 128 / 192 / 224 / 256 / 384 / 512 -> wgrad family 40.4 / 35.4 / 33.8 / 30.3 /
+// 37.2 / 34.9 ms per iteration (every split pays a prologue, an exposed first load and an atomic pass over G).
+int g_wgrad_target = 256;
+int g_wgrad_small_target = 128;   // same for the small-channel kernel (svc_debug_set_wgrad_target with a negative value)
 
 constexpr int TT = 64;      // time steps per staged tile
 constexpr int CA_T = 128;   // rows of A per workgroup (2 x 2 MFMA tiles)
@@ -365,8 +369,9 @@ void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
 }  // namespace
 
 extern "C" int svc_debug_set_wgrad_target(int workgroups) {
-  if (workgroups < 1) return SVC_ERR_BAD_ARG;
-  g_wgrad_target = workgroups;
+  if (workgroups == 0) return SVC_ERR_BAD_ARG;
+  if (workgroups > 0) g_wgrad_target = workgroups;
+  else g_wgrad_small_target = -workgroups;      // negative: the small-channel kernel's target
   return SVC_OK;
 }
 
@@ -412,7 +417,7 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
     q.tiles_per_b = svc::cdiv(a.TA, STT);
     q.n_tiles = q.tiles_per_b * a.B;
     // few time splits: every split adds the whole (tiny) gradient with same-address atomics
-    int splits = std::max(1, 128 / q.n_kgroups);
+    int splits = std::max(1, g_wgrad_small_target / q.n_kgroups);
     splits = std::min(splits, q.n_tiles);
     q.tiles_per_wg = svc::cdiv(q.n_tiles, splits);
     q.splits = svc::cdiv(q.n_tiles, q.tiles_per_wg);

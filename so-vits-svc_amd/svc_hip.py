@@ -656,6 +656,8 @@ def tlib():
         L.svc_debug_set_wgrad_target.argtypes = [i]
         if os.environ.get("SVC_WGRAD_TARGET"):       # tuning aid (A/B on one box)
             L.svc_debug_set_wgrad_target(int(os.environ["SVC_WGRAD_TARGET"]))
+        if os.environ.get("SVC_WGRAD_SMALL_TARGET"):
+            L.svc_debug_set_wgrad_target(-int(os.environ["SVC_WGRAD_SMALL_TARGET"]))
         _train_bound = True
     return L
 
