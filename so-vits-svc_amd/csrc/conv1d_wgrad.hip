@@ -23,7 +23,7 @@ namespace {
 // (profiles/r02_u_wgrad_split_target_sweep.txt) 128 / 192 / 224 / 256 / 384 / 512 -> wgrad family 40.4 / 35.4 / 33.8 / 30.3 /
 // 37.2 / 34.9 ms per iteration (every split pays a prologue, an exposed first load and an atomic pass over G).
 int g_wgrad_target = 256;
-int g_wgrad_small_target = 128;   // same for the small-channel kernel (svc_debug_set_wgrad_target with a negative value)
+int g_wgrad_small_target = 256;   // same for the small-channel kernel (negative argument of svc_debug_set_wgrad_target): 128 / 256 / 512 -> 128.3 / 127.1 / 126.9 ms per iteration
 
 constexpr int TT = 64;      // time steps per staged tile
 constexpr int CA_T = 128;   // rows of A per workgroup (2 x 2 MFMA tiles)
