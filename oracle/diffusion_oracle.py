@@ -161,6 +161,69 @@ def dpm_solver_multistep2(model, betas, x, steps, plus):
     return x
 
 
+def unipc_multistep2(model, betas, x, steps):
+    """UniPC(model_wrapper(model, NoiseScheduleVP('discrete', betas), 'noise'), variant='bh2') [data prediction]
+    .sample(x, steps, order=2, skip_type='time_uniform', method='multistep') — diffusion/uni_pc.py:70-81,103-135 (schedule, no
+    tail clipping), :172-196 (model time, noise model), :287-296 (data prediction), :473-590 (B(h) update) and :592-672 (multistep
+    driver: first step order 1 with corrector, then order 2 predictor + corrector, last step order 1 without corrector; the
+    model value kept for a time step is the one evaluated at the PREDICTED state), restated on fp32 scalars;
+    model(x, model_time[1]) -> noise."""
+    log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+    N = log_alphas.shape[0]
+    t_arr = torch.linspace(0., 1., N + 1)[1:]
+    la = lambda t: _interp(t, t_arr, log_alphas)
+    std = lambda t: torch.sqrt(1. - torch.exp(2. * la(t)))
+    lam = lambda t: la(t) - 0.5 * torch.log(1. - torch.exp(2. * la(t)))
+    ts = torch.linspace(1., 1. / N, steps + 1)
+
+    def mfn(xc, t):                                                                    # data_prediction_fn
+        noise = model(xc, ((t - 1. / N) * N).reshape(1))
+        return (xc - std(t) * noise) / torch.exp(la(t))
+
+    def update(xc, ms, tp, t, order, use_corrector):
+        lam0, lam_t = lam(tp[-1]), lam(t)
+        h = lam_t - lam0
+        rks, D1s = [], []
+        for i in range(1, order):
+            rk = (lam(tp[-(i + 1)]) - lam0) / h
+            rks.append(rk)
+            D1s.append((ms[-(i + 1)] - ms[-1]) / rk)
+        rks.append(1.)
+        rks = torch.tensor(rks)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = torch.expm1(hh)                                                          # variant 'bh2'
+        R, b, factorial_i = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append((h_phi_k * factorial_i / B_h).reshape(1))
+            factorial_i *= (i + 1)
+            h_phi_k = h_phi_k / hh - 1 / factorial_i
+        R, b = torch.stack(R), torch.cat(b)
+        alpha_t = torch.exp(la(t))
+        x_t_ = std(t) / std(tp[-1]) * xc - alpha_t * h_phi_1 * ms[-1]
+        pred_res = 0.5 * D1s[0] if D1s else 0                                          # order 2: rhos_p = [0.5]
+        x_t = x_t_ - alpha_t * B_h * pred_res
+        model_t = None
+        if use_corrector:
+            rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+            model_t = mfn(x_t, t)
+            corr_res = rhos_c[0] * D1s[0] if D1s else 0
+            x_t = x_t_ - alpha_t * B_h * (corr_res + rhos_c[-1] * (model_t - ms[-1]))
+        return x_t, model_t
+    tp, ms = [ts[0]], [mfn(x, ts[0])]
+    x, m = update(x, ms, tp, ts[1], 1, True)
+    tp.append(ts[1])
+    ms.append(m)
+    for step in range(2, steps + 1):
+        order = min(2, steps + 1 - step)
+        x, m = update(x, ms, tp, ts[step], order, step != steps)
+        tp = [tp[1], ts[step]]
+        ms = [ms[1], m]
+    return x
+
+
 def sample(sd, c, cond_btH, method, infer_speedup, gt_spec=None, k_step=None, x_T=None, step_noise=None, spec_min=-12., spec_max=2.):
     """GaussianDiffusion.forward(infer=True): returns mel [B,T,M]."""
     S_ = schedule(c["timesteps"])
@@ -205,6 +268,9 @@ def sample(sd, c, cond_btH, method, infer_speedup, gt_spec=None, k_step=None, x_
         elif method in ("dpm-solver", "dpm-solver++"):
             x = dpm_solver_multistep2(lambda xc, t_in: wavenet(sd, c, xc, t_in.expand(b), cond), S_["betas"][:t], x,
                                       steps=t // infer_speedup, plus=(method == "dpm-solver++"))
+        elif method == "unipc":
+            x = unipc_multistep2(lambda xc, t_in: wavenet(sd, c, xc, t_in.expand(b), cond), S_["betas"][:t], x,
+                                 steps=t // infer_speedup)
         else:
             raise NotImplementedError(method)
     else:

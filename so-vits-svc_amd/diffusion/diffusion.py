@@ -2,11 +2,11 @@
 (SURVEY.md §8f row 2).  Same constructor, buffers (`state_dict` keys) and `forward` signature as the reference.
 
 Inference samplers implemented: plain ancestral sampling (`p_sample`, :155-162), DDIM (`p_sample_ddim`, :143-153),
-PNDM/PLMS (`p_sample_plms`, :164-199) and DPM-Solver / DPM-Solver++ in the configuration this file calls them with
+PNDM/PLMS (`p_sample_plms`, :164-199), DPM-Solver / DPM-Solver++ and UniPC in the configuration this file calls them with
 (multistep order 2, :257-303 -> diffusion/dpm_solver_pytorch.py).  Every per-step update is a scalar-coefficient
 combination of [B,1,M,T] tensors: the coefficients come from the host copy of the schedule (all batch items share the
-step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  'unipc' calls into a third-party
-solver library (diffusion/uni_pc.py) that is not mirrored: it raises NotImplementedError.  Training (`infer=False` -> p_losses, :210-243) runs on the autograd ops of
+step index, so no device gather / sync), the arithmetic runs as svc_ew_f32 launches.  UniPC (:339-371 -> diffusion/uni_pc.py,
+variant bh2, multistep order 2) is restated the same way.  Training (`infer=False` -> p_losses, :210-243) runs on the autograd ops of
 svc_autograd.py."""
 from collections import deque
 from functools import partial
@@ -203,6 +203,86 @@ class GaussianDiffusion(nn.Module):
             m_prev = [m_prev[1], model(x, ts[step]) if step < steps else None]
         return x
 
+    # -- UniPC (diffusion/diffusion.py:339-371 -> diffusion/uni_pc.py) ------------------------------------------------------
+    def _sample_unipc(self, x, cond, t, steps):
+        """The one configuration the reference calls (diffusion.py:356-371): UniPC(variant='bh2', data prediction),
+        multistep, order 2, uniform time steps, on NoiseScheduleVP('discrete', betas[:t]) — diffusion/uni_pc.py:70-81,103-135
+        (schedule; unlike the DPM-Solver library no tail clipping), :172-196 (model time), :287-296 (data prediction),
+        :473-590 (the B(h) predictor / corrector) and :592-672 (driver: first step order 1 with corrector, then order-2
+        predictor + corrector, last step order 1 without corrector; the model value kept for a time step is the one evaluated
+        at the PREDICTED state, so every step costs one denoiser call).  The schedule is fp32 scalar arithmetic on the host —
+        evaluated with the same torch CPU ops in the same order as the library does on its 1-element tensors, including
+        torch.linalg.solve for the 2x2 corrector system; every state update is a scalar-coefficient combination of [B,1,M,T]
+        tensors = svc_ew_f32 launches."""
+        if steps < 2:
+            raise ValueError("unipc needs t // infer_speedup >= 2 steps (the library asserts steps >= order)")
+        betas = torch.from_numpy(np.ascontiguousarray(self._host_arr("betas")[:t], dtype=np.float32))
+        log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+        N = log_alphas.shape[0]
+        t_arr = torch.linspace(0., 1., N + 1)[1:]
+
+        def la(tc):                                            # interpolate_fn (:681-721): piecewise linear, extrapolating
+            i = int(torch.searchsorted(t_arr, tc.reshape(1), right=False))
+            i0 = 0 if i == 0 else (N - 2 if i == N else i - 1)
+            return log_alphas[i0] + (tc - t_arr[i0]) * (log_alphas[i0 + 1] - log_alphas[i0]) / (t_arr[i0 + 1] - t_arr[i0])
+        std = lambda tc: torch.sqrt(1. - torch.exp(2. * la(tc)))
+        lam = lambda tc: la(tc) - 0.5 * torch.log(1. - torch.exp(2. * la(tc)))
+        ts = torch.linspace(1., 1. / N, steps + 1)
+        B = x.shape[0]
+
+        def model(xc, tc):                                     # data_prediction_fn: x0 = (x - sigma_t * noise) / alpha_t
+            t_in = torch.full((B,), float((tc - 1. / N) * N), device=xc.device, dtype=torch.float32)
+            noise = self.denoise_fn(xc, t_in, cond=cond)
+            a = torch.exp(la(tc))
+            return _lin(1. / a, xc, -(std(tc) / a), noise)
+
+        def update(xc, ms, tp, tc, order, use_corrector):
+            lam0 = lam(tp[-1])
+            h = lam(tc) - lam0
+            rk = (lam(tp[-2]) - lam0) / h if order == 2 else None
+            rks = torch.tensor([rk, 1.] if order == 2 else [1.])
+            hh = -h
+            h_phi_1 = torch.expm1(hh)
+            h_phi_k = h_phi_1 / hh - 1
+            B_h = torch.expm1(hh)                              # variant 'bh2'
+            R, bvec, factorial_i = [], [], 1
+            for i in range(1, order + 1):
+                R.append(torch.pow(rks, i - 1))
+                bvec.append((h_phi_k * factorial_i / B_h).reshape(1))
+                factorial_i *= (i + 1)
+                h_phi_k = h_phi_k / hh - 1 / factorial_i
+            alpha_t = torch.exp(la(tc))
+            c_x = std(tc) / std(tp[-1])                        # x_t_ = c_x * x + c_m * m0
+            c_m = -(alpha_t * h_phi_1)
+            g = -(alpha_t * B_h)                               # x_t = x_t_ + g * (sum_k rho_k * D1_k)
+            # predictor: order 2 uses rho_p = 0.5 on D1 = (m1 - m0) / rk; order 1 has no correction term
+            if order == 2:
+                kp = g * 0.5 / rk
+                x_t = _lin(1.0, _lin(c_x, xc, c_m - kp, ms[-1]), kp, ms[-2])
+            else:
+                x_t = _lin(c_x, xc, c_m, ms[-1])
+            if not use_corrector:
+                return x_t, None
+            rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(torch.stack(R), torch.cat(bvec))
+            model_t = model(x_t, tc)
+            kc_t = g * rhos_c[-1]                              # on D1_t = model_t - m0
+            if order == 2:
+                kc = g * rhos_c[0] / rk                        # on (m1 - m0)
+                x_c = _lin(1.0, _lin(c_x, xc, c_m - kc - kc_t, ms[-1]), kc, ms[-2])
+            else:
+                x_c = _lin(c_x, xc, c_m - kc_t, ms[-1])
+            return _lin(1.0, x_c, kc_t, model_t), model_t
+
+        tp, ms = [ts[0]], [model(x, ts[0])]
+        x, m = update(x, ms, tp, ts[1], 1, True)
+        tp.append(ts[1])
+        ms.append(m)
+        for step in range(2, steps + 1):
+            x, m = update(x, ms, tp, ts[step], min(2, steps + 1 - step), step != steps)
+            tp = [tp[1], ts[step]]
+            ms = [ms[1], m]
+        return x
+
     def _host_arr(self, name):
         self._h(name, 0)
         return self._host[1][name]
@@ -264,8 +344,7 @@ class GaussianDiffusion(nn.Module):
             if method in ("dpm-solver", "dpm-solver++"):
                 x = self._sample_dpm_solver(x, cond, t, t // infer_speedup, plus=(method == "dpm-solver++"))
             elif method == "unipc":
-                raise NotImplementedError("sampler 'unipc' (third-party solver library diffusion/uni_pc.py) is not mirrored; "
-                                          "use 'dpm-solver', 'dpm-solver++', 'ddim' or 'pndm'")
+                x = self._sample_unipc(x, cond, t, t // infer_speedup)
             elif method == "pndm":
                 self.noise_list = deque(maxlen=4)
                 for i in reversed(range(0, t, infer_speedup)):

@@ -1,4 +1,4 @@
-"""Golden vectors for the DPM-Solver / DPM-Solver++ samplers (the reference's defaults) from the REAL reference modules:
+"""Golden vectors for the DPM-Solver / DPM-Solver++ samplers (the reference's defaults) and UniPC from the REAL reference modules:
 Unit2Mel -> GaussianDiffusion.forward(method='dpm-solver' / 'dpm-solver++') -> diffusion/dpm_solver_pytorch.py.
 Inputs are those of diffusion_small.npz.  usage: python tests/golden/make_golden_diffusion_dpm.py"""
 import json
@@ -15,7 +15,9 @@ sys.path.insert(0, ROOT)
 
 CASES = [("dpm_full", "dpm-solver", 10, False, None), ("dpmpp_full", "dpm-solver++", 10, False, None),
          ("dpm_shallow", "dpm-solver", 5, True, 40), ("dpmpp_shallow", "dpm-solver++", 5, True, 40),
-         ("dpmpp_shallow3", "dpm-solver++", 10, True, 30)]
+         ("dpmpp_shallow3", "dpm-solver++", 10, True, 30),
+         # UniPC (diffusion/diffusion.py:339-371 -> diffusion/uni_pc.py, variant bh2, multistep order 2)
+         ("unipc_full", "unipc", 10, False, None), ("unipc_shallow", "unipc", 5, True, 40), ("unipc_shallow3", "unipc", 10, True, 30)]
 
 
 def main():

@@ -243,6 +243,50 @@ def test_unit2mel_dpm_solver_matches_reference_golden(dev, name, method, speedup
     assert np.abs(mel.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
 
 
+# ---- UniPC (diffusion/diffusion.py:339-371 -> diffusion/uni_pc.py: bh2, multistep order 2) -------------------------------
+UNIPC_CASES = [("unipc_full", "unipc", 10, False, None), ("unipc_shallow", "unipc", 5, True, 40), ("unipc_shallow3", "unipc", 10, True, 30)]
+
+
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", UNIPC_CASES)
+def test_oracle_reproduces_reference_unipc(name, method, speedup, shallow, k_step):
+    test_oracle_reproduces_reference_dpm_solver(name, method, speedup, shallow, k_step)
+
+
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", UNIPC_CASES)
+def test_mirror_unipc_host_schedule_on_cpu(name, method, speedup, shallow, k_step, monkeypatch):
+    """GaussianDiffusion._sample_unipc (host-side schedule, 2x2 corrector solve, predictor / corrector driver) with the two
+    device calls replaced by CPU stand-ins, against the real uni_pc library's output."""
+    import diffusion.diffusion as DD
+    z, meta = _load()
+    zd = np.load(os.path.join(G, "diffusion_dpm_small.npz"))
+    c = DO.small_cfg()
+    sd = DO.make_state_dict(c, meta["seed"])
+    t = lambda k: torch.from_numpy(z[k])
+    cond = DO.condition(sd, c, t("units"), t("f0"), t("volume"), t("spk_id")).transpose(1, 2)
+    monkeypatch.setattr(DD, "_lin", lambda a, x, b, y: float(a) * x + float(b) * y)
+    gd = DD.GaussianDiffusion(lambda x, tt, cond: DO.wavenet(sd, c, x, tt, cond), out_dims=c["out_dims"],
+                              timesteps=c["timesteps"], k_step=c["k_step_max"])
+    with torch.no_grad():
+        if shallow:
+            tt = k_step
+            ns = gd.norm_spec(t("gt")).transpose(1, 2)[:, None, :, :]
+            S_ = DO.schedule(c["timesteps"])
+            x = S_["sqrt_alphas_cumprod"][tt - 1] * ns + S_["sqrt_one_minus_alphas_cumprod"][tt - 1] * t("x_T")
+        else:
+            tt = gd.k_step
+            x = t("x_T")
+        x = gd._sample_unipc(x, cond, tt, tt // speedup)
+        mel = gd.denorm_spec(x.squeeze(1).transpose(1, 2))
+    ref = zd["mel_" + name]
+    assert np.abs(mel.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,method,speedup,shallow,k_step", UNIPC_CASES)
+def test_unit2mel_unipc_matches_reference_golden(dev, name, method, speedup, shallow, k_step):
+    test_unit2mel_dpm_solver_matches_reference_golden(dev, name, method, speedup, shallow, k_step)
+
+
 @pytest.mark.parametrize("igs", [0, 1, 5, 7, 12])
 def test_solver_lr_schedule_matches_torch_steplr(igs):
     """diffusion/solver.py mirror: lr trajectory == train_diff.py:55-60's set-up (lr pre-decayed by the global step, StepLR
