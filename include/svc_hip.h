@@ -445,6 +445,15 @@ int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, con
 int svc_lrelu_tail_fwd_f32(const float* x, float* y, long long rows, int P, int L, float slope, void* stream);
 int svc_lrelu_tail_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int P, int L, float slope,
                            void* stream);
+/* torch.nn.utils.spectral_norm of a conv weight (models.py:170,205 with use_spectral_norm=True; one power iteration):
+ * W [R][K] = weight_orig viewed as [Cout, rest], u [R], v [K] = the module's weight_u / weight_v buffers.  fwd with
+ * power_iteration != 0 (training mode) updates v <- normalize(W^T u), u <- normalize(W v) IN PLACE, then (both modes)
+ * sigma[0] = u . (W v) and w = W / sigma; tmp: R floats of workspace.  bwd (u, v constants, as in torch):
+ * dW = g / sigma - (sum g*W) / sigma^2 * u v^T; dot_ws: one double of workspace. */
+int svc_spectral_norm_fwd_f32(const float* W, float* u, float* v, float* w, float* sigma, float* tmp, int R, int K,
+                              int power_iteration, float eps, void* stream);
+int svc_spectral_norm_bwd_f32(const float* W, const float* u, const float* v, const float* sigma, const float* g, float* dW,
+                              double* dot_ws, int R, int K, void* stream);
 int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream);
 int svc_band_scatter_add_f32(float* M, const float* band, long long n_rows, int T, int window, void* stream);
 /* Embedding lookups in channel-major form, y[b,c,t] = W[idx[b,t], c] (models.py:393,453,136) and the scatter-add of

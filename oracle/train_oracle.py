@@ -51,6 +51,24 @@ def _wn(sd, prefix):
     return v * (g / norm)
 
 
+def _eff_weight(sd, prefix, training=True):
+    """The effective conv weight of a normalised layer: weight_norm (models.py default) or, when the state dict holds
+    `weight_orig`, torch.nn.utils.spectral_norm's compute_weight — one power iteration per call in training mode that UPDATES
+    sd[prefix.weight_u / weight_v] (the module's buffers are updated in place), sigma = u . (W v), w = W / sigma with the
+    gradient flowing through sigma at constant u, v."""
+    if prefix + ".weight_orig" not in sd:
+        return _wn(sd, prefix)
+    W, u, v = sd[prefix + ".weight_orig"], sd[prefix + ".weight_u"], sd[prefix + ".weight_v"]
+    Wm = W.reshape(W.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(Wm.t(), u), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(Wm, v), dim=0, eps=1e-12)
+        sd[prefix + ".weight_u"], sd[prefix + ".weight_v"] = u, v
+    sigma = torch.dot(u, torch.mv(Wm, v))
+    return W / sigma
+
+
 def disc_p(x, sd, prefix, period):
     fmap = []
     b, c, t = x.shape
@@ -60,10 +78,10 @@ def disc_p(x, sd, prefix, period):
         t = t + n_pad
     x = x.view(b, c, t // period, period)
     for i, s in enumerate([3, 3, 3, 3, 1]):
-        x = F.conv2d(x, _wn(sd, f"{prefix}.convs.{i}"), sd[f"{prefix}.convs.{i}.bias"], (s, 1), (2, 0))
+        x = F.conv2d(x, _eff_weight(sd, f"{prefix}.convs.{i}"), sd[f"{prefix}.convs.{i}.bias"], (s, 1), (2, 0))
         x = F.leaky_relu(x, LRELU_SLOPE)
         fmap.append(x)
-    x = F.conv2d(x, _wn(sd, prefix + ".conv_post"), sd[prefix + ".conv_post.bias"], 1, (1, 0))
+    x = F.conv2d(x, _eff_weight(sd, prefix + ".conv_post"), sd[prefix + ".conv_post.bias"], 1, (1, 0))
     fmap.append(x)
     return torch.flatten(x, 1, -1), fmap
 
@@ -72,10 +90,10 @@ def disc_s(x, sd, prefix):
     fmap = []
     cfgs = [(1, 7, 1), (4, 20, 4), (4, 20, 16), (4, 20, 64), (4, 20, 256), (1, 2, 1)]
     for i, (s, p, g) in enumerate(cfgs):
-        x = F.conv1d(x, _wn(sd, f"{prefix}.convs.{i}"), sd[f"{prefix}.convs.{i}.bias"], s, p, 1, g)
+        x = F.conv1d(x, _eff_weight(sd, f"{prefix}.convs.{i}"), sd[f"{prefix}.convs.{i}.bias"], s, p, 1, g)
         x = F.leaky_relu(x, LRELU_SLOPE)
         fmap.append(x)
-    x = F.conv1d(x, _wn(sd, prefix + ".conv_post"), sd[prefix + ".conv_post.bias"], 1, 1)
+    x = F.conv1d(x, _eff_weight(sd, prefix + ".conv_post"), sd[prefix + ".conv_post.bias"], 1, 1)
     fmap.append(x)
     return torch.flatten(x, 1, -1), fmap
 

@@ -497,6 +497,102 @@ __global__ void lrelu_tail_bwd_kernel(const float4* __restrict__ y, const float4
   }
 }
 
+// ---- spectral norm (torch.nn.utils.spectral_norm, one power iteration; models.py:170,205 with use_spectral_norm=True) --------
+// W [R][K] (weight_orig viewed as [Cout, rest]), u [R], v [K].  Training: v <- normalize(W^T u), u <- normalize(W v) IN PLACE
+// (the buffers of the module), then sigma = u . (W v) and w = W / sigma.  Eval: sigma from the stored u, v.
+// Backward (u, v constants): dW = g / sigma - (sum g*W) / sigma^2 * u v^T.
+__global__ void sn_matvec_t_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ out, int R,
+                                   int K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  double acc = 0.0;
+  for (int r = 0; r < R; ++r) acc += (double)W[(long long)r * K + j] * (double)u[r];
+  out[j] = (float)acc;
+}
+__global__ void sn_matvec_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ out, int K) {
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) acc += (double)W[(long long)r * K + j] * (double)v[j];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] = (float)sh[0];
+}
+// single block: x <- x / max(||x||, eps)   (F.normalize(x, dim=0, eps))
+__global__ void sn_normalize_kernel(float* __restrict__ x, int n, float eps) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)x[i] * (double)x[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float nr = fmaxf((float)sqrt(sh[0]), eps);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = x[i] / nr;
+}
+// single block: u <- normalize(wv) when `update`, sigma = sum u[r] * wv[r]
+__global__ void sn_sigma_kernel(float* __restrict__ u, const float* __restrict__ wv, float* __restrict__ sigma, int R, float eps,
+                                int update) {
+  __shared__ double sh[256];
+  if (update) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) acc += (double)wv[i] * (double)wv[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float nr = fmaxf((float)sqrt(sh[0]), eps);
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += blockDim.x) u[i] = wv[i] / nr;
+    __syncthreads();
+  }
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < R; i += blockDim.x) acc += (double)u[i] * (double)wv[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sigma[0] = (float)sh[0];
+}
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ sigma, float* __restrict__ w, long long n) {
+  const float s = sigma[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) w[i] = W[i] / s;
+}
+__global__ void sn_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ out, long long n) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc += (double)a[i] * (double)b[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
+__global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
+                              const float* __restrict__ sigma, const double* __restrict__ dot, float* __restrict__ dW, int R,
+                              int K) {
+  const double s = sigma[0];
+  const double c = dot[0] / (s * s);
+  const long long n = (long long)R * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), j = (int)(i - (long long)r * K);
+    dW[i] = (float)((double)g[i] / s - c * (double)u[r] * (double)v[j]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -579,6 +675,37 @@ int svc_lrelu_tail_bwd_f32(const float* y, const float* dy, float* dx, long long
                      (hipStream_t)stream, reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dy),
                      reinterpret_cast<float4*>(dx), n4, P / 4, L, slope);
   return svc::check_launch("lrelu_tail_bwd");
+}
+
+int svc_spectral_norm_fwd_f32(const float* W, float* u, float* v, float* w, float* sigma, float* tmp, int R, int K,
+                              int power_iteration, float eps, void* stream) {
+  SVC_REQUIRE(W && u && v && w && sigma && tmp && R > 0 && K > 0, "spectral_norm_fwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (power_iteration) {
+    hipLaunchKernelGGL(sn_matvec_t_kernel, dim3(svc::cdiv(K, 256)), dim3(256), 0, s, W, u, v, R, K);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, s, v, K, eps);
+  }
+  hipLaunchKernelGGL(sn_matvec_kernel, dim3(R), dim3(256), 0, s, W, v, tmp, K);
+  hipLaunchKernelGGL(sn_sigma_kernel, dim3(1), dim3(256), 0, s, u, tmp, sigma, R, eps, power_iteration ? 1 : 0);
+  const long long n = (long long)R * K;
+  hipLaunchKernelGGL(sn_scale_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, W, sigma, w, n);
+  return svc::check_launch("spectral_norm_fwd");
+}
+
+int svc_spectral_norm_bwd_f32(const float* W, const float* u, const float* v, const float* sigma, const float* g, float* dW,
+                              double* dot_ws, int R, int K, void* stream) {
+  SVC_REQUIRE(W && u && v && sigma && g && dW && dot_ws && R > 0 && K > 0, "spectral_norm_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dot_ws, 0, sizeof(double), s) != hipSuccess) {
+    svc::set_error("spectral_norm_bwd: memset failed");
+    return SVC_ERR_HIP;
+  }
+  const long long n = (long long)R * K;
+  const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(sn_dot_kernel, dim3(grid), dim3(256), 0, s, g, W, dot_ws, n);
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, g, u, v, sigma,
+                     dot_ws, dW, R, K);
+  return svc::check_launch("spectral_norm_bwd");
 }
 
 }  // extern "C"

@@ -5,8 +5,7 @@ constructor signatures, attribute names and state_dict layout (751 keys for the 
 `SynthesizerTrn.infer` (reference models.py:496-532, incl. automatic f0 prediction, optional hipGraph replay of the whole
 path) runs the fused inference kernels; `SynthesizerTrn.forward` (:463-493), `Encoder` (enc_q) and the
 MultiPeriodDiscriminator run the training graph on svc_autograd Functions (HIP forward + HIP backward), dropout included.
-`use_transformer_flow` (TransformerCouplingBlock) included.  Not built (raise NotImplementedError): spectral-norm
-discriminators.
+`use_transformer_flow` (TransformerCouplingBlock) and `use_spectral_norm` discriminators included.
 """
 import math
 import os
@@ -472,6 +471,29 @@ class SynthesizerTrn(nn.Module):
 _DISCP_PAD_ROWS = os.environ.get("SVC_DISCP_PAD", "1") != "0"
 
 
+class _SpecConv(nn.Module):
+    """spectral_norm(Conv1d / Conv2d((k,1))) parameter holder (`use_spectral_norm=True`, models.py:170,205): `weight_orig`,
+    `bias` and the `weight_u` / `weight_v` buffers under torch.nn.utils.spectral_norm's names and shapes."""
+
+    def __init__(self, cin, cout, k, stride, padding, groups=1, conv2d=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding, self.groups, self.conv2d = cin, cout, k, stride, padding, groups, conv2d
+        shape = (cout, cin // groups, k, 1) if conv2d else (cout, cin // groups, k)
+        w = torch.empty(*shape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1 / math.sqrt((cin // groups) * k)
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self.weight_orig = nn.Parameter(w)
+        self.register_buffer("weight_u", torch.nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", torch.nn.functional.normalize(torch.randn((cin // groups) * k), dim=0, eps=1e-12))
+
+    def forward(self, x, inner=1, lp=None, out_blocks=None):
+        # one power iteration per forward call in training mode, in place on the buffers (torch's forward pre-hook)
+        w = A.spectral_norm(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        w = w.view(self.cout, self.cin // self.groups, self.k)
+        return A.conv1d(x, w, self.bias, self.stride, self.padding, 1, self.groups, inner=inner, lp=lp, out_blocks=out_blocks)
+
+
 class _NormConv(nn.Module):
     """weight_norm(Conv1d / Conv2d((k,1))) parameter holder of the discriminators; `weight_v` keeps the REFERENCE shape
     ([Cout,Cin,K] for Conv1d, [Cout,Cin,K,1] for Conv2d) so checkpoints (D_*.pth) load key-for-key."""
@@ -537,15 +559,14 @@ class DiscriminatorP(nn.Module):
 
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
         super().__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("spectral_norm discriminators are not used by so-vits-svc configs")
         self.period = period
         self.use_spectral_norm = use_spectral_norm
+        conv = _SpecConv if use_spectral_norm else _NormConv
         pad = commons.get_padding(kernel_size, 1)
         chans = [(1, 32), (32, 128), (128, 512), (512, 1024)]
-        self.convs = nn.ModuleList([_NormConv(a, b, kernel_size, stride, pad, conv2d=True) for a, b in chans] +
-                                   [_NormConv(1024, 1024, kernel_size, 1, pad, conv2d=True)])
-        self.conv_post = _NormConv(1024, 1, 3, 1, 1, conv2d=True)
+        self.convs = nn.ModuleList([conv(a, b, kernel_size, stride, pad, conv2d=True) for a, b in chans] +
+                                   [conv(1024, 1024, kernel_size, 1, pad, conv2d=True)])
+        self.conv_post = conv(1024, 1, 3, 1, 1, conv2d=True)
 
     def forward(self, x):
         b, c, t = x.shape
@@ -577,13 +598,12 @@ class DiscriminatorS(nn.Module):
 
     def __init__(self, use_spectral_norm=False):
         super().__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("spectral_norm discriminators are not used by so-vits-svc configs")
+        conv = _SpecConv if use_spectral_norm else _NormConv
         self.convs = nn.ModuleList([
-            _NormConv(1, 16, 15, 1, 7), _NormConv(16, 64, 41, 4, 20, groups=4), _NormConv(64, 256, 41, 4, 20, groups=16),
-            _NormConv(256, 1024, 41, 4, 20, groups=64), _NormConv(1024, 1024, 41, 4, 20, groups=256),
-            _NormConv(1024, 1024, 5, 1, 2)])
-        self.conv_post = _NormConv(1024, 1, 3, 1, 1)
+            conv(1, 16, 15, 1, 7), conv(16, 64, 41, 4, 20, groups=4), conv(64, 256, 41, 4, 20, groups=16),
+            conv(256, 1024, 41, 4, 20, groups=64), conv(1024, 1024, 41, 4, 20, groups=256),
+            conv(1024, 1024, 5, 1, 2)])
+        self.conv_post = conv(1024, 1, 3, 1, 1)
 
     def forward(self, x):
         fmap = []
@@ -601,11 +621,24 @@ class MultiPeriodDiscriminator(nn.Module):
     def __init__(self, use_spectral_norm=False):
         super().__init__()
         periods = [2, 3, 5, 7, 11]
+        self.use_spectral_norm = use_spectral_norm
         self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm=use_spectral_norm)] +
                                             [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods])
 
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        if self.use_spectral_norm:
+            # every forward call of a spectrally normalised layer runs a power iteration on its u / v buffers: the reference
+            # calls each discriminator on y and then on y_hat (models.py:246-247), i.e. TWO iterations per layer, the second
+            # pass seeing the vectors the first one left — one batched pass would not reproduce that
+            for d in self.discriminators:
+                out_r, fmap_r = d(y)
+                out_g, fmap_g = d(y_hat)
+                y_d_rs.append(out_r)
+                y_d_gs.append(out_g)
+                fmap_rs.append(fmap_r)
+                fmap_gs.append(fmap_g)
+            return y_d_rs, y_d_gs, fmap_rs, fmap_gs
         n = y.shape[0]
         yy = torch.cat([y, y_hat], 0)      # one pass over both signals (same weights): halves the launches
         # (tried: one HIP stream per sub-discriminator — forward and, through autograd's stream bookkeeping, backward launches

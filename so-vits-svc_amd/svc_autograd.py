@@ -379,6 +379,28 @@ def packed_add_item(p, side, B, T, gap):
 # ---------------------------------------------------------------------------------------------------------------
 # functional API
 # ---------------------------------------------------------------------------------------------------------------
+class _SpectralNorm(Function):
+    """torch.nn.utils.spectral_norm's compute_weight (one power iteration in training mode, in place on the u / v buffers;
+    gradient through sigma with u, v held constant)."""
+
+    @staticmethod
+    def forward(ctx, W, u, v, power_iteration, eps):
+        Wd = W.detach()
+        w, sigma = S.spectral_norm_fwd(Wd, u, v, power_iteration, eps)
+        # torch clones u, v after the iteration so that the tensors saved for backward survive the next in-place update
+        ctx.save_for_backward(W, u.clone(), v.clone(), sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        W, u, v, sigma = ctx.saved_tensors
+        return S.spectral_norm_bwd(W.detach(), u, v, sigma, g), None, None, None, None
+
+
+def spectral_norm(weight_orig, u, v, training, eps=1e-12):
+    return _SpectralNorm.apply(weight_orig, u, v, bool(training), eps)
+
+
 def weight_norm(v, g):
     return _WeightNorm.apply(v, g)
 

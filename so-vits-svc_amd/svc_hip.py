@@ -1061,7 +1061,7 @@ TRAIN_EXPORTS2 = [
     "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",
     "svc_nsf_source_train_f32", "svc_nsf_linear_fwd_f32", "svc_nsf_linear_bwd_f32", "svc_kl_fwd_f64", "svc_kl_bwd_f32",
     "svc_stft_frame_f32", "svc_stft_frame_bwd_f32", "svc_dft_basis_f32", "svc_cmag_f32", "svc_cmag_bwd_f32",
-    "svc_lrelu_tail_fwd_f32", "svc_lrelu_tail_bwd_f32",
+    "svc_lrelu_tail_fwd_f32", "svc_lrelu_tail_bwd_f32", "svc_spectral_norm_fwd_f32", "svc_spectral_norm_bwd_f32",
 ]
 EXPORTS += TRAIN_EXPORTS2
 _train2_bound = False
@@ -1078,6 +1078,8 @@ def t2lib():
         L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, _f32p, i, vp]
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_lrelu_tail_fwd_f32.argtypes = [_f32p, _f32p, ll, i, i, f, vp]
+        L.svc_spectral_norm_fwd_f32.argtypes = [_f32p] * 6 + [i, i, i, f, vp]
+        L.svc_spectral_norm_bwd_f32.argtypes = [_f32p] * 6 + [vp, i, i, vp]
         L.svc_lrelu_tail_bwd_f32.argtypes = [_f32p, _f32p, _f32p, ll, i, i, f, vp]
         L.svc_band_scatter_add_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_embed_fwd_f32.argtypes = [vp, _f32p, _f32p, i, i, i, vp]
@@ -1134,6 +1136,35 @@ def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0, mask=None, mask_mo
     check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), ptr(mask), mask_mode,
                                            stream_ptr()), "attn_softmax_bwd")
     return dP
+
+
+def spectral_norm_fwd(W, u, v, power_iteration, eps=1e-12):
+    """-> (w = W / sigma, sigma [1]); with power_iteration the buffers u, v are updated in place first (one iteration)."""
+    require_gpu(W, u, v)
+    if not (W.is_contiguous() and u.is_contiguous() and v.is_contiguous()):
+        raise SvcError("spectral_norm: weight_orig / weight_u / weight_v must be contiguous")
+    R = W.shape[0]
+    K = W.numel() // R
+    if u.numel() != R or v.numel() != K:
+        raise SvcError(f"spectral_norm: u [{u.numel()}] / v [{v.numel()}] do not match the [{R}, {K}] weight matrix")
+    w = torch.empty_like(W)
+    sigma = torch.empty(1, device=W.device, dtype=torch.float32)
+    tmp = torch.empty(R, device=W.device, dtype=torch.float32)
+    check(t2lib().svc_spectral_norm_fwd_f32(ptr(W), ptr(u), ptr(v), ptr(w), ptr(sigma), ptr(tmp), R, K,
+                                            1 if power_iteration else 0, float(eps), stream_ptr()), "spectral_norm_fwd")
+    return w, sigma
+
+
+def spectral_norm_bwd(W, u, v, sigma, g):
+    require_gpu(W, u, v, sigma, g)
+    R = W.shape[0]
+    K = W.numel() // R
+    g = g.contiguous()
+    dW = torch.empty_like(W)
+    ws = torch.empty(1, device=W.device, dtype=torch.float64)
+    check(t2lib().svc_spectral_norm_bwd_f32(ptr(W), ptr(u), ptr(v), ptr(sigma), ptr(g), ptr(dW), C.c_void_p(ws.data_ptr()), R, K,
+                                            stream_ptr()), "spectral_norm_bwd")
+    return dW
 
 
 def _tail_rows(x):

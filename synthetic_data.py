@@ -323,6 +323,25 @@ def make_mpd_state_dict(seed=4321):
     return sd
 
 
+def make_mpd_sn_state_dict(seed=4321):
+    """MultiPeriodDiscriminator(use_spectral_norm=True): torch.nn.utils.spectral_norm's keys — weight_orig (the weight_v tensor
+    of make_mpd_state_dict), bias, and unit-norm weight_u [Cout] / weight_v [rest] buffers."""
+    base = make_mpd_state_dict(seed)
+    sd = {}
+    for name, t in base.items():
+        if name.endswith(".bias"):
+            sd[name] = t
+        elif name.endswith(".weight_v"):
+            pre = name[:-len(".weight_v")]
+            sd[pre + ".weight_orig"] = t
+            gen = _gen("mpd_sn." + pre, seed)
+            u = torch.randn(t.shape[0], generator=gen)
+            v = torch.randn(t.numel() // t.shape[0], generator=gen)
+            sd[pre + ".weight_u"] = u / u.norm()
+            sd[pre + ".weight_v"] = v / v.norm()
+    return sd
+
+
 def train_config():
     """small_config with dropout off (so the training graph is deterministic given the injected noise)."""
     c = small_config()
