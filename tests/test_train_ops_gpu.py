@@ -354,3 +354,14 @@ def test_conv_transpose1d_module_weight_plan(dev, Cin, Cout, K, u, pad, wn, T):
         _close(xh.grad, xr.grad, 2e-5, "grad x")
         for k, p in m.named_parameters():
             _close(p.grad, ps[k].grad, 5e-5, f"grad {k} (pass {it})")
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 192, 100), (16, 192, 768), (1, 7, 1), (3, 33, 65), (2, 768, 130)])
+def test_channel_layer_norm_fwd_bwd(dev, B, C, T):
+    """svc_layernorm_{fwd,bwd}_f32 (modules.LayerNorm, modules/modules.py:23-35: LN over the channel dim of [B,C,T]) against
+    torch's layer_norm on the transposed tensor: output and the gradients of x, gamma, beta."""
+    import svc_autograd as A
+    torch.manual_seed(21)
+    t = dict(x=_p(B, C, T), gamma=(1.0 + 0.1 * torch.randn(C)).requires_grad_(True), beta=_p(C, scale=0.1))
+    _run_pair(lambda x, gamma, beta: A.layer_norm(x, gamma, beta, 1e-5),
+              lambda x, gamma, beta: F.layer_norm(x.transpose(1, 2), (C,), gamma, beta, 1e-5).transpose(1, 2), t, dev, tol=3e-5)
