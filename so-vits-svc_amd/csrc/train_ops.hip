@@ -354,6 +354,161 @@ __global__ void gconv_wgrad_kernel(const float* __restrict__ dy, const float* __
   if (threadIdx.x == 0) dw[((long long)co * Cg + cl) * KS + k] = (float)s;
 }
 
+// ---- grouped strided Conv1d, LDS-tiled (v2) --------------------------------------------------------------------------
+// The first versions above run one thread per output with one global load per FMA (and, for the weight gradient, one
+// workgroup per weight element that re-reads its whole dy / x rows): 315 / 233 / 691 us per launch on DiscriminatorS'
+// layers, 8.5 ms of a B=16 training iteration for 0.03 TFLOP (profiles/r02_w_train_B16_kernel_stats_final_build.txt).
+// v2 stages the operands of ONE group in LDS and lets every thread produce all Og outputs (forward), all Cg inputs (dgrad)
+// or KPT taps of one (o, cl) pair (wgrad) from them: Og (resp. Cg, ~1) FMAs per LDS read, weights read as LDS broadcasts.
+// Index maths validated against torch by a numpy emulation before the HIP transcription (round 2, no GPU minute left for
+// iteration): staging maps and loops below follow it line by line.
+int g_gconv_version = 2;
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+constexpr int GC_TT = 256;      // outputs (fwd) / inputs (dgrad) per workgroup
+template <int OG>
+__global__ __launch_bounds__(GC_TT) void gconv_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                           int Cout, int Tin, int Tout, int KS, int stride, int pad, int Cg,
+                                                           int Qn) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* ws = gsm;                               // [Cg*KS][OG]
+  float* xs = gsm + Cg * KS * OG;                // [Cg][stride][Qn]: input position pp = q*stride + r at [r][q]
+  const int tid = threadIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * GC_TT, p0 = t0 * stride - pad;
+  const int NP = (GC_TT - 1) * stride + KS;
+  for (int idx = tid; idx < Cg * NP; idx += GC_TT) {
+    const int cl = idx / NP, pp = idx - cl * NP;
+    const int ti = p0 + pp;
+    const float v = (ti >= 0 && ti < Tin) ? x[((long long)b * Cin + g * Cg + cl) * Tin + ti] : 0.f;
+    const int q = pp / stride, r = pp - q * stride;
+    xs[(cl * stride + r) * Qn + q] = v;
+  }
+  const int nw = Cg * KS;
+  for (int idx = tid; idx < nw * OG; idx += GC_TT) {
+    const int j = idx / OG, o = idx - j * OG;
+    ws[idx] = w[(long long)(g * OG + o) * nw + j];
+  }
+  __syncthreads();
+  float acc[OG];
+#pragma unroll
+  for (int o = 0; o < OG; ++o) acc[o] = bias ? bias[g * OG + o] : 0.f;
+  for (int cl = 0; cl < Cg; ++cl)
+    for (int r = 0; r < stride; ++r) {
+      const float* xr = xs + (cl * stride + r) * Qn + tid;
+      for (int q = 0, k = r; k < KS; ++q, k += stride) {
+        const float xv = xr[q];
+        const float4* w4 = reinterpret_cast<const float4*>(ws + (cl * KS + k) * OG);
+#pragma unroll
+        for (int o4 = 0; o4 < OG / 4; ++o4) {
+          const float4 wv = w4[o4];
+          acc[4 * o4 + 0] = fmaf(wv.x, xv, acc[4 * o4 + 0]);
+          acc[4 * o4 + 1] = fmaf(wv.y, xv, acc[4 * o4 + 1]);
+          acc[4 * o4 + 2] = fmaf(wv.z, xv, acc[4 * o4 + 2]);
+          acc[4 * o4 + 3] = fmaf(wv.w, xv, acc[4 * o4 + 3]);
+        }
+      }
+    }
+  const int t = t0 + tid;
+  if (t < Tout) {
+#pragma unroll
+    for (int o = 0; o < OG; ++o) y[((long long)b * Cout + g * OG + o) * Tout + t] = acc[o];
+  }
+}
+
+template <int OG, int CG>
+__global__ __launch_bounds__(GC_TT) void gconv_dgrad2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int Cin, int Cout, int Tin, int Tout,
+                                                             int KS, int stride, int pad, int Qd) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* ws = gsm;                               // [OG][CG][KS]
+  float* ds = gsm + OG * CG * KS;                // [OG][Qd]: dy at t = tlo + q
+  const int tid = threadIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int ti0 = blockIdx.x * GC_TT;
+  const int tlo = floor_div(ti0 + pad - (KS - 1), stride);
+  for (int idx = tid; idx < OG * Qd; idx += GC_TT) {
+    const int o = idx / Qd, q = idx - o * Qd;
+    const int t = tlo + q;
+    ds[idx] = (t >= 0 && t < Tout) ? dy[((long long)b * Cout + g * OG + o) * Tout + t] : 0.f;
+  }
+  for (int idx = tid; idx < OG * CG * KS; idx += GC_TT) ws[idx] = w[(long long)g * OG * CG * KS + idx];
+  __syncthreads();
+  const int ti = ti0 + tid;
+  const int kf = (ti + pad) % stride, tf = (ti + pad - kf) / stride;     // tap k = kf + j*stride reaches output t = tf - j
+  float acc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+  for (int o = 0; o < OG; ++o) {
+    const float* dr = ds + o * Qd + (tf - tlo);
+    const float* wr = ws + o * CG * KS;
+    for (int j = 0, k = kf; k < KS; ++j, k += stride) {
+      const float dv = dr[-j];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = fmaf(wr[c * KS + k], dv, acc[c]);
+    }
+  }
+  if (ti < Tin) {
+#pragma unroll
+    for (int c = 0; c < CG; ++c) dx[((long long)b * Cin + g * CG + c) * Tin + ti] = acc[c];
+  }
+}
+
+constexpr int GW_TT = 64;       // output time steps per staged tile
+constexpr int GW_KPT = 11;      // taps per thread
+constexpr int GW_PD = GW_TT + 1;
+template <int OG, int CG>
+__global__ __launch_bounds__(256) void gconv_wgrad2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dw, int B, int Cin, int Cout, int Tin, int Tout,
+                                                           int KS, int stride, int pad, int n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* ds = gsm;                               // [OG][GW_PD]
+  const int XW = (GW_TT - 1) * stride + KS;
+  float* xs = gsm + OG * GW_PD;                  // [CG][XW]
+  const int tid = threadIdx.x, g = blockIdx.y;
+  const int NKQ = (KS + GW_KPT - 1) / GW_KPT;
+  const bool worker = tid < OG * CG * NKQ;
+  const int pair = tid / NKQ, kq = tid - pair * NKQ;
+  const int o = worker ? pair / CG : 0, cl = worker ? pair - (pair / CG) * CG : 0;
+  const int kbase = kq * GW_KPT;
+  float acc[GW_KPT];
+#pragma unroll
+  for (int i = 0; i < GW_KPT; ++i) acc[i] = 0.f;
+  const int n_t = (Tout + GW_TT - 1) / GW_TT;
+  const int total = B * n_t;
+  for (int tile = blockIdx.x; tile < total; tile += n_chunks) {
+    const int b = tile / n_t, t0 = (tile - b * n_t) * GW_TT;
+    const int p0 = t0 * stride - pad;
+    __syncthreads();                             // previous tile consumed
+    for (int idx = tid; idx < OG * GW_TT; idx += 256) {
+      const int oo = idx / GW_TT, tl = idx - oo * GW_TT;
+      const int t = t0 + tl;
+      ds[oo * GW_PD + tl] = t < Tout ? dy[((long long)b * Cout + g * OG + oo) * Tout + t] : 0.f;
+    }
+    for (int idx = tid; idx < CG * XW; idx += 256) {
+      const int cc = idx / XW, pp = idx - cc * XW;
+      const int ti = p0 + pp;
+      xs[idx] = (ti >= 0 && ti < Tin) ? x[((long long)b * Cin + g * CG + cc) * Tin + ti] : 0.f;
+    }
+    __syncthreads();
+    if (worker) {
+      const float* dr = ds + o * GW_PD;
+      const float* xr = xs + cl * XW + kbase;
+      for (int tl = 0; tl < GW_TT; ++tl) {
+        const float dv = dr[tl];
+        const float* xp = xr + tl * stride;
+#pragma unroll
+        for (int i = 0; i < GW_KPT; ++i)
+          if (kbase + i < KS) acc[i] = fmaf(dv, xp[i], acc[i]);
+      }
+    }
+  }
+  if (worker) {
+#pragma unroll
+    for (int i = 0; i < GW_KPT; ++i)
+      if (kbase + i < KS) atomicAdd(dw + ((long long)(g * OG + o) * CG + cl) * KS + kbase + i, acc[i]);
+  }
+}
+
 // ---- scalar reductions for the losses (modules/losses.py:4-58, train.py:202,206) --------------------------------
 // out += scale * sum_i f(a_i, b_i [, c_i, d_i])   accumulated in double per block, atomically added (double)
 __global__ void reduce_scalar_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
@@ -535,9 +690,29 @@ int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s,
   return svc::check_launch("decimate_bwd");
 }
 
+int svc_debug_set_gconv_version(int version) {
+  if (version != 1 && version != 2) return SVC_ERR_BAD_ARG;
+  g_gconv_version = version;
+  return SVC_OK;
+}
+
 int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Tin,
                         int Tout, int KS, int stride, int pad, int groups, void* stream) {
   SVC_REQUIRE(x && w && y && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_fwd: bad args");
+  const int Cg = Cin / groups, Og = Cout / groups;
+  int Qn = GC_TT + (KS - 1) / stride + 1;
+  Qn |= 1;
+  const size_t lds = sizeof(float) * ((size_t)Cg * KS * Og + (size_t)Cg * stride * Qn);
+  if (g_gconv_version == 2 && (Og == 4 || Og == 16) && lds <= 60 * 1024 && stride >= 1) {
+    const dim3 grid(svc::cdiv(Tout, GC_TT), groups, B);
+    if (Og == 16)
+      hipLaunchKernelGGL(gconv_fwd2_kernel<16>, grid, dim3(GC_TT), lds, (hipStream_t)stream, x, w, bias, y, Cin, Cout, Tin, Tout,
+                         KS, stride, pad, Cg, Qn);
+    else
+      hipLaunchKernelGGL(gconv_fwd2_kernel<4>, grid, dim3(GC_TT), lds, (hipStream_t)stream, x, w, bias, y, Cin, Cout, Tin, Tout,
+                         KS, stride, pad, Cg, Qn);
+    return svc::check_launch("gconv_fwd2");
+  }
   hipLaunchKernelGGL(gconv_fwd_kernel, dim3(svc::cdiv(Tout, 64), Cout, B), dim3(64), 0, (hipStream_t)stream, x, w, bias, y,
                      Cin, Cout, Tin, Tout, KS, stride, pad, groups);
   return svc::check_launch("gconv_fwd");
@@ -546,6 +721,19 @@ int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float
 int svc_gconv1d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int Tin, int Tout, int KS,
                           int stride, int pad, int groups, void* stream) {
   SVC_REQUIRE(dy && w && dx && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_dgrad: bad args");
+  const int Cg = Cin / groups, Og = Cout / groups;
+  const int Qd = (GC_TT + KS - 2) / stride + 2;
+  const size_t lds = sizeof(float) * ((size_t)Og * Cg * KS + (size_t)Og * Qd);
+  if (g_gconv_version == 2 && (Og == 4 || Og == 16) && Cg == 4 && lds <= 60 * 1024) {
+    const dim3 grid(svc::cdiv(Tin, GC_TT), groups, B);
+    if (Og == 16)
+      hipLaunchKernelGGL((gconv_dgrad2_kernel<16, 4>), grid, dim3(GC_TT), lds, (hipStream_t)stream, dy, w, dx, Cin, Cout, Tin, Tout,
+                         KS, stride, pad, Qd);
+    else
+      hipLaunchKernelGGL((gconv_dgrad2_kernel<4, 4>), grid, dim3(GC_TT), lds, (hipStream_t)stream, dy, w, dx, Cin, Cout, Tin, Tout,
+                         KS, stride, pad, Qd);
+    return svc::check_launch("gconv_dgrad2");
+  }
   hipLaunchKernelGGL(gconv_dgrad_kernel, dim3(svc::cdiv(Tin, 64), Cin, B), dim3(64), 0, (hipStream_t)stream, dy, w, dx, Cin,
                      Cout, Tin, Tout, KS, stride, pad, groups);
   return svc::check_launch("gconv_dgrad");
@@ -554,6 +742,25 @@ int svc_gconv1d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int
 int svc_gconv1d_wgrad_f32(const float* dy, const float* x, float* dw, int B, int Cin, int Cout, int Tin, int Tout, int KS,
                           int stride, int pad, int groups, void* stream) {
   SVC_REQUIRE(dy && x && dw && groups >= 1 && Cin % groups == 0 && Cout % groups == 0, "gconv_wgrad: bad args");
+  const int Cg = Cin / groups, Og = Cout / groups;
+  const int NKQ = (KS + GW_KPT - 1) / GW_KPT;
+  const size_t lds = sizeof(float) * ((size_t)Og * GW_PD + (size_t)Cg * ((GW_TT - 1) * stride + KS));
+  if (g_gconv_version == 2 && (Og == 4 || Og == 16) && Cg == 4 && Og * Cg * NKQ <= 256 && lds <= 60 * 1024) {
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cg * KS, (hipStream_t)stream) != hipSuccess) {
+      svc::set_error("gconv_wgrad: memset failed");
+      return SVC_ERR_HIP;
+    }
+    const int total = B * svc::cdiv(Tout, GW_TT);
+    const int n_chunks = std::max(1, std::min(total, 1024 / groups));
+    const dim3 grid(n_chunks, groups);
+    if (Og == 16)
+      hipLaunchKernelGGL((gconv_wgrad2_kernel<16, 4>), grid, dim3(256), lds, (hipStream_t)stream, dy, x, dw, B, Cin, Cout, Tin,
+                         Tout, KS, stride, pad, n_chunks);
+    else
+      hipLaunchKernelGGL((gconv_wgrad2_kernel<4, 4>), grid, dim3(256), lds, (hipStream_t)stream, dy, x, dw, B, Cin, Cout, Tin,
+                         Tout, KS, stride, pad, n_chunks);
+    return svc::check_launch("gconv_wgrad2");
+  }
   hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(KS, Cin / groups, Cout), dim3(64), 0, (hipStream_t)stream, dy, x, dw, B, Cin,
                      Cout, Tin, Tout, KS, stride, pad, groups);
   return svc::check_launch("gconv_wgrad");

@@ -69,7 +69,8 @@ def test_conv_transpose1d_fwd_bwd(dev, B, Cin, Cout, T, K, u, pad):
               lambda x, w, bias: F.conv_transpose1d(x, w, bias, u, pad), t, dev)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,T,groups", [(2, 16, 64, 2048, 4), (2, 64, 256, 512, 16), (1, 1024, 1024, 32, 256)])
+@pytest.mark.parametrize("B,Cin,Cout,T,groups", [(2, 16, 64, 2048, 4), (2, 64, 256, 512, 16), (1, 1024, 1024, 32, 256),
+                                                (3, 16, 64, 1001, 4), (2, 256, 1024, 130, 64), (1, 24, 24, 77, 3)])
 def test_grouped_conv_fwd_bwd(dev, B, Cin, Cout, T, groups):
     import svc_autograd as A
     torch.manual_seed(4)
