@@ -9,7 +9,7 @@ What is re-designed rather than mirrored:
     without a tape,
   * no `.item()` host syncs inside the step: the losses come back as device scalars.
 Out of scope here (SURVEY §8f "next"): DataLoader / on-disk formats, TensorBoard, evaluation audio, checkpoint rotation.
-fp16/bf16 autocast (`fp16_run`) is not implemented — the engine computes in fp32 like the reference's default config.
+`fp16_run` configs are accepted but computed in fp32 (no reduced-precision kernels yet; a warning says so).
 """
 import torch
 import torch.distributed as dist
@@ -64,7 +64,12 @@ class TrainStep:
         self.segment_size = _get(t, "segment_size")
         self.c_mel, self.c_kl = _get(t, "c_mel"), _get(t, "c_kl")
         if _get(t, "fp16_run"):
-            raise NotImplementedError("fp16_run/bf16 autocast is not implemented: the MI355X engine trains in fp32")
+            # train.py:114,143,166: autocast + GradScaler are a speed option of the reference.  The engine has no reduced-
+            # precision kernels yet: the step runs in fp32 (at least the reference's precision, no loss scaling needed) and
+            # says so instead of refusing the config.
+            import warnings
+            warnings.warn("fp16_run / half_type: the MI355X engine has no fp16/bf16 kernels yet — training runs in fp32 "
+                          "(GradScaler is not needed and not applied)", stacklevel=2)
 
         self.use_graph = False
         self._graphs = {}
