@@ -501,6 +501,8 @@ int svc_cmag_bwd_f32(const float* re, const float* im, const float* mag, const f
 
 /* Tuning / debugging knob of svc_conv1d_f32 (tile-config override and ablation switches); 0 restores defaults. */
 int svc_debug_set_conv_cfg(int cfg);
+/* Tuning aid: 1 selects the software-pipelined inner loop of svc_gemm_f32's 128x128 kernel (built, not yet measured; default 0). */
+int svc_debug_set_gemm_pipelined(int on);
 /* Tuning aid: 1 selects the operand-preloading instantiations of svc_resblock_pair_f32 (built, not yet measured; default 0). */
 int svc_debug_set_pair_pipelined(int on);
 /* Tuning aid: 1 selects the first (one thread per output) grouped-conv kernels, 2 the LDS-tiled ones (default). */
