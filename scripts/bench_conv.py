@@ -1,6 +1,7 @@
 """Micro-benchmark of svc_conv1d_f32 on the decoder's MRF stage shapes (T=862 -> 10 s clip).  Launches are captured
 into a hipGraph (N per replay) so host/ctypes overhead does not pollute the timing.
-usage: bench_conv.py [dbgcfg ...]   (svc_debug_set_conv_cfg codes: dbg*1000 + noksc*100 + (tilecfg+1))"""
+usage: bench_conv.py [dbgcfg | strip=M ...]   (svc_debug_set_conv_cfg codes: dbg*1000 + noksc*100 + (tilecfg+1);
+strip=M sets svc_debug_set_conv_strip(M) for the runs that follow: 0 tiled kernels only, 1 automatic)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "so-vits-svc_amd"))
@@ -17,6 +18,7 @@ for i, (u, C) in enumerate(zip([8, 8, 2, 2, 2], [256, 128, 64, 32, 16])):
         shapes.append((C, L, k, 1 if k == 3 else 5, C))
 extra = [(192, 862, 5, 1, 384), (192, 862, 3, 1, 768), (768, 862, 3, 1, 192), (192, 862, 1, 1, 576)]
 N = 10
+MODE = os.environ.get("BENCH_CONV_MODE", "both")
 
 
 def run(Cin, L, k, d, Cout, quiet=False):
@@ -26,8 +28,13 @@ def run(Cin, L, k, d, Cout, quiet=False):
     wp = S.pack_conv1d_weight(w)
     out = torch.empty(1, Cout, L, device=dev)
     pad = (k * d - d) // 2
-    kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, res=x if Cout == Cin else None,
-              res_mode=1 if Cout == Cin else 0, out=out)
+    if MODE == "conv1":      # first conv of a ResBlock1 pair: lrelu in, lrelu out, no residual
+        kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, post_act=S.ACT_LRELU, post_slope=0.1, out=out)
+    elif MODE == "conv2":    # second conv: plain in, residual add
+        kw = dict(bias=b, dil=d, pad_left=pad, res=x if Cout == Cin else None, res_mode=1 if Cout == Cin else 0, out=out)
+    else:                    # round-1/2 form: lrelu in + residual
+        kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, res=x if Cout == Cin else None,
+                  res_mode=1 if Cout == Cin else 0, out=out)
     S.conv1d(x, wp, Cout, k, **kw)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -49,7 +56,12 @@ def run(Cin, L, k, d, Cout, quiet=False):
     return ms, fl
 
 
-for code in ([int(a) for a in sys.argv[1:]] or [0]):
+for arg in (sys.argv[1:] or ["0"]):
+    if arg.startswith("strip="):
+        S.lib().svc_debug_set_conv_strip(int(arg[6:]))
+        print(f"=== conv strip mode {arg[6:]}")
+        continue
+    code = int(arg)
     S.lib().svc_debug_set_conv_cfg(code)
     print(f"--- debug cfg {code}")
     tot_ms = tot_fl = 0

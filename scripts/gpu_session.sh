@@ -1,0 +1,38 @@
+#!/bin/bash
+# One gpurun call = a list of named steps (arguments), each writing under gpurun_out/<tag>_*.  Replaces the one-shot
+# scripts of rounds 1-2.  usage: gpurun -- 'bash scripts/gpu_session.sh TAG step [step ...]'
+#   convtests   pytest of tests/test_conv1d_gpu.py          fulltests  whole -m gpu suite
+#   convbench   bench_conv.py strip=0 / strip=1 in the pair's two forms
+#   pairbench   bench_pair.py with the PIPE variants off / on      gemmbench  bench_train_kernels.py gemm, pipelined off / on
+#   inferab     bench.py --mode infer under SVC_CONV_STRIP x SVC_MRF_STREAMS
+#   bench       the driver's default bench.py line          prof       rocprofv3 kernel-trace stats of the infer step (serialised)
+#   trainprof   rocprofv3 kernel-trace stats of the training step  pmc  FETCH_SIZE / WRITE_SIZE passes of the infer step
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+TAG=$1; shift
+O=gpurun_out/$TAG
+for step in "$@"; do
+case $step in
+convtests) timeout 600 python -m pytest tests/test_conv1d_gpu.py -m gpu -q --timeout=300 -rf > ${O}_convtests.log 2>&1; tail -15 ${O}_convtests.log ;;
+fulltests) timeout 1200 python -m pytest tests -m gpu -q --timeout=300 -rf > ${O}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> ${O}_pytest_gpu.log; tail -15 ${O}_pytest_gpu.log ;;
+convbench) for m in conv1 conv2; do BENCH_CONV_MODE=$m timeout 300 python scripts/bench_conv.py strip=0 0 strip=1 0 > ${O}_convbench_$m.txt 2>&1; cat ${O}_convbench_$m.txt; done ;;
+pairbench) for pp in 0 1; do SVC_PAIR_PIPELINED=$pp timeout 300 python scripts/bench_pair.py > ${O}_pairbench_pipe$pp.txt 2>&1; tail -8 ${O}_pairbench_pipe$pp.txt; done ;;
+gemmbench) for pp in 0 1; do SVC_GEMM_PIPELINED=$pp timeout 300 python scripts/bench_train_kernels.py gemm > ${O}_gemmbench_pipe$pp.txt 2>&1; cat ${O}_gemmbench_pipe$pp.txt; done ;;
+inferab) for st in 0 1; do for ms in 1 0; do SVC_CONV_STRIP=$st SVC_MRF_STREAMS=$ms timeout 300 python bench.py --mode infer --steps 30 --warmup 5 --no-cpu-baseline > ${O}_infer_strip${st}_streams${ms}.json 2> ${O}_infer_strip${st}_streams${ms}.err; cat ${O}_infer_strip${st}_streams${ms}.json; done; done ;;
+bench) timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cat ${O}_bench.json; tail -3 ${O}_bench.err ;;
+prof) rm -rf gpurun_out/prof_stats; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline > ${O}_prof_bench.json 2> ${O}_prof_bench.err
+      DB=$(find gpurun_out/prof_stats -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_infer_T862_kernel_stats_serialised.txt 2>&1; head -40 ${O}_infer_T862_kernel_stats_serialised.txt ;;
+trainprof) rm -rf gpurun_out/prof_train; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline > ${O}_trainprof_bench.json 2> ${O}_trainprof_bench.err
+      DB=$(find gpurun_out/prof_train -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_train_B16_kernel_stats.txt 2>&1; head -60 ${O}_train_B16_kernel_stats.txt ;;
+pmc) rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > ${O}_pmc_fetch.log 2>&1
+     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > ${O}_pmc_write.log 2>&1
+     python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write 4 ${O}_pmc_conv.json > ${O}_pmc_summary.txt 2>&1; cat ${O}_pmc_summary.txt ;;
+*) echo "custom step: $step"; eval "$step" ;;
+esac
+done
+find gpurun_out -name '*.db' -size +30M -delete
+find gpurun_out -name '*counter_collection.csv' -size +20M -delete
+du -sh gpurun_out

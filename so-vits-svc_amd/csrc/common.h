@@ -44,6 +44,9 @@ inline int check_launch(const char* what) {
     }                                   \
   } while (0)
 
+// conv1d_strip.hip: long-sequence dense conv, one workgroup per CU; returns 1 when the shape is not one of its shapes
+int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
 

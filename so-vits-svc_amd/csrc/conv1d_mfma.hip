@@ -1020,6 +1020,11 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     snprintf(pname, sizeof(pname), "%s", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma");
   svc::ProfScope prof(s, pname, flop, bytes);
 
+  // long sequences that one round of 224-column strips covers (the decoder's MRF convs): conv1d_strip.hip
+  if (g_force_cfg < 0) {
+    const int rs = svc::conv1d_strip_try(a, s);
+    if (rs <= 0) return rs;
+  }
   const long long cols = (long long)a.B * a.Tout;
   // workgroup counts of the candidate tilings for short sequences
   const long long wg64x128 = (long long)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 128) * a.B * a.n_phase;
