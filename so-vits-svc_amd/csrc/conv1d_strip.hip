@@ -34,8 +34,8 @@ struct StripP {
   int XW;          // LDS row width of the X tile (floats, multiple of 4)
   int BC;          // input channels per chunk
   int n_t_tiles, n_m_tiles;
-  int npw, np;     // LDS-DMA pieces (1 KiB) per chunk: weights, total
-  unsigned xw4_magic;   // ceil(2^32 / (XW/4)): slot -> row by multiply-high
+  int npw;         // 1 KiB LDS-DMA pieces of a chunk's weight block
+  int buf_f;       // floats per LDS buffer (W block + X block)
 };
 
 // One LDS-DMA piece: lane l's 16 B at base + off[l] land at LDS byte address lds_byte + l*16 (wave-uniform LDS base in M0).
@@ -78,46 +78,93 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
   const int mtile = bid % p.n_m_tiles;
   const int b = bid / p.n_m_tiles;
   const int t0 = tt * BN, co0 = mtile * BM;
-  const int XW = p.XW, XW4 = XW >> 2, BC = p.BC, NPW = p.npw, NP = p.np;
+  const int XW = p.XW, XW4 = XW >> 2, BC = p.BC, NPW = p.npw;
 
   const float* xb = a.x + (long long)b * a.x_bs;
   const int tin0 = t0 - a.pad_left;
   const int sh = ((tin0 % 4) + 4) % 4;   // tile start rounded down to a 16 B boundary
   const int tin_base = tin0 - sh;
 
-  // ---- LDS-DMA: a chunk is NP pieces of 1 KiB, linear in LDS: pieces 0..NPW-1 the W block [BC*KSC][BM] (RPP whole rows per
-  // piece), pieces NPW.. the X block [BC][XW].  Piece pc is fetched by wave pc % 4.  Its source is (chunk base of the tensor, in
-  // SGPRs) + (per-lane 32-bit byte offset, computed when the piece is issued).  Every lane reads a VALID address: weight
-  // columns >= CoutP, rows / slots past the block are clamped (they feed output rows / LDS words nobody uses); X slots outside
-  // [0, Tin) — only the first and last tile of a row have them — are clamped too and zeroed in LDS afterwards by the wave that
-  // fetched them (edge_fix, wave-uniform branch).
-  const int XF4 = BC * XW4, WROWS = BC * KSC;
-  const int buf_f = NP * 256;   // floats per buffer
+  // ---- LDS-DMA.  A chunk in LDS = W block [BC*KSC][BM] (NPW pieces of 1 KiB = RPP whole rows each) then X block [BC][XW].
+  // Wave w fetches the W pieces pc = w, w+4, ... and the X rows r = w, w+4, ...; an X row is PPR pieces, piece pp covering the
+  // float4 columns [min(64*pp, XW4-64), +64) — the last piece overlaps its neighbour instead of running past the row (XW4 >= 64).
+  // A piece's source is (uniform base: tensor chunk base + piece / row offset, all scalar arithmetic) + (a per-lane byte offset:
+  // constant for W pieces, 4 VALU for X pieces), so issuing a piece costs ~10 SALU + 1 VMEM: it hides under one fp32 MFMA.
+  // Every lane reads a VALID address: weight columns >= CoutP are clamped (they feed output rows nobody stores), X columns
+  // outside [0, Tin) — only the first and last tile of a row have them — are clamped and zeroed in LDS afterwards by the wave
+  // that fetched them, in the same in-place pass that applies the leaky-ReLU pre-activation (fix_rows).
+  const int PPR = (XW4 + 63) >> 6;
+  const int wfl = NPW * 256;                     // floats of the W block
+  const int buf_f = p.buf_f;                     // floats per buffer
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-  const unsigned wcol = 4u * (unsigned)min(co0 + (lane % BM4) * 4, a.CoutP - 4);
+  const unsigned woff = 4u * ((unsigned)(lane / BM4) * (unsigned)a.CoutP + (unsigned)min(co0 + (lane % BM4) * 4, a.CoutP - 4));
   const char* wsrc = reinterpret_cast<const char*>(a.w);
   const char* xsrc = reinterpret_cast<const char*>(xb);
   const long long wstep = (long long)BC * KSC * a.CoutP * 4, xstep = (long long)BC * a.x_cs * 4;
-  auto issue_piece = [&](int pc, int buf) {   // pc, buf wave-uniform
-    const unsigned dst = lds_base + ((unsigned)buf * (unsigned)NP + (unsigned)pc) * 1024u;
-    if (pc < NPW) {
-      const int row = min(pc * RPP + lane / BM4, WROWS - 1);
-      strip_glds16(4u * (unsigned)row * (unsigned)a.CoutP + wcol, wsrc, dst);
-    } else {
-      const int sx = min((pc - NPW) * 64 + lane, XF4 - 1);
-      const int r = (int)__umulhi((unsigned)sx, p.xw4_magic), c4 = sx - r * XW4;
-      const int tin = min(max(tin_base + c4 * 4, 0), a.Tin - 4);
-      strip_glds16(4u * ((unsigned)r * (unsigned)a.x_cs + (unsigned)tin), xsrc, dst);
-    }
+  const long long wpiece = (long long)RPP * a.CoutP * 4, xrow = a.x_cs * 4;
+  const int nw_mine = (NPW - wave + 3) >> 2;
+  const int steps_mine = nw_mine + ((BC - wave + 3) >> 2) * PPR;
+  // Issue state of the chunk being fetched, all wave-uniform and advanced incrementally (no multiplies per piece):
+  int si = 0, xpp = 0;
+  const char *wptr = nullptr, *xptr = nullptr;
+  unsigned wdst = 0, xdst = 0;
+  auto issue_begin = [&](int buf) {
+    const unsigned bufb = lds_base + (unsigned)buf * (unsigned)buf_f * 4u;
+    si = 0; xpp = 0;
+    wptr = wsrc + wave * wpiece;
+    xptr = xsrc + wave * xrow;
+    wdst = bufb + (unsigned)wave * 1024u;
+    xdst = bufb + 4u * (unsigned)(wfl + wave * XW);
+  };
+  // One piece in three parts, so that each part fits under ONE fp32 MFMA (64 cycles) when they are placed between the MFMAs of
+  // a tap: A = addresses (branch-free selects between the W and the X form), B = the DMA instruction, C = state update.
+  bool isw = false;
+  const char* ibase = nullptr;
+  unsigned idst = 0, ioff = 0;
+  auto issue_a = [&]() {
+    isw = si < nw_mine;
+    const int c4s = min(64 * xpp, XW4 - 64);
+    const int tin = min(max(tin_base + 4 * (c4s + lane), 0), a.Tin - 4);
+    ibase = isw ? wptr : xptr;
+    idst = isw ? wdst : xdst + 16u * (unsigned)c4s;
+    ioff = isw ? woff : 4u * (unsigned)tin;
+    asm volatile("" ::"s"(ibase), "s"(idst), "v"(ioff));   // materialise here (the compiler would sink all of it next to the DMA)
+  };
+  auto issue_b = [&]() {
+    if (si < steps_mine) strip_glds16(ioff, ibase, idst);
+  };
+  bool wrap = false;
+  auto issue_c = [&]() {
+    wrap = !isw && xpp + 1 == PPR;
+    wptr += isw ? 4 * wpiece : 0;
+    wdst += isw ? 4096u : 0u;
+    xpp = isw ? xpp : (wrap ? 0 : xpp + 1);
+    asm volatile("" ::"s"(wptr), "s"(wdst), "s"(xpp));
+  };
+  auto issue_d = [&]() {
+    xptr += wrap ? 4 * xrow : 0;
+    xdst += wrap ? 16u * (unsigned)XW : 0u;
+    ++si;
+    asm volatile("" ::"s"(xptr), "s"(xdst), "s"(si));
   };
   const bool edge = tin_base < 0 || tin_base + XW > a.Tin;   // this tile's X block reaches past an end of the sequence
-  auto edge_fix = [&](int buf) {
-    for (int pc = NPW + ((wave - NPW) & 3); pc < NP; pc += 4) {   // this wave's X pieces
-      const int sx = (pc - NPW) * 64 + lane;
-      const int r = (int)__umulhi((unsigned)sx, p.xw4_magic), c4 = sx - r * XW4;
-      const int tin = tin_base + c4 * 4;
-      if (sx < XF4 && (tin < 0 || tin >= a.Tin))
-        *reinterpret_cast<float4*>(smem + (buf * NP + pc) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float ps = a.pre_slope;
+  auto fix_rows = [&](int buf) {   // own rows, in place: zero padding (edge tiles) and the pre-activation max(v, slope*v)
+    if (!(PREACT || edge)) return;
+    for (int r = wave; r < BC; r += 4) {
+      float* row = smem + buf * buf_f + wfl + r * XW;
+      for (int c4 = lane; c4 < XW4; c4 += 64) {
+        const int tin = tin_base + c4 * 4;
+        float4 v = *reinterpret_cast<float4*>(row + c4 * 4);
+        if (tin < 0 || tin >= a.Tin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PREACT) {
+          v.x = __builtin_amdgcn_fmed3f(v.x, v.x * ps, __builtin_inff());
+          v.y = __builtin_amdgcn_fmed3f(v.y, v.y * ps, __builtin_inff());
+          v.z = __builtin_amdgcn_fmed3f(v.z, v.z * ps, __builtin_inff());
+          v.w = __builtin_amdgcn_fmed3f(v.w, v.w * ps, __builtin_inff());
+        }
+        *reinterpret_cast<float4*>(row + c4 * 4) = v;
+      }
     }
   };
 
@@ -127,26 +174,24 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[j][r] = 0.f;
 
-  const float ps = a.pre_slope;
   const int dil = a.dil;
   const int n_cc = BC / KPI;
+  const int q_issue = min(n_cc, (steps_mine + KSC - 1) / KSC);   // channel groups whose taps carry a piece each
 
-  // One chunk of MFMAs over buffer `buf`.  ISSUE: the pieces of the next chunk (this wave's: pc = wave, wave+4, ...) are issued
-  // one per tap, after the tap's first MFMA — under the matrix pipe's 64 busy cycles.
-  auto chunk = [&](int buf, auto issue_tag) {
-    constexpr bool ISSUE = decltype(issue_tag)::value;
-    const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
-    const float* xl = smem + buf * buf_f + NPW * 256 + wn * (NT * TS) + ln + sh + lk * XW;
-    int pc = wave;
-    float av[KSC], bv[KSC][NT];
+  // MFMAs over channel groups [q0, q1) of buffer `buf`.  ISSUE: one piece of the next chunk is issued per tap, after the tap's
+  // first MFMA — under the matrix pipe's 64 busy cycles.  Operand reads run two taps ahead of their MFMAs, across the loop
+  // back-edge and across the two calls of a chunk (qlast = the chunk's last group: its look-ahead re-reads itself, unused).
+  float av[KSC], bv[KSC][NT];
 #define SVC_STRIP_LD(k_, wa_, xa_)                                           \
   {                                                                          \
     av[k_] = (wa_)[(k_) * BM];                                               \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
   }
-    SVC_STRIP_LD(0, wl, xl)
-    SVC_STRIP_LD(1, wl, xl)
-    for (int q = 0; q < n_cc; ++q) {
+  auto groups = [&](int buf, int q0, int q1, auto issue_tag) {   // (ISSUE: the pieces go to the OTHER buffer, set by issue_begin)
+    constexpr bool ISSUE = decltype(issue_tag)::value;
+    const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
+    const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + ln + sh + lk * XW;
+    for (int q = q0; q < q1; ++q) {
       const float* wa = wl + q * (KPI * KSC * BM);
       const float* xa = xl + q * (KPI * XW);
       const int qn = min(q + 1, n_cc - 1);
@@ -154,50 +199,54 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
       const float* xnx = xl + qn * (KPI * XW);
 #pragma unroll
       for (int k = 0; k < KSC; ++k) {
-        // operand reads run two taps ahead of the MFMAs that use them — across the loop back-edge too
         __builtin_amdgcn_sched_barrier(0);
         if (k + 2 < KSC) SVC_STRIP_LD(k + 2, wa, xa)
         else SVC_STRIP_LD(k + 2 - KSC, wnx, xnx)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          float bj = bv[k][j];
-          if constexpr (PREACT) bj = __builtin_amdgcn_fmed3f(bj, bj * ps, __builtin_inff());   // max(v, slope*v), 0 <= slope <= 1
-          if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bj, acc[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bj, acc[j], 0, 0, 0);
+          if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k][j], acc[j], 0, 0, 0);
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k][j], acc[j], 0, 0, 0);
           if constexpr (ISSUE) {
-            if (j == 0) {
+            if (j <= 3) {
               __builtin_amdgcn_sched_barrier(0);
-              if (pc < NP) {
-                issue_piece(pc, buf ^ 1);
-                pc += 4;
-              }
+              if (j == 0) issue_a();
+              else if (j == 1) issue_b();
+              else if (j == 2) issue_c();
+              else issue_d();
               __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
       }
     }
-#undef SVC_STRIP_LD
-    if constexpr (ISSUE) {
-      for (; pc < NP; pc += 4) issue_piece(pc, buf ^ 1);   // (not reached for the shapes the launcher admits: taps >= pieces per wave)
-    }
+  };
+  auto first_reads = [&](int buf) {
+    const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
+    const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + ln + sh + lk * XW;
+    SVC_STRIP_LD(0, wl, xl)
+    SVC_STRIP_LD(1, wl, xl)
   };
 
-  // ---- first chunk in, then [barrier, MFMAs of chunk i with the DMA of chunk i+1 riding along, wait for own pieces]
-  for (int pc = wave; pc < NP; pc += 4) issue_piece(pc, 0);
+  // ---- first chunk in, then [barrier, MFMAs of chunk i with the DMA of chunk i+1 riding along, wait for own pieces, fix rows]
+  issue_begin(0);
+  while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
   wsrc += wstep;
   xsrc += xstep;
   strip_vmcnt0();
-  if (edge) edge_fix(0);
+  fix_rows(0);
   int it = 0;
   for (int c0 = BC; c0 < a.Cin; c0 += BC, ++it) {
-    __syncthreads();   // chunk `it` has landed for every wave; everyone is done reading the other buffer
-    chunk(it & 1, std::true_type{});
+    __syncthreads();   // chunk `it` has landed (and is activated) for every wave; everyone is done reading the other buffer
+    issue_begin((it & 1) ^ 1);
+    first_reads(it & 1);
+    groups(it & 1, 0, q_issue, std::true_type{});
+    groups(it & 1, q_issue, n_cc, std::false_type{});
+    while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }   // (not reached for the shapes the launcher admits)
     wsrc += wstep;
     xsrc += xstep;
     strip_vmcnt0();    // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
-    if (edge) edge_fix((it + 1) & 1);
+    fix_rows((it + 1) & 1);
   }
   __syncthreads();
 
@@ -243,7 +292,9 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
       for (int j = 0; j < NT; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
     }
   }
-  chunk(it & 1, std::false_type{});
+  first_reads(it & 1);
+  groups(it & 1, 0, n_cc, std::false_type{});
+#undef SVC_STRIP_LD
 
   // ---- epilogue straight from the accumulators (same expression and order as conv_epilogue's plain path).  The accumulate
   // operand y_old (beta != 0: the last conv of an MRF chain adds into the stage sum) is not prefetched — accumulators plus one
@@ -297,30 +348,31 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   memset(&p, 0, sizeof(p));
   p.a = a;
   int xw = BN + (a.KS - 1) * a.dil + 3;
-  xw = (xw + 3) & ~3;
+  xw = std::max((xw + 3) & ~3, 256);   // >= 64 float4 per row: the last DMA piece of a row overlaps instead of overrunning
   if (TS == 16) {   // consecutive channel rows on disjoint bank halves for the 16-lane groups of a B read
     while ((xw & 31) != 16) xw += 4;
   }
   p.XW = xw;
-  // largest chunk (power-of-two multiple of KPI dividing Cin) whose two buffers fit 160 KiB and whose pieces per wave do not
-  // outnumber the chunk's taps (one piece rides on each tap of the previous chunk)
-  int bc = 0, npw = 0, np = 0;
+  // largest chunk (power-of-two multiple of KPI dividing Cin) whose weight block is whole pieces, whose two buffers fit
+  // 160 KiB, and whose pieces per wave do not outnumber the chunk's taps (one piece rides on each tap of the previous chunk)
+  constexpr int RPP = 64 / (BM / 4);
+  const int ppr = (xw / 4 + 63) / 64;
+  int bc = 0, npw = 0, buf_f = 0;
   for (int c = 64; c >= KPI; c >>= 1) {
-    if (c > a.Cin || a.Cin % c) continue;
-    const int w_pieces = svc::cdiv(c * a.KS * (BM / 4), 64), x_pieces = svc::cdiv(c * (xw / 4), 64);
-    const int n = w_pieces + x_pieces;
-    if ((size_t)2 * n * 1024 <= 160 * 1024 && svc::cdiv(n, 4) <= (c / KPI) * a.KS) { bc = c; npw = w_pieces; np = n; break; }
+    if (c > a.Cin || a.Cin % c || (c * a.KS) % RPP) continue;
+    const int w_pieces = c * a.KS / RPP;
+    const int f = w_pieces * 256 + c * xw;
+    const int steps = svc::cdiv(w_pieces, 4) + svc::cdiv(c, 4) * ppr;
+    if ((size_t)2 * f * 4 <= 160 * 1024 && steps <= (c / KPI) * a.KS) { bc = c; npw = w_pieces; buf_f = f; break; }
   }
   if (bc == 0) return 1;
   p.BC = bc;
   p.npw = npw;
-  p.np = np;
-  const unsigned xw4 = (unsigned)(xw / 4);
-  p.xw4_magic = (unsigned)((0x100000000ull + xw4 - 1) / xw4);
+  p.buf_f = buf_f;
   p.n_t_tiles = svc::cdiv(a.Tout, BN);
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
   const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
-  const size_t lds = (size_t)2 * np * 1024;
+  const size_t lds = (size_t)2 * buf_f * 4;
   auto kd = conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES>;
   static bool done = false;
   if (!done) {

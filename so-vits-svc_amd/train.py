@@ -87,10 +87,29 @@ class TrainStep:
         """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
         returns a dict of 0-dim device tensors."""
         if self.use_graph:
+            items = self._dense_spec(items)
             if all(r is not None for r in self._reducers()):
                 return self._call_graph_dp(items, noise)
             return self._call_graph(items, noise)
         return self._step_body(items, noise)
+
+    def _dense_spec(self, items):
+        """The graph paths key on tensor shapes and copy every item into static buffers.  A loader batch whose `spec` slot is
+        a data_utils.SpecContextBatch (items without a cached .spec.pt, or vol-augmented ones: a random half of the items
+        with vol_aug) or None is turned into the dense [B, F, T] spectrogram HERE — eagerly, outside any capture: the frame
+        count comes from the host (`int(n_frames.max())`) and would otherwise be frozen into the captured graph."""
+        c, f0, spec, y, spk, lengths, uv, volume = items
+        if torch.is_tensor(spec):
+            return items
+        if spec is None:
+            from data_utils import batch_spectrogram
+            spec = batch_spectrogram(y, lengths, self.n_fft, self.sr, self.hop, self.win)
+        else:
+            from data_utils import context_spectrogram
+            spec = context_spectrogram(spec.to(y.device), self.n_fft, self.sr, self.hop, self.win)
+        if spec.shape[2] < c.shape[2]:            # keep the frame axis the collate's (graph key = padded batch shape)
+            spec = torch.nn.functional.pad(spec, (0, c.shape[2] - spec.shape[2]))
+        return (c, f0, spec, y, spk, lengths, uv, volume)
 
     def _call_graph(self, items, noise=None):
         nkeys = sorted(noise) if noise is not None else []
@@ -151,11 +170,15 @@ class TrainStep:
         ev.record()
 
     def _step_body(self, items, noise=None):
-        ctx = self._seg_d(items, noise)
-        self.optim_d.step()
-        out = self._seg_g(ctx)
-        self.optim_g.step()
-        S.wgrad_slab.active = False      # gradients consumed: later backward passes outside this loop allocate normally
+        try:
+            ctx = self._seg_d(items, noise)
+            self.optim_d.step()
+            out = self._seg_g(ctx)
+            self.optim_g.step()
+        finally:
+            # gradients consumed (or the step raised): later backward passes in this process must not receive views of a
+            # slab that the next reset() zeroes
+            S.wgrad_slab.active = False
         return out
 
     def _seg_d(self, items, noise=None):

@@ -181,8 +181,9 @@ def strip_mode():
 
 @pytest.mark.parametrize("arr,B,Cin,Cout,T,KS,dil", STRIP_CASES)
 def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil):
-    """Every epilogue form the MRF stage uses (vdecoder/hifigan/models.py:60-67,382-388), strip kernel vs the tiled kernel
-    (same MFMA chain, same epilogue expression: bit-equal) and vs torch CPU fp32."""
+    """Every epilogue form the MRF stage uses (vdecoder/hifigan/models.py:60-67,382-388), strip kernel vs the kernels it
+    replaces (fp32 round-off: these short test sequences take split-K / register-fed tilings there, and the 16x16x4 instruction
+    groups its products differently from 32x32x2) and vs torch CPU fp32."""
     import svc_hip as S
     g = torch.Generator().manual_seed(arr * 7919 + Cin + Cout + T + KS + dil)
     x = torch.randn(B, Cin, T, generator=g)
@@ -210,7 +211,7 @@ def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil):
             S.conv1d(xd, wp, Cout, KS, bias=bd, dil=dil, pad_left=pad, out=out, beta=beta, out_div=div, **kw)
             torch.cuda.synchronize()
             outs.append(out.cpu())
-        assert torch.equal(outs[0], outs[1]), (name, (outs[0] - outs[1]).abs().max().item())
+        assert _rel(outs[0], outs[1]) < 3e-6, (name, (outs[0] - outs[1]).abs().max().item())
         assert _rel(outs[0], ref) < 3e-6, name
     assert S.lib().svc_debug_set_conv_strip(-1) - n0 == len(forms), "the strip kernel was not the one that ran"
 
@@ -231,7 +232,10 @@ def test_conv1d_strip_auto_selection_mrf_shapes(dev, strip_mode):
         strip_mode(0)
         y0 = S.conv1d(x, wp, C, 3, pad_left=1, res=x, res_mode=1)
         strip_mode(1)
-        assert torch.equal(y, y0), (C, L)
+        if C <= 128:   # same instruction, same order of the reduction, same epilogue expression as the 32x32-tile kernels: bit-equal
+            assert torch.equal(y, y0), (C, L)
+        else:          # 256 channels run the 16x16x4 form
+            assert _rel(y, y0) < 3e-6, (C, L)
     x = torch.randn(16, 128, 1024, device=dev)
     wp = S.pack_conv1d_weight(torch.randn(128, 128, 3, device=dev) * 0.05)
     n0 = S.lib().svc_debug_set_conv_strip(-1)
