@@ -503,7 +503,8 @@ int svc_cmag_bwd_f32(const float* re, const float* im, const float* mag, const f
 int svc_debug_set_conv_cfg(int cfg);
 /* svc_conv1d_f32 routes long dense convolutions (B*T covered by one round of 224-column strips: the decoder's MRF ResBlock
  * convs, vdecoder/hifigan/models.py:41-67) to the one-workgroup-per-CU strip kernel (csrc/conv1d_strip.hip).
- * mode 0: never, 1: automatic (default), 2..5: force wave arrangement 0..3 (32x32 4x1 / 2x2 / 1x4, 16x16 4x1) for eligible shapes;
+ * mode 0: never, 1: automatic (default), 2..5: force strip arrangement 0..3 (32x32 4x1 / 2x2 / 1x4, 16x16 4x1) for eligible shapes,
+ * mode + 10: the same with one wave per strip instead of two (A/B of the first form of the kernel);
  * a negative mode changes nothing and returns the number of launches that have taken the strip kernel so far (tests). */
 int svc_debug_set_conv_strip(int mode);
 /* Tuning aid: 1 selects the software-pipelined inner loop of svc_gemm_f32's 128x128 kernel (built, not yet measured; default 0). */

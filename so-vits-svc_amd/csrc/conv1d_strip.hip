@@ -54,9 +54,15 @@ template <> struct AccT<32> { typedef f32x16 type; };
 template <> struct AccT<16> { typedef f32x4 type; };
 
 // TS: MFMA tile edge (32: v_mfma_f32_32x32x2_f32, 16: v_mfma_f32_16x16x4_f32); WM x WN waves (rows x strips), NT tiles per strip.
-template <int TS, int WM, int WN, int NT, int KSC, bool PREACT, bool HAS_RES>
-__global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
-  static_assert(WM * WN == 4, "one wave per SIMD");
+// WPS waves per SIMD share a strip: 1 = one wave owns all NT tiles (a wave alone on its SIMD pays for every non-MFMA instruction
+// of its stream: ds_reads, DMA issue, addressing — measured 1.2..1.6x the MFMA time, profiles/r03a_*, r03b_*); 2 = the strip's
+// tiles are split 4 + 3 between two waves of the same SIMD (waves w and w + 4), so one wave's operand reads / DMA issue /
+// epilogue stores run under the other's MFMAs.
+template <int TS, int WM, int WN, int NT, int KSC, bool PREACT, bool HAS_RES, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) {
+  static_assert(WM * WN == 4, "one strip per SIMD");
+  static_assert(WPS == 1 || (WPS == 2 && NT == 7), "two waves per SIMD split a 7-tile strip 4 + 3");
+  constexpr int NWV = 4 * WPS;
   static_assert(KSC >= 3, "the operand pipeline runs two taps ahead");
   constexpr bool M16 = TS == 16;
   constexpr int KPI = M16 ? 4 : 2;    // input channels consumed per MFMA
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int strip = wave & 3, half = wave >> 2;   // waves w and w + 4 run on the same SIMD (cyclic wave -> SIMD placement)
+  const int wm = strip / WN, wn = strip % WN;
   const int ln = lane & (TS - 1), lk = lane / TS;
 
   int bid = blockIdx.x;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
   const int tin_base = tin0 - sh;
 
   // ---- LDS-DMA.  A chunk in LDS = W block [BC*KSC][BM] (NPW pieces of 1 KiB = RPP whole rows each) then X block [BC][XW].
-  // Wave w fetches the W pieces pc = w, w+4, ... and the X rows r = w, w+4, ...; an X row is PPR pieces, piece pp covering the
+  // Wave w of the NWV waves fetches the W pieces pc = w, w+NWV, ... and the X rows r = w, w+NWV, ...; an X row is PPR pieces, piece pp covering the
   // float4 columns [min(64*pp, XW4-64), +64) — the last piece overlaps its neighbour instead of running past the row (XW4 >= 64).
   // A piece's source is (uniform base: tensor chunk base + piece / row offset, all scalar arithmetic) + (a per-lane byte offset:
   // constant for W pieces, 4 VALU for X pieces), so issuing a piece costs ~10 SALU + 1 VMEM: it hides under one fp32 MFMA.
@@ -102,8 +109,8 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
   const char* xsrc = reinterpret_cast<const char*>(xb);
   const long long wstep = (long long)BC * KSC * a.CoutP * 4, xstep = (long long)BC * a.x_cs * 4;
   const long long wpiece = (long long)RPP * a.CoutP * 4, xrow = a.x_cs * 4;
-  const int nw_mine = (NPW - wave + 3) >> 2;
-  const int steps_mine = nw_mine + ((BC - wave + 3) >> 2) * PPR;
+  const int nw_mine = max(0, (NPW - wave + NWV - 1) / NWV);
+  const int steps_mine = nw_mine + max(0, (BC - wave + NWV - 1) / NWV) * PPR;
   // Issue state of the chunk being fetched, all wave-uniform and advanced incrementally (no multiplies per piece):
   int si = 0, xpp = 0;
   const char *wptr = nullptr, *xptr = nullptr;
@@ -136,14 +143,14 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
   bool wrap = false;
   auto issue_c = [&]() {
     wrap = !isw && xpp + 1 == PPR;
-    wptr += isw ? 4 * wpiece : 0;
-    wdst += isw ? 4096u : 0u;
+    wptr += isw ? NWV * wpiece : 0;
+    wdst += isw ? 1024u * NWV : 0u;
     xpp = isw ? xpp : (wrap ? 0 : xpp + 1);
     asm volatile("" ::"s"(wptr), "s"(wdst), "s"(xpp));
   };
   auto issue_d = [&]() {
-    xptr += wrap ? 4 * xrow : 0;
-    xdst += wrap ? 16u * (unsigned)XW : 0u;
+    xptr += wrap ? NWV * xrow : 0;
+    xdst += wrap ? 4u * NWV * (unsigned)XW : 0u;
     ++si;
     asm volatile("" ::"s"(xptr), "s"(xdst), "s"(si));
   };
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
   const float ps = a.pre_slope;
   auto fix_rows = [&](int buf) {   // own rows, in place: zero padding (edge tiles) and the pre-activation max(v, slope*v)
     if (!(PREACT || edge)) return;
-    for (int r = wave; r < BC; r += 4) {
+    for (int r = wave; r < BC; r += NWV) {
       float* row = smem + buf * buf_f + wfl + r * XW;
       for (int c4 = lane; c4 < XW4; c4 += 64) {
         const int tin = tin_base + c4 * 4;
@@ -168,172 +175,191 @@ __global__ __launch_bounds__(256, 1) void conv1d_strip_kernel(StripP p) {
     }
   };
 
-  acc_t acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < NACC; ++r) acc[j][r] = 0.f;
+  // ---- everything from here on is per wave: NTW tiles starting at tile J0 of the strip
+  auto body = [&](auto ntw_tag, auto j0_tag) {
+    constexpr int NTW = decltype(ntw_tag)::value, J0 = decltype(j0_tag)::value;
+    acc_t acc[NTW];
+  #pragma unroll
+    for (int j = 0; j < NTW; ++j)
+  #pragma unroll
+      for (int r = 0; r < NACC; ++r) acc[j][r] = 0.f;
 
-  const int dil = a.dil;
-  const int n_cc = BC / KPI;
-  const int q_issue = min(n_cc, (steps_mine + KSC - 1) / KSC);   // channel groups whose taps carry a piece each
+    const int dil = a.dil;
+    const int n_cc = BC / KPI;
+    const int q_issue = min(n_cc, (steps_mine + KSC - 1) / KSC);   // channel groups whose taps carry a piece each
 
-  // MFMAs over channel groups [q0, q1) of buffer `buf`.  ISSUE: one piece of the next chunk is issued per tap, after the tap's
-  // first MFMA — under the matrix pipe's 64 busy cycles.  Operand reads run two taps ahead of their MFMAs, across the loop
-  // back-edge and across the two calls of a chunk (qlast = the chunk's last group: its look-ahead re-reads itself, unused).
-  float av[KSC], bv[KSC][NT];
-#define SVC_STRIP_LD(k_, wa_, xa_)                                           \
-  {                                                                          \
-    av[k_] = (wa_)[(k_) * BM];                                               \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
-  }
-  auto groups = [&](int buf, int q0, int q1, auto issue_tag) {   // (ISSUE: the pieces go to the OTHER buffer, set by issue_begin)
-    constexpr bool ISSUE = decltype(issue_tag)::value;
-    const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
-    const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + ln + sh + lk * XW;
-    for (int q = q0; q < q1; ++q) {
-      const float* wa = wl + q * (KPI * KSC * BM);
-      const float* xa = xl + q * (KPI * XW);
-      const int qn = min(q + 1, n_cc - 1);
-      const float* wnx = wl + qn * (KPI * KSC * BM);
-      const float* xnx = xl + qn * (KPI * XW);
-#pragma unroll
-      for (int k = 0; k < KSC; ++k) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < KSC) SVC_STRIP_LD(k + 2, wa, xa)
-        else SVC_STRIP_LD(k + 2 - KSC, wnx, xnx)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k][j], acc[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k][j], acc[j], 0, 0, 0);
-          if constexpr (ISSUE) {
-            if (j <= 3) {
-              __builtin_amdgcn_sched_barrier(0);
-              if (j == 0) issue_a();
-              else if (j == 1) issue_b();
-              else if (j == 2) issue_c();
-              else issue_d();
-              __builtin_amdgcn_sched_barrier(0);
+    // MFMAs over channel groups [q0, q1) of buffer `buf`.  ISSUE: one piece of the next chunk is issued per tap, after the tap's
+    // first MFMA — under the matrix pipe's 64 busy cycles.  Operand reads run two taps ahead of their MFMAs, across the loop
+    // back-edge and across the two calls of a chunk (qlast = the chunk's last group: its look-ahead re-reads itself, unused).
+    float av[KSC], bv[KSC][NTW];
+  #define SVC_STRIP_LD(k_, wa_, xa_)                                           \
+    {                                                                          \
+      av[k_] = (wa_)[(k_) * BM];                                               \
+      _Pragma("unroll") for (int j = 0; j < NTW; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
+    }
+    auto groups = [&](int buf, int q0, int q1, auto issue_tag) {   // (ISSUE: the pieces go to the OTHER buffer, set by issue_begin)
+      constexpr bool ISSUE = decltype(issue_tag)::value;
+      const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
+      const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
+      for (int q = q0; q < q1; ++q) {
+        const float* wa = wl + q * (KPI * KSC * BM);
+        const float* xa = xl + q * (KPI * XW);
+        const int qn = min(q + 1, n_cc - 1);
+        const float* wnx = wl + qn * (KPI * KSC * BM);
+        const float* xnx = xl + qn * (KPI * XW);
+  #pragma unroll
+        for (int k = 0; k < KSC; ++k) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (k + 2 < KSC) SVC_STRIP_LD(k + 2, wa, xa)
+          else SVC_STRIP_LD(k + 2 - KSC, wnx, xnx)
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k][j], acc[j], 0, 0, 0);
+            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k][j], acc[j], 0, 0, 0);
+            if constexpr (ISSUE) {
+              if (j <= 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) issue_a();
+                else if (j == 1) issue_b();
+                else if (j == 2) issue_c();
+                else issue_d();
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           }
         }
       }
-    }
-  };
-  auto first_reads = [&](int buf) {
-    const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
-    const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + ln + sh + lk * XW;
-    SVC_STRIP_LD(0, wl, xl)
-    SVC_STRIP_LD(1, wl, xl)
-  };
+    };
+    auto first_reads = [&](int buf) {
+      const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
+      const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
+      SVC_STRIP_LD(0, wl, xl)
+      SVC_STRIP_LD(1, wl, xl)
+    };
 
-  // ---- first chunk in, then [barrier, MFMAs of chunk i with the DMA of chunk i+1 riding along, wait for own pieces, fix rows]
-  issue_begin(0);
-  while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
-  wsrc += wstep;
-  xsrc += xstep;
-  strip_vmcnt0();
-  fix_rows(0);
-  int it = 0;
-  for (int c0 = BC; c0 < a.Cin; c0 += BC, ++it) {
-    __syncthreads();   // chunk `it` has landed (and is activated) for every wave; everyone is done reading the other buffer
-    issue_begin((it & 1) ^ 1);
-    first_reads(it & 1);
-    groups(it & 1, 0, q_issue, std::true_type{});
-    groups(it & 1, q_issue, n_cc, std::false_type{});
-    while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }   // (not reached for the shapes the launcher admits)
+    // ---- first chunk in, then [barrier, MFMAs of chunk i with the DMA of chunk i+1 riding along, wait for own pieces, fix rows]
+    issue_begin(0);
+    while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
     wsrc += wstep;
     xsrc += xstep;
-    strip_vmcnt0();    // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
-    fix_rows((it + 1) & 1);
-  }
-  __syncthreads();
-
-  // ---- this lane's outputs: row(r) = rowu + rowc(r) + 4*lk, column(j) = colb + j*TS.  Addresses are
-  //   (uniform row base in SGPRs: tensor + (rowu + rowc(r)) * channel stride)  +  (per-lane 32-bit byte offset of (4*lk, column j))
-  // so the prefetch / epilogue need 7 offset registers per tensor instead of 112 pointers.  Columns past Tout are clamped for
-  // loads and masked for stores; a wave whose TS rows lie past Cout (Cout is a multiple of TS) reads row block 0 and stores nothing.
-  const int rowu = co0 + wm * TS;
-  const bool rows_ok = rowu < a.Cout;
-  const int rowl = rows_ok ? rowu : 0;
-  const int colb = t0 + wn * (NT * TS) + ln;
-  auto rowc = [](int r) { return M16 ? r : (r & 3) + 8 * (r >> 2); };
-  float rr[NT][NACC], bc_[NACC];
-  float* yb = a.y + (long long)b * a.y_bs;
-  const float* resb = a.res ? a.res + (long long)b * a.res_bs : a.x;
-  const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
-  unsigned roff[NT], yoff[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const unsigned tc = (unsigned)min(colb + j * TS, a.Tout - 1);
-    roff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.res_cs + tc);
-    yoff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.y_cs + tc);
-  }
-  // Residual prefetch, issued in front of the LAST chunk's MFMAs: global_load_dword <accumulation register>, <lane offset>,
-  // <uniform row base>.  Written as asm so that the loads (a) use the SGPR-base form — left to itself the compiler materialises
-  // 112 64-bit addresses, spills them, and guards every load with a branch — and (b) land in the accumulation-register half of
-  // the file next to the accumulators.  Invisible to hipcc's s_waitcnt bookkeeping: the epilogue waits vmcnt(0) itself.
-#pragma unroll
-  for (int r = 0; r < NACC; ++r) bc_[r] = 0.f;
-  if (a.bias) {
-#pragma unroll
-    for (int r = 0; r < NACC; ++r) bc_[r] = a.bias[rowl + rowc(r) + 4 * lk];
-  }
-  if (condb) {
-#pragma unroll
-    for (int r = 0; r < NACC; ++r) bc_[r] = bc_[r] + condb[(rowl + rowc(r) + 4 * lk) * a.cond_cs];
-  }
-  if constexpr (HAS_RES) {
-#pragma unroll
-    for (int r = 0; r < NACC; ++r) {
-      const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
-#pragma unroll
-      for (int j = 0; j < NT; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
+    strip_vmcnt0();
+    fix_rows(0);
+    int it = 0;
+    for (int c0 = BC; c0 < a.Cin; c0 += BC, ++it) {
+      __syncthreads();   // chunk `it` has landed (and is activated) for every wave; everyone is done reading the other buffer
+      issue_begin((it & 1) ^ 1);
+      first_reads(it & 1);
+      groups(it & 1, 0, q_issue, std::true_type{});
+      groups(it & 1, q_issue, n_cc, std::false_type{});
+      while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }   // (not reached for the shapes the launcher admits)
+      wsrc += wstep;
+      xsrc += xstep;
+      strip_vmcnt0();    // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
+      fix_rows((it + 1) & 1);
     }
-  }
-  first_reads(it & 1);
-  groups(it & 1, 0, n_cc, std::false_type{});
-#undef SVC_STRIP_LD
+    __syncthreads();
 
-  // ---- epilogue straight from the accumulators (same expression and order as conv_epilogue's plain path).  The accumulate
-  // operand y_old (beta != 0: the last conv of an MRF chain adds into the stage sum) is not prefetched — accumulators plus one
-  // prefetched tensor fill the accumulation registers — but fetched here tile by tile: 2 of a stage's 18 launches pay for it.
-  const float oslope = a.post_act == SVC_ACT_LRELU ? a.post_slope : 1.f;   // the launcher admits none / leaky-ReLU with 0 <= slope <= 1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual prefetch (landed long ago)
-  // Column predicates are per MFMA tile (7 exec-mask regions, not 112); the accumulate / divide form (last conv of an MRF
-  // chain: y = (v + beta*y_old) / out_div, IEEE division as in conv_epilogue) is a wave-uniform second copy.
-  auto finish = [&](auto accdiv_tag) {
-    constexpr bool ACCDIV = decltype(accdiv_tag)::value;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (rows_ok && colb + j * TS < a.Tout) {
-        float yo[NACC];
-        if constexpr (ACCDIV) {
-#pragma unroll
-          for (int r = 0; r < NACC; ++r) {
-            const float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(yo[r]) : "v"(yoff[j]), "s"(yp));
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-          float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
-          float v = acc[j][r] + bc_[r];
-          v = __builtin_amdgcn_fmed3f(v, v * oslope, __builtin_inff());   // == svc_lrelu for 0 <= slope <= 1; slope 1: identity
-          if constexpr (HAS_RES) v = v + rr[j][r];
-          if constexpr (ACCDIV) {
-            v = v + a.beta * yo[r];
-            v = v / a.out_div;
-          }
-          asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
-        }
+    // ---- this lane's outputs: row(r) = rowu + rowc(r) + 4*lk, column(j) = colb + j*TS.  Addresses are
+    //   (uniform row base in SGPRs: tensor + (rowu + rowc(r)) * channel stride)  +  (per-lane 32-bit byte offset of (4*lk, column j))
+    // so the prefetch / epilogue need 7 offset registers per tensor instead of 112 pointers.  Columns past Tout are clamped for
+    // loads and masked for stores; a wave whose TS rows lie past Cout (Cout is a multiple of TS) reads row block 0 and stores nothing.
+    const int rowu = co0 + wm * TS;
+    const bool rows_ok = rowu < a.Cout;
+    const int rowl = rows_ok ? rowu : 0;
+    const int colb = t0 + wn * (NT * TS) + J0 * TS + ln;
+    auto rowc = [](int r) { return M16 ? r : (r & 3) + 8 * (r >> 2); };
+    float rr[NTW][NACC], bc_[NACC];
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float* resb = a.res ? a.res + (long long)b * a.res_bs : a.x;
+    const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
+    unsigned roff[NTW], yoff[NTW];
+  #pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const unsigned tc = (unsigned)min(colb + j * TS, a.Tout - 1);
+      roff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.res_cs + tc);
+      yoff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.y_cs + tc);
+    }
+    // Residual prefetch, issued in front of the LAST chunk's MFMAs: global_load_dword <accumulation register>, <lane offset>,
+    // <uniform row base>.  Written as asm so that the loads (a) use the SGPR-base form — left to itself the compiler materialises
+    // 112 64-bit addresses, spills them, and guards every load with a branch — and (b) land in the accumulation-register half of
+    // the file next to the accumulators.  Invisible to hipcc's s_waitcnt bookkeeping: the epilogue waits vmcnt(0) itself.
+  #pragma unroll
+    for (int r = 0; r < NACC; ++r) bc_[r] = 0.f;
+    if (a.bias) {
+  #pragma unroll
+      for (int r = 0; r < NACC; ++r) bc_[r] = a.bias[rowl + rowc(r) + 4 * lk];
+    }
+    if (condb) {
+  #pragma unroll
+      for (int r = 0; r < NACC; ++r) bc_[r] = bc_[r] + condb[(rowl + rowc(r) + 4 * lk) * a.cond_cs];
+    }
+    if constexpr (HAS_RES) {
+  #pragma unroll
+      for (int r = 0; r < NACC; ++r) {
+        const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
+  #pragma unroll
+        for (int j = 0; j < NTW; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
       }
     }
+    first_reads(it & 1);
+    groups(it & 1, 0, n_cc, std::false_type{});
+  #undef SVC_STRIP_LD
+
+    // ---- epilogue straight from the accumulators (same expression and order as conv_epilogue's plain path).  The accumulate
+    // operand y_old (beta != 0: the last conv of an MRF chain adds into the stage sum) is not prefetched — accumulators plus one
+    // prefetched tensor fill the accumulation registers — but fetched here tile by tile: 2 of a stage's 18 launches pay for it.
+    const float oslope = a.post_act == SVC_ACT_LRELU ? a.post_slope : 1.f;   // the launcher admits none / leaky-ReLU with 0 <= slope <= 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual prefetch (landed long ago)
+    if constexpr (HAS_RES) {   // ... and tie every later use of rr to this point (the asm loads are invisible to the scheduler)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) asm volatile("" : "+a"(rr[j][r]));
+    }
+    // Column predicates are per MFMA tile (7 exec-mask regions, not 112); the accumulate / divide form (last conv of an MRF
+    // chain: y = (v + beta*y_old) / out_div, IEEE division as in conv_epilogue) is a wave-uniform second copy.
+    auto finish = [&](auto accdiv_tag) {
+      constexpr bool ACCDIV = decltype(accdiv_tag)::value;
+  #pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        if (rows_ok && colb + j * TS < a.Tout) {
+          float yo[NACC];
+          if constexpr (ACCDIV) {
+  #pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+              const float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(yo[r]) : "v"(yoff[j]), "s"(yp));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) asm volatile("" : "+v"(yo[r]));   // uses of yo stay behind the wait
+          }
+  #pragma unroll
+          for (int r = 0; r < NACC; ++r) {
+            float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
+            float v = acc[j][r] + bc_[r];
+            v = __builtin_amdgcn_fmed3f(v, v * oslope, __builtin_inff());   // == svc_lrelu for 0 <= slope <= 1; slope 1: identity
+            if constexpr (HAS_RES) v = v + rr[j][r];
+            if constexpr (ACCDIV) {
+              v = v + a.beta * yo[r];
+              v = v / a.out_div;
+            }
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
+          }
+        }
+      }
+    };
+    if (a.beta != 0.f || a.out_div != 1.f) finish(std::true_type{});
+    else finish(std::false_type{});
+
   };
-  if (a.beta != 0.f || a.out_div != 1.f) finish(std::true_type{});
-  else finish(std::false_type{});
+  if constexpr (WPS == 1) {
+    body(std::integral_constant<int, NT>{}, std::integral_constant<int, 0>{});
+  } else {
+    if (half == 0) body(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{});
+  }
 }
 
 int g_strip_mode = 1;   // 0: off, 1: auto (svc_debug_set_conv_strip)
@@ -341,7 +367,7 @@ int g_strip_launches = 0;   // launches that took this kernel (tests ask through
 
 struct StripCfg { int TS, WM, WN; };
 
-template <int TS, int WM, int WN, int KSC, bool PREACT, bool HAS_RES>
+template <int TS, int WM, int WN, int KSC, bool PREACT, bool HAS_RES, int WPS>
 int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   constexpr int NT = 7, KPI = TS == 16 ? 4 : 2, BM = WM * TS, BN = WN * NT * TS;
   StripP p;
@@ -362,7 +388,7 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
     if (c > a.Cin || a.Cin % c || (c * a.KS) % RPP) continue;
     const int w_pieces = c * a.KS / RPP;
     const int f = w_pieces * 256 + c * xw;
-    const int steps = svc::cdiv(w_pieces, 4) + svc::cdiv(c, 4) * ppr;
+    const int steps = svc::cdiv(w_pieces, 4 * WPS) + svc::cdiv(c, 4 * WPS) * ppr;
     if ((size_t)2 * f * 4 <= 160 * 1024 && steps <= (c / KPI) * a.KS) { bc = c; npw = w_pieces; buf_f = f; break; }
   }
   if (bc == 0) return 1;
@@ -373,32 +399,40 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
   const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
   const size_t lds = (size_t)2 * buf_f * 4;
-  auto kd = conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES>;
+  auto kd = conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES, WPS>;
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(256 * WPS), lds, s, p);
   ++g_strip_launches;
   return svc::check_launch("conv1d_strip");
 }
 
-template <int TS, int WM, int WN, int KSC>
+template <int TS, int WM, int WN, int KSC, int WPS>
 int strip_launch_mode(const svc_conv1d_args& a, hipStream_t s) {
   const bool pre = a.pre_slope != 1.f, res = a.res_mode != 0;
-  if (pre && !res) return strip_launch<TS, WM, WN, KSC, true, false>(a, s);    // first conv of a ResBlock1 pair
-  if (!pre && res) return strip_launch<TS, WM, WN, KSC, false, true>(a, s);    // second conv (its input was activated by the first's epilogue)
-  if (pre && res) return strip_launch<TS, WM, WN, KSC, true, true>(a, s);      // ResBlock2 / un-fused second activation
+  if (pre && !res) return strip_launch<TS, WM, WN, KSC, true, false, WPS>(a, s);    // first conv of a ResBlock1 pair
+  if (!pre && res) return strip_launch<TS, WM, WN, KSC, false, true, WPS>(a, s);    // second conv (its input was activated by the first's epilogue)
+  if (pre && res) return strip_launch<TS, WM, WN, KSC, true, true, WPS>(a, s);      // ResBlock2 / un-fused second activation
   return 1;
 }
 
 template <int TS, int WM, int WN>
-int strip_launch_ks(const svc_conv1d_args& a, hipStream_t s) {
+int strip_launch_ks(const svc_conv1d_args& a, hipStream_t s, int wps) {
+  if (wps == 1) {
+    switch (a.KS) {
+      case 3: return strip_launch_mode<TS, WM, WN, 3, 1>(a, s);
+      case 7: return strip_launch_mode<TS, WM, WN, 7, 1>(a, s);
+      case 11: return strip_launch_mode<TS, WM, WN, 11, 1>(a, s);
+      default: return 1;
+    }
+  }
   switch (a.KS) {
-    case 3: return strip_launch_mode<TS, WM, WN, 3>(a, s);
-    case 7: return strip_launch_mode<TS, WM, WN, 7>(a, s);
-    case 11: return strip_launch_mode<TS, WM, WN, 11>(a, s);
+    case 3: return strip_launch_mode<TS, WM, WN, 3, 2>(a, s);
+    case 7: return strip_launch_mode<TS, WM, WN, 7, 2>(a, s);
+    case 11: return strip_launch_mode<TS, WM, WN, 11, 2>(a, s);
     default: return 1;
   }
 }
@@ -416,8 +450,10 @@ namespace svc {
 // Returns 1 when the shape is not one for this kernel (the caller then runs conv1d_mfma_kernel), else the launch status.
 // mode 1 (default): take the strip kernel when one of its four wave arrangements covers the launch in whole rounds of the
 // chip at >= 85 % (useful tile area / (rounds * 256 CUs * tile area)); modes 2..5 force arrangement 0..3 (tests / tuning).
+// mode + 10: the same with ONE wave per SIMD (the first form of this kernel, kept for A/B).
 int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
   if (g_strip_mode == 0) return 1;
+  const int wps = g_strip_mode >= 10 ? 1 : 2, mode = g_strip_mode % 10;
   if (a.epi != SVC_EPI_PLAIN || a.n_phase != 1 || a.y_ts != 1 || a.y_t0 != 0 || a.mask || a.premask) return 1;
   if (a.cond && a.cond_ts != 0) return 1;
   if (!(a.res_mode == 0 || a.res_mode == 1)) return 1;
@@ -435,8 +471,8 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
     const int BM = cfgs[i].WM * cfgs[i].TS, BN = cfgs[i].WN * 7 * cfgs[i].TS;
     const double n = (double)svc::cdiv(a.Cout, BM) * svc::cdiv(a.Tout, BN) * a.B;
     const double eff = ((double)a.Cout * a.Tout * a.B) / (std::ceil(n / 256.0) * 256.0 * BM * BN);
-    if (g_strip_mode >= 2) {
-      if (g_strip_mode - 2 == i) { best = i; best_eff = 1.0; }
+    if (mode >= 2) {
+      if (mode - 2 == i) { best = i; best_eff = 1.0; }
     } else if (n >= 200 && eff > best_eff) {
       best = i;
       best_eff = eff;
@@ -444,10 +480,10 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
   }
   if (best < 0 || best_eff < 0.85) return 1;
   switch (best) {
-    case 0: return strip_launch_ks<32, 4, 1>(a, s);
-    case 1: return strip_launch_ks<32, 2, 2>(a, s);
-    case 2: return strip_launch_ks<32, 1, 4>(a, s);
-    default: return strip_launch_ks<16, 4, 1>(a, s);
+    case 0: return strip_launch_ks<32, 4, 1>(a, s, wps);
+    case 1: return strip_launch_ks<32, 2, 2>(a, s, wps);
+    case 2: return strip_launch_ks<32, 1, 4>(a, s, wps);
+    default: return strip_launch_ks<16, 4, 1>(a, s, wps);
   }
 }
 

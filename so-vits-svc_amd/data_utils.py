@@ -127,8 +127,9 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
             max_shift = min(1, np.log10(1 / max_amp))
             log10_vol_shift = random.uniform(-1, max_shift)
             scale = 10 ** log10_vol_shift
-            # re-scaled audio: the reference re-transforms the whole re-scaled utterance (:105-110); done on the GPU here
-            full = spec.full * scale if isinstance(spec, SpecContext) else audio_norm * scale
+            # re-scaled audio: the reference re-transforms the re-scaled utterance AFTER cutting it to lmin * hop samples
+            # (data_utils.py:96-110), so the last frames see reflect padding, not trailing samples; done on the GPU here
+            full = audio_norm * scale
             audio_norm = audio_norm * scale
             volume = volume * scale
             spec = SpecContext(full=full, n_frames=c.shape[1])

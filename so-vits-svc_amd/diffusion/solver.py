@@ -41,13 +41,15 @@ class TrainStep:
 
     def _body(self, data, noise):
         S.wgrad_slab.active = True       # weight / bias gradients of the iteration accumulate into one pre-zeroed slab
-        S.wgrad_slab.reset()
-        self.opt.zero_grad()
-        loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
-                          gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
-        loss.backward()
-        self.opt.step()
-        S.wgrad_slab.active = False
+        try:
+            S.wgrad_slab.reset()
+            self.opt.zero_grad()
+            loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
+                              gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
+            loss.backward()
+            self.opt.step()
+        finally:
+            S.wgrad_slab.active = False  # also when the step raises: later backward passes must not get views of this slab
         return loss.detach()
 
     def _mod(self):

@@ -8,7 +8,8 @@ What is re-designed rather than mirrored:
     computed or all-reduced there, and the real branch (whose feature maps are detached by `feature_loss`) runs
     without a tape,
   * no `.item()` host syncs inside the step: the losses come back as device scalars.
-Out of scope here (SURVEY §8f "next"): DataLoader / on-disk formats, TensorBoard, evaluation audio, checkpoint rotation.
+`main()` / `run()` / `train_and_evaluate()` / `evaluate()` at the end of the file are the entry point behind the reference's CLI
+(`svc_run.py train.py -c ... -m ...`): same logs/<model> layout, checkpoints, epoch / warm-up / ExponentialLR bookkeeping.
 `fp16_run` configs are accepted but computed in fp32 (no reduced-precision kernels yet; a warning says so).
 """
 import torch
@@ -49,6 +50,13 @@ def build(hps, device):
     net_g = DataParallel(net_g)
     net_d = DataParallel(net_d)
     return net_g, net_d, optim_g, optim_d
+
+
+def _sn_buffers(net_d):
+    """The power-iteration vectors of spectral-norm discriminators (`weight_u` / `weight_v`, models.py:170,205): advanced in
+    place by every training-mode forward, so the warm-up and capture runs of a graph must hand them back untouched."""
+    mod = net_d.module if hasattr(net_d, "module") else net_d
+    return [b for n, b in mod.named_buffers() if n.endswith("weight_u") or n.endswith("weight_v")]
 
 
 class TrainStep:
@@ -122,6 +130,8 @@ class TrainStep:
             static = [t.clone() if t is not None else None for t in items]
             run = lambda: self._step_body(static[:n_in], dict(zip(nkeys, static[n_in:])) if nkeys else None)
             snaps = (self.optim_g.snapshot(), self.optim_d.snapshot())
+            sn = _sn_buffers(self.net_d)
+            sn_saved = [b.clone() for b in sn]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -130,6 +140,8 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             self.optim_g.restore(snaps[0])               # ... without counting as training steps
             self.optim_d.restore(snaps[1])
+            for b, v in zip(sn, sn_saved):
+                b.copy_(v)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with S.graph_capture(graph):
@@ -261,6 +273,8 @@ class TrainStep:
             s_items = static[:n_in]
             s_noise = dict(zip(nkeys, static[n_in:])) if nkeys else None
             snaps = (self.optim_g.snapshot(), self.optim_d.snapshot())
+            sn = _sn_buffers(self.net_d)
+            sn_saved = [b.clone() for b in sn]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -269,6 +283,8 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             self.optim_g.restore(snaps[0])               # also invalidates every packed-weight cache (version bump)
             self.optim_d.restore(snaps[1])
+            for b, v in zip(sn, sn_saved):
+                b.copy_(v)
             torch.cuda.synchronize()
             # SVC_DP_CAPTURE_COLLECTIVES=1 (opt-in, RCCL only): let the autograd hooks fire DURING capture, so the per-bucket
             # all-reduces are recorded on RCCL's stream inside the two graphs and overlap the rest of the captured backward
@@ -301,17 +317,19 @@ class TrainStep:
         for s, t in zip(static, items):
             if s is not None:
                 s.copy_(t, non_blocking=True)
-        g1.replay()
-        if not captured:
-            red_d.reduce_all()
-        self.optim_d.arena.touched = list(touched_d)
-        self.optim_d.step()
-        g2.replay()
-        if not captured:
-            red_g.reduce_all()
-        self.optim_g.arena.touched = list(touched_g)
-        self.optim_g.step()
-        S.wgrad_slab.active = False
+        try:
+            g1.replay()
+            if not captured:
+                red_d.reduce_all()
+            self.optim_d.arena.touched = list(touched_d)
+            self.optim_d.step()
+            g2.replay()
+            if not captured:
+                red_g.reduce_all()
+            self.optim_g.arena.touched = list(touched_g)
+            self.optim_g.step()
+        finally:
+            S.wgrad_slab.active = False
         res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
         self._mark_replay()
         return res
@@ -321,3 +339,202 @@ def init_distributed(rank, world, device):
     """train.py:57: one process per GPU; backend "nccl" is RCCL on ROCm."""
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+
+# ---- the entry point: `python svc_run.py train.py -c configs/config.json -m 44k` (reference train.py:35-340) -----------------
+# Same CLI, same logs/<model>/{config.json, train.log, G_<step>.pth, D_<step>.pth} layout, same checkpoint dicts
+# (utils.save_checkpoint), same epoch / warm-up / ExponentialLR bookkeeping as the reference's main() / run() /
+# train_and_evaluate() / evaluate().  What differs is below the loop: TrainStep (HIP forward + backward, fused AdamW, RCCL
+# reducer) instead of DDP + autocast + GradScaler, and every rank reads ITS shard of the file list (the reference gives every
+# rank the same batches — SURVEY.md §2a).
+global_step = 0
+
+
+class _ShardSampler(torch.utils.data.Sampler):
+    """File order as the reference's loader (shuffle=False, train.py:66-67), rank r taking items r, r + world, ..."""
+
+    def __init__(self, n_items, rank, world):
+        from data_parallel import shard_indices
+        self.idx = shard_indices(n_items, rank, world, shuffle=False, drop_last=False)
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+
+class _NullWriter:
+    """Stands in for torch.utils.tensorboard.SummaryWriter when tensorboard is not installed: the run still logs to train.log."""
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def _writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:      # noqa: BLE001 — tensorboard / protobuf missing or broken: not a reason to stop training
+        return _NullWriter()
+
+
+def _to_device(items, device):
+    out = []
+    for t in items:
+        out.append(t if t is None else (t.to(device, non_blocking=True) if hasattr(t, "to") else t))
+    return out
+
+
+def main():
+    """train.py:35-46: one process per GPU of the node."""
+    import utils
+    assert torch.cuda.is_available(), "CPU training is not allowed."
+    hps = utils.get_hparams()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:          # already one process per GPU (torch.distributed.run)
+        run(int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), int(os.environ["WORLD_SIZE"]), hps)
+        return
+    n_gpus = torch.cuda.device_count()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(hps.train.port)
+    if n_gpus == 1:
+        run(0, 1, hps)
+    else:
+        import torch.multiprocessing as mp
+        mp.spawn(run, nprocs=n_gpus, args=(n_gpus, hps,))
+
+
+def run(rank, n_gpus, hps):
+    """train.py:49-147."""
+    global global_step
+    import multiprocessing
+    import utils
+    from data_utils import TextAudioCollate, TextAudioSpeakerLoader
+    from torch.utils.data import DataLoader
+    logger = writer = writer_eval = None
+    if rank == 0:
+        logger = utils.get_logger(hps.model_dir)
+        logger.info(hps)
+        utils.check_git_hash(hps.model_dir)
+        writer = _writer(hps.model_dir)
+        writer_eval = _writer(os.path.join(hps.model_dir, "eval"))
+    device = torch.device("cuda", rank)
+    torch.cuda.set_device(device)
+    if n_gpus > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="env://", world_size=n_gpus, rank=rank, device_id=device)
+    torch.manual_seed(hps.train.seed)
+    collate_fn = TextAudioCollate()
+    all_in_mem = hps.train.all_in_mem
+    train_dataset = TextAudioSpeakerLoader(hps.data.training_files, hps, all_in_mem=all_in_mem)
+    num_workers = 0 if all_in_mem else (5 if multiprocessing.cpu_count() > 4 else multiprocessing.cpu_count())
+    num_workers = int(os.environ.get("SVC_LOADER_WORKERS", num_workers))
+    sampler = _ShardSampler(len(train_dataset), rank, n_gpus) if n_gpus > 1 else None
+    train_loader = DataLoader(train_dataset, num_workers=num_workers, shuffle=False, sampler=sampler, pin_memory=True,
+                              batch_size=hps.train.batch_size, collate_fn=collate_fn)
+    eval_loader = None
+    if rank == 0:
+        eval_dataset = TextAudioSpeakerLoader(hps.data.validation_files, hps, all_in_mem=all_in_mem, vol_aug=False)
+        eval_loader = DataLoader(eval_dataset, num_workers=min(1, num_workers), shuffle=False, batch_size=1, pin_memory=False,
+                                 drop_last=False, collate_fn=collate_fn)
+
+    net_g, net_d, optim_g, optim_d = build(hps, device)
+
+    skip_optimizer = False
+    try:
+        _, _, _, epoch_str = utils.load_checkpoint(utils.latest_checkpoint_path(hps.model_dir, "G_*.pth"), net_g, optim_g,
+                                                   skip_optimizer)
+        _, _, _, epoch_str = utils.load_checkpoint(utils.latest_checkpoint_path(hps.model_dir, "D_*.pth"), net_d, optim_d,
+                                                   skip_optimizer)
+        epoch_str = max(epoch_str, 1)
+        name = utils.latest_checkpoint_path(hps.model_dir, "D_*.pth")
+        global_step = int(name[name.rfind("_") + 1:name.rfind(".")]) + 1
+    except Exception:      # noqa: BLE001 — same policy as train.py:106-109: no (readable) checkpoint = fresh start
+        print("load old checkpoint failed...")
+        epoch_str = 1
+        global_step = 0
+    for opt in (optim_g, optim_d):
+        for group in opt.param_groups:
+            group.setdefault("initial_lr", hps.train.learning_rate)
+    warmup_epoch = hps.train.warmup_epochs
+    scheduler_g = torch.optim.lr_scheduler.ExponentialLR(optim_g, gamma=hps.train.lr_decay, last_epoch=epoch_str - 2)
+    scheduler_d = torch.optim.lr_scheduler.ExponentialLR(optim_d, gamma=hps.train.lr_decay, last_epoch=epoch_str - 2)
+    step = TrainStep(hps, net_g, net_d, optim_g, optim_d)
+    if os.environ.get("SVC_TRAIN_GRAPH", "0") == "1":   # one hipGraph per padded batch shape: for loaders that bucket lengths
+        step.enable_graph(True)
+
+    for epoch in range(epoch_str, hps.train.epochs + 1):
+        if epoch <= warmup_epoch:                                                     # train.py:126-131
+            for opt in (optim_g, optim_d):
+                for group in opt.param_groups:
+                    group["lr"] = hps.train.learning_rate / warmup_epoch * epoch
+        train_and_evaluate(rank, epoch, hps, step, [train_loader, eval_loader], logger, [writer, writer_eval], device)
+        scheduler_g.step()
+        scheduler_d.step()
+
+
+def train_and_evaluate(rank, epoch, hps, step, loaders, logger, writers, device):
+    """train.py:136-275: one epoch; logging / evaluation / checkpoints on rank 0 at the reference's intervals."""
+    global global_step
+    import time
+    import utils
+    train_loader, eval_loader = loaders
+    writer, writer_eval = writers
+    net_g, net_d, optim_g, optim_d = step.net_g, step.net_d, step.optim_g, step.optim_d
+    net_g.train()
+    net_d.train()
+    t_epoch = time.time()
+    for batch_idx, items in enumerate(train_loader):
+        out = step(_to_device(items, device))
+        if rank == 0:
+            if global_step % hps.train.log_interval == 0:
+                lr = optim_g.param_groups[0]["lr"]
+                losses = [out["loss_disc"], out["loss_gen"], out["loss_fm"], out["loss_mel"], out["loss_kl"]]
+                vals = [float(x) for x in losses]
+                logger.info("Train Epoch: {} [{:.0f}%]".format(epoch, 100. * batch_idx / len(train_loader)))
+                logger.info(f"Losses: {vals}, step: {global_step}, lr: {lr}, reference_loss: {sum(vals)}")
+                scalars = {"loss/g/total": float(out["loss_gen_all"]), "loss/d/total": vals[0], "learning_rate": lr,
+                           "loss/g/fm": vals[2], "loss/g/mel": vals[3], "loss/g/kl": vals[4], "loss/g/lf0": float(out["loss_lf0"])}
+                utils.summarize(writer=writer, global_step=global_step, scalars=scalars)
+            if global_step % hps.train.eval_interval == 0:
+                evaluate(hps, net_g, eval_loader, writer_eval, device)
+                utils.save_checkpoint(net_g, optim_g, hps.train.learning_rate, epoch,
+                                      os.path.join(hps.model_dir, "G_{}.pth".format(global_step)))
+                utils.save_checkpoint(net_d, optim_d, hps.train.learning_rate, epoch,
+                                      os.path.join(hps.model_dir, "D_{}.pth".format(global_step)))
+                keep_ckpts = getattr(hps.train, "keep_ckpts", 0)
+                if keep_ckpts > 0:
+                    utils.clean_checkpoints(path_to_models=hps.model_dir, n_ckpts_to_keep=keep_ckpts, sort_by_time=True)
+        global_step += 1
+    if rank == 0:
+        logger.info(f"====> Epoch: {epoch}, cost {format(time.time() - t_epoch, '.2f')} s")
+
+
+def evaluate(hps, generator, eval_loader, writer_eval, device):
+    """train.py:278-335: the first item of every validation batch through SynthesizerTrn.infer; audio and the mel L1 distance
+    go to the eval writer."""
+    import utils
+    gen = generator.module if hasattr(generator, "module") else generator
+    gen.eval()
+    d = hps.data
+    audio, dist_sum, n = {}, 0.0, 0
+    with torch.no_grad():
+        for batch_idx, items in enumerate(eval_loader):
+            c, f0, spec, y, spk, _, uv, volume = _to_device(items, device)
+            vol = volume[:1] if volume is not None else None
+            y_hat, _ = gen.infer(c[:1], f0[:1], uv[:1], g=spk[:1], vol=vol)
+            y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1).float(), d.filter_length, d.n_mel_channels, d.sampling_rate,
+                                              d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
+            y_mel = mel_spectrogram_torch(y[:1].squeeze(1).float(), d.filter_length, d.n_mel_channels, d.sampling_rate,
+                                          d.hop_length, d.win_length, d.mel_fmin, d.mel_fmax)
+            T = min(y_mel.shape[-1], y_hat_mel.shape[-1])
+            dist_sum += float((y_mel[..., :T] - y_hat_mel[..., :T]).abs().mean())
+            n += 1
+            audio.update({f"gen/audio_{batch_idx}": y_hat[0], f"gt/audio_{batch_idx}": y[0]})
+    utils.summarize(writer=writer_eval, global_step=global_step, audios=audio, audio_sampling_rate=d.sampling_rate,
+                    scalars={"eval/mel_l1": dist_sum / max(n, 1)})
+    gen.train()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,8 +153,8 @@ def test_resblock_pair_equals_two_conv_launches(dev, C, K, d, B, T):
 
 
 # ---- conv1d_strip.hip: the one-workgroup-per-CU strip kernel for long dense convs (MRF ResBlock convs) -------------------
-# Forced arrangement (svc_debug_set_conv_strip(2 + i)): 0 = 32x32 MFMA 4x1 waves (128 x 224 tile), 1 = 2x2 (64 x 448),
-# 2 = 1x4 (32 x 896), 3 = 16x16 MFMA 4x1 (64 x 112).  Shapes cover ragged tails (T not a multiple of the strip), sequences
+# Forced arrangement (svc_debug_set_conv_strip(2 + i)): 0 = 32x32 MFMA 4x1 strips (128 x 224 tile), 1 = 2x2 (64 x 448),
+# 2 = 1x4 (32 x 896), 3 = 16x16 MFMA 4x1 (64 x 112); + 10 = one wave per strip instead of two (4 + 3 tiles).  Shapes cover ragged tails (T not a multiple of the strip), sequences
 # shorter than one strip, several row tiles, a wave whose rows lie past Cout, batches, and both tensor-edge paddings.
 STRIP_CASES = [
     # arr, B, Cin, Cout, T, KS, dil
@@ -179,8 +179,9 @@ def strip_mode():
     S.lib().svc_debug_set_conv_strip(1)
 
 
+@pytest.mark.parametrize("wps", [2, 1])
 @pytest.mark.parametrize("arr,B,Cin,Cout,T,KS,dil", STRIP_CASES)
-def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil):
+def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil, wps):
     """Every epilogue form the MRF stage uses (vdecoder/hifigan/models.py:60-67,382-388), strip kernel vs the kernels it
     replaces (fp32 round-off: these short test sequences take split-K / register-fed tilings there, and the 16x16x4 instruction
     groups its products differently from 32x32x2) and vs torch CPU fp32."""
@@ -205,7 +206,7 @@ def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil):
     for name, kw, beta, div, ref_fn in forms:
         ref = ref_fn()
         outs = []
-        for mode in (2 + arr, 0):
+        for mode in (2 + arr + (10 if wps == 1 else 0), 0):
             strip_mode(mode)
             out = prev.to(dev).clone()
             S.conv1d(xd, wp, Cout, KS, bias=bd, dil=dil, pad_left=pad, out=out, beta=beta, out_div=div, **kw)
