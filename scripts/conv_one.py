@@ -14,7 +14,13 @@ w = torch.randn(Cout, Cin, k, device=dev) / (Cin * k) ** 0.5
 b = torch.randn(Cout, device=dev)
 wp = S.pack_conv1d_weight(w)
 out = torch.empty(1, Cout, L, device=dev)
+mode = os.environ.get("BENCH_CONV_MODE", "both")
+if mode == "conv1":
+    kw = dict(pre_slope=0.1, post_act=S.ACT_LRELU, post_slope=0.1)
+elif mode == "conv2":
+    kw = dict(res=x if Cin == Cout else None, res_mode=1 if Cin == Cout else 0)
+else:
+    kw = dict(pre_slope=0.1, res=x if Cin == Cout else None, res_mode=1 if Cin == Cout else 0)
 for _ in range(n):
-    S.conv1d(x, wp, Cout, k, bias=b, dil=d, pad_left=(k * d - d) // 2, pre_slope=0.1, res=x if Cin == Cout else None,
-             res_mode=1 if Cin == Cout else 0, out=out)
+    S.conv1d(x, wp, Cout, k, bias=b, dil=d, pad_left=(k * d - d) // 2, out=out, **kw)
 torch.cuda.synchronize()

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   const int tin_base = tin0 - sh;
 
   // ---- LDS-DMA.  A chunk in LDS = W block [BC*KSC][BM] (NPW pieces of 1 KiB = RPP whole rows each) then X block [BC][XW].
-  // Wave w of the NWV waves fetches the W pieces pc = w, w+NWV, ... and the X rows r = w, w+NWV, ...; an X row is PPR pieces, piece pp covering the
+  // Fetching wave w (of four) takes the W pieces pc = w, w+4, ... and the X rows r = w, w+4, ...; an X row is PPR pieces, piece pp covering the
   // float4 columns [min(64*pp, XW4-64), +64) — the last piece overlaps its neighbour instead of running past the row (XW4 >= 64).
   // A piece's source is (uniform base: tensor chunk base + piece / row offset, all scalar arithmetic) + (a per-lane byte offset:
   // constant for W pieces, 4 VALU for X pieces), so issuing a piece costs ~10 SALU + 1 VMEM: it hides under one fp32 MFMA.
@@ -109,8 +109,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   const char* xsrc = reinterpret_cast<const char*>(xb);
   const long long wstep = (long long)BC * KSC * a.CoutP * 4, xstep = (long long)BC * a.x_cs * 4;
   const long long wpiece = (long long)RPP * a.CoutP * 4, xrow = a.x_cs * 4;
-  const int nw_mine = max(0, (NPW - wave + NWV - 1) / NWV);
-  const int steps_mine = nw_mine + max(0, (BC - wave + NWV - 1) / NWV) * PPR;
+  // Who fetches: with one wave per SIMD, all four; with two, ONLY the second wave of each SIMD (waves 4..7, the 3-tile halves).
+  // Their partner (4 tiles) goes from the barrier straight to its MFMAs and keeps the matrix pipe busy while the burst is issued;
+  // the 3-tile wave has one MFMA slot per tap of slack (44 x 64 cycles per chunk at k = 11), more than the burst costs.
+  const bool is_dma = WPS == 1 || half == 1;
+  const int dw = strip;   // index among the four fetching waves
+  const int nw_mine = is_dma ? max(0, (NPW - dw + 3) / 4) : 0;
+  const int steps_mine = is_dma ? nw_mine + max(0, (BC - dw + 3) / 4) * PPR : 0;
   // Issue state of the chunk being fetched, all wave-uniform and advanced incrementally (no multiplies per piece):
   int si = 0, xpp = 0;
   const char *wptr = nullptr, *xptr = nullptr;
@@ -118,10 +123,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   auto issue_begin = [&](int buf) {
     const unsigned bufb = lds_base + (unsigned)buf * (unsigned)buf_f * 4u;
     si = 0; xpp = 0;
-    wptr = wsrc + wave * wpiece;
-    xptr = xsrc + wave * xrow;
-    wdst = bufb + (unsigned)wave * 1024u;
-    xdst = bufb + 4u * (unsigned)(wfl + wave * XW);
+    wptr = wsrc + dw * wpiece;
+    xptr = xsrc + dw * xrow;
+    wdst = bufb + (unsigned)dw * 1024u;
+    xdst = bufb + 4u * (unsigned)(wfl + dw * XW);
   };
   // One piece in three parts, so that each part fits under ONE fp32 MFMA (64 cycles) when they are placed between the MFMAs of
   // a tap: A = addresses (branch-free selects between the W and the X form), B = the DMA instruction, C = state update.
@@ -143,22 +148,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   bool wrap = false;
   auto issue_c = [&]() {
     wrap = !isw && xpp + 1 == PPR;
-    wptr += isw ? NWV * wpiece : 0;
-    wdst += isw ? 1024u * NWV : 0u;
+    wptr += isw ? 4 * wpiece : 0;
+    wdst += isw ? 4096u : 0u;
     xpp = isw ? xpp : (wrap ? 0 : xpp + 1);
     asm volatile("" ::"s"(wptr), "s"(wdst), "s"(xpp));
   };
   auto issue_d = [&]() {
-    xptr += wrap ? NWV * xrow : 0;
-    xdst += wrap ? 4u * NWV * (unsigned)XW : 0u;
+    xptr += wrap ? 4 * xrow : 0;
+    xdst += wrap ? 16u * (unsigned)XW : 0u;
     ++si;
     asm volatile("" ::"s"(xptr), "s"(xdst), "s"(si));
   };
   const bool edge = tin_base < 0 || tin_base + XW > a.Tin;   // this tile's X block reaches past an end of the sequence
   const float ps = a.pre_slope;
   auto fix_rows = [&](int buf) {   // own rows, in place: zero padding (edge tiles) and the pre-activation max(v, slope*v)
-    if (!(PREACT || edge)) return;
-    for (int r = wave; r < BC; r += NWV) {
+    if (!(PREACT || edge) || !is_dma) return;
+    for (int r = dw; r < BC; r += 4) {
       float* row = smem + buf * buf_f + wfl + r * XW;
       for (int c4 = lane; c4 < XW4; c4 += 64) {
         const int tin = tin_base + c4 * 4;
@@ -186,19 +191,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
 
     const int dil = a.dil;
     const int n_cc = BC / KPI;
-    const int q_issue = min(n_cc, (steps_mine + KSC - 1) / KSC);   // channel groups whose taps carry a piece each
 
-    // MFMAs over channel groups [q0, q1) of buffer `buf`.  ISSUE: one piece of the next chunk is issued per tap, after the tap's
-    // first MFMA — under the matrix pipe's 64 busy cycles.  Operand reads run two taps ahead of their MFMAs, across the loop
-    // back-edge and across the two calls of a chunk (qlast = the chunk's last group: its look-ahead re-reads itself, unused).
+    // MFMAs over channel groups [q0, q1) of buffer `buf`.  Operand reads run two taps ahead of their MFMAs, across the loop
+    // back-edge too (the chunk's last group looks ahead at itself: re-read, unused).
     float av[KSC], bv[KSC][NTW];
   #define SVC_STRIP_LD(k_, wa_, xa_)                                           \
     {                                                                          \
       av[k_] = (wa_)[(k_) * BM];                                               \
       _Pragma("unroll") for (int j = 0; j < NTW; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
     }
-    auto groups = [&](int buf, int q0, int q1, auto issue_tag) {   // (ISSUE: the pieces go to the OTHER buffer, set by issue_begin)
-      constexpr bool ISSUE = decltype(issue_tag)::value;
+    auto groups = [&](int buf, int q0, int q1) {
       const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
       const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
       for (int q = q0; q < q1; ++q) {
@@ -217,16 +219,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
           for (int j = 0; j < NTW; ++j) {
             if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k][j], acc[j], 0, 0, 0);
             else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k][j], acc[j], 0, 0, 0);
-            if constexpr (ISSUE) {
-              if (j <= 3) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (j == 0) issue_a();
-                else if (j == 1) issue_b();
-                else if (j == 2) issue_c();
-                else issue_d();
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
           }
         }
       }
@@ -238,7 +230,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       SVC_STRIP_LD(1, wl, xl)
     };
 
-    // ---- first chunk in, then [barrier, MFMAs of chunk i with the DMA of chunk i+1 riding along, wait for own pieces, fix rows]
+    // ---- first chunk in, then [barrier, DMA burst of chunk i+1, MFMAs of chunk i, wait for own pieces, fix own rows]
     issue_begin(0);
     while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
     wsrc += wstep;
@@ -248,11 +240,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
     int it = 0;
     for (int c0 = BC; c0 < a.Cin; c0 += BC, ++it) {
       __syncthreads();   // chunk `it` has landed (and is activated) for every wave; everyone is done reading the other buffer
+      // the next chunk's pieces go out as ONE burst, before this wave has any operand read in flight: an LDS-DMA instruction
+      // issued behind pending ds_reads waits for them (measured: one piece per tap inside the MFMA stream cost ~75 cycles of
+      // every SIMD per piece, 1.3x the MFMA time at 128 channels, 1.8x at 256 — profiles/r03b_*, r03c_*); back to back after the
+      // barrier a piece costs ~60 cycles of the issuing wave only
       issue_begin((it & 1) ^ 1);
+      while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
       first_reads(it & 1);
-      groups(it & 1, 0, q_issue, std::true_type{});
-      groups(it & 1, q_issue, n_cc, std::false_type{});
-      while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }   // (not reached for the shapes the launcher admits)
+      groups(it & 1, 0, n_cc);
       wsrc += wstep;
       xsrc += xstep;
       strip_vmcnt0();    // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
@@ -303,7 +298,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       }
     }
     first_reads(it & 1);
-    groups(it & 1, 0, n_cc, std::false_type{});
+    groups(it & 1, 0, n_cc);
   #undef SVC_STRIP_LD
 
     // ---- epilogue straight from the accumulators (same expression and order as conv_epilogue's plain path).  The accumulate
@@ -379,17 +374,14 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
     while ((xw & 31) != 16) xw += 4;
   }
   p.XW = xw;
-  // largest chunk (power-of-two multiple of KPI dividing Cin) whose weight block is whole pieces, whose two buffers fit
-  // 160 KiB, and whose pieces per wave do not outnumber the chunk's taps (one piece rides on each tap of the previous chunk)
+  // largest chunk (power-of-two multiple of KPI dividing Cin) whose weight block is whole pieces and whose two buffers fit 160 KiB
   constexpr int RPP = 64 / (BM / 4);
-  const int ppr = (xw / 4 + 63) / 64;
   int bc = 0, npw = 0, buf_f = 0;
   for (int c = 64; c >= KPI; c >>= 1) {
     if (c > a.Cin || a.Cin % c || (c * a.KS) % RPP) continue;
     const int w_pieces = c * a.KS / RPP;
     const int f = w_pieces * 256 + c * xw;
-    const int steps = svc::cdiv(w_pieces, 4 * WPS) + svc::cdiv(c, 4 * WPS) * ppr;
-    if ((size_t)2 * f * 4 <= 160 * 1024 && steps <= (c / KPI) * a.KS) { bc = c; npw = w_pieces; buf_f = f; break; }
+    if ((size_t)2 * f * 4 <= 160 * 1024) { bc = c; npw = w_pieces; buf_f = f; break; }
   }
   if (bc == 0) return 1;
   p.BC = bc;
@@ -473,7 +465,7 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
     const double eff = ((double)a.Cout * a.Tout * a.B) / (std::ceil(n / 256.0) * 256.0 * BM * BN);
     if (mode >= 2) {
       if (mode - 2 == i) { best = i; best_eff = 1.0; }
-    } else if (n >= 200 && eff > best_eff) {
+    } else if (i < 3 && n >= 200 && eff > best_eff) {   // (the 16x16x4 form loses to the tiled kernel at 256 channels: forced modes only)
       best = i;
       best_eff = eff;
     }

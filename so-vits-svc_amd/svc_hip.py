@@ -122,6 +122,9 @@ def lib():
         L.svc_resample_sinc_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 2 + [C.c_int] * 7 + [C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
+        L.svc_debug_set_conv_strip.argtypes = [C.c_int]
+        if os.environ.get("SVC_CONV_STRIP"):     # A/B switch of the strip kernel (csrc/conv1d_strip.hip), read once at load
+            L.svc_debug_set_conv_strip(int(os.environ["SVC_CONV_STRIP"]))
         _lib = L
     return _lib
 
@@ -654,9 +657,6 @@ def tlib():
         L.svc_adamw_advance.argtypes = [_f32p, vp]
         L.svc_debug_set_conv_cfg.argtypes = [i]
         L.svc_debug_set_wgrad_target.argtypes = [i]
-        L.svc_debug_set_conv_strip.argtypes = [i]
-        if os.environ.get("SVC_CONV_STRIP"):
-            L.svc_debug_set_conv_strip(int(os.environ["SVC_CONV_STRIP"]))
         L.svc_debug_set_gconv_version.argtypes = [i]
         L.svc_debug_set_pair_pipelined.argtypes = [i]
         L.svc_debug_set_gemm_pipelined.argtypes = [i]

@@ -218,8 +218,9 @@ def test_conv1d_strip_kernel(dev, strip_mode, arr, B, Cin, Cout, T, KS, dil, wps
 
 
 def test_conv1d_strip_auto_selection_mrf_shapes(dev, strip_mode):
-    """Automatic routing: the five MRF stage shapes of a 10 s clip (T = 862 frames) except the fused 16-channel stage go to the
-    strip kernel; short / batched training shapes do not."""
+    """Automatic routing: the 128 / 64 / 32-channel MRF stage shapes of a 10 s clip (T = 862 frames) go to the strip kernel
+    (the 256-channel stage stays on the tiled kernel, which measures faster there; 16 channels run the fused pair); short /
+    batched training shapes do not."""
     import svc_hip as S
     strip_mode(1)
     L = 862
@@ -229,14 +230,12 @@ def test_conv1d_strip_auto_selection_mrf_shapes(dev, strip_mode):
         wp = S.pack_conv1d_weight(torch.randn(C, C, 3, device=dev) * 0.05)
         n0 = S.lib().svc_debug_set_conv_strip(-1)
         y = S.conv1d(x, wp, C, 3, pad_left=1, res=x, res_mode=1)
-        assert S.lib().svc_debug_set_conv_strip(-1) == n0 + 1, (C, L)
+        assert S.lib().svc_debug_set_conv_strip(-1) == n0 + (1 if C <= 128 else 0), (C, L)
         strip_mode(0)
         y0 = S.conv1d(x, wp, C, 3, pad_left=1, res=x, res_mode=1)
         strip_mode(1)
-        if C <= 128:   # same instruction, same order of the reduction, same epilogue expression as the 32x32-tile kernels: bit-equal
-            assert torch.equal(y, y0), (C, L)
-        else:          # 256 channels run the 16x16x4 form
-            assert _rel(y, y0) < 3e-6, (C, L)
+        # same instruction, same order of the reduction, same epilogue expression as the 32x32-tile kernels: bit-equal
+        assert torch.equal(y, y0), (C, L)
     x = torch.randn(16, 128, 1024, device=dev)
     wp = S.pack_conv1d_weight(torch.randn(128, 128, 3, device=dev) * 0.05)
     n0 = S.lib().svc_debug_set_conv_strip(-1)
