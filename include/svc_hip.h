@@ -507,10 +507,6 @@ int svc_debug_set_conv_cfg(int cfg);
  * mode + 10: the same with one wave per strip instead of two (A/B of the first form of the kernel);
  * a negative mode changes nothing and returns the number of launches that have taken the strip kernel so far (tests). */
 int svc_debug_set_conv_strip(int mode);
-/* Tuning aid: 1 selects the software-pipelined inner loop of svc_gemm_f32's 128x128 kernel (built, not yet measured; default 0). */
-int svc_debug_set_gemm_pipelined(int on);
-/* Tuning aid: 1 selects the operand-preloading instantiations of svc_resblock_pair_f32 (built, not yet measured; default 0). */
-int svc_debug_set_pair_pipelined(int on);
 /* Tuning aid: 1 selects the first (one thread per output) grouped-conv kernels, 2 the LDS-tiled ones (default). */
 int svc_debug_set_gconv_version(int version);
 /* Tuning aid: number of workgroups svc_conv1d_wgrad_f32 splits a 3..5-tap launch into over time (default 256 = one per CU);

@@ -3,7 +3,7 @@
 # scripts of rounds 1-2.  usage: gpurun -- 'bash scripts/gpu_session.sh TAG step [step ...]'
 #   convtests   pytest of tests/test_conv1d_gpu.py          fulltests  whole -m gpu suite
 #   convbench   bench_conv.py strip=0 / strip=1 in the pair's two forms
-#   pairbench   bench_pair.py with the PIPE variants off / on      gemmbench  bench_train_kernels.py gemm, pipelined off / on
+#   pairbench   bench_pair.py (fused ResBlock pair vs two launches)   gemmbench  bench_train_kernels.py gemm
 #   inferab     bench.py --mode infer under SVC_CONV_STRIP x SVC_MRF_STREAMS
 #   bench       the driver's default bench.py line          prof       rocprofv3 kernel-trace stats of the infer step (serialised)
 #   trainprof   rocprofv3 kernel-trace stats of the training step  pmc  FETCH_SIZE / WRITE_SIZE passes of the infer step
@@ -18,8 +18,8 @@ case $step in
 convtests) timeout 600 python -m pytest tests/test_conv1d_gpu.py -m gpu -q --timeout=300 -rf > ${O}_convtests.log 2>&1; tail -15 ${O}_convtests.log ;;
 fulltests) timeout 1200 python -m pytest tests -m gpu -q --timeout=300 -rf > ${O}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> ${O}_pytest_gpu.log; tail -15 ${O}_pytest_gpu.log ;;
 convbench) for m in conv1 conv2; do BENCH_CONV_MODE=$m timeout 300 python scripts/bench_conv.py strip=0 0 strip=1 0 > ${O}_convbench_$m.txt 2>&1; cat ${O}_convbench_$m.txt; done ;;
-pairbench) for pp in 0 1; do SVC_PAIR_PIPELINED=$pp timeout 300 python scripts/bench_pair.py > ${O}_pairbench_pipe$pp.txt 2>&1; tail -8 ${O}_pairbench_pipe$pp.txt; done ;;
-gemmbench) for pp in 0 1; do SVC_GEMM_PIPELINED=$pp timeout 300 python scripts/bench_train_kernels.py gemm > ${O}_gemmbench_pipe$pp.txt 2>&1; cat ${O}_gemmbench_pipe$pp.txt; done ;;
+pairbench) timeout 300 python scripts/bench_pair.py > ${O}_pairbench.txt 2>&1; tail -8 ${O}_pairbench.txt ;;
+gemmbench) timeout 300 python scripts/bench_train_kernels.py gemm > ${O}_gemmbench.txt 2>&1; cat ${O}_gemmbench.txt ;;
 inferab) for st in 0 1; do for ms in 1 0; do SVC_CONV_STRIP=$st SVC_MRF_STREAMS=$ms timeout 300 python bench.py --mode infer --steps 30 --warmup 5 --no-cpu-baseline > ${O}_infer_strip${st}_streams${ms}.json 2> ${O}_infer_strip${st}_streams${ms}.err; cat ${O}_infer_strip${st}_streams${ms}.json; done; done ;;
 bench) timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cat ${O}_bench.json; tail -3 ${O}_bench.err ;;
 prof) rm -rf gpurun_out/prof_stats; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline > ${O}_prof_bench.json 2> ${O}_prof_bench.err

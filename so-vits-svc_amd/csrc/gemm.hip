@@ -11,8 +11,6 @@
 
 namespace {
 
-int g_gemm_pipe = 0;   // 1: gemm_f32_big_kernel<true> (svc_debug_set_gemm_pipelined); unmeasured -> off
-
 constexpr int GM = 64, GN = 64, GK = 32, GP = 65;
 
 struct GemmP {
@@ -75,11 +73,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 // MFMA loop over chunk i (same software pipeline as conv1d_mfma).  Used when both M and N are >= 96.
 constexpr int HM = 128, HN = 128, HK = 16, HP = 129;
 
-// PIPE: the operands of k-step kk+2 are read from LDS BEFORE the four MFMAs of step kk (second register set, order pinned
-// with sched_barrier).  In the plain form hipcc reuses one register set: ds_read2 x2 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs
-// -> next reads, i.e. the LDS latency is exposed once per 4 MFMAs (read off the ISA).  Built, default off until measured
-// (svc_debug_set_gemm_pipelined).
-template <bool PIPE>
+// (round 3: a software-pipelined inner loop — second operand register set, reads two k-steps ahead — measured 66.1 vs 64.6 us
+// on the QK^T shape, profiles/r03a_gemmbench_*: slower, deleted.)
 __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmP p) {
   const svc_gemm_args& a = p.a;
   __shared__ float As[HK * HP];
@@ -140,36 +135,16 @@ __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmP p) {
     store_chunk(k0);
     __syncthreads();
     if (k0 + HK < a.K) load_chunk(k0 + HK);
-    if constexpr (PIPE) {
-      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
-      for (int kk = 0; kk < HK; kk += 2) {
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        if (kk + 2 < HK) {
-          na0 = ap[(kk + 2) * HP];
-          na1 = ap[(kk + 2) * HP + 32];
-          nb0 = bp[(kk + 2) * HP];
-          nb1 = bp[(kk + 2) * HP + 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);     // the next step's reads stay in front of this step's MFMAs
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < HK; kk += 2) {
-        const float a0 = ap[kk * HP], a1 = ap[kk * HP + 32];
-        const float b0 = bp[kk * HP], b1 = bp[kk * HP + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
+    for (int kk = 0; kk < HK; kk += 2) {
+      const float a0 = ap[kk * HP], a1 = ap[kk * HP + 32];
+      const float b0 = bp[kk * HP], b1 = bp[kk * HP + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+  
   }
   float* Cb = a.C + (long long)b * a.c_bs;
 #pragma unroll
@@ -192,11 +167,6 @@ __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmP p) {
 
 }  // namespace
 
-extern "C" int svc_debug_set_gemm_pipelined(int on) {
-  g_gemm_pipe = on ? 1 : 0;
-  return SVC_OK;
-}
-
 extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
   SVC_REQUIRE(ap != nullptr, "gemm: null args");
   const svc_gemm_args& a = *ap;
@@ -211,8 +181,7 @@ extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
   p.b_n_fast = (a.b_ns == 1 || (a.b_ks != 1 && llabs(a.b_ns) < llabs(a.b_ks))) ? 1 : 0;
   if (a.M >= 96 && a.N >= 96) {
     dim3 grid(svc::cdiv(a.N, HN), svc::cdiv(a.M, HM), a.batch);
-    if (g_gemm_pipe) hipLaunchKernelGGL(gemm_f32_big_kernel<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_f32_big_kernel<false>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(gemm_f32_big_kernel, grid, dim3(256), 0, s, p);
   } else {
     dim3 grid(svc::cdiv(a.N, GN), svc::cdiv(a.M, GM), a.batch);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);

@@ -38,11 +38,9 @@ struct PairCfg {
 
 __device__ __forceinline__ float lrelu01(float v, float s) { return fmaxf(v, v * s); }   // 0 <= s <= 1
 
-// PIPE: operand reads hoisted in front of the MFMA chain of a column tile.  In the plain form hipcc emits, per MFMA,
-// ds_read -> s_waitcnt lgkmcnt(0) -> leaky-ReLU -> MFMA on ONE reused operand register (read off the ISA of <16,3>): LDS
-// latency, VALU and the dependent MFMA never overlap, ~6x the MFMA issue time.  Same accumulation order, so the results stay
-// bit-identical to the plain form.  Built but NOT the default until it has been measured (svc_debug_set_pair_pipelined).
-template <int C, int KS, bool PIPE>
+// (round 3: the operand-preloading variant of this kernel measured identical to this form — 1716 vs 1716 us over the 18 pair
+// shapes, profiles/r03a_pairbench_* — and was deleted.)
+template <int C, int KS>
 __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(PairP p) {
   using Cf = PairCfg<C, KS>;
   constexpr int TS = Cf::TS, KPI = Cf::KPI, NG = Cf::NG, NW = Cf::NW, BN = Cf::BN, NTHR = NW * 64;
@@ -107,29 +105,14 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
       const int col0 = ct * TS;
       if constexpr (M16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (PIPE) {
-          float xv[NG][KS];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
+        for (int g = 0; g < NG; ++g) {
+          const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) xv[g][k] = xr[k * d];
-          }
-          __builtin_amdgcn_sched_barrier(0);      // keep the reads in front: the scheduler otherwise sinks each to its MFMA
-#pragma unroll
-          for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[g][k], lrelu01(xv[g][k], slope), acc, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[g][k], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
-          }
+          for (int k = 0; k < KS; ++k)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[g][k], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
         }
+      
         const int t = t0 - H2 + col0 + ln;
         const bool ok = t >= 0 && t < a.T;
 #pragma unroll
@@ -141,21 +124,10 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
         for (int g = 0; g < NG; ++g) {
           const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
           const float* wr = wl + ((g * KPI + lk) * KS) * C + ln;
-          if constexpr (PIPE) {
-            float xv[KS], wv[KS];
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-              xv[k] = xr[k * d];
-              wv[k] = wr[k * C];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[k], lrelu01(xv[k], slope), acc, 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
-          }
+          for (int k = 0; k < KS; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
+        
         }
         const int t = t0 - H2 + col0 + ln;
         const bool ok = t >= 0 && t < a.T;
@@ -171,27 +143,13 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
       const int t = t0 + col0 + ln;
       if constexpr (M16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (PIPE) {
-          float mv[NG][KS];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
+        for (int g = 0; g < NG; ++g) {
+          const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) mv[g][k] = mr[k];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[g][k], mv[g][k], acc, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[g][k], mr[k], acc, 0, 0, 0);
-          }
+          for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[g][k], mr[k], acc, 0, 0, 0);
         }
+      
         if (t < a.T) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -211,20 +169,9 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
         for (int g = 0; g < NG; ++g) {
           const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
           const float* wr = wl + C * KS * C + ((g * KPI + lk) * KS) * C + ln;
-          if constexpr (PIPE) {
-            float mv[KS], wv[KS];
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-              mv[k] = mr[k];
-              wv[k] = wr[k * C];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[k], mv[k], acc, 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], mr[k], acc, 0, 0, 0);
-          }
+          for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], mr[k], acc, 0, 0, 0);
+        
         }
         if (t < a.T) {
 #pragma unroll
@@ -244,7 +191,6 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
 }
 
 int g_cus = 0;
-int g_pair_pipe = 0;   // 1: the operand-preloading instantiations (svc_debug_set_pair_pipelined); unmeasured -> off
 
 template <int C, int KS>
 int launch_pair(const svc_resblock_pair_args& a, hipStream_t s) {
@@ -269,12 +215,12 @@ int launch_pair(const svc_resblock_pair_args& a, hipStream_t s) {
     svc::set_error("resblock_pair: tile does not fit LDS (C=%d KS=%d dil=%d)", C, KS, a.dil1);
     return SVC_ERR_UNSUPPORTED;
   }
-  auto kern = g_pair_pipe ? mrf_pair_kernel<C, KS, true> : mrf_pair_kernel<C, KS, false>;
+  auto kern = mrf_pair_kernel<C, KS>;
   if (lds > 64 * 1024) {
-    static bool done[2] = {false, false};
-    if (!done[g_pair_pipe ? 1 : 0]) {
+    static bool done = false;
+    if (!done) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done[g_pair_pipe ? 1 : 0] = true;
+      done = true;
     }
   }
   if (!g_cus) {
@@ -291,11 +237,6 @@ int launch_pair(const svc_resblock_pair_args& a, hipStream_t s) {
 }
 
 }  // namespace
-
-extern "C" int svc_debug_set_pair_pipelined(int on) {
-  g_pair_pipe = on ? 1 : 0;
-  return SVC_OK;
-}
 
 extern "C" int svc_resblock_pair_f32(const svc_resblock_pair_args* ap, void* stream) {
   SVC_REQUIRE(ap != nullptr, "resblock_pair: null args");

@@ -621,7 +621,7 @@ TRAIN_EXPORTS = [
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
     "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_adamw_advance", "svc_debug_set_conv_cfg",
-    "svc_debug_set_wgrad_target", "svc_debug_set_conv_strip", "svc_debug_set_gconv_version", "svc_debug_set_pair_pipelined", "svc_debug_set_gemm_pipelined",
+    "svc_debug_set_wgrad_target", "svc_debug_set_conv_strip", "svc_debug_set_gconv_version",
 ]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
@@ -658,12 +658,6 @@ def tlib():
         L.svc_debug_set_conv_cfg.argtypes = [i]
         L.svc_debug_set_wgrad_target.argtypes = [i]
         L.svc_debug_set_gconv_version.argtypes = [i]
-        L.svc_debug_set_pair_pipelined.argtypes = [i]
-        L.svc_debug_set_gemm_pipelined.argtypes = [i]
-        if os.environ.get("SVC_GEMM_PIPELINED"):
-            L.svc_debug_set_gemm_pipelined(int(os.environ["SVC_GEMM_PIPELINED"]))
-        if os.environ.get("SVC_PAIR_PIPELINED"):
-            L.svc_debug_set_pair_pipelined(int(os.environ["SVC_PAIR_PIPELINED"]))
         if os.environ.get("SVC_GCONV_VERSION"):
             L.svc_debug_set_gconv_version(int(os.environ["SVC_GCONV_VERSION"]))
         if os.environ.get("SVC_WGRAD_TARGET"):       # tuning aid (A/B on one box)
