@@ -1,0 +1,203 @@
+"""Extra objects of bench.py's JSON line (rank 0, one GPU): the other BASELINE.json configs and the box's identity.
+
+  device           what this box is (name, CUs, clocks / power cap when rocm-smi answers) + one calibration launch — the
+                   128-channel k=11 MRF conv in a hipGraph — so a run-to-run difference can be attributed to the box
+  e2e              configs[1] end to end: 16 kHz wave -> ContentVec768L12 units (HuBERT-base stack) -> SynthesizerTrn.infer
+  snake_b8         configs[3]: nsf-snake-hifigan decoder, 30 s clips (T = 2584 frames), batch 8
+  diffusion_train  configs[4]: WaveNet unit2mel training step, 20 x 512, B = 48 crops of 172 frames, fp32
+  diffusion_infer  the same model sampling a 10 s clip: 100 DDIM steps (timesteps 1000, speedup 10)
+
+Random-init weights of the named architectures (no checkpoint exists in the reference tree), synthetic inputs.  Nothing here
+imports oracle/.  Every leg is bounded (a few seconds) and failure-tolerant: a leg that raises reports {"error": ...} instead of
+taking the headline line down with it."""
+import os
+import subprocess
+import time
+
+import torch
+
+HOP = 512
+
+
+def _timeit(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def _graphed(fn, warm=2):
+    """Capture fn() into a hipGraph (after `warm` eager calls); returns (replay, outputs of the captured call)."""
+    import svc_hip as S
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with S.graph_capture(g):
+        out = fn()
+    return g.replay, out
+
+
+def _families(fn, n=3):
+    import svc_hip as S
+    S.prof_enable(True)
+    S.prof_reset()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    rep = S.prof_report()
+    S.prof_enable(False)
+    return {k: dict(ms_per_step=round(v["ms"] / n, 4), calls=v["calls"] // n,
+                    tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
+            for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def device_info(dev):
+    import svc_hip as S
+    name, cus = S.device_info()
+    props = torch.cuda.get_device_properties(dev)
+    info = dict(name=name, cus=cus, hbm_gb=round(props.total_memory / 2 ** 30, 1), torch=torch.__version__,
+                hip=getattr(torch.version, "hip", None))
+    try:      # best effort: clocks and power cap as rocm-smi reports them right now (idle values; DVFS moves them under load)
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showmaxpower", "--showpower", "-d", str(dev.index or 0)],
+                             capture_output=True, text=True, timeout=20).stdout
+        keep = [l.strip() for l in out.splitlines() if any(k in l for k in ("sclk", "mclk", "Max Graphics Package Power",
+                                                                             "Average Graphics Package Power", "Socket Power"))]
+        info["rocm_smi"] = keep[:8]
+    except Exception as e:      # noqa: BLE001
+        info["rocm_smi"] = f"unavailable ({type(e).__name__})"
+    # calibration: ten launches of the decoder's 128-channel k = 11, dilation 5 conv on a 10 s clip's stage length, in one graph
+    x = torch.randn(1, 128, 55168, device=dev)
+    w = torch.randn(128, 128, 11, device=dev) / (128 * 11) ** 0.5
+    wp = S.pack_conv1d_weight(w)
+    b = torch.zeros(128, device=dev)
+    out = torch.empty_like(x)
+    n = 10
+
+    def launches():
+        for _ in range(n):
+            S.conv1d(x, wp, 128, 11, bias=b, dil=5, pad_left=25, res=x, res_mode=1, out=out)
+    replay, _ = _graphed(launches, warm=1)
+    dt = _timeit(replay, 5, warm=2) / n
+    info["calibration"] = dict(kernel="svc_conv1d_f32 128->128 k=11 d=5 T=55168 (+residual), 10 launches per graph replay",
+                               us_per_launch=round(dt * 1e6, 1), tflops=round(2.0 * 128 * 128 * 11 * 55168 / dt / 1e12, 1))
+    return info
+
+
+def bench_e2e(dev, net, inputs, frames):
+    """wav16k -> units -> infer.  `net` is the headline SynthesizerTrn (graph mode on), `inputs` its (c, f0, uv, sid)."""
+    import utils
+    from vencoder.ContentVec768L12 import ContentVec768L12
+    from vencoder.hubert import hubert_model as HM
+    torch.manual_seed(7)
+    enc = ContentVec768L12(device=dev, model=HM.Hubert())       # random-init HuBERT-base stack (no checkpoint in the tree)
+    n16 = int(round(frames * HOP / 44100 * 16000))
+    wav = 0.3 * torch.randn(n16, device=dev)
+    c, f0, uv, sid = inputs
+
+    def units():
+        return enc.encoder(wav)
+
+    def whole():
+        u = units()
+        cc = utils.repeat_expand_2d(u.squeeze(0), frames, "left").unsqueeze(0)
+        return net.infer(cc, f0, uv, g=sid, noice_scale=0.4)
+    u = units()
+    t_units_eager = _timeit(units, 5)
+    fam = _families(units)
+    replay, _ = _graphed(units)
+    t_units = _timeit(replay, 10)
+    t_whole = _timeit(whole, 5)
+    n = frames * HOP
+    return dict(workload=f"10.01 s clip: {n16} samples @16 kHz -> ContentVec768L12 (HuBERT-base, 12 layers, layer-12 output "
+                         f"{tuple(u.shape)}) -> repeat_expand to {frames} frames -> SynthesizerTrn.infer",
+                unit_encoder_ms=round(1e3 * t_units, 3), unit_encoder_eager_ms=round(1e3 * t_units_eager, 3),
+                e2e_ms=round(1e3 * t_whole, 3), e2e_samples_per_s=n / t_whole,
+                note="unit encoder replayed from its own hipGraph; e2e = eager encoder launches + graph-replayed synthesizer",
+                unit_encoder_families=fam)
+
+
+def bench_snake_b8(dev, steps=3):
+    import models
+    import synthetic_data as W
+    cfg = W.full_config()
+    cfg["vocoder_name"] = "nsf-snake-hifigan"
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(W.make_state_dict(cfg, 77))
+    net = net.to(dev).eval()
+    B, T = 8, 2584
+    c, f0, uv, sid = [t.to(dev) for t in W.make_inputs(cfg, B, T, seed=21)]
+    net.enable_graph(True)
+
+    def step():
+        return net.infer(c, f0, uv, g=sid, noice_scale=0.4)
+    dt = _timeit(step, steps, warm=2)
+    n = B * T * HOP
+    del net
+    torch.cuda.empty_cache()
+    return dict(workload="BASELINE configs[3]: nsf-snake-hifigan (SnakeAlias activations), batch 8 x 30.0 s clips "
+                         f"(T={T} frames, {T * HOP} samples each), fp32, hipGraph replay",
+                ms_per_step=round(1e3 * dt, 3), samples_per_s=n / dt, rtf=dt / (n / 44100.0), steps=steps)
+
+
+def bench_diffusion(dev):
+    from diffusion import solver
+    from diffusion.unit2mel import Unit2Mel
+    torch.manual_seed(0)
+    L, C, H, M = 20, 512, 256, 128
+    net = Unit2Mel(768, 1, False, M, L, C, H, 1000, 1000).to(dev)
+    torch.nn.init.normal_(net.decoder.denoise_fn.output_projection.weight, std=0.02)
+    # ---- training step (configs_template/diffusion_template.yaml: batch 48, 2 s crops = 172 frames)
+    net.train()
+    B, T = 48, 172
+    step = solver.TrainStep(net, solver.build_optimizer(net, lr=1e-4))
+    data = dict(units=torch.randn(B, T, 768, device=dev), f0=200 + 100 * torch.rand(B, T, 1, device=dev),
+                volume=torch.rand(B, T, 1, device=dev), spk_id=torch.zeros(B, 1, dtype=torch.long, device=dev),
+                mel=-6 + 2 * torch.randn(B, T, M, device=dev))
+    step.enable_graph(True)
+    dt = _timeit(lambda: step(data), 8, warm=3)
+    flop_fwd = 2.0 * B * T * (M * C + L * (C * 2 * C * 3 + H * 2 * C + C * 2 * C) + C * C + C * M + 768 * H)
+    train = dict(workload=f"BASELINE configs[4]: WaveNet unit2mel {L} x {C}, {M} mels, 768-d units, batch {B} x {T} frames, fp32, "
+                          "FusedAdamW, whole iteration replayed from one hipGraph",
+                 ms_per_step=round(1e3 * dt, 3), steps_per_s=round(1.0 / dt, 3), tflops=round(3 * flop_fwd / dt / 1e12, 1))
+    step.enable_graph(False)
+    # ---- sampling a 10 s clip: 100 DDIM steps
+    net.eval()
+    Ti = 862
+    units = torch.randn(1, Ti, 768, device=dev)
+    f0 = 100 + 300 * torch.rand(1, Ti, 1, device=dev)
+    vol = torch.rand(1, Ti, 1, device=dev)
+    spk = torch.zeros(1, 1, dtype=torch.long, device=dev)
+
+    def sample():
+        with torch.no_grad():
+            return net(units, f0, vol, spk_id=spk, infer=True, infer_speedup=10, method="ddim", use_tqdm=False)
+    t_eager = _timeit(sample, 2, warm=1)
+    infer = dict(workload="10 s clip (T=862 frames): Unit2Mel conditioning + 100 DDIM denoiser steps (timesteps 1000, speedup 10)",
+                 ms_per_clip_eager=round(1e3 * t_eager, 2))
+    try:
+        replay, _ = _graphed(sample, warm=1)
+        t_graph = _timeit(replay, 3, warm=1)
+        infer.update(ms_per_clip=round(1e3 * t_graph, 2), launch="hipGraph replay of the whole 100-step sampler")
+    except Exception as e:      # noqa: BLE001 — a sampler that syncs with the host cannot be captured: report the eager figure
+        infer.update(ms_per_clip=infer["ms_per_clip_eager"], launch=f"eager (capture failed: {type(e).__name__}: {str(e)[:120]})")
+    del net, step
+    torch.cuda.empty_cache()
+    return train, infer
+
+
+def guarded(fn, *a, **k):
+    try:
+        return fn(*a, **k)
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        return dict(error=f"{type(e).__name__}: {str(e)[:300]}", where=traceback.format_exc().strip().splitlines()[-3:])

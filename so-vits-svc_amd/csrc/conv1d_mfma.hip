@@ -26,6 +26,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -45,6 +46,7 @@ struct ConvP {
   int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
   int db_ni;      // DB kernels: LDS-DMA pieces (1 KiB each) per wave per chunk
   int fast_epi;   // DB kernels: 1 = plain epilogue with all residual / accumulate loads issued up front (conv_epilogue<BATCH>)
+  int direct_epi; // DB kernels: 1 = epilogue straight from the accumulators (conv_epilogue_direct): no LDS transpose, no barrier
   const float* zero;  // DB kernels: 16 B of zeros in global memory (source of padding / out-of-tile pieces)
 };
 
@@ -241,6 +243,106 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem,
   }
 #undef SVC_F4_MAP
 #undef F4C
+}
+
+// ---- direct epilogue (DB kernels, 32x32 tiles, plain epilogue without mask / time-varying cond): a lane's accumulator register
+// is 32 consecutive time steps of one output row (MFMA C layout), so bias / activation / residual / accumulate / store run
+// straight from the accumulators with 128-byte row segments per half wave: no LDS transpose, no barriers, and the residual loads
+// of ALL of the wave's tiles are in flight together.  Round 2 measured the LDS epilogue at 27 us of a 192 us launch (14 %), with
+// every workgroup of a launch in it at the same time; round 3's conv1d_strip.hip showed the direct form costs ~2 us.  Same
+// expression and order as conv_epilogue: bit-identical results.  Addresses = (wave-uniform row base in SGPRs) + (per-lane 32-bit
+// byte offset), written as asm so that hipcc neither materialises one 64-bit address per element nor branches per load.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, f32x16 (&acc)[MT][NT], int b_, int t0, int rowu0_, int col0, int lane) {
+  const svc_conv1d_args& a = p.a;
+  const int b = __builtin_amdgcn_readfirstlane(b_), rowu0 = __builtin_amdgcn_readfirstlane(rowu0_);   // wave-uniform by construction
+  const int ln = lane & 31, lk = lane >> 5;
+  float* yb = a.y + (long long)b * a.y_bs;
+  const float* resb = a.res ? a.res + (long long)b * a.res_bs : a.x;
+  const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
+  const bool has_res = a.res_mode != 0;
+  const float oslope = a.post_act == SVC_ACT_LRELU ? a.post_slope : 1.f;   // launcher: none, or leaky-ReLU with 0 <= slope <= 1
+  auto rowc = [](int r) { return (r & 3) + 8 * (r >> 2); };
+  unsigned roff[NT], yoff[NT];
+  bool colok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = t0 + col0 + j * 32 + ln;
+    const unsigned tc = (unsigned)min(t, a.Tout - 1);
+    colok[j] = t < a.Tout;
+    roff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.res_cs + tc);
+    yoff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.y_cs + tc);
+  }
+  float rr[MT][NT][16];
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int rowl = rowu0 + i * 32 < a.Cout ? rowu0 + i * 32 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rr[i][j][r]) : "v"(roff[j]), "s"(rp));
+      }
+    }
+  }
+  float bc_[MT][16];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rowl = rowu0 + i * 32 < a.Cout ? rowu0 + i * 32 : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = rowl + rowc(r) + 4 * lk;
+      bc_[i][r] = (a.bias ? a.bias[co] : 0.f) + (condb ? condb[co * a.cond_cs] : 0.f);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (has_res) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rr[i][j][r]));   // uses of rr stay behind the wait
+  }
+  auto finish = [&](auto accdiv_tag) {
+    constexpr bool ACCDIV = decltype(accdiv_tag)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bool rows_ok = rowu0 + i * 32 < a.Cout;
+      const int rowl = rows_ok ? rowu0 + i * 32 : 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (rows_ok && colok[j]) {
+          float yo[16];
+          if constexpr (ACCDIV) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(yo[r]) : "v"(yoff[j]), "s"(yp));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(yo[r]));
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* yp = yb + (long long)(rowl + rowc(r)) * a.y_cs;
+            float v = acc[i][j][r] + bc_[i][r];
+            v = __builtin_amdgcn_fmed3f(v, v * oslope, __builtin_inff());   // == svc_lrelu for 0 <= slope <= 1; slope 1: identity
+            if (has_res) v = v + rr[i][j][r];
+            if constexpr (ACCDIV) {
+              v = v + a.beta * yo[r];
+              v = v / a.out_div;
+            }
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
+          }
+        }
+      }
+    }
+  };
+  if (a.beta != 0.f || a.out_div != 1.f) finish(std::true_type{});
+  else finish(std::false_type{});
 }
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
@@ -654,6 +756,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
   // thread owns 4 consecutive time steps of one output row: 16 B residual loads / stores, full cache lines per row.
   // Split-K partial tiles are summed here (fixed order wk = 0..WK-1: deterministic).
   if ((dbg & 4) && acc_probe(acc32[0][0], acc16[0][0]) != 12345.678f) return;
+  if constexpr (DB) {
+    if (p.direct_epi) {
+      conv_epilogue_direct<MT, NT>(p, acc32, b, t0, co0 + wm * (MT * TS), wn * (NT * TS), lane);
+      return;
+    }
+  }
   constexpr int CP = BN + 4;
   __syncthreads();
   {
@@ -686,6 +794,7 @@ int g_no224 = 1;       // 1: the 128x224 one-workgroup-per-CU tile stays out of 
                        // owns a whole CU (223 VGPR + 112 AGPR, 116 KB LDS): with the decoder's three MRF chains on concurrent
                        // streams the 128x128 tile (two workgroups per CU, from different launches) lets one launch's epilogue
                        // overlap another's MFMA loop: clip 8.29 / 8.44 ms with 128x224 vs 8.17 / 8.19 ms without (same box)
+int g_direct_epi = 1;  // 1: DB kernels store straight from the accumulators where the epilogue form allows (svc_debug_set_conv_cfg: +1000000000 disables)
 int g_fast_epi = 1;    // 1: DB kernels batch the epilogue's residual loads (svc_debug_set_conv_cfg: +10000000 disables)
 int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
 
@@ -779,6 +888,10 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       p.db_ni = ni;
       p.fast_epi = (g_fast_epi && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
                     (a.cond == nullptr || a.cond_ts == 0) && p.yvec && (a.Tout % 4) == 0 && a.Tout >= 4) ? 1 : 0;
+      p.direct_epi = (g_direct_epi && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
+                      (a.cond == nullptr || a.cond_ts == 0) && a.n_phase == 1 && a.y_ts == 1 && a.y_t0 == 0 && (a.Cout % 32) == 0 &&
+                      (a.post_act == SVC_ACT_NONE || (a.post_act == SVC_ACT_LRELU && a.post_slope >= 0.f && a.post_slope <= 1.f)) &&
+                      a.y_cs >= 0 && a.y_cs < (1ll << 24) && a.res_cs >= 0 && a.res_cs < (1ll << 24)) ? 1 : 0;
       p.zero = zero;
       p.dump_off = 0;
       const size_t lds = std::max((size_t)2 * ni * NWV * 1024, epi_bytes);
@@ -989,7 +1102,8 @@ int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
 
 extern "C" int svc_debug_set_conv_cfg(int cfg) {
   // cfg = nodb*10000 + dbg*1000 + noksc*100 + (forced tile config + 1), 0 / negative = defaults
-  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; g_no224 = 1; return SVC_OK; }
+  if (cfg <= 0) { g_force_cfg = -1; g_no_ksc = 0; g_dbg = 0; g_db_mode = 1; g_db_budget_kb = 64; g_direct_mode = 1; g_fast_epi = 1; g_no224 = 1; g_direct_epi = 1; return SVC_OK; }
+  g_direct_epi = ((cfg / 1000000000) % 10) ? 0 : 1;
   g_fast_epi = ((cfg / 10000000) % 10) ? 0 : 1;
   g_no224 = ((cfg / 100000000) % 10) ? 0 : 1;
   g_direct_mode = ((cfg / 1000000) % 10) ? 0 : 1;

@@ -36,6 +36,7 @@ struct StripP {
   int n_t_tiles, n_m_tiles;
   int npw;         // 1 KiB LDS-DMA pieces of a chunk's weight block
   int buf_f;       // floats per LDS buffer (W block + X block)
+  int dbg;         // timing experiments (results are then garbage): 1 no output stores, 2 no MFMA loop, 4 no residual prefetch
 };
 
 // One LDS-DMA piece: lane l's 16 B at base + off[l] land at LDS byte address lds_byte + l*16 (wave-uniform LDS base in M0).
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       _Pragma("unroll") for (int j = 0; j < NTW; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
     }
     auto groups = [&](int buf, int q0, int q1) {
+      if (p.dbg & 2) return;
       const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
       const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
       for (int q = q0; q < q1; ++q) {
@@ -290,11 +292,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       for (int r = 0; r < NACC; ++r) bc_[r] = bc_[r] + condb[(rowl + rowc(r) + 4 * lk) * a.cond_cs];
     }
     if constexpr (HAS_RES) {
+      if (!(p.dbg & 4)) {
   #pragma unroll
       for (int r = 0; r < NACC; ++r) {
         const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
   #pragma unroll
         for (int j = 0; j < NTW; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
+      }
       }
     }
     first_reads(it & 1);
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
               v = v + a.beta * yo[r];
               v = v / a.out_div;
             }
-            asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
+            if (!(p.dbg & 1) || r == 0) asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
           }
         }
       }
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
 }
 
 int g_strip_mode = 1;   // 0: off, 1: auto (svc_debug_set_conv_strip)
+int g_strip_dbg = 0;        // StripP.dbg (svc_debug_set_conv_strip(1000 * dbg + mode))
 int g_strip_launches = 0;   // launches that took this kernel (tests ask through svc_debug_set_conv_strip(-1))
 
 struct StripCfg { int TS, WM, WN; };
@@ -387,6 +392,7 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   p.BC = bc;
   p.npw = npw;
   p.buf_f = buf_f;
+  p.dbg = g_strip_dbg;
   p.n_t_tiles = svc::cdiv(a.Tout, BN);
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
   const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
@@ -433,7 +439,8 @@ int strip_launch_ks(const svc_conv1d_args& a, hipStream_t s, int wps) {
 
 extern "C" int svc_debug_set_conv_strip(int mode) {
   if (mode < 0) return g_strip_launches;
-  g_strip_mode = mode;
+  g_strip_dbg = mode / 1000;      // timing experiments only (garbage results): see StripP.dbg
+  g_strip_mode = mode % 1000;
   return SVC_OK;
 }
 

@@ -241,3 +241,39 @@ def test_conv1d_strip_auto_selection_mrf_shapes(dev, strip_mode):
     n0 = S.lib().svc_debug_set_conv_strip(-1)
     S.conv1d(x, wp, 128, 3, pad_left=1, res=x, res_mode=1)
     assert S.lib().svc_debug_set_conv_strip(-1) == n0
+
+
+@pytest.mark.parametrize("Cin,Cout,T,KS,dil", [(128, 128, 20004, 11, 5), (64, 64, 33000, 3, 1), (256, 256, 6896, 7, 3),
+                                               (32, 32, 40000, 7, 1), (128, 64, 17000, 5, 1)])
+def test_conv1d_direct_epilogue_equals_lds_epilogue(dev, strip_mode, Cin, Cout, T, KS, dil):
+    """The tiled LDS-DMA kernels' register -> global epilogue (conv_epilogue_direct) against their LDS-transposed one
+    (svc_debug_set_conv_cfg(1000000000) switches it off): same expression, same order -> bit-equal, for every epilogue form
+    of the MRF stage, with a ragged last tile; and against torch CPU."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(Cin + Cout + T + KS)
+    x = torch.randn(1, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(1, Cout, T, generator=g)
+    prev = torch.randn(1, Cout, T, generator=g)
+    pad = (KS * dil - dil) // 2
+    xd, wp, bd, resd = x.to(dev), S.pack_conv1d_weight(w.to(dev)), b.to(dev), res.to(dev)
+    conv = lambda xx: F.conv1d(xx, w, b, dilation=dil, padding=pad)
+    forms = [("conv1", dict(pre_slope=0.1, post_act=S.ACT_LRELU, post_slope=0.1), 0.0, 1.0, lambda: F.leaky_relu(conv(F.leaky_relu(x, 0.1)), 0.1)),
+             ("conv2", dict(res=resd, res_mode=1), 0.0, 1.0, lambda: conv(x) + res),
+             ("conv2-end", dict(res=resd, res_mode=1), 1.0, 3.0, lambda: (conv(x) + res + prev) / 3.0),
+             ("plain", dict(), 0.0, 1.0, lambda: conv(x))]
+    strip_mode(0)
+    try:
+        for name, kw, beta, div, ref_fn in forms:
+            outs = []
+            for code in (0, 1000000000):
+                S.lib().svc_debug_set_conv_cfg(code)
+                out = prev.to(dev).clone()
+                S.conv1d(xd, wp, Cout, KS, bias=bd, dil=dil, pad_left=pad, out=out, beta=beta, out_div=div, **kw)
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+            assert torch.equal(outs[0], outs[1]), (name, (outs[0] - outs[1]).abs().max().item())
+            assert _rel(outs[0], ref_fn()) < 3e-6, name
+    finally:
+        S.lib().svc_debug_set_conv_cfg(0)
