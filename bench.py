@@ -384,6 +384,7 @@ def main():
         # the three MRF ResBlock chains of a decoder stage run on concurrent HIP streams in the timed region; a launch's
         # hipEvent duration is only meaningful when launches do not overlap, so this profiling pass serialises them
         import vdecoder.hifigan.models as _gen
+        mrf_streams_was = _gen._MRF_STREAMS
         _gen._MRF_STREAMS = False
         step()
         torch.cuda.synchronize()
@@ -395,6 +396,7 @@ def main():
         torch.cuda.synchronize()
         rep = S.prof_report()
         S.prof_enable(False)
+        _gen._MRF_STREAMS = mrf_streams_was
         fam = max(rep.items(), key=lambda kv: kv[1]["ms"])
         name, r = fam
         achieved = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0

@@ -295,11 +295,12 @@ class Svc(object):
         return c.unsqueeze(0), f0, uv
 
     # -- the hot path -------------------------------------------------------------------------------------
-    def infer_units(self, c, f0, uv, sid, auto_predict_f0=False, noice_scale=0.4, vol=None, seed=52468, noise=None):
+    def infer_units(self, c, f0, uv, sid, auto_predict_f0=False, noice_scale=0.4, vol=None, seed=52468, noise=None, lengths=None):
         """(c [B,ssl,T], f0 [B,T], uv [B,T], sid) -> (audio [B,1,T*hop], f0): net_g_ms.infer (infer_tool.py:297)."""
         with torch.no_grad():
             return self.net_g_ms.infer(c.to(self.dev), f0=f0.to(self.dev), g=sid.to(self.dev), uv=uv.to(self.dev),
-                                       predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol, seed=seed, noise=noise)
+                                       predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol, seed=seed, noise=noise,
+                                       lengths=lengths)
 
     def _features(self, speaker, tran, raw_path, cluster_infer_ratio, f0_filter, f0_predictor, cr_threshold, frame, spk_mix):
         """Everything of infer() in front of the synthesizer (:270-290): (wav, c, f0, uv, sid, n_frames)."""
@@ -495,9 +496,18 @@ class Svc(object):
             audio.extend(list(_audio))
         return np.array(audio)
 
+    #: chunks whose frame counts fall into the same bucket (multiples of this many frames, ~0.37 s) share one synthesizer call
+    BATCH_BUCKET_FRAMES = 32
+
     def _run_jobs_batched(self, jobs, spk, tran, audio_sr, kw):
-        """Front-ends chunk by chunk (they are per-utterance models / CPU code), then ONE synthesizer call per group of
-        chunks with the same frame count; fills j["audio"] exactly as the serial loop would."""
+        """Front-ends chunk by chunk (they are per-utterance models / CPU code), then ONE synthesizer call per BUCKET of chunks:
+        chunks are grouped by frame count rounded up to BATCH_BUCKET_FRAMES, zero-padded to the bucket's longest item, and run
+        with per-item lengths (SynthesizerTrn.infer(lengths=...): the attention / flow / encoder masks are the true lengths, as
+        if each chunk ran alone).  Every item gets exactly the noise the serial loop would give it — the reference re-seeds per
+        chunk (models.py:498-501), so the draws are made per item at its own length and padded.  The decoder has no mask: an
+        item's samples within its receptive field of the padded tail differ from the serial run, but that region (< 0.25 s)
+        lies inside the `pad_seconds` (0.5 s) of silence slice_inference adds to every chunk and trims again (:460,470).
+        Fills j["audio"] exactly as the serial loop would."""
         global_frame = 0
         feats = []
         for j in jobs:
@@ -509,35 +519,48 @@ class Svc(object):
             global_frame += n_frames
             feats.append(dict(j=j, wav=wav, c=c, f0=f0, uv=uv, sid=sid, T=n_frames))
         groups = {}
+        bucket = self.BATCH_BUCKET_FRAMES
         for f in feats:
-            groups.setdefault((f["T"], tuple(f["sid"].shape)), []).append(f)
+            key = (-(-f["T"] // bucket), tuple(f["sid"].shape)) if not kw["spk_mix"] else (id(f),)   # speaker-mix tensors are per utterance
+            groups.setdefault(key, []).append(f)
         start = time.time()
-        for (T, _), items in groups.items():
+        net = self.net_g_ms
+        for items in groups.values():
             B = len(items)
-            c = torch.cat([f["c"] for f in items], 0)
-            f0 = torch.cat([f["f0"] for f in items], 0)
-            uv = torch.cat([f["uv"] for f in items], 0)
+            T = max(f["T"] for f in items)
+            ragged = any(f["T"] != T for f in items)
+            padT = lambda t, f: torch.nn.functional.pad(t, (0, T - f["T"]))            # noqa: E731
+            c = torch.cat([padT(f["c"], f) for f in items], 0)
+            f0 = torch.cat([padT(f["f0"], f) for f in items], 0)
+            uv = torch.cat([padT(f["uv"], f) for f in items], 0)
             vol = None
             if self.vol_embedding:
-                vol = torch.cat([self.volume_extractor.extract(torch.as_tensor(f["wav"], dtype=torch.float32).to(self.dev)[None, :])[None, :]
+                vol = torch.cat([padT(self.volume_extractor.extract(torch.as_tensor(f["wav"], dtype=torch.float32).to(self.dev)[None, :])[None, :], f)
                                  for f in items], 0).to(self.dev)
-            if kw["spk_mix"]:
-                if B > 1:
-                    raise NotImplementedError("batch_chunks with per-frame speaker mixing: the mix tensor is per utterance")
-                sid = items[0]["sid"]
-            else:
-                sid = torch.cat([f["sid"] for f in items], 0)
-            # the serial loop re-seeds per chunk (models.py:498-501): equal-length chunks see the SAME draws
-            net = self.net_g_ms
-            torch.manual_seed(52468)
+            sid = items[0]["sid"] if kw["spk_mix"] else torch.cat([f["sid"] for f in items], 0)
+            # the serial loop re-seeds per chunk (models.py:498-501): item b sees the draws of a B = 1 call at ITS length
             L = T * net.dec.upp
-            noise = dict(enc_p=torch.randn(1, net.inter_channels, T, device=self.dev).expand(B, -1, -1).contiguous(),
-                         rand_ini=torch.rand(1, 9, device=self.dev).expand(B, -1).contiguous(),
-                         sine=torch.randn(1, L, 9, device=self.dev).expand(B, -1, -1).contiguous())
+            enc_p, rand_ini, sine = [], [], []
+            draws = {}
+            for f in items:
+                if f["T"] not in draws:
+                    torch.manual_seed(52468)
+                    Lf = f["T"] * net.dec.upp
+                    draws[f["T"]] = (torch.randn(1, net.inter_channels, f["T"], device=self.dev), torch.rand(1, 9, device=self.dev),
+                                     torch.randn(1, Lf, 9, device=self.dev))
+                e, r, sn = draws[f["T"]]
+                enc_p.append(padT(e, f))
+                rand_ini.append(r)
+                sine.append(torch.nn.functional.pad(sn, (0, 0, 0, L - sn.shape[1])))
+            noise = dict(enc_p=torch.cat(enc_p, 0).contiguous(), rand_ini=torch.cat(rand_ini, 0).contiguous(),
+                         sine=torch.cat(sine, 0).contiguous())
+            lengths = torch.tensor([f["T"] for f in items], device=self.dev) if ragged else None
             audio, f0o = self.infer_units(c, f0, uv, sid, auto_predict_f0=kw["auto_predict_f0"], noice_scale=kw["noice_scale"],
-                                          vol=vol, noise=noise)
+                                          vol=vol, noise=noise, lengths=lengths)
             for b, f in enumerate(items):
-                a = self._post(f["wav"], audio[b, 0].data.float(), f["c"], f0o[b:b + 1], f["sid"], None if vol is None else vol[b:b + 1],
+                n = f["T"] * net.dec.upp
+                a = self._post(f["wav"], audio[b, 0, :n].data.float(), f["c"], f0o[b:b + 1, :f["T"]], f["sid"],
+                               None if vol is None else vol[b:b + 1, :f["T"]],
                                kw["k_step"], kw["second_encoding"], kw["enhancer_adaptive_key"], kw["loudness_envelope_adjustment"])
                 f["j"]["audio"] = a.cpu().numpy()
         print("vits use time:{} ({} chunks in {} synthesizer calls)".format(time.time() - start, len(feats), len(groups)))

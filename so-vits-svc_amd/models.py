@@ -382,14 +382,18 @@ class SynthesizerTrn(nn.Module):
             g = g.unsqueeze(0)
         return self.emb_g(g).transpose(1, 2).contiguous()            # [B, H, 1]
 
-    def _infer_body(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol):
+    def _infer_body(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths=None):
         """The device work of infer(): every line is one or a few HIP kernels (no torch arithmetic)."""
         B, _, T = c.shape
         # (tried: for T % 4 != 0 — 862 frames = 10 s — run the encoder / flow section on T rounded up to 4 with the extra
         # frames masked off, so that every row is 16-byte aligned and the convs take their float4 / LDS-DMA paths: exact,
         # but same-box A/B 10.46/10.57 ms without vs 10.72/10.62 ms with — those T=862 launches are latency-bound, not
         # staging-bound, and the padding mask costs the attention kernel 6 %.)
-        x_mask = torch.ones((B, 1, T), device=c.device, dtype=torch.float32)      # c_lengths == T (models.py:503)
+        if lengths is None:
+            x_mask = torch.ones((B, 1, T), device=c.device, dtype=torch.float32)      # c_lengths == T (models.py:503)
+        else:   # extension (Svc.slice_inference(batch_chunks=True)): items of different frame counts padded to T; the mask is
+            #     commons.sequence_mask(c_lengths, T) (models.py:504) of the TRUE lengths, built on the device (graph-capturable)
+            x_mask = (torch.arange(T, device=c.device).view(1, 1, T) < lengths.view(B, 1, 1)).to(torch.float32)
         m = mask2d(x_mask)
         # the decoder's harmonic source + noise convs only need f0: start them now, underneath the encoder and the flow
         src_noise = noise if "sine" in noise else None
@@ -408,7 +412,7 @@ class SynthesizerTrn(nn.Module):
                                       vol_w=self.emb_vol.weight.view(-1) if volv is not None else None,
                                       vol_b=self.emb_vol.bias if volv is not None else None)
         z_p, m_p, logs_p, _ = self.enc_p(x_enc, x_mask, noice_scale=noice_scale, noise=noise.get("enc_p"),
-                                         x_is_embedded=True, full_mask=True)
+                                         x_is_embedded=True, full_mask=lengths is None)
         z = self.flow(z_p, x_mask, g=g, reverse=True)
         # `z * c_mask` (models.py:531) is the identity here: the flow's last update already multiplies by the mask
         if source is not None:
@@ -418,10 +422,11 @@ class SynthesizerTrn(nn.Module):
         return o, f0
 
     @torch.no_grad()
-    def infer(self, c, f0, uv, g=None, noice_scale=0.35, seed=52468, predict_f0=False, vol=None, noise=None):
+    def infer(self, c, f0, uv, g=None, noice_scale=0.35, seed=52468, predict_f0=False, vol=None, noise=None, lengths=None):
         """Reference models.py:495-532.  `noise` (optional dict enc_p/rand_ini/sine) injects the RNG draws
         explicitly (parity tests); otherwise they are drawn from torch's generator for c.device in the reference's
-        order after seeding with `seed`."""
+        order after seeding with `seed`.  `lengths` (extension, [B] frame counts on the device): the batch holds items of
+        different lengths zero-padded to T; masks come from the true lengths (the reference always passes c.size(-1))."""
         if not c.is_cuda:
             raise S.SvcError("SynthesizerTrn.infer needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
         c = c.float().contiguous()
@@ -435,22 +440,28 @@ class SynthesizerTrn(nn.Module):
             noise = dict(enc_p=torch.randn(B, self.inter_channels, T, device=c.device),       # :160
                          rand_ini=torch.rand(B, 9, device=c.device),                          # hifigan :147
                          sine=torch.randn(B, L, 9, device=c.device))                          # hifigan :266
+        if lengths is not None:
+            lengths = lengths.to(device=c.device, dtype=torch.int64).contiguous()
         if self.use_graph:
-            return self._infer_graph(c, f0, uv, g, noise, noice_scale, predict_f0, vol)
-        return self._infer_body(c, f0, uv, g, noise, noice_scale, predict_f0, vol)
+            return self._infer_graph(c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths)
+        return self._infer_body(c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths)
 
     # ------------------------------------------------------------------------------------------------------
-    def _infer_graph(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol):
-        key = (tuple(c.shape), tuple(g.shape), float(noice_scale), bool(predict_f0), vol is not None, str(c.device))
+    def _infer_graph(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths=None):
+        key = (tuple(c.shape), tuple(g.shape), float(noice_scale), bool(predict_f0), vol is not None, lengths is not None,
+               str(c.device))
         ent = self._graphs.get(key)
         ins = dict(c=c, f0=f0, uv=uv, g=g, enc_p=noise["enc_p"], rand_ini=noise["rand_ini"], sine=noise["sine"])
         if vol is not None:
             ins["vol"] = vol.float().contiguous()
+        if lengths is not None:
+            ins["lengths"] = lengths
         if ent is None:
             static = {k: v.clone() for k, v in ins.items()}
             run = lambda: self._infer_body(static["c"], static["f0"], static["uv"], static["g"],
                                            dict(enc_p=static["enc_p"], rand_ini=static["rand_ini"],
-                                                sine=static["sine"]), noice_scale, predict_f0, static.get("vol"))
+                                                sine=static["sine"]), noice_scale, predict_f0, static.get("vol"),
+                                           static.get("lengths"))
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):

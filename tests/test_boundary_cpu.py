@@ -126,6 +126,23 @@ def test_launcher_puts_the_engine_first(tmp_path):
     assert r2.returncode != 0 and "reference models.py was imported" in r2.stderr
 
 
+def test_launcher_train_entry_point_starts_training(tmp_path):
+    """`svc_run.py train.py -c ... -m ...` substitutes the engine's train.py for the checkout's — which must then
+    actually RUN (round 2's had no __main__: the command printed nothing and exited 0).  Without a GPU the engine's main() has
+    to refuse loudly, exactly like the reference's (`assert torch.cuda.is_available(), "CPU training is not allowed."`,
+    train.py:37), after having parsed the reference's CLI and created logs/<model>/config.json."""
+    (tmp_path / "train.py").write_text("print('REFERENCE LOOP')\n")
+    cfg = dict(train=dict(port="8001"), data={}, model={})
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "svc_run.py"), "train.py", "-c", "cfg.json", "-m", "unit"],
+                       capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert "REFERENCE LOOP" not in r.stdout
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the training entry point is exercised end to end by tests/test_train_gpu.py")
+    assert r.returncode != 0, "the launcher returned success without training"
+    assert "CPU training is not allowed" in r.stderr, r.stderr[-1500:]
+
+
 def _reference_module(name, relpath):
     """Import a reference file under an alias with the absent third-party imports stubbed (test-side only)."""
     import importlib.util

@@ -209,6 +209,34 @@ def test_slice_inference_batched_chunks_equal_serial(dev, tmp_path, monkeypatch,
     assert np.abs(serial - batched).max() <= 2e-5 * max(1.0, np.abs(serial).max())
 
 
+def test_slice_inference_batches_unequal_silence_sliced_chunks(dev, tmp_path, monkeypatch, patched_factories):
+    """the DEFAULT use — a song sliced at silences into chunks of different lengths (no forced clipping).
+    batch_chunks=True groups chunks by frame-count bucket, pads to the bucket's longest item and runs the synthesizer with
+    per-item lengths; every chunk must come out as the serial B=1 loop (infer_tool.py:446-495) produces it."""
+    import svc_audio
+    from inference.infer_tool import Svc
+    cfg = W.small_config()
+    patched_factories["ssl_dim"] = cfg["ssl_dim"]
+    monkeypatch.chdir(tmp_path)
+    net, ck, cj = _write_model(str(tmp_path), cfg, 9)
+    voiced = (1.10, 1.27, 0.93, 1.31, 1.18, 0.71, 1.22)          # seven voiced stretches of different lengths, 1 s gaps
+    wav = _song(seconds_voiced=voiced, gap=1.0)
+    svc_audio.write_wav("song.wav", wav, SR)
+    svc = Svc(ck, cj, "cuda:0", "")
+    calls = []
+    orig = svc.net_g_ms.infer
+    svc.net_g_ms.infer = lambda c, *a, **k: (calls.append((c.shape[0], c.shape[2], k.get("lengths") is not None)), orig(c, *a, **k))[1]
+    serial = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5)
+    n_serial = len(calls)
+    lens = sorted({t for _, t, _ in calls})
+    assert n_serial >= 6 and len(lens) >= 4 and all(b == 1 for b, _, _ in calls), calls
+    calls.clear()
+    batched = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5, batch_chunks=True)
+    assert len(calls) < n_serial and any(b >= 2 and ragged for b, _, ragged in calls), calls     # unequal chunks went through together
+    assert serial.shape == batched.shape
+    assert np.abs(serial - batched).max() <= 2e-5 * max(1.0, np.abs(serial).max())
+
+
 @pytest.mark.parametrize("src,dst,n", [(44100, 16000, 44100 * 3 + 17), (48000, 44100, 30011), (16000, 44100, 9001),
                                        (44100, 16000, 400)])
 def test_resample_matches_oracle(dev, src, dst, n):

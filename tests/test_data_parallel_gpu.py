@@ -23,18 +23,26 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, graph=False):
+def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if capture:
+            os.environ["SVC_DP_CAPTURE_COLLECTIVES"] = "1"
         root = os.path.dirname(HERE)
         for p in (root, os.path.join(root, "so-vits-svc_amd"), HERE):
             if p not in sys.path:
                 sys.path.insert(0, p)
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(0)
+        if backend == "nccl":                              # one rank per GPU over RCCL (needs >= `world` devices)
+            dev = torch.device("cuda", rank)
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dev = torch.device("cuda:0")
+            torch.cuda.set_device(0)
         import train as T
         from test_train_loop_gpu import _hps
         from train_common import load_case
@@ -59,9 +67,11 @@ def _worker(rank, world, port, q, graph=False):
             out = step(items, noise=nz)
         if graph:
             assert any(k[0] == "dp" for k in step._graphs), "the data-parallel hipGraph path was not taken"
-        flat = torch.cat([net_g.arena.param.detach(), net_d.arena.param.detach()]).cpu()
-        parts = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(parts, flat)
+        flat_dev = torch.cat([net_g.arena.param.detach(), net_d.arena.param.detach()])
+        parts = [torch.empty_like(flat_dev) for _ in range(world)]
+        dist.all_gather(parts, flat_dev)                    # (device tensors: valid for gloo and nccl alike)
+        parts = [t.cpu() for t in parts]
+        flat = flat_dev.cpu()
         same = torch.equal(parts[0], parts[1])
         fin = all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v))
         stats = (dict(net_g.reducer.stats), dict(net_d.reducer.stats))
@@ -72,11 +82,11 @@ def _worker(rank, world, port, q, graph=False):
         q.put((rank, traceback.format_exc(), None, None))
 
 
-def _run_two_ranks(graph):
+def _run_two_ranks(graph, backend="gloo", capture=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph, backend, capture)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -198,3 +208,20 @@ def test_two_rank_diffusion_training_equals_full_batch():
         p.join(timeout=60)
     for rank, msg, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+
+
+@needs_two_gpus
+def test_two_rank_training_over_rccl():
+    """the N > 1 path over the REAL transport (backend "nccl" = RCCL over xGMI), one rank per GPU: eager
+    bucket-overlapped mode, the default two-graph mode, and the captured-collective mode (all-reduces inside the hipGraphs,
+    overlapped with the replayed backward).  Every mode must leave both ranks bit-identical; the two graph modes run the same
+    kernels on the same gradients and must agree with each other to fp32 atomics' noise.  Skipped on one-GPU boxes — it runs
+    the moment the suite sees a multi-GPU node."""
+    _run_two_ranks(False, backend="nccl")
+    two = next(f for r, _, _, f in _run_two_ranks(True, backend="nccl") if f is not None)
+    cap = next(f for r, _, _, f in _run_two_ranks(True, backend="nccl", capture=True) if f is not None)
+    d = (two - cap).abs()
+    assert d.max().item() <= 2.5 * 2e-4 * 3 and d.mean().item() <= 0.02 * 2e-4, (d.max().item(), d.mean().item())

@@ -177,7 +177,8 @@ def test_context_spectrogram_equals_reference_per_item_transform(dev, tmp_path):
         T = c.shape[1]
         if random.choice([True, False]) and ds.vol_aug and vol is not None:
             max_amp = float(torch.max(torch.abs(audio))) + 1e-5
-            full = full * (10 ** random.uniform(-1, min(1, np.log10(1 / max_amp))))
+            # the reference re-transforms `audio_norm`, which get_audio has ALREADY cut to lmin * hop samples (data_utils.py:96-110)
+            full = audio * (10 ** random.uniform(-1, min(1, np.log10(1 / max_amp))))
         ref = TO.spectrogram(full, NFFT, HOP, NFFT)[0][:, :T]
         if T > 800:
             s0 = random.randint(0, T - 800)
