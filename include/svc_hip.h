@@ -383,6 +383,15 @@ int svc_decimate_f32(const float* x, float* y, int B, int C, int T, int s, int w
 int svc_decimate_bwd_f32(const float* dy, float* dx, int B, int C, int T, int s, int w, int off, int Q, int lp,
                          void* stream);
 
+/* HuBERT / ContentVec positional convolution (vencoder/hubert/hubert_model.py:116-129, fairseq `pos_conv`):
+ *   y = x + gelu(conv1d(x, w, bias, kernel KS, padding pad, groups)[..., :T])      x, y: [B, C, T], 48 channels per group.
+ * svc_posconv_pack_f32 folds weight_norm(dim=2) (g: [KS] or NULL) and packs v:[C][48][KS] to [groups][48][KS][64] (the two
+ * 32-row MFMA tiles of a group read full rows; rows 48..63 are zero).  One MFMA kernel, x tile staged in LDS, weights streamed
+ * from L2, bias + exact GELU + residual in the epilogue. */
+int svc_posconv_pack_f32(const float* v, const float* g, float* dst, int C, int KS, int groups, void* stream);
+int svc_posconv_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
+                    int groups, void* stream);
+
 /* Grouped strided Conv1d (DiscriminatorS, models.py:206-211): w:[Cout][Cin/groups][KS]. */
 int svc_gconv1d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Tin,
                         int Tout, int KS, int stride, int pad, int groups, void* stream);

@@ -122,6 +122,8 @@ def lib():
         L.svc_resample_sinc_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 2 + [C.c_int] * 7 + [C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
+        L.svc_posconv_pack_f32.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svc_posconv_f32.argtypes = [_f32p] * 4 + [C.c_int] * 6 + [C.c_void_p]
         L.svc_debug_set_conv_strip.argtypes = [C.c_int]
         if os.environ.get("SVC_CONV_STRIP"):     # A/B switch of the strip kernel (csrc/conv1d_strip.hip), read once at load
             L.svc_debug_set_conv_strip(int(os.environ["SVC_CONV_STRIP"]))
@@ -133,7 +135,7 @@ EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_debug_set_attention_waves", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -506,6 +508,28 @@ def channel_norm_gelu(x, gamma, beta, eps=1e-5, gelu=True):
     y = torch.empty_like(x)
     check(lib().svc_channel_norm_gelu_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), B, Cc, T, eps, 1 if gelu else 0, stream_ptr()),
           "channel_norm_gelu")
+    return y
+
+
+def posconv_pack(v, g=None, groups=16):
+    """HuBERT positional-conv weight v [C, C/groups, KS] (+ weight_norm dim=2 gain g [KS]) -> the MFMA kernel's packed layout."""
+    require_gpu(v, g)
+    v = v.contiguous().float()
+    Cc, cg, KS = v.shape
+    dst = torch.empty((groups, cg, KS, 64), device=v.device, dtype=torch.float32)
+    gg = g.reshape(-1).contiguous().float() if g is not None else None
+    check(lib().svc_posconv_pack_f32(ptr(v), ptr(gg), ptr(dst), Cc, KS, groups, stream_ptr()), "posconv_pack")
+    return dst
+
+
+def posconv(x, wpacked, bias, pad=64):
+    """y = x + gelu(grouped_conv1d(x, w, bias, padding=pad)[..., :T]) (vencoder/hubert/hubert_model.py:116-129), one MFMA kernel."""
+    require_gpu(x, wpacked, bias)
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    G, cg, KS, _ = wpacked.shape
+    y = torch.empty_like(x)
+    check(lib().svc_posconv_f32(ptr(x), ptr(wpacked), ptr(bias), ptr(y), B, Cc, T, KS, pad, G, stream_ptr()), "posconv")
     return y
 
 

@@ -65,3 +65,27 @@ def test_hubert_units_match_oracle(dev, B, n):
     assert u.shape == ref.shape
     err = (u.cpu() - ref).abs().max().item()
     assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 500), (2, 77), (1, 31), (1, 130)])
+def test_positional_conv_matches_torch(dev, B, T):
+    """csrc/posconv.hip (grouped k = 128 conv on the matrix pipe + GELU + residual in one launch) against torch's
+    weight-normed Conv1d(768, 768, 128, padding=64, groups=16) exactly as the reference module computes it
+    (vencoder/hubert/hubert_model.py:116-129)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    conv = torch.nn.Conv1d(768, 768, 128, padding=64, groups=16)
+    conv = torch.nn.utils.weight_norm(conv, name="weight", dim=2)
+    with torch.no_grad():
+        conv.weight_v.copy_(torch.randn(conv.weight_v.shape, generator=g) * 0.02)
+        conv.weight_g.copy_(torch.rand(conv.weight_g.shape, generator=g) + 0.5)
+        conv.bias.copy_(torch.randn(768, generator=g) * 0.1)
+    x = torch.randn(B, 768, T, generator=g)
+    with torch.no_grad():
+        ref = x + torch.nn.functional.gelu(conv(x)[:, :, :-1])
+    wp = S.posconv_pack(conv.weight_v.detach().to(dev), conv.weight_g.detach().to(dev), groups=16)
+    y = S.posconv(x.to(dev), wp, conv.bias.detach().to(dev), pad=64)
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
