@@ -222,16 +222,28 @@ def test_slice_inference_batches_unequal_silence_sliced_chunks(dev, tmp_path, mo
     voiced = (1.10, 1.27, 0.93, 1.31, 1.18, 0.71, 1.22)          # seven voiced stretches of different lengths, 1 s gaps
     wav = _song(seconds_voiced=voiced, gap=1.0)
     svc_audio.write_wav("song.wav", wav, SR)
+    # the slicer's own segmentation of this song (it merges stretches shorter than its min_length) is exercised by the tests
+    # above; here the segmentation is handed over explicitly (`chunks=`: [(is_silence, samples)], what slicer.chunks2audio
+    # returns) so that the chunk list is exactly seven voiced chunks of seven different lengths between silences
+    chunks, pos = [], 0
+    for i, sec in enumerate(voiced):
+        n = int(SR * sec)
+        chunks.append((False, wav[pos:pos + n]))
+        pos += n
+        if i + 1 < len(voiced):
+            g = int(SR * 1.0)
+            chunks.append((True, wav[pos:pos + g]))
+            pos += g
     svc = Svc(ck, cj, "cuda:0", "")
     calls = []
     orig = svc.net_g_ms.infer
     svc.net_g_ms.infer = lambda c, *a, **k: (calls.append((c.shape[0], c.shape[2], k.get("lengths") is not None)), orig(c, *a, **k))[1]
-    serial = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5)
+    serial = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5, chunks=chunks)
     n_serial = len(calls)
     lens = sorted({t for _, t, _ in calls})
     assert n_serial >= 6 and len(lens) >= 4 and all(b == 1 for b, _, _ in calls), calls
     calls.clear()
-    batched = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5, batch_chunks=True)
+    batched = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, pad_seconds=0.5, batch_chunks=True, chunks=chunks)
     assert len(calls) < n_serial and any(b >= 2 and ragged for b, _, ragged in calls), calls     # unequal chunks went through together
     assert serial.shape == batched.shape
     assert np.abs(serial - batched).max() <= 2e-5 * max(1.0, np.abs(serial).max())
