@@ -7,7 +7,12 @@ import bench
 import synthetic_data as W
 import train as TR
 dev = torch.device("cuda:0")
+if os.environ.get("SVC_CONV_CFG"):
+    import svc_hip
+    svc_hip.tlib().svc_debug_set_conv_cfg(int(os.environ["SVC_CONV_CFG"]))
 cfg = W.full_config()
+if os.environ.get("SVC_BENCH_PDROP") is not None:
+    cfg["p_dropout"] = float(os.environ["SVC_BENCH_PDROP"])
 hps = bench.train_hps(cfg)
 torch.manual_seed(1234)
 net_g, net_d, og, od = TR.build(hps, dev)

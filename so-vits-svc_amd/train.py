@@ -165,14 +165,17 @@ class TrainStep:
         return res
 
     def _serialize_replays(self):
-        """Wait (on the host) for the previous replay of the iteration graph before enqueueing the next one.
-        Measured on MI355X / ROCm 7.2 (profiles/r02_o_train_replay_after_sync_determinism.txt): when a replay is enqueued
-        right behind another one that started on an idle GPU — i.e. the second replay after any host synchronisation — the
-        iteration it produces is wrong (losses off from the next step on, sometimes diverging to NaN), while replays
-        separated by a host wait, and eager iterations, reproduce each other to fp32 round-off run after run.  The training
-        iteration is ~140 ms of GPU work and the host has nothing else to do, so the wait costs one launch latency."""
+        """OPT-IN (SVC_TRAIN_SERIALIZE=1): wait on the host for the previous replay of the iteration graph before enqueueing
+        the next one.  Round 2 needed this: with a mid-run synchronize (diag SYNC=at2 / at5) the iterations after it came out
+        bimodal / NaN when the next replay was enqueued behind a running one (profiles/r02_o_*).  Round 3 re-ran exactly those
+        reproducers WITHOUT the wait — 35 runs over SYNC=none / at2 / at5, with and without the gradient slab, with and without
+        dropout draws in the graph, on the round-3 kernels and on the round-2 conv epilogue path (profiles/r03p_*, r03q_*,
+        r03r_replay_diag.txt) — and every run reproduced the same loss trajectory to fp32 round-off.  The round-2 traces predate
+        that round's LayerNorm / grouped-conv kernel rewrites (the replaced kernels are the suspects; no stand-alone reproducer
+        was ever found), so the wait is no longer taken by default; tests/test_train_loop_gpu.py pins back-to-back replays
+        against eager iterations."""
         ev = self.__dict__.get("_replay_done")
-        if ev is not None:
+        if ev is not None and os.environ.get("SVC_TRAIN_SERIALIZE", "0") == "1":
             ev.synchronize()
 
     def _mark_replay(self):
