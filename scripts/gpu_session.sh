@@ -22,13 +22,13 @@ pairbench) timeout 300 python scripts/bench_pair.py > ${O}_pairbench.txt 2>&1; t
 gemmbench) timeout 300 python scripts/bench_train_kernels.py gemm > ${O}_gemmbench.txt 2>&1; cat ${O}_gemmbench.txt ;;
 inferab) for st in 0 1; do for ms in 1 0; do SVC_CONV_STRIP=$st SVC_MRF_STREAMS=$ms timeout 300 python bench.py --mode infer --steps 30 --warmup 5 --no-cpu-baseline > ${O}_infer_strip${st}_streams${ms}.json 2> ${O}_infer_strip${st}_streams${ms}.err; cat ${O}_infer_strip${st}_streams${ms}.json; done; done ;;
 bench) timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cat ${O}_bench.json; tail -3 ${O}_bench.err ;;
-prof) rm -rf gpurun_out/prof_stats; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline > ${O}_prof_bench.json 2> ${O}_prof_bench.err
+prof) rm -rf gpurun_out/prof_stats; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o run -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline --no-extras --no-host-io > ${O}_prof_bench.json 2> ${O}_prof_bench.err
       DB=$(find gpurun_out/prof_stats -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_infer_T862_kernel_stats_serialised.txt 2>&1; head -40 ${O}_infer_T862_kernel_stats_serialised.txt ;;
-trainprof) rm -rf gpurun_out/prof_train; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline > ${O}_trainprof_bench.json 2> ${O}_trainprof_bench.err
+trainprof) rm -rf gpurun_out/prof_train; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-extras > ${O}_trainprof_bench.json 2> ${O}_trainprof_bench.err
       DB=$(find gpurun_out/prof_train -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_train_B16_kernel_stats.txt 2>&1; head -60 ${O}_train_B16_kernel_stats.txt ;;
 pmc) rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
-     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > ${O}_pmc_fetch.log 2>&1
-     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > ${O}_pmc_write.log 2>&1
+     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-extras --no-host-io > ${O}_pmc_fetch.log 2>&1
+     SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --mode infer --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-roofline --no-extras --no-host-io > ${O}_pmc_write.log 2>&1
      python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write 4 ${O}_pmc_conv.json > ${O}_pmc_summary.txt 2>&1; cat ${O}_pmc_summary.txt ;;
 *) echo "custom step: $step"; eval "$step" ;;
 esac

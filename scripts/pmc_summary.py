@@ -17,7 +17,7 @@ from collections import defaultdict
 
 def family(name):
     name = re.sub(r"\s*\[clone.*$", "", name)
-    if "conv1d_mfma" in name:
+    if "conv1d_mfma" in name or "conv1d_strip" in name:      # one family in bench.py's roofline: every dense conv launch
         return "conv1d_mfma"
     m = re.match(r"(?:void\s+)?(?:\(anonymous namespace\)::)?([A-Za-z_0-9:]+)", name)
     return (m.group(1) if m else name).split("::")[-1].replace("_kernel", "")

@@ -1238,6 +1238,9 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     case 4: SVC_KS_CASES(2, 1, 1, 4, false)   // 64 x 128
     case 5: return launch_cfg<2, 1, 1, 1, 4, false>(a, s);   // 64 x 32, 4-way split-K
     case 7: SVC_KS_CASES(1, 7, 4, 1, false)   // 128 x 224
+    // (round 3: a 128 x 128 tile with 8 waves, two per 64 x 64 wave tile splitting the reduction, for the 256-channel stage
+    //  whose 128 x 128 tiling covers only 108 CUs: 224 vs 112 us at k = 11 on the register-staged path — not kept,
+    //  profiles/r03t_cfg8_*)
     default: return launch_cfg<1, 1, 1, 1, 4, false>(a, s);  // 32 x 32, 4-way split-K
   }
 }
