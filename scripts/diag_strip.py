@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CASES = [(0, 2, 128, 128, 1000, 11, 5), (0, 1, 64, 96, 460, 3, 1), (0, 1, 128, 256, 300, 7, 3), (1, 1, 64, 64, 1500, 7, 5),
          (1, 2, 64, 64, 100, 3, 1), (1, 1, 32, 128, 904, 11, 1), (2, 1, 32, 32, 2000, 11, 3), (2, 2, 32, 32, 8, 3, 5),
-         (3, 1, 256, 256, 300, 11, 5), (3, 2, 32, 64, 252, 3, 1), (3, 1, 128, 128, 700, 7, 3)]
+         (3, 1, 256, 256, 300, 11, 5), (3, 2, 32, 64, 252, 3, 1), (3, 1, 128, 128, 700, 7, 3),
+         (4, 1, 256, 256, 300, 11, 5), (4, 2, 64, 96, 460, 3, 1), (4, 1, 128, 128, 700, 7, 3)]
 
 if len(sys.argv) == 1:
     for i in range(len(CASES)):

@@ -59,9 +59,12 @@ template <> struct AccT<16> { typedef f32x4 type; };
 // of its stream: ds_reads, DMA issue, addressing — measured 1.2..1.6x the MFMA time, profiles/r03a_*, r03b_*); 2 = the strip's
 // tiles are split 4 + 3 between two waves of the same SIMD (waves w and w + 4), so one wave's operand reads / DMA issue /
 // epilogue stores run under the other's MFMAs.
-template <int TS, int WM, int WN, int NT, int KSC, bool PREACT, bool HAS_RES, int WPS>
+// SPLITK (WM = WN = 1, WPS = 1): ONE strip per workgroup, every wave computes all NT tiles over its own quarter of the input
+// channels and the four partial strips meet in LDS — for stages with few columns and many channels (256 channels x 6896
+// samples: 32-row strips give 8 x 31 = 248 workgroups where the row-parallel arrangements give 62).
+template <int TS, int WM, int WN, int NT, int KSC, bool PREACT, bool HAS_RES, int WPS, bool SPLITK = false>
 __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) {
-  static_assert(WM * WN == 4, "one strip per SIMD");
+  static_assert(SPLITK ? (WM == 1 && WN == 1 && WPS == 1 && TS == 32) : WM * WN == 4, "one strip per SIMD");
   static_assert(WPS == 1 || (WPS == 2 && NT == 7), "two waves per SIMD split a 7-tile strip 4 + 3");
   constexpr int NWV = 4 * WPS;
   static_assert(KSC >= 3, "the operand pipeline runs two taps ahead");
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int strip = wave & 3, half = wave >> 2;   // waves w and w + 4 run on the same SIMD (cyclic wave -> SIMD placement)
-  const int wm = strip / WN, wn = strip % WN;
+  const int wm = SPLITK ? 0 : strip / WN, wn = SPLITK ? 0 : strip % WN;
   const int ln = lane & (TS - 1), lk = lane / TS;
 
   int bid = blockIdx.x;
@@ -192,6 +195,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
 
     const int dil = a.dil;
     const int n_cc = BC / KPI;
+    // split-K: wave `strip` reduces the channel groups [qa, qb) of every chunk (n_cc is a multiple of 4: launcher)
+    const int qa = SPLITK ? strip * (n_cc >> 2) : 0, qb = SPLITK ? qa + (n_cc >> 2) : n_cc;
 
     // MFMAs over channel groups [q0, q1) of buffer `buf`.  Operand reads run two taps ahead of their MFMAs, across the loop
     // back-edge too (the chunk's last group looks ahead at itself: re-read, unused).
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       for (int q = q0; q < q1; ++q) {
         const float* wa = wl + q * (KPI * KSC * BM);
         const float* xa = xl + q * (KPI * XW);
-        const int qn = min(q + 1, n_cc - 1);
+        const int qn = min(q + 1, qb - 1);
         const float* wnx = wl + qn * (KPI * KSC * BM);
         const float* xnx = xl + qn * (KPI * XW);
   #pragma unroll
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       }
     };
     auto first_reads = [&](int buf) {
-      const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
-      const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
+      const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM) + qa * (KPI * KSC * BM);
+      const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW + qa * (KPI * XW);
       SVC_STRIP_LD(0, wl, xl)
       SVC_STRIP_LD(1, wl, xl)
     };
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       issue_begin((it & 1) ^ 1);
       while (si < steps_mine) { issue_a(); issue_b(); issue_c(); issue_d(); }
       first_reads(it & 1);
-      groups(it & 1, 0, n_cc);
+      groups(it & 1, qa, qb);
       wsrc += wstep;
       xsrc += xstep;
       strip_vmcnt0();    // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
@@ -266,14 +271,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
     const int rowl = rows_ok ? rowu : 0;
     const int colb = t0 + wn * (NT * TS) + J0 * TS + ln;
     auto rowc = [](int r) { return M16 ? r : (r & 3) + 8 * (r >> 2); };
-    float rr[NTW][NACC], bc_[NACC];
+    // tiles this wave finishes: all of its own (NTW), or — split-K — tiles strip, strip + 4 of the reduced strip
+    constexpr int NE = SPLITK ? (NT + 3) / 4 : NTW;
+    auto jcol = [&](int j) { return SPLITK ? strip + 4 * j : j; };
+    float rr[NE][NACC], bc_[NACC];
     float* yb = a.y + (long long)b * a.y_bs;
     const float* resb = a.res ? a.res + (long long)b * a.res_bs : a.x;
     const float* condb = a.cond ? a.cond + (long long)b * a.cond_bs : nullptr;
-    unsigned roff[NTW], yoff[NTW];
+    unsigned roff[NE], yoff[NE];
   #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const unsigned tc = (unsigned)min(colb + j * TS, a.Tout - 1);
+    for (int j = 0; j < NE; ++j) {
+      const unsigned tc = (unsigned)min(colb + jcol(j) * TS, a.Tout - 1);
       roff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.res_cs + tc);
       yoff[j] = 4u * ((unsigned)(4 * lk) * (unsigned)a.y_cs + tc);
     }
@@ -297,12 +305,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       for (int r = 0; r < NACC; ++r) {
         const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
   #pragma unroll
-        for (int j = 0; j < NTW; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
+        for (int j = 0; j < NE; ++j) asm volatile("global_load_dword %0, %1, %2" : "=a"(rr[j][r]) : "v"(roff[j]), "s"(rp));
       }
       }
     }
     first_reads(it & 1);
-    groups(it & 1, 0, n_cc);
+    groups(it & 1, qa, qb);
   #undef SVC_STRIP_LD
 
     // ---- epilogue straight from the accumulators (same expression and order as conv_epilogue's plain path).  The accumulate
@@ -312,17 +320,39 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual prefetch (landed long ago)
     if constexpr (HAS_RES) {   // ... and tie every later use of rr to this point (the asm loads are invisible to the scheduler)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
+      for (int j = 0; j < NE; ++j)
 #pragma unroll
         for (int r = 0; r < NACC; ++r) asm volatile("" : "+a"(rr[j][r]));
+    }
+    if constexpr (SPLITK) {
+      // the four partial strips meet in LDS ([wave][tile][reg][lane]: every access is 64 consecutive floats), summed in the
+      // fixed order wave 0..3 by the wave that finishes the tile; the sums replace acc[0 .. NE)
+      __syncthreads();                                   // everyone is done reading operands: the buffers are free
+      float* red = smem;
+  #pragma unroll
+      for (int j = 0; j < NTW; ++j)
+  #pragma unroll
+        for (int r = 0; r < NACC; ++r) red[((strip * NT + j) * NACC + r) * 64 + lane] = acc[j][r];
+      __syncthreads();
+  #pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int jt = min(jcol(j), NT - 1);
+  #pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+          float v = red[((0 * NT + jt) * NACC + r) * 64 + lane];
+  #pragma unroll
+          for (int w = 1; w < 4; ++w) v += red[((w * NT + jt) * NACC + r) * 64 + lane];
+          acc[j][r] = v;
+        }
+      }
     }
     // Column predicates are per MFMA tile (7 exec-mask regions, not 112); the accumulate / divide form (last conv of an MRF
     // chain: y = (v + beta*y_old) / out_div, IEEE division as in conv_epilogue) is a wave-uniform second copy.
     auto finish = [&](auto accdiv_tag) {
       constexpr bool ACCDIV = decltype(accdiv_tag)::value;
   #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        if (rows_ok && colb + j * TS < a.Tout) {
+      for (int j = 0; j < NE; ++j) {
+        if (rows_ok && jcol(j) < NT && colb + jcol(j) * TS < a.Tout) {
           float yo[NACC];
           if constexpr (ACCDIV) {
   #pragma unroll
@@ -367,9 +397,10 @@ int g_strip_launches = 0;   // launches that took this kernel (tests ask through
 
 struct StripCfg { int TS, WM, WN; };
 
-template <int TS, int WM, int WN, int KSC, bool PREACT, bool HAS_RES, int WPS>
+template <int TS, int WM, int WN, int KSC, bool PREACT, bool HAS_RES, int WPS, bool SPLITK = false>
 int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   constexpr int NT = 7, KPI = TS == 16 ? 4 : 2, BM = WM * TS, BN = WN * NT * TS;
+  constexpr int CMULT = SPLITK ? 4 * KPI : KPI;   // split-K: whole channel groups per wave
   StripP p;
   memset(&p, 0, sizeof(p));
   p.a = a;
@@ -382,7 +413,7 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   // largest chunk (power-of-two multiple of KPI dividing Cin) whose weight block is whole pieces and whose two buffers fit 160 KiB
   constexpr int RPP = 64 / (BM / 4);
   int bc = 0, npw = 0, buf_f = 0;
-  for (int c = 64; c >= KPI; c >>= 1) {
+  for (int c = 64; c >= CMULT; c >>= 1) {
     if (c > a.Cin || a.Cin % c || (c * a.KS) % RPP) continue;
     const int w_pieces = c * a.KS / RPP;
     const int f = w_pieces * 256 + c * xw;
@@ -396,8 +427,8 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
   p.n_t_tiles = svc::cdiv(a.Tout, BN);
   p.n_m_tiles = svc::cdiv(a.Cout, BM);
   const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
-  const size_t lds = (size_t)2 * buf_f * 4;
-  auto kd = conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES, WPS>;
+  const size_t lds = std::max((size_t)2 * buf_f * 4, SPLITK ? (size_t)4 * NT * 16 * 64 * 4 : (size_t)0);
+  auto kd = conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES, WPS, SPLITK>;
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -415,6 +446,24 @@ int strip_launch_mode(const svc_conv1d_args& a, hipStream_t s) {
   if (!pre && res) return strip_launch<TS, WM, WN, KSC, false, true, WPS>(a, s);    // second conv (its input was activated by the first's epilogue)
   if (pre && res) return strip_launch<TS, WM, WN, KSC, true, true, WPS>(a, s);      // ResBlock2 / un-fused second activation
   return 1;
+}
+
+template <int KSC>
+int strip_launch_splitk_mode(const svc_conv1d_args& a, hipStream_t s) {
+  const bool pre = a.pre_slope != 1.f, res = a.res_mode != 0;
+  if (pre && !res) return strip_launch<32, 1, 1, KSC, true, false, 1, true>(a, s);
+  if (!pre && res) return strip_launch<32, 1, 1, KSC, false, true, 1, true>(a, s);
+  if (pre && res) return strip_launch<32, 1, 1, KSC, true, true, 1, true>(a, s);
+  return 1;
+}
+
+int strip_launch_splitk(const svc_conv1d_args& a, hipStream_t s) {
+  switch (a.KS) {
+    case 3: return strip_launch_splitk_mode<3>(a, s);
+    case 7: return strip_launch_splitk_mode<7>(a, s);
+    case 11: return strip_launch_splitk_mode<11>(a, s);
+    default: return 1;
+  }
 }
 
 template <int TS, int WM, int WN>
@@ -448,7 +497,7 @@ namespace svc {
 
 // Returns 1 when the shape is not one for this kernel (the caller then runs conv1d_mfma_kernel), else the launch status.
 // mode 1 (default): take the strip kernel when one of its four wave arrangements covers the launch in whole rounds of the
-// chip at >= 85 % (useful tile area / (rounds * 256 CUs * tile area)); modes 2..5 force arrangement 0..3 (tests / tuning).
+// chip at >= 85 % (useful tile area / (rounds * 256 CUs * tile area)); modes 2..6 force arrangement 0..4 (tests / tuning; 4 = split-K).
 // mode + 10: the same with ONE wave per SIMD (the first form of this kernel, kept for A/B).
 int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
   if (g_strip_mode == 0) return 1;
@@ -463,16 +512,17 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
   if (!xvec || (a.Cin % 4) != 0 || a.x_cs < 0 || (a.Cout % 32) != 0 || a.Tin < 4) return 1;
   if (a.x_cs >= (1ll << 23) || (long long)a.CoutP * a.KS * 4 * 64 >= (1ll << 31)) return 1;    // 32-bit byte offsets inside a chunk
   if (a.y_cs < 0 || a.y_cs >= (1ll << 24) || a.res_cs < 0 || a.res_cs >= (1ll << 24)) return 1;   // ... and of 16 output rows
-  static const StripCfg cfgs[4] = {{32, 4, 1}, {32, 2, 2}, {32, 1, 4}, {16, 4, 1}};
+  static const StripCfg cfgs[5] = {{32, 4, 1}, {32, 2, 2}, {32, 1, 4}, {16, 4, 1}, {32, 1, 1}};   // the last one: split-K
   int best = -1;
   double best_eff = 0.0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     const int BM = cfgs[i].WM * cfgs[i].TS, BN = cfgs[i].WN * 7 * cfgs[i].TS;
     const double n = (double)svc::cdiv(a.Cout, BM) * svc::cdiv(a.Tout, BN) * a.B;
     const double eff = ((double)a.Cout * a.Tout * a.B) / (std::ceil(n / 256.0) * 256.0 * BM * BN);
     if (mode >= 2) {
       if (mode - 2 == i) { best = i; best_eff = 1.0; }
-    } else if (i < 3 && n >= 200 && eff > best_eff) {   // (the 16x16x4 form loses to the tiled kernel at 256 channels: forced modes only)
+    } else if (i < 3 && n >= 200 && eff > best_eff) {   // (the 16x16x4 and split-K forms lose to the tiled kernel at 256 channels — 127 vs
+                                                         //  112..123 us at k = 11, profiles/r03v_* — and stay forced-mode only)
       best = i;
       best_eff = eff;
     }
@@ -482,6 +532,7 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
     case 0: return strip_launch_ks<32, 4, 1>(a, s, wps);
     case 1: return strip_launch_ks<32, 2, 2>(a, s, wps);
     case 2: return strip_launch_ks<32, 1, 4>(a, s, wps);
+    case 4: return strip_launch_splitk(a, s);
     default: return strip_launch_ks<16, 4, 1>(a, s, wps);
   }
 }
