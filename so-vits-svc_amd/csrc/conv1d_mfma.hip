@@ -24,6 +24,7 @@
 // modules/modules.py:288-307 (coupling pre/post), modules/attentions.py:198-205,337-345 (q,k,v,o,FFN),
 // models.py:400,139 (pre, proj).
 #include "common.h"
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -376,6 +377,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
   const int lk = lane / TS;        // which K index of the instruction this lane feeds
 
   // block -> (phase, t tile, m tile, batch); phase fastest so the polyphase siblings share the X tile in L2
+  // (round 3: an XCD-aware map — all row tiles of a column tile on the XCD whose L2 holds its X rows — changed nothing on the
+  //  training shapes (3..12 row tiles) or the decoder's, profiles/r04a_trainconv_swz*.txt: X is not what these launches wait for)
   int bid = blockIdx.x;
   const int ph = bid % a.n_phase;
   bid /= a.n_phase;
@@ -589,6 +592,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
     issue(0);
     svc_vmcnt0();
     if (act) activate(0);
+    // The chunk loop is instantiated per activation form (ACT = leaky-ReLU applied to each B operand as it is read, 1..3
+    // taps with a slope != 1) and the form chosen ONCE, outside it: chosen per chunk, the two MFMA loops kept the 64
+    // accumulator registers in different places and every chunk paid 64 v_mov_b64 to move them over and back.
+    auto chunks = [&](auto act_tag) {
+    constexpr bool ACT = decltype(act_tag)::value;
     int it = 0;
     for (int c0 = 0; c0 < a.Cin; c0 += BC, ++it) {
       __syncthreads();  // chunk `it` is in LDS (landed + activated by its owners); everyone is done reading the other buffer
@@ -596,41 +604,65 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
       const float* wbuf = wbase + (it & 1) * buf_f;
       const float* xbuf = xbase + (it & 1) * buf_f;
       const int n_cc = BC / KPI;
+      // (round 3: ONE continuous operand pipeline over the chunk — reads of step s + 2 in front of the MFMAs of step s across
+      //  channel pairs, operand ring, sched_barrier between groups — instead of restarting at every channel pair: slower on
+      //  every shape, 1 x 1 convs included (profiles/r03z_trainconv.txt vs r03y_*): the per-pair restart is not what holds
+      //  the short-reduction shapes back)
       if constexpr (KSC > 0) {
         const int dil = a.dil;
-        for (int q = 0; q < n_cc; ++q) {
-          const int cl = q * KPI + lk;
-          const float* wa = wbuf + cl * (KSC * BM);
-          const float* xa = xbuf + cl * XW;
-          float av[KSC][MT], bv[KSC][NT];
+        // ACT: leaky-ReLU applied to each B operand as it is read (1..3 taps, see above).  Instantiated twice: plain inputs
+        // (slope 1: every training conv, the encoder / flow convs) must not pay its 3 VALU per operand — nor their effect on
+        // the schedule: the VALU sat outside the sched groups below and the k = 3 loop ran at ~100 cycles per MFMA against
+        // ~70 for k = 5, which has no such pass (profiles/r04b_trainconv_dbg.txt).
+        {
+          for (int q = 0; q < n_cc; ++q) {
+            const int cl = q * KPI + lk;
+            const float* wa = wbuf + cl * (KSC * BM);
+            const float* xa = xbuf + cl * XW;
+            float av[KSC][MT], bv[KSC][NT];
+            auto fetch = [&](int k) {
 #pragma unroll
-          for (int k = 0; k < KSC; ++k) {
+              for (int i = 0; i < MT; ++i) av[k][i] = wa[k * BM + i * TS];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[k][i] = wa[k * BM + i * TS];
+              for (int j = 0; j < NT; ++j) bv[k][j] = xa[k * dil + j * TS];
+            };
+            if constexpr (ACT) {
+              // explicit order (fences): the sched groups below do not place the activation's VALU — left to itself the
+              // scheduler waited for every read and chained the three MFMAs of one accumulator back to back
+              fetch(0);
+              if constexpr (KSC > 1) fetch(1);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              if constexpr (ACT_ON_READ) {
-                const float v = xa[k * dil + j * TS];
-                bv[k][j] = fmaxf(v, v * ps);
-              } else {
-                bv[k][j] = xa[k * dil + j * TS];
+              for (int k = 0; k < KSC; ++k) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[k][j] = fmaxf(bv[k][j], bv[k][j] * ps);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                  for (int j = 0; j < NT; ++j)
+                    acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
+                if (k + 2 < KSC) fetch(k + 2);
+                __builtin_amdgcn_sched_barrier(0);
               }
-            }
-          }
+            } else {
 #pragma unroll
-          for (int k = 0; k < KSC; ++k)
+              for (int k = 0; k < KSC; ++k) fetch(k);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+              for (int k = 0; k < KSC; ++k)
 #pragma unroll
-              for (int j = 0; j < NT; ++j)
-                acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
-          if constexpr (KSC >= 3) {
-            constexpr int DSPT = (MT + 1) / 2 + (NT + 1) / 2;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * DSPT, 0);
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int k = 0; k < KSC; ++k) {
-              __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-              if (k + 2 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, DSPT, 0);
+                  for (int j = 0; j < NT; ++j)
+                    acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][i], bv[k][j], acc32[i][j], 0, 0, 0);
+              if constexpr (KSC >= 3) {
+                constexpr int DSPT = (MT + 1) / 2 + (NT + 1) / 2;
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * DSPT, 0);
+#pragma unroll
+                for (int k = 0; k < KSC; ++k) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                  if (k + 2 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, DSPT, 0);
+                }
+              }
             }
           }
         }
@@ -667,6 +699,13 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
         svc_vmcnt0();  // this wave's pieces of chunk it+1 have landed (they had the whole MFMA loop to do so)
         if (act) activate((it + 1) & 1);
       }
+    }
+    };
+    if constexpr (ACT_ON_READ) {
+      if (ps != 1.f) chunks(std::true_type{});
+      else chunks(std::false_type{});
+    } else {
+      chunks(std::false_type{});
     }
   } else {
   const int cur = BC;
@@ -794,6 +833,7 @@ int g_no224 = 1;       // 1: the 128x224 one-workgroup-per-CU tile stays out of 
                        // owns a whole CU (223 VGPR + 112 AGPR, 116 KB LDS): with the decoder's three MRF chains on concurrent
                        // streams the 128x128 tile (two workgroups per CU, from different launches) lets one launch's epilogue
                        // overlap another's MFMA loop: clip 8.29 / 8.44 ms with 128x224 vs 8.17 / 8.19 ms without (same box)
+int g_no192 = -1;     // 1: never pick the 64x192 tiling (A/B switch: environment SVC_CONV_NO192=1, read at the first launch)
 int g_direct_epi = 1;  // 1: DB kernels store straight from the accumulators where the epilogue form allows (svc_debug_set_conv_cfg: +1000000000 disables)
 int g_fast_epi = 1;    // 1: DB kernels batch the epilogue's residual loads (svc_debug_set_conv_cfg: +10000000 disables)
 int g_direct_mode = 1; // 1: short-sequence split-K shapes run the register-fed direct kernel (svc_debug_set_conv_cfg: +1000000 disables)
@@ -863,6 +903,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   if constexpr (!M16 && WK == 1) {
     const size_t epi_bytes = (size_t)BM * (BN + 4) * 4;
     // (tried: 80 KiB for the 128x128 tiles, two per CU, half as many chunks / barriers: no measurable change)
+    // (round 3: a 128 KiB budget — twice the chunk, half the hand-overs — for launches of at most one workgroup per CU: no
+    //  change on any shape, profiles/r03y_trainconv_solo{64,128}.txt)
     const size_t budget = std::max((size_t)(BM * BN >= 128 * 128 ? g_db_budget_kb : 64) * 1024, epi_bytes);
     bool use_db = g_db_mode != 0 && xvec && a.pre_slope >= 0.f && a.pre_slope <= 1.f && (a.Cin % KG) == 0 &&
                   std::llabs((long long)a.x_cs) * 4 * 64 < (1ll << 31) && (long long)a.CoutP * a.KS * 4 * 64 < (1ll << 31);
@@ -1134,6 +1176,10 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     snprintf(pname, sizeof(pname), "%s", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma");
   svc::ProfScope prof(s, pname, flop, bytes);
 
+  if (g_no192 < 0) {
+    const char* e = getenv("SVC_CONV_NO192");
+    g_no192 = (e && e[0] == '1') ? 1 : 0;
+  }
   // long sequences that one round of 224-column strips covers (the decoder's MRF convs): conv1d_strip.hip
   if (g_force_cfg < 0) {
     const int rs = svc::conv1d_strip_try(a, s);
@@ -1182,6 +1228,14 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
         const double t224 = std::ceil(n224 / 256.0) * 128 * 224 * 1.04;
         if (t224 < best) { best = t224; cfg = 7; }
       }
+      // 64x192 (three column tiles per wave): the training graph's 192- and 384-row convolutions at B x T = 16 x 768 —
+      // 6 (12) row tiles x 384 column tiles = 2.25 (4.5) tiles per SIMD, which 2x2-tile waves round up to 4 (8) tile times
+      // and 3-tile waves to 3 (6).  Batched launches only: a single utterance's stages are tuned separately (§4).
+      if (m64 && a.B > 1 && !g_no192) {
+        const double n192 = (double)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 192) * a.B;
+        const double t192 = std::ceil(n192 / 256.0) * 64 * 192 * 1.03;
+        if (t192 < best) { best = t192; cfg = 9; }
+      }
     }
   }
   {
@@ -1196,7 +1250,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   }
   if (g_force_cfg >= 0 && a.Cout > 16) {
     const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
-                    (a.epi != SVC_EPI_GATE && g_force_cfg <= 7 && g_force_cfg >= 1);
+                    (a.epi != SVC_EPI_GATE && ((g_force_cfg <= 7 && g_force_cfg >= 1) || g_force_cfg == 9));
     if (ok) cfg = g_force_cfg;
   }
   if ((cfg == 5 || cfg == 6 || (a.epi == SVC_EPI_GATE && cfg != 3 && cfg != 4)) && direct_ok(a) && g_direct_mode) {
@@ -1238,6 +1292,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     case 4: SVC_KS_CASES(2, 1, 1, 4, false)   // 64 x 128
     case 5: return launch_cfg<2, 1, 1, 1, 4, false>(a, s);   // 64 x 32, 4-way split-K
     case 7: SVC_KS_CASES(1, 7, 4, 1, false)   // 128 x 224
+    case 9: SVC_KS_CASES(1, 3, 2, 2, false)   // 64 x 192
     // (round 3: a 128 x 128 tile with 8 waves, two per 64 x 64 wave tile splitting the reduction, for the 256-channel stage
     //  whose 128 x 128 tiling covers only 108 CUs: 224 vs 112 us at k = 11 on the register-staged path — not kept,
     //  profiles/r03t_cfg8_*)

@@ -97,10 +97,9 @@ __device__ __forceinline__ void wmap_index(const WMap& p, int r, int c, int k, i
     m = p.Kd - 1 - mm;
   }
 }
-__global__ void conv_weight_prep_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ wp,
-                                        float* __restrict__ wt, float* __restrict__ norm, WMap p) {
-  __shared__ double sh[256];
-  const int r = blockIdx.x;
+__device__ __forceinline__ void conv_weight_prep_row(const float* __restrict__ v, const float* __restrict__ g,
+                                                     float* __restrict__ wp, float* __restrict__ wt, float* __restrict__ norm,
+                                                     const WMap& p, int r, double* sh) {
   const int n = p.C2 * p.K;
   const float* vr = v + (long long)r * n;
   float sc = 1.f;
@@ -122,6 +121,29 @@ __global__ void conv_weight_prep_kernel(const float* __restrict__ v, const float
     wp[((long long)i * p.Kd + m) * p.OdP + o] = val;
     if (wt) wt[((long long)o * p.Kd + (p.Kd - 1 - m)) * p.IdP + i] = val;
   }
+}
+__global__ void conv_weight_prep_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ wp,
+                                        float* __restrict__ wt, float* __restrict__ norm, WMap p) {
+  __shared__ double sh[256];
+  conv_weight_prep_row(v, g, wp, wt, norm, p, blockIdx.x, sh);
+}
+// the same for MANY convolutions in one launch: block -> (plan, row) through the prefix sums of the plans' row counts.  A
+// training iteration prepares ~360 weights (generator + discriminators, the latter twice), each a 5..12 us launch that is
+// latency- not bandwidth-bound (profiles/r03l_train_*: 359 x 11.8 us = 4.2 ms of a 110 ms step); together they move ~1 GB.
+__global__ void conv_weight_prep_multi_kernel(const svc_conv_weight_args* __restrict__ tab, const int* __restrict__ row_start,
+                                              int n_plans) {
+  __shared__ double sh[256];
+  const int row = blockIdx.x;
+  int lo = 0, hi = n_plans - 1;            // last plan whose first row is <= row
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (row_start[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  const svc_conv_weight_args a = tab[lo];
+  WMap p;
+  p.kind = a.kind; p.R = a.R; p.C2 = a.C2; p.K = a.K; p.Od = a.Od; p.Id = a.Id; p.Kd = a.Kd; p.OdP = a.OdP; p.IdP = a.IdP;
+  p.s = a.s; p.shift = a.shift;
+  conv_weight_prep_row(a.v, a.g, a.wp, a.wt, a.norm, p, row - row_start[lo], sh);
 }
 // adjoint: dwd [Od][Id][Kd] (svc_conv1d_wgrad_f32's output) -> dv (and dg): dw[r][c][k] = dwd[o][i][m],
 // dg[r] = <dw, v> / ||v||,  dv = (g/||v||) (dw - v <dw,v>/||v||^2);  without g: dv = dw.
@@ -620,6 +642,25 @@ int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream) {
   hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(p.R), dim3(256), 0, (hipStream_t)stream, args->v, args->g, args->wp,
                      args->wt, args->norm, p);
   return svc::check_launch("conv_weight_prep");
+}
+
+int svc_conv_weight_prep_multi_f32(const svc_conv_weight_args* host_args, const svc_conv_weight_args* dev_args,
+                                   const int* dev_row_start, int n_plans, void* stream) {
+  SVC_REQUIRE(host_args && dev_args && dev_row_start && n_plans > 0, "conv_weight_prep_multi: null table");
+  long long rows = 0;
+  for (int i = 0; i < n_plans; ++i) {
+    const svc_conv_weight_args& a = host_args[i];
+    SVC_REQUIRE(a.v && a.wp, "conv_weight_prep_multi: null tensor in plan %d", i);
+    SVC_REQUIRE(!a.g || a.norm, "conv_weight_prep_multi: weight-normed plan %d needs the norm output", i);
+    WMap p;
+    const int rc = wmap_from(a, p);
+    if (rc != SVC_OK) return rc;
+    rows += a.R;
+  }
+  SVC_REQUIRE(rows < (1ll << 31), "conv_weight_prep_multi: too many rows");
+  hipLaunchKernelGGL(conv_weight_prep_multi_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dev_args,
+                     dev_row_start, n_plans);
+  return svc::check_launch("conv_weight_prep_multi");
 }
 
 int svc_conv_weight_grad_f32(const svc_conv_weight_args* args, const float* dwd, float* dv, float* dg, void* stream) {

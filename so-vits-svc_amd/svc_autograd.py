@@ -81,7 +81,16 @@ class _ConvPlanned(Function):
         Tout = Tin + 2 * pad - dil * (plan.Kd - 1)
         if tout is not None:
             Tout = tout if exact else min(Tout, tout)
-        y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
+        # 1x1 conv of a [B, C, 1] tensor (the speaker-conditioning convs `cond_layer(g)`, modules/modules.py:96-97,114): as B rows
+        # of ONE column each launch fills 1/128 of a tile (0.3 TFLOP/s, 150 us per call at B = 16: profiles/r03w_*).  The batch
+        # becomes the column axis instead: [1, C, B] — the same GEMM in one tile row.
+        ctx.batch_cols = bool(Tin == 1 and Tout == 1 and plan.Kd == 1 and pad == 0 and x.shape[0] > 1)
+        if ctx.batch_cols:
+            x = x.squeeze(2).t().contiguous().unsqueeze(0)                       # [1, Cin, B]
+            y = S.conv1d(x, wp, plan.Od, 1, bias=bias)                            # [1, Od, B]
+            y = y.squeeze(0).t().contiguous().unsqueeze(2)                       # [B, Od, 1]
+        else:
+            y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
         ctx.save_for_backward(x, v, g)
         ctx.plan = plan
         ctx.cfg = (pad, dil, bias is not None)
@@ -93,9 +102,13 @@ class _ConvPlanned(Function):
         plan = ctx.plan
         pad, dil, has_bias = ctx.cfg
         dy = _c(dy)
+        if ctx.batch_cols:                                                       # x was saved as [1, Cin, B]
+            dy = dy.squeeze(2).t().contiguous().unsqueeze(0)                     # [1, Od, B]
         dx = dv = dg = db = None
         if ctx.needs_input_grad[0]:
             dx = S.conv1d(dy, plan.wt, plan.Id, plan.Kd, dil=dil, pad_left=dil * (plan.Kd - 1) - pad, Tout=x.shape[2])
+            if ctx.batch_cols:
+                dx = dx.squeeze(0).t().contiguous().unsqueeze(2)                 # [B, Cin, 1]
         want_db = has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             if want_db:

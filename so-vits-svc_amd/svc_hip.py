@@ -640,7 +640,7 @@ class ConvWeightArgs(C.Structure):
 
 
 TRAIN_EXPORTS = [
-    "svc_conv_weight_prep_f32", "svc_conv_weight_grad_f32",
+    "svc_conv_weight_prep_f32", "svc_conv_weight_prep_multi_f32", "svc_conv_weight_grad_f32",
     "svc_weight_norm_fwd_f32", "svc_weight_norm_bwd_f32", "svc_pack_conv1d_weight_T", "svc_conv1d_wgrad_f32",
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
@@ -663,6 +663,7 @@ def tlib():
         L.svc_conv1d_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]
         L.svc_conv_weight_prep_f32.argtypes = [C.POINTER(ConvWeightArgs), vp]
         L.svc_conv_weight_grad_f32.argtypes = [C.POINTER(ConvWeightArgs), _f32p, _f32p, _f32p, vp]
+        L.svc_conv_weight_prep_multi_f32.argtypes = [C.POINTER(ConvWeightArgs), vp, vp, i, vp]
         L.svc_gemm_f32.argtypes = [C.POINTER(GemmArgs), vp]
         L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
         L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
@@ -811,14 +812,22 @@ class ConvWeightPlan:
         if g is not None and (g.numel() != self.R or not g.is_contiguous()):
             raise SvcError("ConvWeightPlan: weight_g must hold one contiguous value per row")
 
+    def _alloc(self, device):
+        if self.wp is None or self.wp.device != device:
+            self.wp = torch.zeros((self.Id, self.Kd, self.OdP), device=device, dtype=torch.float32)
+            self.wt = torch.zeros((self.Od, self.Kd, self.IdP), device=device, dtype=torch.float32)
+            self.norm = torch.empty((self.R,), device=device, dtype=torch.float32)
+
     def prepare(self, v, g=None):
         """-> (wp [Id,Kd,OdP], wt [Od,Kd,IdP]) for v (and g) as they are now."""
         self._check(v, g)
-        if self.wp is None or self.wp.device != v.device:
-            self.wp = torch.zeros((self.Id, self.Kd, self.OdP), device=v.device, dtype=torch.float32)
-            self.wt = torch.zeros((self.Od, self.Kd, self.IdP), device=v.device, dtype=torch.float32)
-            self.norm = torch.empty((self.R,), device=v.device, dtype=torch.float32)
+        fresh = self.__dict__.get("_fresh")
+        if fresh is not None and fresh == (v.data_ptr(), g.data_ptr() if g is not None else 0) and self.wp is not None:
+            return self.wp, self.wt      # filled by the open PlanSets bracket's one launch from exactly these tensors
+        self._alloc(v.device)
         check(tlib().svc_conv_weight_prep_f32(C.byref(self._args(v, g)), stream_ptr()), "conv_weight_prep")
+        if PlanSets.recording is not None:
+            PlanSets.recording.note(self, v, g)
         return self.wp, self.wt
 
     def grad(self, v, g, dwd):
@@ -834,6 +843,72 @@ class ConvWeightPlan:
         check(tlib().svc_conv_weight_grad_f32(C.byref(self._args(v, g)), ptr(dwd), ptr(dv), ptr(dg), stream_ptr()),
               "conv_weight_grad")
         return dv, dg
+
+
+class PlanSets:
+    """One-launch weight preparation for a group of ConvWeightPlans (svc_conv_weight_prep_multi_f32).
+
+    A training loop brackets a forward pass whose convolution weights are parameters with `enter(tag, params)` /
+    `leave(tag)`.  The first bracketed pass records which plans were prepared from which parameters; from then on
+    `enter` prepares them all in ONE launch and hands each plan a token naming the parameter storage it was prepared from,
+    so the pass's own `plan.prepare(v, g)` calls return the already filled operands (any other tensor prepares as usual).
+    `leave` withdraws the tokens: operands are never reused outside the bracket, i.e. across an optimizer step — the caller
+    must not update the parameters inside one.
+    Plans fed from computed tensors (spectral-norm weights) are not parameters' storage and stay on their own launch."""
+
+    recording = None      # the instance whose bracket is open and recording (one at a time)
+
+    def __init__(self):
+        self.sets, self.rec, self.ptrs, self.enabled = {}, None, None, os.environ.get("SVC_PLAN_SETS", "1") != "0"
+        self._retired = []   # tables of replaced sets: a captured graph may still point at them
+
+    def note(self, plan, v, g):
+        if self.rec is None:
+            return
+        if v.data_ptr() in self.ptrs and (g is None or g.data_ptr() in self.ptrs) and all(e[0] is not plan for e in self.rec):
+            self.rec.append((plan, v, g))
+
+    def enter(self, tag, params):
+        if not self.enabled:
+            return
+        ent = self.sets.get(tag)
+        if ent is not None and all(v.data_ptr() == pv and (g.data_ptr() if g is not None else 0) == pg and pl.wp is not None
+                                   for (pl, v, g), (pv, pg) in zip(ent["items"], ent["ptrs"])):
+            check(tlib().svc_conv_weight_prep_multi_f32(ent["host"], ent["dev"].data_ptr(), ent["rows"].data_ptr(),
+                                                        len(ent["items"]), stream_ptr()), "conv_weight_prep_multi")
+            for (pl, v, g), key in zip(ent["items"], ent["ptrs"]):
+                pl._fresh = key
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return               # building a table copies host memory: not inside a capture (this pass prepares plan by plan)
+        old = self.sets.pop(tag, None)
+        if old is not None:
+            self._retired.append((old["dev"], old["rows"], old["host"]))
+        self.rec, self.ptrs = [], {p.data_ptr() for p in params}
+        PlanSets.recording = self
+
+    def leave(self, tag):
+        if not self.enabled:
+            return
+        if self.rec is not None:
+            items, self.rec, self.ptrs = self.rec, None, None
+            PlanSets.recording = None
+            if items:
+                host = (ConvWeightArgs * len(items))(*[pl._args(v, g) for pl, v, g in items])
+                dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(items[0][1].device)
+                starts, acc = [], 0
+                for pl, _, _ in items:
+                    starts.append(acc)
+                    acc += pl.R
+                rows = torch.tensor(starts, dtype=torch.int32).to(dev.device)
+                self.sets[tag] = dict(items=items, host=host, dev=dev, rows=rows,
+                                      ptrs=[(v.data_ptr(), g.data_ptr() if g is not None else 0) for _, v, g in items])
+            return
+        ent = self.sets.get(tag)
+        if ent is not None:
+            for pl, _, _ in ent["items"]:
+                pl.__dict__.pop("_fresh", None)
+
 
 
 class ZeroSlab:

@@ -81,6 +81,7 @@ class TrainStep:
 
         self.use_graph = False
         self._graphs = {}
+        self.plan_sets = S.PlanSets()     # one-launch weight preparation per forward pass (G, D, D again after its step)
 
     def enable_graph(self, on=True):
         """Replay the whole iteration (forward, both backwards, both optimizer steps: ~7000 launches) from ONE hipGraph
@@ -212,15 +213,23 @@ class TrainStep:
             spec = context_spectrogram(spec.to(y.device), self.n_fft, self.sr, self.hop, self.win)
         mel = spec_to_mel_torch(spec, self.n_fft, self.n_mels, self.sr, self.fmin, self.fmax)            # :158-164
         kw = dict(noise=noise) if noise is not None else {}
-        y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
-            c, f0, uv, spec, g=spk, c_lengths=lengths, spec_lengths=lengths, vol=volume, **kw)            # :167-169
+        self.plan_sets.enter("g", net_g.parameters())
+        try:
+            y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
+                c, f0, uv, spec, g=spk, c_lengths=lengths, spec_lengths=lengths, vol=volume, **kw)        # :167-169
+        finally:
+            self.plan_sets.leave("g")
         y_mel = commons.slice_segments(mel, ids_slice, seg_frames)                                        # :171
         y_hat_mel = mel_spectrogram_torch(y_hat.squeeze(1), self.n_fft, self.n_mels, self.sr, self.hop, self.win,
                                           self.fmin, self.fmax)                                           # :172-181
         y = commons.slice_segments(y, ids_slice * self.hop, self.segment_size)                            # :182
 
         # ---- discriminator step (:184-195) ----
-        y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+        self.plan_sets.enter("d", net_d.parameters())
+        try:
+            y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+        finally:
+            self.plan_sets.leave("d")
         loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         loss_disc.backward()
@@ -233,8 +242,12 @@ class TrainStep:
         gmod = net_g.module if hasattr(net_g, "module") else net_g
         dmod = net_d.module if hasattr(net_d, "module") else net_d
         y, y_hat, y_mel, y_hat_mel = ctx["y"], ctx["y_hat"], ctx["y_mel"], ctx["y_hat_mel"]
-        with no_param_grads(dmod):
-            _, y_d_hat_g, fmap_r, fmap_g = dmod.forward_gen_step(y, y_hat)
+        self.plan_sets.enter("d_gen", dmod.parameters())      # D's weights as its optimizer step just left them
+        try:
+            with no_param_grads(dmod):
+                _, y_d_hat_g, fmap_r, fmap_g = dmod.forward_gen_step(y, y_hat)
+        finally:
+            self.plan_sets.leave("d_gen")
         loss_mel = A.sum_abs_diff(y_mel, y_hat_mel) / y_mel.numel() * self.c_mel                           # :202
         loss_kl = kl_loss(ctx["z_p"], ctx["logs_q"], ctx["m_p"], ctx["logs_p"], ctx["z_mask"]) * self.c_kl  # :203
         loss_fm = feature_loss(fmap_r, fmap_g)

@@ -27,6 +27,11 @@ CASES = [
     (1, 128, 128, 20000, 3, 1),
     (1, 64, 64, 20000, 7, 5),
     (1, 192, 512, 20000, 7, 1),
+    # batched training shapes: the 64 x 192 tiling (three column tiles per wave) is selected for these
+    (16, 192, 192, 768, 1, 1),
+    (16, 384, 192, 768, 5, 1),
+    (4, 192, 384, 700, 5, 2),
+    (16, 96, 192, 767, 3, 1),      # T not a multiple of 4: the scalar-staging instantiation of the same tiling
 ]
 
 

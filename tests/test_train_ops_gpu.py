@@ -366,3 +366,55 @@ def test_channel_layer_norm_fwd_bwd(dev, B, C, T):
     t = dict(x=_p(B, C, T), gamma=(1.0 + 0.1 * torch.randn(C)).requires_grad_(True), beta=_p(C, scale=0.1))
     _run_pair(lambda x, gamma, beta: A.layer_norm(x, gamma, beta, 1e-5),
               lambda x, gamma, beta: F.layer_norm(x.transpose(1, 2), (C,), gamma, beta, 1e-5).transpose(1, 2), t, dev, tol=3e-5)
+
+
+def test_plan_sets_one_launch_equals_per_plan_preparation(dev):
+    """svc_hip.PlanSets (svc_conv_weight_prep_multi_f32): a bracketed forward pass records its plans once, later brackets fill
+    every plan's operands in ONE launch.  Dense weight-normed, plain dense, strided and transposed maps together; the
+    operands must be bit-equal to the per-plan launch after every parameter change, the modules' own prepare() calls inside
+    the bracket must not launch again (the operands keep a poison value written behind their back only if they do), and
+    outside the bracket prepare() must launch as before."""
+    import svc_hip as S
+    import svc_nn
+    torch.manual_seed(21)
+    mods = torch.nn.ModuleList([svc_nn.Conv1d(16, 24, 3, padding=1, weight_norm=True), svc_nn.Conv1d(192, 384, 5, padding=2),
+                                svc_nn.Conv1d(1, 16, 16, stride=8, padding=4), svc_nn.Conv1d(12, 20, 5, stride=3, padding=2, weight_norm=True),
+                                svc_nn.ConvTranspose1d(32, 16, 16, stride=8, padding=4, weight_norm=True),
+                                svc_nn.Conv1d(1024, 1, 3, padding=1, weight_norm=True)]).to(dev)
+    xs = [torch.randn(2, m.in_channels, 64, device=dev) for m in mods]
+
+    def forward():
+        return [m.forward_train(x) for m, x in zip(mods, xs)]
+
+    sets = S.PlanSets()
+    sets.enter("pass", mods.parameters())
+    ref0 = forward()                                     # recording pass: per-plan launches
+    sets.leave("pass")
+    assert len(sets.sets["pass"]["items"]) == len(mods)
+    plans = [m.__dict__["_svc_plan"] for m in mods]
+    masks = [(pl.wp != 0, pl.wt != 0) for pl in plans]   # mapped entries (the zero-filled padding is never written)
+    for it in range(2):
+        with torch.no_grad():
+            for p in mods.parameters():
+                p.mul_(1.0 + 0.25 * (it + 1)).add_(0.01)
+        ref = [(pl.prepare(*_vg(m))[0].clone(), pl.wt.clone(), pl.norm.clone()) for pl, m in zip(plans, mods)]
+        for pl in plans:
+            pl.wp.fill_(7.0); pl.wt.fill_(7.0)           # stale operands: the bracket must rewrite every mapped entry
+        sets.enter("pass", mods.parameters())
+        try:
+            for pl, m, (wp, wt, nm), (mp, mt) in zip(plans, mods, ref, masks):
+                got_wp, got_wt = pl.prepare(*_vg(m))     # served by the bracket's launch
+                assert torch.equal(got_wp[mp], wp[mp]) and torch.equal(got_wt[mt], wt[mt])
+                if hasattr(m, "weight_g"):
+                    assert torch.equal(pl.norm, nm)
+                pl.wp.fill_(3.0)
+                assert pl.prepare(*_vg(m))[0].flatten()[0].item() == 3.0      # no second launch inside the bracket
+        finally:
+            sets.leave("pass")
+        pl, m = plans[0], mods[0]
+        assert pl.prepare(*_vg(m))[0].flatten()[0].item() != 3.0              # outside: prepares again (entry 0 is mapped)
+    torch.cuda.synchronize()
+
+
+def _vg(m):
+    return (m.weight_v, m.weight_g) if hasattr(m, "weight_g") else (m.weight, None)
