@@ -62,8 +62,9 @@ int svc_prof_report(char* buf, int len);
 int svc_pack_conv1d_weight(const float* v, const float* g, float* dst, int Cout, int Cin, int KS,
                            int CoutP, int gate_half, void* stream);
 /* ConvTranspose1d weight v:[Cin][Cout][KS] (+ optional g:[Cin], norm over (Cout,KS): weight_norm dim=0
- * on a transposed conv, vdecoder/hifigan/models.py:340-342) -> polyphase blocks
- * dst:[stride][Cin][M][CoutP], M = ceil(KS/stride), dst[p][ci][mr][co] = w[ci][co][p + (M-1-mr)*stride]. */
+ * on a transposed conv, vdecoder/hifigan/models.py:340-342) -> stride*Cin*M*CoutP floats, M = ceil(KS/stride), private to
+ * svc_conv_transpose1d_f32: polyphase blocks dst[p][ci][mr][co] = w[ci][co][p + (M-1-mr)*stride], or — strides 2, 4, 8, 16 —
+ * the phases as rows of one convolution, dst[ci][mr][co*stride + p]. */
 int svc_pack_convt1d_weight(const float* v, const float* g, float* dst, int Cin, int Cout, int KS,
                             int CoutP, int stride, void* stream);
 

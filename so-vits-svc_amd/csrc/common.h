@@ -1,6 +1,7 @@
 // common.h — shared host-side helpers for libsvc_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -46,6 +47,12 @@ inline int check_launch(const char* what) {
 
 // conv1d_strip.hip: long-sequence dense conv, one workgroup per CU; returns 1 when the shape is not one of its shapes
 int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s);
+// ConvTranspose1d weight layout: true = phases as rows [Cin][M][u*CoutP] (row = co*u + phase), one dense convolution;
+// false = one block per phase [u][Cin][M][CoutP].  Powers of two divide every row tile of the conv kernels (16..128).
+inline bool convt_rows_layout(int stride) {
+  static const bool on = [] { const char* e = getenv("SVC_CONVT_ROWS"); return !(e && e[0] == '0'); }();   // A/B switch
+  return on && stride >= 2 && stride <= 16 && (stride & (stride - 1)) == 0;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }

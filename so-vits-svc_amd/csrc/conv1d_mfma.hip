@@ -34,6 +34,12 @@ namespace {
 constexpr int WLD = 16;   // float4 weight loads in flight per thread per chunk
 constexpr int XLD4 = 12;  // float4 (or 4x scalar) activation loads in flight per thread per chunk
 constexpr int MAXHALO = 50;  // (KS-1)*dil supported by the staging maps (k=11, d=5)
+// DB kernels: steps per trip of the operand ring for a compile-time tap count (0 = per-pair pipeline) and its look-ahead.
+// Measured on one box (profiles/r04d..f_*): k = 3 gains 8..14 % with two channel pairs per trip (147 -> 135 us on the training
+// graph's 768 -> 192 FFN conv, 43 -> 40.5 us on the decoder's 256-channel stage); k = 1 (8 steps) no change; k = 5 (10 steps)
+// and k = 5 / 7 / 11 (one pair per trip) 2..5 % slower than the per-pair form with its sched groups; look-ahead 3 = look-ahead 2.
+constexpr int RING_D = 2;
+constexpr int ring_steps(int ksc) { return ksc == 3 ? 6 : 0; }
 
 struct ConvP {
   svc_conv1d_args a;
@@ -42,6 +48,8 @@ struct ConvP {
   int n_t_tiles;  // number of BN tiles along t
   int n_m_tiles;
   int dump_off;   // float offset of the per-thread dump slots (staging writes of out-of-chunk slots)
+  int row_phases; // u > 1: polyphase ConvTranspose1d with the u phases as output ROWS (row = co*u + phase): the epilogue writes
+                  // row r, column q to y[r / u][q*u + r % u + y_t0] — u*BN consecutive samples per channel and tile
   int xvec;       // 1: X rows are 16 B aligned -> float4 staging (selects the XVEC kernel instantiation)
   int yvec;       // 1: y / res / y2 rows are 16 B aligned and unit-stride in time -> float4 epilogue
   int dbg;        // tuning experiments: 1 no staging, 2 no MFMA, 4 no epilogue (results are then garbage)
@@ -94,6 +102,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const float* smem,
   const bool yvec = p.yvec != 0;
   const int H = a.Cout >> 1;
 
+  if constexpr (EPI == SVC_EPI_PLAIN) {
+    if (p.row_phases > 1) {
+      // phases-as-rows ConvTranspose1d: consecutive threads write consecutive output samples (q*u + phase) of one channel:
+      // full cache lines, where the phase-per-workgroup form writes every u-th float from u different workgroups
+      const int u = p.row_phases, lu = 31 - __builtin_clz(u);      // u is a power of two (svc::convt_rows_layout)
+      const int cout = a.Cout >> lu, cobase = co0 >> lu;
+      const bool has_res = a.res_mode == 1;
+      for (int idx = tid; idx < BM * BN; idx += NTHR) {
+        const int phs = idx & (u - 1), e = idx >> lu;               // e = (channel, column) pair, phase fastest
+        const int co_l = e / BN, tl = e - co_l * BN;                // BN is a compile-time constant
+        const int co = cobase + co_l, tq = t0 + tl;
+        const int tt = (tq << lu) + phs + a.y_t0;
+        if (co >= cout || tq >= a.Tout || tt < 0 || tt >= a.y_len) continue;
+        const int prow = (co_l << lu) + phs;
+        float v = smem[prow * CP + tl];
+#pragma unroll
+        for (int w = 1; w < WK; ++w) v += smem[(w * BM + prow) * CP + tl];
+        v += biasp ? biasp[co] : 0.f;
+        v = apply_act(v, a.post_act, a.post_slope);
+        if (has_res) v += resb[(long long)co * a.res_cs + tt];
+        if (a.out_div != 1.f) v /= a.out_div;
+        yb[(long long)co * a.y_cs + tt] = v;
+      }
+      return;
+    }
+  }
   auto tile4 = [&](int prow, int c4) -> float4 {
     float4 q = *reinterpret_cast<const float4*>(smem + prow * CP + c4 * 4);
 #pragma unroll
@@ -614,6 +648,52 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
         // (slope 1: every training conv, the encoder / flow convs) must not pay its 3 VALU per operand — nor their effect on
         // the schedule: the VALU sat outside the sched groups below and the k = 3 loop ran at ~100 cycles per MFMA against
         // ~70 for k = 5, which has no such pass (profiles/r04b_trainconv_dbg.txt).
+        if constexpr (!ACT && ring_steps(KSC) > 0) {
+          // Operand ring: one pipeline over the chunk's (channel pair, tap) steps — the reads of step s + RING_D are issued in
+          // front of the MFMAs of step s, across channel pairs; R steps (compile-time slots) = R / KSC channel pairs per loop
+          // trip.  The per-pair form below restarts its pipeline at every pair (one exposed LDS latency per KSC * MT * NT
+          // MFMAs); which form wins is per tap count and measured (ring_steps()).  Same MFMA order either way: bit-equal.
+          constexpr int R = ring_steps(KSC) > 0 ? ring_steps(KSC) : KSC, D = RING_D;   // (never 0: the discarded branch is still parsed)
+          constexpr int QPB = R / KSC;                 // channel pairs per trip (launcher: BC % (KPI * QPB) == 0)
+          const int n_blk = n_cc / QPB;
+          constexpr int wblk = QPB * KPI * KSC * BM;
+          const int xblk = QPB * KPI * XW;
+          const float* wq = wbuf + lk * (KSC * BM);
+          const float* xq = xbuf + lk * XW;
+          float av[R][MT], bv[R][NT];
+          auto fetch = [&](int r, const float* wb, const float* xb_) {
+            const int ql = r / KSC, k = r % KSC;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[r][i] = wb[ql * (KPI * KSC * BM) + k * BM + i * TS];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[r][j] = xb_[ql * KPI * XW + k * dil + j * TS];
+          };
+#pragma unroll
+          for (int r = 0; r < D; ++r) fetch(r, wq, xq);
+          for (int blk = 0; blk < n_blk; ++blk) {
+            const bool more = blk + 1 < n_blk;         // past the chunk's last trip the look-ahead re-reads this trip (unused)
+            const float* wn = more ? wq + wblk : wq;
+            const float* xn = more ? xq + xblk : xq;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              if (r + D < R) fetch(r + D, wq, xq);
+              else fetch(r + D - R, wn, xn);
+#pragma unroll
+              for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                  acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r][i], bv[r][j], acc32[i][j], 0, 0, 0);
+            }
+            constexpr int DSPT = (MT + 1) / 2 + (NT + 1) / 2;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x100, DSPT, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            }
+            wq = wn;
+            xq = xn;
+          }
+        } else
         {
           for (int q = 0; q < n_cc; ++q) {
             const int cl = q * KPI + lk;
@@ -823,6 +903,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
   conv_epilogue<BM, BN, NTHR, WK, EPI, DB && NT != 7>(p, smem, tid, b, ph, t0, co0);
 }
 
+thread_local int t_row_phases = 1;  // set by svc_conv_transpose1d_f32 around its dispatch (see ConvP::row_phases)
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
 int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
@@ -852,6 +933,11 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
   const bool xvec = a.premask == nullptr && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_bs % 4) == 0 &&
                     (a.x_cs % 4) == 0 && (a.Tin % 4) == 0;
   p.xvec = xvec ? 1 : 0;
+  p.row_phases = t_row_phases;
+  if (p.row_phases > 1 && (BM % p.row_phases) != 0) {
+    svc::set_error("conv1d: %d row phases do not divide the %d-row tile", p.row_phases, BM);
+    return SVC_ERR_UNSUPPORTED;
+  }
   p.dbg = g_dbg;
   auto al4 = [](const void* ptr, long long bs, long long cs) {
     return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 4) == 0 && (cs % 4) == 0);
@@ -911,7 +997,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     int bcd = 0, ni = 0;
     if (use_db) {
       // largest chunk (multiple of KG dividing Cin) whose two buffers fit the budget and 16 pieces per wave
-      for (int c = std::min(a.Cin, 64) / KG * KG; c >= KG; c -= KG) {
+      constexpr int CQ = (KSC > 0 && ring_steps(KSC) > 0) ? KG * (ring_steps(KSC) / KSC) : KG;   // whole ring trips per chunk
+      for (int c = std::min(a.Cin, 64) / CQ * CQ; c >= CQ; c -= CQ) {
         if (a.Cin % c) continue;
         const int tot4 = c * (a.KS * BM + xw) / 4;
         const int n = svc::cdiv(tot4, NWV * 64);
@@ -928,9 +1015,9 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       }
       p.BC = bcd;
       p.db_ni = ni;
-      p.fast_epi = (g_fast_epi && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
+      p.fast_epi = (g_fast_epi && p.row_phases == 1 && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
                     (a.cond == nullptr || a.cond_ts == 0) && p.yvec && (a.Tout % 4) == 0 && a.Tout >= 4) ? 1 : 0;
-      p.direct_epi = (g_direct_epi && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
+      p.direct_epi = (g_direct_epi && p.row_phases == 1 && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
                       (a.cond == nullptr || a.cond_ts == 0) && a.n_phase == 1 && a.y_ts == 1 && a.y_t0 == 0 && (a.Cout % 32) == 0 &&
                       (a.post_act == SVC_ACT_NONE || (a.post_act == SVC_ACT_LRELU && a.post_slope >= 0.f && a.post_slope <= 1.f)) &&
                       a.y_cs >= 0 && a.y_cs < (1ll << 24) && a.res_cs >= 0 && a.res_cs < (1ll << 24)) ? 1 : 0;
@@ -1106,7 +1193,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_direct_kernel(ConvP p) {
 // shapes the register-fed kernel takes: dense (one phase), no pre-mask, 1 / 3 / 5 / 7 taps, an even channel count, a
 // pre-activation expressible as max(x, slope*x), and 32-bit byte offsets inside one batch row of x and inside the weights
 static bool direct_ok(const svc_conv1d_args& a) {
-  return a.n_phase == 1 && a.premask == nullptr && (a.KS == 1 || a.KS == 3 || a.KS == 5 || a.KS == 7) && (a.Cin % 2) == 0 &&
+  return a.n_phase == 1 && a.premask == nullptr && (a.KS == 1 || a.KS == 3 || a.KS == 5 || a.KS == 7 || (a.KS == 2 && a.epi == SVC_EPI_PLAIN)) && (a.Cin % 2) == 0 &&
          a.pre_slope >= 0.f && a.pre_slope <= 1.f && (long long)a.Cin * a.KS * a.CoutP < (1ll << 29) &&
          std::llabs((long long)a.x_cs) * a.Cin + a.Tin < (1ll << 29);
 }
@@ -1117,6 +1204,11 @@ int launch_direct(const svc_conv1d_args& a, hipStream_t s) {
   ConvP p;
   memset(&p, 0, sizeof(p));
   p.a = a;
+  p.row_phases = t_row_phases;
+  if (p.row_phases > 1 && (BM % p.row_phases) != 0) {
+    svc::set_error("conv1d: %d row phases do not divide the %d-row tile", p.row_phases, BM);
+    return SVC_ERR_UNSUPPORTED;
+  }
   auto al4 = [](const void* ptr, long long bs, long long cs) {
     return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 4) == 0 && (cs % 4) == 0);
   };
@@ -1134,6 +1226,9 @@ template <int MT, int EPI>
 int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
   switch (a.KS) {
     case 1: return launch_direct<MT, EPI, 1>(a, s);
+    case 2:   // (plain epilogue only, direct_ok(): the two taps per phase of the decoder's x8 ConvTranspose1d stages)
+      if constexpr (EPI == SVC_EPI_PLAIN) return launch_direct<MT, EPI, 2>(a, s);
+      else return SVC_ERR_UNSUPPORTED;
     case 3: return launch_direct<MT, EPI, 3>(a, s);
     case 5: return launch_direct<MT, EPI, 5>(a, s);
     default: return launch_direct<MT, EPI, 7>(a, s);
@@ -1170,10 +1265,10 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   const double bytes = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout) + 4.0 * a.Cin * a.KS * a.Cout;
   char pname[160];
   if (svc::prof_on() && svc::prof_shapes())   // SVC_PROF_SHAPES=1: one profile row per shape (tuning aid)
-    snprintf(pname, sizeof(pname), "%s[B%d,Ci%d,Co%d,K%d,d%d,T%d,e%d]", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma", a.B,
+    snprintf(pname, sizeof(pname), "%s[B%d,Ci%d,Co%d,K%d,d%d,T%d,e%d]", (a.n_phase > 1 || t_row_phases > 1) ? "convt1d_mfma" : "conv1d_mfma", a.B,
              a.Cin, a.Cout, a.KS, a.dil, a.Tout, a.epi);
   else
-    snprintf(pname, sizeof(pname), "%s", a.n_phase > 1 ? "convt1d_mfma" : "conv1d_mfma");
+    snprintf(pname, sizeof(pname), "%s", (a.n_phase > 1 || t_row_phases > 1) ? "convt1d_mfma" : "conv1d_mfma");
   svc::ProfScope prof(s, pname, flop, bytes);
 
   if (g_no192 < 0) {
@@ -1253,6 +1348,11 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
                     (a.epi != SVC_EPI_GATE && ((g_force_cfg <= 7 && g_force_cfg >= 1) || g_force_cfg == 9));
     if (ok) cfg = g_force_cfg;
   }
+  // phases-as-rows ConvTranspose1d (two taps per phase): the register-fed kernel for the short first stage and for the x2
+  // stages, whose <= 128 rows make them streaming work (profiles/r04h_ups_*: 75 vs 98 us at 512 -> 256 x8 on 862 frames,
+  // 52 vs 72 us at 64 -> 32 x2, 58 vs 65 us at 32 -> 16 x2); the LDS-staged tiles for the 1024-row x8 stage (127 us)
+  if (t_row_phases > 1 && g_force_cfg < 0 && a.epi == SVC_EPI_PLAIN && direct_ok(a) && g_direct_mode && (cols < 16384 || a.Cout <= 128))
+    return (a.Cout % 64) == 0 ? launch_direct_ks<2, SVC_EPI_PLAIN>(a, s) : launch_direct_ks<1, SVC_EPI_PLAIN>(a, s);
   if ((cfg == 5 || cfg == 6 || (a.epi == SVC_EPI_GATE && cfg != 3 && cfg != 4)) && direct_ok(a) && g_direct_mode) {
     const bool two = cfg == 5 || a.epi == SVC_EPI_GATE;
     if (a.epi == SVC_EPI_GATE) return launch_direct_ks<2, SVC_EPI_GATE>(a, s);
@@ -1325,8 +1425,21 @@ extern "C" int svc_conv_transpose1d_f32(const svc_convt1d_args* ap, void* stream
   a.Tout = (Lout - 1 + t.padding) / u + 1;   // number of q positions
   a.KS = M; a.dil = 1; a.pad_left = M - 1; a.CoutP = t.CoutP;
   a.epi = SVC_EPI_PLAIN; a.post_act = SVC_ACT_NONE; a.res_mode = t.res ? 1 : 0;
-  a.n_phase = u; a.y_ts = u; a.y_t0 = -t.padding; a.y_len = Lout;
-  a.w_phase_stride = (long long)t.Cin * M * t.CoutP;
   a.pre_slope = t.pre_slope; a.post_slope = 0.f; a.beta = 0.f; a.out_div = 1.f;
+  a.y_t0 = -t.padding; a.y_len = Lout;
+  if (svc::convt_rows_layout(u)) {
+    // phases as output ROWS of ONE dense convolution (weight packed [Cin][M][u*CoutP], row = co*u + phase): every workgroup
+    // holds all u phases of its channels and writes u*BN consecutive samples per channel.  The phase-per-workgroup form
+    // below stored every u-th float from u different workgroups: 150 us for the 512 -> 256 x8 stage of a 10 s clip (24 TFLOP/s)
+    // and 62..76 us for the three x2 stages, which move 28 MB each (profiles/r03u_infer_*).
+    a.Cout = u * t.Cout; a.CoutP = u * t.CoutP;
+    a.n_phase = 1; a.y_ts = 1; a.w_phase_stride = 0;
+    t_row_phases = u;
+    const int rc = conv1d_dispatch(a, stream);
+    t_row_phases = 1;
+    return rc;
+  }
+  a.n_phase = u; a.y_ts = u;
+  a.w_phase_stride = (long long)t.Cin * M * t.CoutP;
   return conv1d_dispatch(a, stream);
 }

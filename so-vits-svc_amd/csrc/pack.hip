@@ -53,9 +53,10 @@ __global__ void pack_conv1d_kernel(const float* __restrict__ v, const float* __r
 }
 
 // ConvTranspose1d: v [Cin][Cout][KS], g [Cin]; norm over (Cout,KS) per ci.  One block per ci.
-// dst[ph][ci][mr][CoutP] = w[ci][co][ph + (M-1-mr)*u]  (taps time-reversed so each phase is a plain correlation)
+// dst[ph][ci][mr][CoutP] = w[ci][co][ph + (M-1-mr)*u]  (taps time-reversed so each phase is a plain correlation), or — rows
+// layout, svc::convt_rows_layout(u) — dst[ci][mr][co*u + ph] (the same element count): the u phases are rows of ONE convolution
 __global__ void pack_convt1d_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ dst,
-                                    int Cin, int Cout, int KS, int CoutP, int u, int M) {
+                                    int Cin, int Cout, int KS, int CoutP, int u, int M, int rows) {
   __shared__ double sh[256];
   const int ci = blockIdx.x;
   const int n = Cout * KS;
@@ -77,7 +78,8 @@ __global__ void pack_convt1d_kernel(const float* __restrict__ v, const float* __
     const int k = ph + (M - 1 - mr) * u;
     float val = 0.f;
     if (co < Cout && k < KS) val = v[(long long)ci * n + co * KS + k] * scale;
-    dst[(((long long)ph * Cin + ci) * M + mr) * CoutP + co] = val;
+    if (rows) dst[((long long)ci * M + mr) * ((long long)u * CoutP) + (long long)co * u + ph] = val;
+    else dst[(((long long)ph * Cin + ci) * M + mr) * CoutP + co] = val;
   }
 }
 
@@ -101,6 +103,6 @@ extern "C" int svc_pack_convt1d_weight(const float* v, const float* g, float* ds
   SVC_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && CoutP >= Cout && stride >= 1, "pack_convt1d: bad shape");
   const int M = (KS + stride - 1) / stride;
   hipLaunchKernelGGL(pack_convt1d_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, v, g, dst, Cin, Cout, KS,
-                     CoutP, stride, M);
+                     CoutP, stride, M, svc::convt_rows_layout(stride) ? 1 : 0);
   return svc::check_launch("pack_convt1d");
 }

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvc_hip.so")
+LIB_PATH = os.environ.get("SVC_HIP_LIB") or os.path.join(_HERE, "libsvc_hip.so")   # (override: kernel A/B builds)
 
 EPI_PLAIN, EPI_GATE, EPI_RES_SKIP = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_GELU = 0, 1, 2, 3, 4
