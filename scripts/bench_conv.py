@@ -30,6 +30,12 @@ def run(Cin, L, k, d, Cout, quiet=False):
     pad = (k * d - d) // 2
     if MODE == "conv1":      # first conv of a ResBlock1 pair: lrelu in, lrelu out, no residual
         kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, post_act=S.ACT_LRELU, post_slope=0.1, out=out)
+    elif MODE == "pre":      # pre-activation only
+        kw = dict(bias=b, dil=d, pad_left=pad, pre_slope=0.1, out=out)
+    elif MODE == "post":     # post-activation only
+        kw = dict(bias=b, dil=d, pad_left=pad, post_act=S.ACT_LRELU, post_slope=0.1, out=out)
+    elif MODE == "plain":
+        kw = dict(bias=b, dil=d, pad_left=pad, out=out)
     elif MODE == "conv2":    # second conv: plain in, residual add
         kw = dict(bias=b, dil=d, pad_left=pad, res=x if Cout == Cin else None, res_mode=1 if Cout == Cin else 0, out=out)
     else:                    # round-1/2 form: lrelu in + residual

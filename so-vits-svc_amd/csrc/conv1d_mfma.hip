@@ -608,6 +608,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
     // barrier needed), right after the MFMA loop of the previous chunk; the barrier at the top of the loop publishes it.
     // (For 1..3 taps the chunks are short and that pass — a dependent LDS round trip per chunk — costs more than applying
     // the activation to each operand as it is read: 2 VALU per B operand, hidden under the MFMAs.)
+    // (round 3, profiles/r04l_convbench_*: the pre-activation costs a 256-channel launch 8..12 us whatever the tap count and
+    //  whichever way it is applied — on read for every k, or the in-place pass for every k >= 3: 48.3 / 89 / 124 us either way
+    //  against 40 / 77.5 / 113 us for plain input)
+    //  (on read WITH sched groups that place the VALU: 83 us at k = 7, no change at k = 3 / 11, profiles/r04m_*: the register
+    //  allocator reuses the B registers tap after tap, which rules the look-ahead out)
     constexpr bool ACT_ON_READ = KSC >= 1 && KSC <= 3;
     const float ps = a.pre_slope;
     const bool act = !ACT_ON_READ && ps != 1.f && !(dbg & 8);
