@@ -125,8 +125,8 @@ def bench_e2e(dev, net, inputs, frames):
                          f"{tuple(u.shape)}) -> repeat_expand to {frames} frames -> SynthesizerTrn.infer",
                 unit_encoder_ms=round(1e3 * t_units, 3), unit_encoder_eager_ms=round(1e3 * t_units_eager, 3),
                 repeat_expand_ms=round(1e3 * t_expand, 3), e2e_ms=round(1e3 * t_whole, 3), e2e_samples_per_s=n / t_whole,
-                note="unit encoder and synthesizer each replayed from a hipGraph; repeat_expand_2d (utils.py:396-424) builds its index "
-                     "on the host and gathers on the device",
+                note="unit encoder and synthesizer each replayed from a hipGraph; repeat_expand_2d (utils.py:396-424) is a device "
+                     "gather through an index cached per (source, target) length pair",
                 unit_encoder_families=fam)
 
 

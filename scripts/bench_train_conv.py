@@ -12,8 +12,8 @@ dev = torch.device("cuda:0")
 SHAPES = [  # B, Cin, Cout, T, K, d
     (16, 768, 192, 768, 3, 1), (16, 192, 768, 768, 3, 1), (16, 384, 192, 768, 5, 1), (16, 192, 384, 768, 5, 1),
     (16, 192, 192, 768, 1, 1), (16, 384, 192, 768, 1, 1), (16, 192, 384, 768, 1, 1), (16, 192, 192, 768, 5, 1),
-    (16, 256, 256, 128, 11, 1), (16, 128, 128, 1024, 11, 1), (32, 1024, 1024, 132, 5, 1), (32, 1024, 1024, 112, 5, 1),
-    (1, 256, 256, 6896, 7, 3), (1, 256, 256, 6896, 11, 5),
+    (16, 256, 256, 128, 11, 1), (16, 128, 128, 1024, 11, 1), (32, 1024, 1024, 132, 5, 11), (32, 1024, 1024, 112, 5, 7),
+    (32, 1536, 1024, 132, 2, 11), (16, 1024, 1024, 132, 5, 11), (1, 256, 256, 6896, 7, 3), (1, 256, 256, 6896, 11, 5),
 ]
 N = 10
 

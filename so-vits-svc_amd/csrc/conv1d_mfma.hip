@@ -1331,6 +1331,13 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
       // 64x192 (three column tiles per wave): the training graph's 192- and 384-row convolutions at B x T = 16 x 768 —
       // 6 (12) row tiles x 384 column tiles = 2.25 (4.5) tiles per SIMD, which 2x2-tile waves round up to 4 (8) tile times
       // and 3-tile waves to 3 (6).  Batched launches only: a single utterance's stages are tuned separately (§4).
+      // 128x160 (five column tiles per wave): DiscriminatorP's period-11 maps are 132 columns long (B = 16 / 32 rows of them per
+      // launch, 1024 channels) — two 128-column tiles per row waste 48 % of the second one, one 160-column tile 17 %
+      if (a.B > 1 && !g_no192) {
+        const double n160 = (double)svc::cdiv(a.Cout, 128) * svc::cdiv(a.Tout, 160) * a.B;
+        const double t160 = std::ceil(n160 / 256.0) * 128 * 160 * 1.03;
+        if (t160 < best) { best = t160; cfg = 10; }
+      }
       if (m64 && a.B > 1 && !g_no192) {
         const double n192 = (double)svc::cdiv(a.Cout, 64) * svc::cdiv(a.Tout, 192) * a.B;
         const double t192 = std::ceil(n192 / 256.0) * 64 * 192 * 1.03;
@@ -1350,7 +1357,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   }
   if (g_force_cfg >= 0 && a.Cout > 16) {
     const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
-                    (a.epi != SVC_EPI_GATE && ((g_force_cfg <= 7 && g_force_cfg >= 1) || g_force_cfg == 9));
+                    (a.epi != SVC_EPI_GATE && ((g_force_cfg <= 7 && g_force_cfg >= 1) || g_force_cfg == 9 || g_force_cfg == 10));
     if (ok) cfg = g_force_cfg;
   }
   // phases-as-rows ConvTranspose1d (two taps per phase): the register-fed kernel for the short first stage and for the x2
@@ -1398,6 +1405,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     case 5: return launch_cfg<2, 1, 1, 1, 4, false>(a, s);   // 64 x 32, 4-way split-K
     case 7: SVC_KS_CASES(1, 7, 4, 1, false)   // 128 x 224
     case 9: SVC_KS_CASES(1, 3, 2, 2, false)   // 64 x 192
+    case 10: SVC_KS_CASES(1, 5, 4, 1, false)  // 128 x 160
     // (round 3: a 128 x 128 tile with 8 waves, two per 64 x 64 wave tile splitting the reduction, for the 256-channel stage
     //  whose 128 x 128 tiling covers only 108 CUs: 224 vs 112 us at k = 11 on the register-staged path — not kept,
     //  profiles/r03t_cfg8_*)
