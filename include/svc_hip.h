@@ -305,10 +305,15 @@ typedef struct {
   int kind, R, C2, K, Od, Id, Kd, OdP, IdP, s, shift;
 } svc_conv_weight_args;
 int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream);
-/* svc_conv_weight_prep_f32 for n_plans convolutions in ONE launch.  `host_args` (validated here) and `dev_args` hold the same
- * n_plans structs, the latter in device memory; `dev_row_start` [n_plans] (device) = exclusive prefix sums of the plans' R. */
+/* svc_conv_weight_prep_f32 for n_plans convolutions together: one launch for the row norms of the weight-normed plans, one for
+ * all operand packs.  `host_args` (validated here) and `dev_args` hold the same n_plans structs, the latter in device memory;
+ * `dev_row_start` / `dev_block_start` [n_plans] (device) = exclusive prefix sums of the plans' R resp. of
+ * svc_conv_weight_prep_blocks(R, C2, K) (a scatter workgroup owns SVC_WEIGHT_PREP_ROWS rows x ~SVC_WEIGHT_PREP_COLS elements). */
+#define SVC_WEIGHT_PREP_ROWS 32
+#define SVC_WEIGHT_PREP_COLS 1024
+int svc_conv_weight_prep_blocks(int R, int C2, int K);
 int svc_conv_weight_prep_multi_f32(const svc_conv_weight_args* host_args, const svc_conv_weight_args* dev_args,
-                                   const int* dev_row_start, int n_plans, void* stream);
+                                   const int* dev_row_start, const int* dev_block_start, int n_plans, void* stream);
 int svc_conv_weight_grad_f32(const svc_conv_weight_args* args, const float* dwd, float* dv, float* dg, void* stream);
 
 /* Weight gradient (and any "correlate two [B,C,T] signals over time" product):

@@ -92,3 +92,12 @@ if not flt or "gemm" in flt:
     Bh, T, dk = 32, 768, 96
     q, k = torch.randn(Bh, T, dk, device=dev), torch.randn(Bh, T, dk, device=dev)
     report("gemm QK^T [32 x 768x768x96]", timeit(lambda: S.gemm(q, k, (T * dk, dk, 1), (T * dk, 1, dk), Bh, T, T, dk)), 2.0 * Bh * T * T * dk)
+    # the training graph's own layouts (svc_autograd.py:658-706): q / k / v / dO [BH, dk, T], P / dS [BH, T, T]
+    qc, kc, vc, dO = [torch.randn(Bh, dk, T, device=dev) for _ in range(4)]
+    P = torch.randn(Bh, T, T, device=dev)
+    out = torch.empty(Bh, dk, T, device=dev)
+    fl = 2.0 * Bh * T * T * dk
+    report("gemm P = q^T k   (T x T x 96)", timeit(lambda: S.gemm(qc, kc, (dk * T, 1, T), (dk * T, T, 1), Bh, T, T, dk)), fl)
+    report("gemm out = v P^T (96 x T x T)", timeit(lambda: S.gemm(vc, P, (dk * T, T, 1), (T * T, 1, T), Bh, dk, T, T, out=out, c_strides=(dk * T, T, 1))), fl)
+    report("gemm dV = dO P   (96 x T x T)", timeit(lambda: S.gemm(dO, P, (dk * T, T, 1), (T * T, T, 1), Bh, dk, T, T, out=out, c_strides=(dk * T, T, 1))), fl)
+    report("gemm dP = dO^T v (T x T x 96)", timeit(lambda: S.gemm(dO, vc, (dk * T, 1, T), (dk * T, T, 1), Bh, T, T, dk)), fl)

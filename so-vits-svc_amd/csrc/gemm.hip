@@ -8,6 +8,8 @@
 // odd pitch so both the staging writes (lanes along whichever operand dimension is contiguous in memory) and the
 // MFMA operand reads (lanes along m / n) are bank-conflict free.
 #include "common.h"
+#include <cstdlib>
+#include <cstdint>
 
 namespace {
 
@@ -165,6 +167,145 @@ __global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmP p) {
     }
 }
 
+
+// ---- register-fed variant (round 3): no LDS, no barrier.  Every attention product of the training graph has each operand
+// contiguous along either its reduction index k or its output index (m resp. n) — q / k / v / dO are [B, C, T] tensors, P / dS
+// are [BH, T, T] — and both forms hand a lane its MFMA fragment straight from global memory:
+//   k-contiguous: lane (m, lk) reads the float4 A[m][8g + 4 lk .. +3]; instruction i of group g consumes element i, i.e. the
+//                 reduction index 8g + 4 lk + i (the pairing of k indices over the two lane halves is free as long as A and B agree);
+//   m-contiguous: lane (m, lk) reads the scalar A[8g + 4 lk + i][m] for instruction i: 128 contiguous bytes per half wave.
+// A wave owns an (MT x NT) block of 32x32 tiles and keeps RD groups of 8 reduction steps in flight in a register ring (L2 /
+// HBM latency is hidden by the wave itself and by up to four waves per SIMD); waves of a workgroup are independent.  The
+// LDS-staged kernels above restage both operands every 16 reduction steps behind two barriers with per-element 64-bit
+// address arithmetic: 120 us (30 TFLOP/s) for out = v P^T (96 x 768 x 768, 32 heads), whose 96 rows also waste a quarter of
+// the 128-row tile.
+template <bool A_KC, bool B_KC, int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_f32_reg_kernel(svc_gemm_args a, int tiles_m, int tiles_n) {
+  constexpr int RD = 3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ln = lane & 31, lk = lane >> 5;
+  long long wt = (long long)blockIdx.x * 4 + wave;          // wave tile: n fastest, then m, then batch
+  const long long total = (long long)tiles_m * tiles_n * a.batch;
+  if (wt >= total) return;
+  const int tn = (int)(wt % tiles_n);
+  wt /= tiles_n;
+  const int tm = (int)(wt % tiles_m);
+  const int b = (int)(wt / tiles_m);
+  const int m0 = tm * (32 * MT), n0 = tn * (32 * NT);
+  const float* Ab = a.A + (long long)b * a.a_bs;
+  const float* Bb = a.B + (long long)b * a.b_bs;
+  const float* pa[MT];
+  const float* pb[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    pa[i] = A_KC ? Ab + (long long)(m0 + i * 32 + ln) * a.a_ms + 4 * lk : Ab + (m0 + i * 32 + ln) + (long long)(4 * lk) * a.a_ks;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    pb[j] = B_KC ? Bb + (long long)(n0 + j * 32 + ln) * a.b_ns + 4 * lk : Bb + (n0 + j * 32 + ln) + (long long)(4 * lk) * a.b_ks;
+  const long long a_gs = A_KC ? 8 : 8 * a.a_ks, b_gs = B_KC ? 8 : 8 * a.b_ks;    // pointer step per group of 8 reduction steps
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[RD][MT], rb[RD][NT];
+  auto fetch = [&](int slot, long long g) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float* q = pa[i] + g * a_gs;
+      if constexpr (A_KC) ra[slot][i] = *reinterpret_cast<const float4*>(q);
+      else ra[slot][i] = make_float4(q[0], q[a.a_ks], q[2 * a.a_ks], q[3 * a.a_ks]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float* q = pb[j] + g * b_gs;
+      if constexpr (B_KC) rb[slot][j] = *reinterpret_cast<const float4*>(q);
+      else rb[slot][j] = make_float4(q[0], q[a.b_ks], q[2 * a.b_ks], q[3 * a.b_ks]);
+    }
+  };
+  auto f4 = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+  const int G = a.K >> 3;                                   // launcher: K % 8 == 0
+  auto mfmas = [&](int u) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4(ra[u][i], e), f4(rb[u][j], e), acc[i][j], 0, 0, 0);
+  };
+  static_assert(RD == 3, "the remainder below assumes a ring of three");
+  fetch(0, 0);
+  fetch(1, min(1, G - 1));
+  const int Gb = (G / RD) * RD;
+  for (int g0 = 0; g0 < Gb; g0 += RD) {                     // whole trips of the ring: straight-line, no conditionals
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      fetch((u + RD - 1) % RD, min(g0 + u + RD - 1, G - 1));  // past the end: re-reads the last group (unused)
+      mfmas(u);
+    }
+  }
+  // the last trip left groups Gb and Gb + 1 (clamped) in slots 0 and 1
+  if (Gb < G) mfmas(0);
+  if (Gb + 1 < G) mfmas(1);
+  float* Cb = a.C + (long long)b * a.c_bs;                  // launcher: c_ns == 1
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float* cp = Cb + (n0 + j * 32 + ln);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        float* q = cp + (long long)m * a.c_ms;
+        float v = a.alpha * acc[i][j][r];
+        if (a.beta != 0.f) v += a.beta * (*q);
+        *q = v;
+      }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_reg(const svc_gemm_args& a, hipStream_t s) {
+  auto go = [&](auto k, int mt, int nt) {
+    const int tiles_m = a.M / (32 * mt), tiles_n = a.N / (32 * nt);
+    const long long total = (long long)tiles_m * tiles_n * a.batch;
+    hipLaunchKernelGGL(k, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, a, tiles_m, tiles_n);
+    return svc::check_launch("gemm_f32_reg");
+  };
+  if ((a.M % 64) == 0 && (a.N % 64) == 0) return go(gemm_f32_reg_kernel<A_KC, B_KC, 2, 2>, 2, 2);
+  if ((a.M % 96) == 0) return go(gemm_f32_reg_kernel<A_KC, B_KC, 3, 1>, 3, 1);
+  return go(gemm_f32_reg_kernel<A_KC, B_KC, 1, 3>, 1, 3);
+}
+
+int g_gemm_reg = -1;   // A/B switch: SVC_GEMM_REG=0 keeps every product on the LDS-staged kernels
+
+// operands as the register-fed kernel needs them; everything else stays on the LDS-staged kernels
+bool reg_ok(const svc_gemm_args& a) {
+  if (g_gemm_reg < 0) {
+    const char* e = getenv("SVC_GEMM_REG");
+    g_gemm_reg = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_gemm_reg) return false;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool a_kc = a.a_ks == 1, a_mc = a.a_ms == 1, b_kc = a.b_ks == 1, b_nc = a.b_ns == 1;
+  if (!(a_kc || a_mc) || !(b_kc || b_nc) || a.c_ns != 1) return false;
+  // long reductions only: measured on the attention products of a B = 16, T = 768 batch (profiles/r04p_gemm_reg{0,1}.txt) the
+  // 96 x T x T products (K = 768) go 95 -> 60 us, the T x T x 96 ones (K = 96: one 64 x 64 tile per wave, twice the operand
+  // traffic per FLOP of the 128 x 128 LDS tile, and a store-heavy epilogue) 64 -> 76 us
+  if ((a.K % 8) != 0 || a.K < 256 || (a.M % 32) != 0 || (a.N % 32) != 0) return false;
+  if (!(((a.M % 64) == 0 && (a.N % 64) == 0) || (a.M % 96) == 0 || (a.N % 96) == 0)) return false;
+  if (a_kc && !(al16(a.A) && (a.a_ms % 4) == 0 && (a.a_bs % 4) == 0)) return false;
+  if (b_kc && !(al16(a.B) && (a.b_ns % 4) == 0 && (a.b_bs % 4) == 0)) return false;
+  if (a.a_ms < 0 || a.a_ks < 0 || a.b_ks < 0 || a.b_ns < 0 || a.c_ms < 0) return false;
+  return true;
+}
+
 }  // namespace
 
 extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
@@ -179,6 +320,13 @@ extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
   p.a = a;
   p.a_m_fast = (a.a_ms == 1 || (a.a_ks != 1 && llabs(a.a_ms) < llabs(a.a_ks))) ? 1 : 0;
   p.b_n_fast = (a.b_ns == 1 || (a.b_ks != 1 && llabs(a.b_ns) < llabs(a.b_ks))) ? 1 : 0;
+  if (reg_ok(a)) {
+    const bool a_kc = a.a_ks == 1, b_kc = a.b_ks == 1;
+    if (a_kc && b_kc) return launch_reg<true, true>(a, s);
+    if (a_kc) return launch_reg<true, false>(a, s);
+    if (b_kc) return launch_reg<false, true>(a, s);
+    return launch_reg<false, false>(a, s);
+  }
   if (a.M >= 96 && a.N >= 96) {
     dim3 grid(svc::cdiv(a.N, HN), svc::cdiv(a.M, HM), a.batch);
     hipLaunchKernelGGL(gemm_f32_big_kernel, grid, dim3(256), 0, s, p);

@@ -97,53 +97,112 @@ __device__ __forceinline__ void wmap_index(const WMap& p, int r, int c, int k, i
     m = p.Kd - 1 - mm;
   }
 }
-__device__ __forceinline__ void conv_weight_prep_row(const float* __restrict__ v, const float* __restrict__ g,
-                                                     float* __restrict__ wp, float* __restrict__ wt, float* __restrict__ norm,
-                                                     const WMap& p, int r, double* sh) {
-  const int n = p.C2 * p.K;
+// Two launches: row norms (one workgroup per weight-normed row), then the scatter.  A scatter workgroup owns WP_ROWS parameter
+// rows x a range of input-channel columns (~WP_COLS elements per row) and writes both operand arrays with the lanes of a half
+// wave along the array's FASTEST index, so that every store instruction fills whole 128-byte lines:
+//   wp [i][m][o]: o = r for dense / strided layers (lanes along rows), o = ph*C2 + c for transposed ones (lanes along columns);
+//   wt [o][m][i]: i = q*C2 + c for dense / strided layers (lanes along columns), i = r for transposed ones (lanes along rows).
+// (Round 2 ran one workgroup per row and stored element j of the row at stride OdP / IdP floats: 4-byte stores to a different
+// line each — the 1024 x 1024 x 5 period convs made the one-launch form spend 640 us per launch, profiles/r04q_train_*; whole
+// rows per workgroup instead left those same weights with 32 workgroups of 160 k elements each.)
+// The reads of the "lanes along rows" pass touch 32 lines at a time (one per row), each consumed within two trips: L1 hits.
+constexpr int WP_ROWS = SVC_WEIGHT_PREP_ROWS, WP_COLS = SVC_WEIGHT_PREP_COLS;
+static_assert(WP_ROWS == 32, "the row pass maps one lane of a half wave to one row");
+__host__ __device__ inline int wp_cols_per_block(int K) { return max(1, WP_COLS / K); }      // input channels per workgroup
+__host__ __device__ inline int wp_blocks(int R, int C2, int K) {
+  const int cpc = wp_cols_per_block(K);
+  return ((R + WP_ROWS - 1) / WP_ROWS) * ((C2 + cpc - 1) / cpc);
+}
+__device__ __forceinline__ void conv_weight_norm_row(const float* __restrict__ v, float* __restrict__ norm, int n, int r, double* sh) {
   const float* vr = v + (long long)r * n;
-  float sc = 1.f;
-  if (g) {
-    double acc = 0.0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      const double x = vr[j];
-      acc += x * x;
-    }
-    const float nr = (float)sqrt(block_sum_d(acc, sh));
-    if (threadIdx.x == 0 && norm) norm[r] = nr;
-    sc = g[r] / nr;
-  }
+  double acc = 0.0;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const int c = j / p.K, k = j - c * p.K;
-    int o, i, m;
-    wmap_index(p, r, c, k, o, i, m);
-    const float val = vr[j] * sc;
-    wp[((long long)i * p.Kd + m) * p.OdP + o] = val;
-    if (wt) wt[((long long)o * p.Kd + (p.Kd - 1 - m)) * p.IdP + i] = val;
+    const double x = vr[j];
+    acc += x * x;
+  }
+  const float nr = (float)sqrt(block_sum_d(acc, sh));
+  if (threadIdx.x == 0) norm[r] = nr;
+}
+__device__ __forceinline__ void conv_weight_scatter_block(const float* __restrict__ v, const float* __restrict__ g,
+                                                          float* __restrict__ wp, float* __restrict__ wt,
+                                                          const float* __restrict__ norm, const WMap& p, int blk) {
+  const int n = p.C2 * p.K;
+  const int cpc = wp_cols_per_block(p.K), n_chunks = (p.C2 + cpc - 1) / cpc;
+  const int grp = blk / n_chunks, chunk = blk - grp * n_chunks;
+  const int r0 = grp * WP_ROWS, nrow = min(WP_ROWS, p.R - r0);
+  const int c_lo = chunk * cpc, c_hi = min(c_lo + cpc, p.C2);
+  const int tid = threadIdx.x, rl = tid & 31, jj = tid >> 5;          // 8 column walkers per row
+  const bool transposed = p.kind == 2;
+  // ---- lanes along rows: wp for dense / strided, wt for transposed
+  if (rl < nrow) {
+    const int r = r0 + rl;
+    const float* vr = v + (long long)r * n;
+    const float s = g ? g[r] / norm[r] : 1.f;
+    for (int j = c_lo * p.K + jj; j < c_hi * p.K; j += 8) {
+      const int c = j / p.K, k = j - c * p.K;
+      int o, i, m;
+      wmap_index(p, r, c, k, o, i, m);
+      const float val = vr[j] * s;
+      if (!transposed) wp[((long long)i * p.Kd + m) * p.OdP + o] = val;
+      else if (wt) wt[((long long)o * p.Kd + (p.Kd - 1 - m)) * p.IdP + i] = val;
+    }
+  }
+  // ---- lanes along columns: wt for dense / strided, wp for transposed (a wave per row, tap by tap)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int rr = wave; rr < nrow; rr += 4) {
+    const int r = r0 + rr;
+    const float* vr = v + (long long)r * n;
+    const float s = g ? g[r] / norm[r] : 1.f;
+    for (int k = 0; k < p.K; ++k) {
+      for (int c = c_lo + lane; c < c_hi; c += 64) {
+        int o, i, m;
+        wmap_index(p, r, c, k, o, i, m);
+        const float val = vr[c * p.K + k] * s;
+        if (transposed) wp[((long long)i * p.Kd + m) * p.OdP + o] = val;
+        else if (wt) wt[((long long)o * p.Kd + (p.Kd - 1 - m)) * p.IdP + i] = val;
+      }
+    }
   }
 }
-__global__ void conv_weight_prep_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ wp,
-                                        float* __restrict__ wt, float* __restrict__ norm, WMap p) {
-  __shared__ double sh[256];
-  conv_weight_prep_row(v, g, wp, wt, norm, p, blockIdx.x, sh);
-}
-// the same for MANY convolutions in one launch: block -> (plan, row) through the prefix sums of the plans' row counts.  A
-// training iteration prepares ~360 weights (generator + discriminators, the latter twice), each a 5..12 us launch that is
-// latency- not bandwidth-bound (profiles/r03l_train_*: 359 x 11.8 us = 4.2 ms of a 110 ms step); together they move ~1 GB.
-__global__ void conv_weight_prep_multi_kernel(const svc_conv_weight_args* __restrict__ tab, const int* __restrict__ row_start,
-                                              int n_plans) {
-  __shared__ double sh[256];
-  const int row = blockIdx.x;
-  int lo = 0, hi = n_plans - 1;            // last plan whose first row is <= row
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (row_start[mid] <= row) lo = mid; else hi = mid - 1;
-  }
-  const svc_conv_weight_args a = tab[lo];
+__device__ __forceinline__ WMap wmap_of(const svc_conv_weight_args& a) {
   WMap p;
   p.kind = a.kind; p.R = a.R; p.C2 = a.C2; p.K = a.K; p.Od = a.Od; p.Id = a.Id; p.Kd = a.Kd; p.OdP = a.OdP; p.IdP = a.IdP;
   p.s = a.s; p.shift = a.shift;
-  conv_weight_prep_row(a.v, a.g, a.wp, a.wt, a.norm, p, row - row_start[lo], sh);
+  return p;
+}
+__device__ __forceinline__ int plan_of(const int* __restrict__ start, int n_plans, int x) {   // last plan whose start is <= x
+  int lo = 0, hi = n_plans - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (start[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void conv_weight_norm_kernel(const float* __restrict__ v, float* __restrict__ norm, int n) {
+  __shared__ double sh[256];
+  conv_weight_norm_row(v, norm, n, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(256) void conv_weight_scatter_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                  float* __restrict__ wp, float* __restrict__ wt,
+                                                                  const float* __restrict__ norm, WMap p) {
+  conv_weight_scatter_block(v, g, wp, wt, norm, p, blockIdx.x);
+}
+// the same for MANY convolutions: workgroup -> (plan, row) resp. (plan, block) through prefix sums over the plans.  A training
+// iteration prepares ~360 weights (generator + discriminators, the latter twice), each a 5..12 us launch that is latency- not
+// bandwidth-bound (profiles/r03l_train_*: 359 x 11.8 us = 4.2 ms of a 110 ms step); together they move ~1.5 GB.
+__global__ __launch_bounds__(256) void conv_weight_norm_multi_kernel(const svc_conv_weight_args* __restrict__ tab,
+                                                                     const int* __restrict__ row_start, int n_plans) {
+  __shared__ double sh[256];
+  const int lo = plan_of(row_start, n_plans, blockIdx.x);
+  const svc_conv_weight_args a = tab[lo];
+  if (a.g) conv_weight_norm_row(a.v, a.norm, a.C2 * a.K, blockIdx.x - row_start[lo], sh);   // (plain weights: nothing to do)
+}
+__global__ __launch_bounds__(256) void conv_weight_scatter_multi_kernel(const svc_conv_weight_args* __restrict__ tab,
+                                                                        const int* __restrict__ block_start, int n_plans) {
+  const int lo = plan_of(block_start, n_plans, blockIdx.x);
+  const svc_conv_weight_args a = tab[lo];
+  const WMap p = wmap_of(a);
+  conv_weight_scatter_block(a.v, a.g, a.wp, a.wt, a.norm, p, blockIdx.x - block_start[lo]);
 }
 // adjoint: dwd [Od][Id][Kd] (svc_conv1d_wgrad_f32's output) -> dv (and dg): dw[r][c][k] = dwd[o][i][m],
 // dg[r] = <dw, v> / ||v||,  dv = (g/||v||) (dw - v <dw,v>/||v||^2);  without g: dv = dw.
@@ -639,15 +698,21 @@ int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream) {
   WMap p;
   const int rc = wmap_from(*args, p);
   if (rc != SVC_OK) return rc;
-  hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(p.R), dim3(256), 0, (hipStream_t)stream, args->v, args->g, args->wp,
-                     args->wt, args->norm, p);
+  if (args->g) hipLaunchKernelGGL(conv_weight_norm_kernel, dim3(p.R), dim3(256), 0, (hipStream_t)stream, args->v, args->norm, p.C2 * p.K);
+  hipLaunchKernelGGL(conv_weight_scatter_kernel, dim3(wp_blocks(p.R, p.C2, p.K)), dim3(256), 0, (hipStream_t)stream, args->v,
+                     args->g, args->wp, args->wt, args->norm, p);
   return svc::check_launch("conv_weight_prep");
 }
 
+int svc_conv_weight_prep_blocks(int R, int C2, int K) {
+  return (R > 0 && C2 > 0 && K > 0) ? wp_blocks(R, C2, K) : 0;
+}
+
 int svc_conv_weight_prep_multi_f32(const svc_conv_weight_args* host_args, const svc_conv_weight_args* dev_args,
-                                   const int* dev_row_start, int n_plans, void* stream) {
-  SVC_REQUIRE(host_args && dev_args && dev_row_start && n_plans > 0, "conv_weight_prep_multi: null table");
-  long long rows = 0;
+                                   const int* dev_row_start, const int* dev_block_start, int n_plans, void* stream) {
+  SVC_REQUIRE(host_args && dev_args && dev_row_start && dev_block_start && n_plans > 0, "conv_weight_prep_multi: null table");
+  long long rows = 0, blocks = 0;
+  bool any_norm = false;
   for (int i = 0; i < n_plans; ++i) {
     const svc_conv_weight_args& a = host_args[i];
     SVC_REQUIRE(a.v && a.wp, "conv_weight_prep_multi: null tensor in plan %d", i);
@@ -656,10 +721,15 @@ int svc_conv_weight_prep_multi_f32(const svc_conv_weight_args* host_args, const 
     const int rc = wmap_from(a, p);
     if (rc != SVC_OK) return rc;
     rows += a.R;
+    blocks += wp_blocks(a.R, a.C2, a.K);
+    any_norm = any_norm || a.g != nullptr;
   }
-  SVC_REQUIRE(rows < (1ll << 31), "conv_weight_prep_multi: too many rows");
-  hipLaunchKernelGGL(conv_weight_prep_multi_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dev_args,
-                     dev_row_start, n_plans);
+  SVC_REQUIRE(rows < (1ll << 31) && blocks < (1ll << 31), "conv_weight_prep_multi: too many rows");
+  if (any_norm)
+    hipLaunchKernelGGL(conv_weight_norm_multi_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dev_args,
+                       dev_row_start, n_plans);
+  hipLaunchKernelGGL(conv_weight_scatter_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dev_args,
+                     dev_block_start, n_plans);
   return svc::check_launch("conv_weight_prep_multi");
 }
 

@@ -32,6 +32,7 @@ class TrainStep:
         self._sched_step()                                          # the constructor's step (it CAN decay: last_epoch 3 -> 4 at step 4)
         self.use_graph = False
         self._graphs = {}
+        self.plan_sets = S.PlanSets()
 
     def enable_graph(self, on=True):
         self.use_graph = bool(on)
@@ -44,8 +45,12 @@ class TrainStep:
         try:
             S.wgrad_slab.reset()
             self.opt.zero_grad()
-            loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
-                              gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
+            self.plan_sets.enter("fwd", self.model.parameters())     # every conv weight of the pass prepared in one launch
+            try:
+                loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
+                                  gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
+            finally:
+                self.plan_sets.leave("fwd")
             loss.backward()
             self.opt.step()
         finally:

@@ -640,7 +640,7 @@ class ConvWeightArgs(C.Structure):
 
 
 TRAIN_EXPORTS = [
-    "svc_conv_weight_prep_f32", "svc_conv_weight_prep_multi_f32", "svc_conv_weight_grad_f32",
+    "svc_conv_weight_prep_f32", "svc_conv_weight_prep_multi_f32", "svc_conv_weight_prep_blocks", "svc_conv_weight_grad_f32",
     "svc_weight_norm_fwd_f32", "svc_weight_norm_bwd_f32", "svc_pack_conv1d_weight_T", "svc_conv1d_wgrad_f32",
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
@@ -663,7 +663,8 @@ def tlib():
         L.svc_conv1d_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]
         L.svc_conv_weight_prep_f32.argtypes = [C.POINTER(ConvWeightArgs), vp]
         L.svc_conv_weight_grad_f32.argtypes = [C.POINTER(ConvWeightArgs), _f32p, _f32p, _f32p, vp]
-        L.svc_conv_weight_prep_multi_f32.argtypes = [C.POINTER(ConvWeightArgs), vp, vp, i, vp]
+        L.svc_conv_weight_prep_multi_f32.argtypes = [C.POINTER(ConvWeightArgs), vp, vp, vp, i, vp]
+        L.svc_conv_weight_prep_blocks.argtypes = [i, i, i]
         L.svc_gemm_f32.argtypes = [C.POINTER(GemmArgs), vp]
         L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
         L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
@@ -846,11 +847,12 @@ class ConvWeightPlan:
 
 
 class PlanSets:
-    """One-launch weight preparation for a group of ConvWeightPlans (svc_conv_weight_prep_multi_f32).
+    """Weight preparation for a whole group of ConvWeightPlans in two launches — row norms, operand packs — instead of one or
+    two per plan (svc_conv_weight_prep_multi_f32).
 
     A training loop brackets a forward pass whose convolution weights are parameters with `enter(tag, params)` /
     `leave(tag)`.  The first bracketed pass records which plans were prepared from which parameters; from then on
-    `enter` prepares them all in ONE launch and hands each plan a token naming the parameter storage it was prepared from,
+    `enter` prepares them all together and hands each plan a token naming the parameter storage it was prepared from,
     so the pass's own `plan.prepare(v, g)` calls return the already filled operands (any other tensor prepares as usual).
     `leave` withdraws the tokens: operands are never reused outside the bracket, i.e. across an optimizer step — the caller
     must not update the parameters inside one.
@@ -874,8 +876,9 @@ class PlanSets:
         ent = self.sets.get(tag)
         if ent is not None and all(v.data_ptr() == pv and (g.data_ptr() if g is not None else 0) == pg and pl.wp is not None
                                    for (pl, v, g), (pv, pg) in zip(ent["items"], ent["ptrs"])):
-            check(tlib().svc_conv_weight_prep_multi_f32(ent["host"], ent["dev"].data_ptr(), ent["rows"].data_ptr(),
-                                                        len(ent["items"]), stream_ptr()), "conv_weight_prep_multi")
+            check(tlib().svc_conv_weight_prep_multi_f32(ent["host"], ent["dev"].data_ptr(), ent["rows"][0].data_ptr(),
+                                                        ent["rows"][1].data_ptr(), len(ent["items"]), stream_ptr()),
+                  "conv_weight_prep_multi")
             for (pl, v, g), key in zip(ent["items"], ent["ptrs"]):
                 pl._fresh = key
             return
@@ -896,11 +899,13 @@ class PlanSets:
             if items:
                 host = (ConvWeightArgs * len(items))(*[pl._args(v, g) for pl, v, g in items])
                 dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(items[0][1].device)
-                starts, acc = [], 0
-                for pl, _, _ in items:
-                    starts.append(acc)
-                    acc += pl.R
-                rows = torch.tensor(starts, dtype=torch.int32).to(dev.device)
+                rstart, bstart, ra, ba = [], [], 0, 0
+                for pl, _, _ in items:       # prefix sums of rows (norm launch) and of scatter workgroups (svc_hip.h)
+                    rstart.append(ra)
+                    bstart.append(ba)
+                    ra += pl.R
+                    ba += tlib().svc_conv_weight_prep_blocks(pl.R, pl.C2, pl.K)
+                rows = torch.tensor([rstart, bstart], dtype=torch.int32).to(dev.device)
                 self.sets[tag] = dict(items=items, host=host, dev=dev, rows=rows,
                                       ptrs=[(v.data_ptr(), g.data_ptr() if g is not None else 0) for _, v, g in items])
             return

@@ -418,3 +418,35 @@ def test_plan_sets_one_launch_equals_per_plan_preparation(dev):
 
 def _vg(m):
     return (m.weight_v, m.weight_g) if hasattr(m, "weight_g") else (m.weight, None)
+
+
+@pytest.mark.parametrize("T,dk,BH", [(256, 96, 4), (320, 96, 2), (128, 96, 2), (288, 64, 3), (96, 40, 2)])
+def test_gemm_attention_forms(dev, T, dk, BH):
+    """svc_gemm_f32 on the six operand layouts of the training graph's attention products (svc_autograd.py:658-706): q / k / v /
+    dO are [BH, dk, T] blocks of [B, C, T] tensors, P / dS are [BH, T, T].  Each operand is contiguous along k or along m / n,
+    which is what the register-fed kernel (csrc/gemm.hip: gemm_f32_reg_kernel) is built for; (96, 40) and T = 160 with dk = 64
+    also exercise the LDS-staged fallback (K % 8, tile divisibility).  Reference: torch matmul on the CPU in fp32."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(T + dk)
+    q, k, v, dO = [torch.randn(BH, dk, T, generator=g) for _ in range(4)]
+    P, dS = [torch.randn(BH, T, T, generator=g) for _ in range(2)]
+    qd, kd, vd, dOd, Pd, dSd = [t.to(dev) for t in (q, k, v, dO, P, dS)]
+    qs = (dk * T, 1, T)
+
+    def close(got, ref, what):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (what, err)
+
+    close(S.gemm(qd, kd, qs, (dk * T, T, 1), BH, T, T, dk, alpha=0.5), 0.5 * q.transpose(1, 2) @ k, "P = q^T k")
+    out = torch.empty(BH, dk, T, device=dev)
+    S.gemm(vd, Pd, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
+    close(out, v @ P.transpose(1, 2), "out = v P^T")
+    S.gemm(dOd, Pd, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
+    close(out, dO @ P, "dV = dO P")
+    close(S.gemm(dOd, vd, (dk * T, 1, T), (dk * T, T, 1), BH, T, T, dk), dO.transpose(1, 2) @ v, "dP = dO^T v")
+    S.gemm(kd, dSd, (dk * T, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1), alpha=0.25)
+    close(out, 0.25 * k @ dS.transpose(1, 2), "dQ = k dS^T")
+    acc = torch.randn(BH, dk, T, generator=g)
+    out.copy_(acc)
+    S.gemm(qd, dSd, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1), alpha=0.25, beta=1.0)
+    close(out, 0.25 * q @ dS + acc, "dK = q dS (+ accumulate)")
