@@ -16,6 +16,7 @@
 // therefore not fixed run to run, error ~1e-7 relative).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -168,42 +169,54 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   // each wave first transposes 16 ca rows at a time through LDS into G's own [cb][k] order: consecutive lanes then
   // add to consecutive addresses (coalesced atomics: one request per cache line instead of one per lane).
   __syncthreads();   // all waves are done with As / Bs
-  const int RW = 32 * nk;                 // floats per staged row
-  const int RP = RW + 1;
-  float* Wt = lds + wave * 16 * (32 * NK + 1);
-  const int cbw = cb0 + wn * 32;
+  // (index arithmetic with the tap count as a compile-time constant for full tap groups: with runtime divisors the two
+  //  divisions per element made this pass ~100 VALU instructions per atomic — 12 k VALU per wave against 2.2 k MFMAs on the
+  //  384 x 192 k = 5 layer, SQ_INSTS_VALU in profiles/r04u_pmc_wgrad.txt)
+  auto combine = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int nkc = FULL ? NK : nk;
+    const int RW = 32 * nkc;                // floats per staged row
+    const int RP = RW + 1;
+    float* Wt = lds + wave * 16 * (32 * NK + 1);
+    const int cbw = cb0 + wn * 32;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+      for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-      for (int q = 0; q < NK; ++q) {
-        if (q < nk) {
+        for (int q = 0; q < NK; ++q) {
+          if (q < nkc) {
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = hf * 8 + rr;
-            const int rl = (rr & 3) + 8 * (rr >> 2) + 4 * lk;      // 0..15 inside this half
-            Wt[rl * RP + ln * nk + q] = acc[q][i][r];
+            for (int rr = 0; rr < 8; ++rr) {
+              const int r = hf * 8 + rr;
+              const int rl = (rr & 3) + 8 * (rr >> 2) + 4 * lk;      // 0..15 inside this half
+              Wt[rl * RP + ln * nkc + q] = acc[q][i][r];
+            }
           }
         }
-      }
-      __syncthreads();   // slab written (uniform trip counts: every wave reaches the barriers)
-      // rows of this half: MFMA row (r&3) + 8*(r>>2) + 4*lk with r in [8hf, 8hf+8) -> 16*hf + rl
-      const int ca_base = ca0 + wm * 64 + i * 32 + 16 * hf;
-      for (int idx = lane; idx < 16 * RW; idx += 64) {
-        const int rl = idx / RW, col = idx - rl * RW;
-        const int cbl = col / nk, q = col - cbl * nk;
-        const int ca = ca_base + rl, cb = cbw + cbl;
-        if (ca < p.Ca && cb < p.Cb) {
-          float* g = p.G + ((long long)ca * p.Cb + cb) * p.KS + k0 + q;
-          const float v = Wt[rl * RP + col];
-          if (p.splits > 1) atomicAdd(g, v);
-          else *g += v;
+        __syncthreads();   // slab written (uniform trip counts: every wave reaches the barriers)
+        // rows of this half: MFMA row (r&3) + 8*(r>>2) + 4*lk with r in [8hf, 8hf+8) -> 16*hf + rl
+        const int ca_base = ca0 + wm * 64 + i * 32 + 16 * hf;
+        for (int rl = 0; rl < 16; ++rl) {
+          const int ca = ca_base + rl;
+          if (ca >= p.Ca) break;              // wave-uniform
+          float* grow = p.G + ((long long)ca * p.Cb + cbw) * p.KS + k0;
+          for (int col = lane; col < RW; col += 64) {
+            const int cbl = FULL ? col / NK : col / nkc, q = col - cbl * nkc;
+            if (cbw + cbl < p.Cb) {
+              float* g = grow + (long long)cbl * p.KS + q;
+              const float v = Wt[rl * RP + col];
+              if (p.splits > 1) atomicAdd(g, v);
+              else *g += v;
+            }
+          }
         }
+        __syncthreads();   // slab consumed before the next half overwrites it
       }
-      __syncthreads();   // slab consumed before the next half overwrites it
     }
-  }
+  };
+  if (nk == NK) combine(std::true_type{});
+  else combine(std::false_type{});
 }
 
 // ---- small-channel variant (Ca, Cb <= 32: the 16/32-channel MRF stages of the decoder, first / last layers) ----------
