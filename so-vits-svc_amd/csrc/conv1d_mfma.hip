@@ -1281,7 +1281,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     g_no192 = (e && e[0] == '1') ? 1 : 0;
   }
   // long sequences that one round of 224-column strips covers (the decoder's MRF convs): conv1d_strip.hip
-  if (g_force_cfg < 0) {
+  if (g_force_cfg < 0 && t_row_phases == 1) {      // (the strip kernel's epilogue knows nothing of phases-as-rows outputs)
     const int rs = svc::conv1d_strip_try(a, s);
     if (rs <= 0) return rs;
   }

@@ -41,6 +41,23 @@ def test_conv_transpose1d(dev, B, Cin, Cout, T, KS, u):
     assert _rel(y.cpu(), ref) < 3e-6
 
 
+def test_conv_transpose1d_three_taps_per_phase_no_padding(dev):
+    """stride 4, kernel 12, padding 0: the phases-as-rows form of a ConvTranspose1d with THREE taps per phase and y_t0 = 0 on a
+    long sequence — a shape the strip kernel (3 / 7 / 11 taps, unshifted output) would accept if it were offered to it; its
+    epilogue knows nothing of (channel, phase) rows, so the dispatcher must keep it on the tiled kernels."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, T, KS, u = 1, 48, 32, 60000, 12, 4
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, KS, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(x, w, b, stride=u, padding=0)
+    wp = S.pack_convt1d_weight(w.to(dev), None, u)
+    y = S.conv_transpose1d(x.to(dev), wp, Cout, KS, u, 0, bias=b.to(dev))
+    assert y.shape == ref.shape
+    assert _rel(y.cpu(), ref) < 3e-6
+
+
 @pytest.mark.parametrize("Cout,KS,s,L", [(256, 128, 64, 64 * 50), (128, 16, 8, 8 * 700), (64, 8, 4, 4 * 1500),
                                          (32, 4, 2, 2 * 3001), (16, 1, 1, 5000), (200, 128, 64, 64 * 21),
                                          (12, 1, 1, 777)])
