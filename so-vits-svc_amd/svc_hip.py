@@ -874,7 +874,12 @@ class PlanSets:
         if not self.enabled:
             return
         ent = self.sets.get(tag)
+        live = {p.data_ptr() for p in params} if ent is not None else None
+        # still valid: the recorded tensors sit where they were AND are storage of the parameters handed in now (a module that
+        # replaced its Parameter objects would otherwise be prepared from the old ones — harmless, the tokens would not match,
+        # but wasted)
         if ent is not None and all(v.data_ptr() == pv and (g.data_ptr() if g is not None else 0) == pg and pl.wp is not None
+                                   and pv in live and (pg == 0 or pg in live)
                                    for (pl, v, g), (pv, pg) in zip(ent["items"], ent["ptrs"])):
             check(tlib().svc_conv_weight_prep_multi_f32(ent["host"], ent["dev"].data_ptr(), ent["rows"][0].data_ptr(),
                                                         ent["rows"][1].data_ptr(), len(ent["items"]), stream_ptr()),
@@ -887,7 +892,7 @@ class PlanSets:
         old = self.sets.pop(tag, None)
         if old is not None:
             self._retired.append((old["dev"], old["rows"], old["host"]))
-        self.rec, self.ptrs = [], {p.data_ptr() for p in params}
+        self.rec, self.ptrs = [], (live if live is not None else {p.data_ptr() for p in params})
         PlanSets.recording = self
 
     def leave(self, tag):
