@@ -448,6 +448,13 @@ def main():
             else:
                 extras["diffusion_train"] = extras["diffusion_infer"] = dres
         train_res = run_train(args, dev, rank, world, dist)
+        if rank == 0 and world == 1 and not args.no_extras and train_res is not None:
+            torch.cuda.empty_cache()
+            # the same iteration driven through the entry point's loader loop (files on disk -> DataLoader -> bucketed collate)
+            tl = X.guarded(X.bench_train_loader, dev, train_hps(cfg))
+            if isinstance(tl, dict) and "bucketed_graph" in tl:
+                tl["vs_train_ms_per_step"] = round(tl["bucketed_graph"]["ms_per_step"] / train_res["ms_per_step"], 3)
+            train_res["train_loader"] = tl
 
     if rank == 0:
         out = dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.infer)", value=value,

@@ -200,6 +200,93 @@ def bench_diffusion(dev):
     return train, infer
 
 
+def write_train_dataset(root, n_items, seed=4321, n_spk=4, ssl_dim=768, n_fft=2048):
+    """BASELINE configs[2]'s synthetic set ON DISK in the reference's formats (preprocess_hubert_f0.py:31-103): per item a
+    44.1 kHz int16 wav, `.soft.pt` units at 50 fps, `.f0.npy` (f0, uv), a cached `.spec.pt`; T ~ U{300..790} frames."""
+    import numpy as np
+    from scipy.io.wavfile import write
+    g = torch.Generator().manual_seed(seed)
+    lines = []
+    for i in range(n_items):
+        d = os.path.join(root, "dataset", f"spk{i % n_spk}")
+        os.makedirs(d, exist_ok=True)
+        T = int(torch.randint(300, 791, (1,), generator=g))
+        p = os.path.join(d, f"u{i}.wav")
+        write(p, 44100, ((torch.rand(T * HOP, generator=g) - 0.5) * 32767).to(torch.int16).numpy())
+        torch.save(torch.randn(1, ssl_dim, T // 2 + 1, generator=g), p + ".soft.pt")
+        f0 = (100 + 300 * torch.rand(T, generator=g)).numpy()
+        for s0 in torch.randint(0, T - 8, (max(1, T // 80),), generator=g).tolist():
+            f0[s0:s0 + 8] = 0
+        np.save(p + ".f0.npy", np.asanyarray((f0, (f0 > 0).astype(float)), dtype=object), allow_pickle=True)
+        torch.save(torch.randn(n_fft // 2 + 1, T, generator=g).abs(), p.replace(".wav", ".spec.pt"))
+        lines.append(p)
+    fl = os.path.join(root, "train.txt")
+    with open(fl, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return fl
+
+
+def bench_train_loader(dev, hps_dict, n_items=96, epochs=3):
+    """The training number THROUGH the entry point's loop: train.make_loaders (reference-format files,
+    DataLoader workers, collate) -> train.train_and_evaluate -> TrainStep, on a synthetic data set of `n_items` utterances with
+    T ~ U{300..790}: once as `svc_run.py train.py` runs by default (length-bucketed collate, one hipGraph per padded shape) and
+    once with SVC_TRAIN_GRAPH=0 (the reference's pad-to-longest collate, eager launches).  The first epoch (graph captures,
+    worker start-up, page cache) is not timed."""
+    import logging
+    import shutil
+    import tempfile
+    import synthetic_data as W
+    import train as TR
+    import utils
+    root = tempfile.mkdtemp(prefix="svc_bench_ds_")
+    try:
+        fl = write_train_dataset(root, n_items)
+        cfg = W.full_config()
+        h = dict(hps_dict)
+        h["train"] = dict(h["train"], use_sr=True, max_speclen=512, vol_aug=False, all_in_mem=False, log_interval=10 ** 9,
+                          eval_interval=10 ** 9, seed=1234, keep_ckpts=0, epochs=epochs)
+        h["data"] = dict(h["data"], training_files=fl, validation_files=fl, max_wav_value=32768.0, unit_interpolate_mode="nearest")
+        h["spk"] = {f"spk{i}": i for i in range(4)}
+        hps = utils.HParams(**h)
+        hps.model_dir = root
+        logger = logging.getLogger("svc_bench_train_loader")
+        logger.addHandler(logging.NullHandler())
+        logger.propagate = False
+        out = {}
+        for name, use_graph in (("bucketed_graph", True), ("eager", False)):
+            torch.manual_seed(1234)
+            net_g, net_d, optim_g, optim_d = TR.build(hps, dev)
+            net_g.module.load_state_dict(W.make_train_state_dict(cfg, 1234))
+            net_d.module.load_state_dict(W.make_mpd_state_dict(1235))
+            step = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d).enable_graph(use_graph)
+            loaders = TR.make_loaders(hps, 0, 1, use_graph)
+            shapes = set()
+            TR.global_step = 1                       # nothing logs / evaluates / saves at these intervals
+            times = []
+            for epoch in range(1, epochs + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                TR.train_and_evaluate(0, epoch, hps, step, loaders, logger, [TR._NullWriter(), TR._NullWriter()], dev)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            n_steps = len(loaders[0])
+            dt = sum(times[1:]) / (n_steps * (epochs - 1))
+            out[name] = dict(ms_per_step=round(1e3 * dt, 2), steps_per_s=round(1.0 / dt, 3), first_epoch_s=round(times[0], 2),
+                             timed_steps=n_steps * (epochs - 1))
+            if use_graph:
+                out[name]["graphs"] = len(step._graphs)
+                out[name]["padded_frames"] = sorted({k[0][0][2] for k in step._graphs})
+                out[name]["eager_fallbacks"] = step.eager_fallbacks
+            del step, net_g, net_d, optim_g, optim_d, loaders
+            torch.cuda.empty_cache()
+        out["workload"] = (f"train.make_loaders + train.train_and_evaluate on {n_items} synthetic utterances on disk (wav, .soft.pt, "
+                           f".f0.npy, .spec.pt; T~U{{300..790}}), batch {hps.train.batch_size}, DataLoader workers as train.run sets them, "
+                           f"{epochs - 1} timed epochs after one warm-up epoch")
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def guarded(fn, *a, **k):
     try:
         return fn(*a, **k)

@@ -38,6 +38,11 @@ struct StripP {
   int buf_f;       // floats per LDS buffer (W block + X block)
   int dbg;         // timing experiments (results are then garbage): 1 no output stores, 2 no MFMA loop, 4 no residual prefetch
 };
+#ifdef SVC_TIMING_DEBUG       // the shipped library has no way to produce garbage: the flags are compiled out
+#define STRIP_DBG(p) ((p).dbg)
+#else
+#define STRIP_DBG(p) 0
+#endif
 
 // One LDS-DMA piece: lane l's 16 B at base + off[l] land at LDS byte address lds_byte + l*16 (wave-uniform LDS base in M0).
 // Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (strip_vmcnt0 before the barrier).
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       _Pragma("unroll") for (int j = 0; j < NTW; ++j) bv[k_][j] = (xa_)[(k_) * dil + j * TS]; \
     }
     auto groups = [&](int buf, int q0, int q1) {
-      if (p.dbg & 2) return;
+      if (STRIP_DBG(p) & 2) return;
       const float* wl = smem + buf * buf_f + wm * TS + ln + lk * (KSC * BM);
       const float* xl = smem + buf * buf_f + wfl + wn * (NT * TS) + J0 * TS + ln + sh + lk * XW;
       for (int q = q0; q < q1; ++q) {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
       for (int r = 0; r < NACC; ++r) bc_[r] = bc_[r] + condb[(rowl + rowc(r) + 4 * lk) * a.cond_cs];
     }
     if constexpr (HAS_RES) {
-      if (!(p.dbg & 4)) {
+      if (!(STRIP_DBG(p) & 4)) {
   #pragma unroll
       for (int r = 0; r < NACC; ++r) {
         const float* rp = resb + (long long)(rowl + rowc(r)) * a.res_cs;   // wave-uniform
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
               v = v + a.beta * yo[r];
               v = v / a.out_div;
             }
-            if (!(p.dbg & 1) || r == 0) asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
+            if (!(STRIP_DBG(p) & 1) || r == 0) asm volatile("global_store_dword %0, %1, %2" : : "v"(yoff[j]), "v"(v), "s"(yp) : "memory");
           }
         }
       }
@@ -488,7 +493,11 @@ int strip_launch_ks(const svc_conv1d_args& a, hipStream_t s, int wps) {
 
 extern "C" int svc_debug_set_conv_strip(int mode) {
   if (mode < 0) return g_strip_launches;
+#ifdef SVC_TIMING_DEBUG
   g_strip_dbg = mode / 1000;      // timing experiments only (garbage results): see StripP.dbg
+#else
+  SVC_REQUIRE(mode < 1000, "svc_debug_set_conv_strip: the timing-decomposition modes (>= 1000: results are garbage) exist only in builds with -DSVC_TIMING_DEBUG");
+#endif
   g_strip_mode = mode % 1000;
   return SVC_OK;
 }

@@ -42,9 +42,9 @@ def shard_indices(n_items, rank, world, epoch=0, shuffle=True, seed=1234, drop_l
         order = list(range(n_items))
     if drop_last:
         order = order[:n_items - n_items % world]
-    else:
+    elif order:
         pad = (-len(order)) % world
-        order = order + order[:pad]
+        order = order + (order * (pad // len(order) + 1))[:pad]       # wrap around as often as needed (n_items < world)
     return order[rank::world]
 
 

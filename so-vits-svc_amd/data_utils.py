@@ -113,7 +113,6 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
         c, f0, uv = c[:, :lmin], f0[:lmin], uv[:lmin]
         if torch.is_tensor(spec):
             spec = spec[:, :lmin]
-        audio_full = audio_norm
         audio_norm = audio_norm[:, :lmin * self.hop_length]
         if not torch.is_tensor(spec):
             spec.n_frames = lmin
@@ -157,13 +156,39 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
         return len(self.audiopaths)
 
 
+FRAME_BUCKETS = (320, 448, 576, 672, 736, 800)     # padded frame counts of a bucketed batch; beyond the last: multiples of 128
+
+
+def bucket_frames(n_frames, buckets=FRAME_BUCKETS):
+    """Smallest bucket >= n_frames.  The loader's crops are at most 800 frames long (data_utils.py:112-118: utterances above
+    800 frames are cut to 790) and a batch is as long as its longest item, so with B = 16 nearly every batch lands in the last
+    one or two buckets; the lower ones serve small batches and short data sets."""
+    for b in buckets:
+        if n_frames <= b:
+            return b
+    return -(-n_frames // 128) * 128
+
+
 class TextAudioCollate:
+    """data_utils.py:131-186.  `buckets` (engine addition, None = the reference's behaviour): pad the frame axis to
+    `bucket_frames(longest item)` instead of the longest item itself, and the waveform to that many hops — the padding is zeros
+    and every consumer masks by `lengths`, so the batch means the same; what changes is that a run sees a handful of padded
+    shapes instead of a new one per batch, which is what lets train.TrainStep replay the iteration from one hipGraph per shape."""
+
+    def __init__(self, buckets=None, hop_length=None):
+        self.buckets, self.hop = buckets, hop_length
+        if buckets is not None and not hop_length:
+            raise ValueError("TextAudioCollate(buckets=...) needs hop_length (the waveform is padded to bucket * hop samples)")
+
     def __call__(self, batch):
         batch = [b for b in batch if b is not None]
         input_lengths, ids_sorted_decreasing = torch.sort(torch.LongTensor([x[0].shape[1] for x in batch]), dim=0,
                                                           descending=True)
         max_c_len = max(x[0].size(1) for x in batch)
         max_wav_len = max(x[3].size(1) for x in batch)
+        if self.buckets is not None:
+            max_c_len = bucket_frames(max_c_len, self.buckets)
+            max_wav_len = max(max_wav_len, max_c_len * self.hop)
         n = len(batch)
         lengths = torch.LongTensor(n)
         c_padded = torch.zeros(n, batch[0][0].shape[0], max_c_len)
@@ -173,6 +198,9 @@ class TextAudioCollate:
             spec_padded = torch.zeros(n, batch[0][2].shape[0], max_c_len)
         else:       # vol_aug re-scales a random half of the items: cached and to-be-computed spectrograms share a batch
             ext_len = max(x[2].ext.shape[0] for x in batch if isinstance(x[2], SpecContext))
+            if self.buckets is not None:          # frames * hop + 2 * pad: the same context margin on the bucketed frame count
+                ctx = next(x[2] for x in batch if isinstance(x[2], SpecContext))
+                ext_len = max(ext_len, max_c_len * self.hop + (ctx.ext.shape[0] - ctx.n_frames * self.hop))
             ext_padded = torch.zeros(n, ext_len)
             ext_frames = torch.zeros(n, dtype=torch.long)
             cached = [x[2] for x in batch if torch.is_tensor(x[2])]

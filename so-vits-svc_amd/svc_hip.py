@@ -813,8 +813,13 @@ class ConvWeightPlan:
         if g is not None and (g.numel() != self.R or not g.is_contiguous()):
             raise SvcError("ConvWeightPlan: weight_g must hold one contiguous value per row")
 
+    def _buffers(self):
+        """Addresses of the persistent operand buffers (what a PlanSets device table bakes in)."""
+        return None if self.wp is None else (self.wp.data_ptr(), self.wt.data_ptr(), self.norm.data_ptr())
+
     def _alloc(self, device):
         if self.wp is None or self.wp.device != device:
+            self.__dict__.pop("_fresh", None)     # new buffers are unfilled: no open bracket's token may vouch for them
             self.wp = torch.zeros((self.Id, self.Kd, self.OdP), device=device, dtype=torch.float32)
             self.wt = torch.zeros((self.Od, self.Kd, self.IdP), device=device, dtype=torch.float32)
             self.norm = torch.empty((self.R,), device=device, dtype=torch.float32)
@@ -878,9 +883,11 @@ class PlanSets:
         # still valid: the recorded tensors sit where they were AND are storage of the parameters handed in now (a module that
         # replaced its Parameter objects would otherwise be prepared from the old ones — harmless, the tokens would not match,
         # but wasted)
+        # ... and every plan still owns the operand buffers whose addresses the device table holds (a plan re-allocates them on
+        # a device change; the multi kernel would scatter into the freed ones)
         if ent is not None and all(v.data_ptr() == pv and (g.data_ptr() if g is not None else 0) == pg and pl.wp is not None
-                                   and pv in live and (pg == 0 or pg in live)
-                                   for (pl, v, g), (pv, pg) in zip(ent["items"], ent["ptrs"])):
+                                   and pv in live and (pg == 0 or pg in live) and pl._buffers() == bufs
+                                   for (pl, v, g), (pv, pg), bufs in zip(ent["items"], ent["ptrs"], ent["bufs"])):
             check(tlib().svc_conv_weight_prep_multi_f32(ent["host"], ent["dev"].data_ptr(), ent["rows"][0].data_ptr(),
                                                         ent["rows"][1].data_ptr(), len(ent["items"]), stream_ptr()),
                   "conv_weight_prep_multi")
@@ -912,7 +919,8 @@ class PlanSets:
                     ba += tlib().svc_conv_weight_prep_blocks(pl.R, pl.C2, pl.K)
                 rows = torch.tensor([rstart, bstart], dtype=torch.int32).to(dev.device)
                 self.sets[tag] = dict(items=items, host=host, dev=dev, rows=rows,
-                                      ptrs=[(v.data_ptr(), g.data_ptr() if g is not None else 0) for _, v, g in items])
+                                      ptrs=[(v.data_ptr(), g.data_ptr() if g is not None else 0) for _, v, g in items],
+                                      bufs=[pl._buffers() for pl, _, _ in items])
             return
         ent = self.sets.get(tag)
         if ent is not None:

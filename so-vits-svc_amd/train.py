@@ -81,6 +81,10 @@ class TrainStep:
 
         self.use_graph = False
         self._graphs = {}
+        # every captured shape keeps its own ~10 GB tape alive: bound the count (bucketed batches need 2-4; a data set of
+        # odd batch sizes falls back to eager launches for the shapes beyond the cap instead of growing without limit)
+        self.max_graphs = int(os.environ.get("SVC_TRAIN_GRAPH_MAX", "8"))
+        self.eager_fallbacks = 0
         self.plan_sets = S.PlanSets()     # one-launch weight preparation per forward pass (G, D, D again after its step)
 
     def enable_graph(self, on=True):
@@ -126,6 +130,9 @@ class TrainStep:
         key = tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
         ent = self._graphs.get(key)
         n_in = len(items) - len(nkeys)
+        if ent is None and len(self._graphs) >= self.max_graphs:
+            self.eager_fallbacks += 1
+            return self._step_body(items[:n_in], dict(zip(nkeys, items[n_in:])) if nkeys else None)
         if ent is None:
             commons.DEVICE_RNG = True
             static = [t.clone() if t is not None else None for t in items]
@@ -166,17 +173,17 @@ class TrainStep:
         return res
 
     def _serialize_replays(self):
-        """OPT-IN (SVC_TRAIN_SERIALIZE=1): wait on the host for the previous replay of the iteration graph before enqueueing
-        the next one.  Round 2 needed this: with a mid-run synchronize (diag SYNC=at2 / at5) the iterations after it came out
-        bimodal / NaN when the next replay was enqueued behind a running one (profiles/r02_o_*).  Round 3 re-ran exactly those
-        reproducers WITHOUT the wait — 35 runs over SYNC=none / at2 / at5, with and without the gradient slab, with and without
-        dropout draws in the graph, on the round-3 kernels and on the round-2 conv epilogue path (profiles/r03p_*, r03q_*,
-        r03r_replay_diag.txt) — and every run reproduced the same loss trajectory to fp32 round-off.  The round-2 traces predate
-        that round's LayerNorm / grouped-conv kernel rewrites (the replaced kernels are the suspects; no stand-alone reproducer
-        was ever found), so the wait is no longer taken by default; tests/test_train_loop_gpu.py pins back-to-back replays
-        against eager iterations."""
+        """Wait on the host for the previous replay of the iteration graph before enqueueing the next one (default ON;
+        SVC_TRAIN_SERIALIZE=0 opts out).  Round 2 needed this: with a mid-run synchronize (diag SYNC=at2 / at5) the iterations
+        after it came out bimodal / NaN when the next replay was enqueued behind a running one (profiles/r02_o_*).  Round 3 re-ran
+        those reproducers WITHOUT the wait — 35 runs (profiles/r03p_*, r03q_*, r03r_replay_diag.txt) — and every run reproduced
+        the same loss trajectory; the round-2 traces predate that round's LayerNorm / grouped-conv kernel rewrites, but no
+        stand-alone reproducer was ever found, i.e. the root cause is NOT known.  The wait costs one graph-launch latency per
+        ~100 ms iteration (the host work of the next batch — loader, collate, input copies — still overlaps the running replay:
+        the wait sits after it), a silent divergence costs a training run: the guard stays until the round-2 failure is
+        explained.  tests/test_train_loop_gpu.py pins back-to-back replays against eager iterations with the wait off."""
         ev = self.__dict__.get("_replay_done")
-        if ev is not None and os.environ.get("SVC_TRAIN_SERIALIZE", "0") == "1":
+        if ev is not None and os.environ.get("SVC_TRAIN_SERIALIZE", "1") == "1":
             ev.synchronize()
 
     def _mark_replay(self):
@@ -283,6 +290,9 @@ class TrainStep:
         key = ("dp",) + tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
         ent = self._graphs.get(key)
         n_in = len(items) - len(nkeys)
+        if ent is None and len(self._graphs) >= self.max_graphs:     # same decision on every rank: the shapes are the loader's
+            self.eager_fallbacks += 1
+            return self._step_body(items[:n_in], dict(zip(nkeys, items[n_in:])) if nkeys else None)
         if ent is None:
             commons.DEVICE_RNG = True
             static = [t.clone() if t is not None else None for t in items]
@@ -409,7 +419,8 @@ def main():
     hps = utils.get_hparams()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:          # already one process per GPU (torch.distributed.run)
-        run(int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), int(os.environ["WORLD_SIZE"]), hps)
+        # RANK = position in the job (process group, data shard, rank-0 duties); LOCAL_RANK = the GPU on this node
+        run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), hps, local_rank=int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))
         return
     n_gpus = torch.cuda.device_count()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -421,13 +432,35 @@ def main():
         mp.spawn(run, nprocs=n_gpus, args=(n_gpus, hps,))
 
 
-def run(rank, n_gpus, hps):
-    """train.py:49-147."""
-    global global_step
+def make_loaders(hps, rank, n_gpus, use_graph):
+    """train.py:61-72: the training loader (this rank's shard of the file list) and, on rank 0, the validation loader.
+    The iteration is replayed from one hipGraph per padded batch shape (SVC_TRAIN_GRAPH=0: eager launches, ~100 ms of host
+    time per iteration).  The reference pads a batch to its longest item (data_utils.py:131-185) — a new shape nearly every
+    batch — so with graphs on the collate pads to a few bucketed frame counts instead (data_utils.FRAME_BUCKETS; zeros, masked
+    by `lengths`).  Workers persist across epochs (the reference re-forks them every epoch)."""
     import multiprocessing
-    import utils
-    from data_utils import TextAudioCollate, TextAudioSpeakerLoader
+    from data_utils import FRAME_BUCKETS, TextAudioCollate, TextAudioSpeakerLoader
     from torch.utils.data import DataLoader
+    collate_fn = TextAudioCollate(buckets=FRAME_BUCKETS, hop_length=hps.data.hop_length) if use_graph else TextAudioCollate()
+    all_in_mem = hps.train.all_in_mem
+    train_dataset = TextAudioSpeakerLoader(hps.data.training_files, hps, all_in_mem=all_in_mem)
+    num_workers = 0 if all_in_mem else (5 if multiprocessing.cpu_count() > 4 else multiprocessing.cpu_count())
+    num_workers = int(os.environ.get("SVC_LOADER_WORKERS", num_workers))
+    sampler = _ShardSampler(len(train_dataset), rank, n_gpus) if n_gpus > 1 else None
+    train_loader = DataLoader(train_dataset, num_workers=num_workers, shuffle=False, sampler=sampler, pin_memory=True,
+                              batch_size=hps.train.batch_size, collate_fn=collate_fn, persistent_workers=num_workers > 0)
+    eval_loader = None
+    if rank == 0:
+        eval_dataset = TextAudioSpeakerLoader(hps.data.validation_files, hps, all_in_mem=all_in_mem, vol_aug=False)
+        eval_loader = DataLoader(eval_dataset, num_workers=min(1, num_workers), shuffle=False, batch_size=1, pin_memory=False,
+                                 drop_last=False, collate_fn=TextAudioCollate())
+    return train_loader, eval_loader
+
+
+def run(rank, n_gpus, hps, local_rank=None):
+    """train.py:49-147.  `rank` is the global rank; `local_rank` (default: the same, one node) selects the device."""
+    global global_step
+    import utils
     logger = writer = writer_eval = None
     if rank == 0:
         logger = utils.get_logger(hps.model_dir)
@@ -435,24 +468,13 @@ def run(rank, n_gpus, hps):
         utils.check_git_hash(hps.model_dir)
         writer = _writer(hps.model_dir)
         writer_eval = _writer(os.path.join(hps.model_dir, "eval"))
-    device = torch.device("cuda", rank)
+    device = torch.device("cuda", rank if local_rank is None else local_rank)
     torch.cuda.set_device(device)
     if n_gpus > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", init_method="env://", world_size=n_gpus, rank=rank, device_id=device)
     torch.manual_seed(hps.train.seed)
-    collate_fn = TextAudioCollate()
-    all_in_mem = hps.train.all_in_mem
-    train_dataset = TextAudioSpeakerLoader(hps.data.training_files, hps, all_in_mem=all_in_mem)
-    num_workers = 0 if all_in_mem else (5 if multiprocessing.cpu_count() > 4 else multiprocessing.cpu_count())
-    num_workers = int(os.environ.get("SVC_LOADER_WORKERS", num_workers))
-    sampler = _ShardSampler(len(train_dataset), rank, n_gpus) if n_gpus > 1 else None
-    train_loader = DataLoader(train_dataset, num_workers=num_workers, shuffle=False, sampler=sampler, pin_memory=True,
-                              batch_size=hps.train.batch_size, collate_fn=collate_fn)
-    eval_loader = None
-    if rank == 0:
-        eval_dataset = TextAudioSpeakerLoader(hps.data.validation_files, hps, all_in_mem=all_in_mem, vol_aug=False)
-        eval_loader = DataLoader(eval_dataset, num_workers=min(1, num_workers), shuffle=False, batch_size=1, pin_memory=False,
-                                 drop_last=False, collate_fn=collate_fn)
+    use_graph = os.environ.get("SVC_TRAIN_GRAPH", "1") == "1"
+    train_loader, eval_loader = make_loaders(hps, rank, n_gpus, use_graph)
 
     net_g, net_d, optim_g, optim_d = build(hps, device)
 
@@ -476,8 +498,7 @@ def run(rank, n_gpus, hps):
     scheduler_g = torch.optim.lr_scheduler.ExponentialLR(optim_g, gamma=hps.train.lr_decay, last_epoch=epoch_str - 2)
     scheduler_d = torch.optim.lr_scheduler.ExponentialLR(optim_d, gamma=hps.train.lr_decay, last_epoch=epoch_str - 2)
     step = TrainStep(hps, net_g, net_d, optim_g, optim_d)
-    if os.environ.get("SVC_TRAIN_GRAPH", "0") == "1":   # one hipGraph per padded batch shape: for loaders that bucket lengths
-        step.enable_graph(True)
+    step.enable_graph(use_graph)
 
     for epoch in range(epoch_str, hps.train.epochs + 1):
         if epoch <= warmup_epoch:                                                     # train.py:126-131

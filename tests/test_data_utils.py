@@ -214,3 +214,33 @@ def test_repeat_expand_2d_left_is_the_reference_sequential_fill():
         x = torch.randn(4, src, generator=g)
         assert torch.equal(U.repeat_expand_2d(x, tgt), ref_loop(x, tgt)), (src, tgt)
     assert U.repeat_expand_2d(torch.randn(3, 10), 25, mode="nearest").shape == (3, 25)
+
+
+def test_bucketed_collate_is_the_plain_collate_zero_padded(tmp_path):
+    """train.run's collate (hipGraph training needs a handful of padded shapes): frame axis padded to data_utils.FRAME_BUCKETS,
+    waveform to bucket * hop, everything else — order, lengths, values — as the reference's collate gives it."""
+    import data_utils
+    fl, cj = _make_dataset(str(tmp_path), n_items=6, with_spec=True, with_vol=True)
+    ds, plain = _ours(fl, cj)
+    bucketed = data_utils.TextAudioCollate(buckets=data_utils.FRAME_BUCKETS, hop_length=HOP)
+    random.seed(5)
+    items = [ds[i] for i in range(6)]
+    a, b = plain(items), bucketed(items)
+    T, Tb = a[0].shape[2], b[0].shape[2]
+    assert Tb == data_utils.bucket_frames(T) == 320 and b[3].shape[2] == Tb * HOP
+    assert torch.equal(a[5], b[5]) and torch.equal(a[4], b[4])                       # lengths, speaker ids: same order
+    for x, y in zip(a, b):
+        if torch.is_tensor(x) and x.dim() >= 2 and x.shape[-1] in (T, a[3].shape[2]):
+            n = x.shape[-1]
+            assert torch.equal(x, y[..., :n]) and float(y[..., n:].abs().sum()) == 0.0
+    # items without a cached spectrogram: the context rows grow with the bucket, by whole frames
+    fl2, cj2 = _make_dataset(str(tmp_path / "b"), n_items=4, with_spec=False)
+    ds2, plain2 = _ours(fl2, cj2)
+    random.seed(6)
+    items2 = [ds2[i] for i in range(4)]
+    a2, b2 = plain2(items2), bucketed(items2)
+    assert isinstance(b2[2], data_utils.SpecContextBatch) and torch.equal(a2[2].n_frames, b2[2].n_frames)
+    assert b2[2].ext.shape[1] == 320 * HOP + (NFFT - HOP) and torch.equal(a2[2].ext, b2[2].ext[:, :a2[2].ext.shape[1]])
+    assert [data_utils.bucket_frames(n) for n in (1, 320, 321, 790, 800, 801, 1000)] == [320, 320, 448, 800, 800, 896, 1024]
+    with pytest.raises(ValueError):
+        data_utils.TextAudioCollate(buckets=(64,))

@@ -22,6 +22,34 @@ def test_mel_basis_matches_independent_implementation():
     assert a.shape == (80, 1025) and np.abs(a - b).max() < 1e-7
 
 
+def test_mel_scale_matches_librosa_published_known_answers():
+    """librosa==0.9.1 (requirements.txt:23; call site modules/mel_processing.py:72) cannot be installed here — the container has
+    no network (`pip download librosa==0.9.1`: "no matching distribution") and no wheel is in the offline wheelhouse — so the
+    basis cannot be compared with librosa's OUTPUT.  What librosa does publish are known answers in its own docstrings
+    (librosa/core/convert.py: `hz_to_mel`, `mel_to_hz`, `mel_frequencies`; librosa/filters.py: `mel`), unchanged between 0.8 and
+    0.10; the restatement reproduces every one of them to the printed precision:
+      hz_to_mel(60) = 0.9; hz_to_mel([110, 220, 440]) = [1.65, 3.3, 6.6]; mel_to_hz(3) = 200.;
+      mel_to_hz([1..5]) = [66.667, 133.333, 200., 266.667, 333.333]; mel_frequencies(n_mels=40) (fmin 0, fmax 11025): the 40
+      values below; filters.mel(sr=22050, n_fft=2048)[0, :2] = [0., 0.016].
+    Together with the element-wise agreement with transformers' independent implementation (test above) this is as far as
+    the basis can be pinned without librosa itself."""
+    assert abs(float(OM.hz_to_mel(60)) - 0.9) < 1e-12
+    assert np.allclose(OM.hz_to_mel([110, 220, 440]), [1.65, 3.3, 6.6], atol=1e-12)
+    assert float(OM.mel_to_hz(3)) == 200.0
+    assert np.array_equal(np.round(OM.mel_to_hz([1, 2, 3, 4, 5]), 3), [66.667, 133.333, 200.0, 266.667, 333.333])
+    doc = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856,
+           1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799,
+           3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272,
+           9246.028, 10096.408, 11025.]
+    mine = OM.mel_to_hz(np.linspace(OM.hz_to_mel(0.0), OM.hz_to_mel(11025.0), 40))
+    assert np.array_equal(np.round(mine, 3), np.array(doc))
+    w = OM.mel_filterbank(22050, 2048, 128)
+    assert w.shape == (128, 1025) and abs(w[0, 0]) == 0.0 and round(float(w[0, 1]), 3) == 0.016
+    # Slaney area normalisation: every filter integrates to ~1 over frequency (2 / (f[i+2] - f[i]) * triangle area)
+    b = OM.mel_filterbank(44100, 2048, 80, 0, 22050).astype(np.float64)
+    assert np.abs(b.sum(1) * (22050 / 1024) - 1.0).max() < 0.06
+
+
 def test_oracle_reproduces_reference_training_step():
     cs = load_case()
     z = cs["z"]

@@ -99,7 +99,7 @@ def test_fused_adamw_matches_torch(dev):
     assert abs(opt.param_groups[0]["lr"] - 5e-4) < 1e-12
 
 
-def test_training_graph_replays_back_to_back_equal_eager(dev):
+def test_training_graph_replays_back_to_back_equal_eager(dev, monkeypatch):
     """replays of the whole-iteration hipGraph enqueued back to back — NO host wait between them (the
     default since round 3, see train.TrainStep._serialize_replays), a host synchronisation in the middle of the sequence (the
     pattern that gave bimodal losses in round 2), different noise every iteration — must reproduce the same number of EAGER
@@ -138,7 +138,7 @@ def test_training_graph_replays_back_to_back_equal_eager(dev):
         flat = torch.cat([net_g.module.state_dict()[k].flatten().float() for k in sorted(cs["sd_g"]) if cs["sd_g"][k].is_floating_point()])
         return [{k: float(v) for k, v in o.items() if torch.is_tensor(v)} for o in outs], flat.cpu()
 
-    assert os.environ.get("SVC_TRAIN_SERIALIZE", "0") != "1"
+    monkeypatch.setenv("SVC_TRAIN_SERIALIZE", "0")        # the host wait between replays is the default; this test pins the path without it
     le, pe = run(False)
     lg, pg = run(True)
     for i, (a, b) in enumerate(zip(le, lg)):

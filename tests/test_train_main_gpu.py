@@ -62,6 +62,19 @@ def test_training_entry_point_trains_checkpoints_and_resumes(dev, tmp_path):
         json.dump(cfg, f)
     r2 = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=900, env=env)
     assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-3000:])
-    log2 = open(os.path.join(mdir, "train.log")).read()
-    assert "Loaded checkpoint" in log2 + r2.stdout + r2.stderr or "====> Epoch: 3" in log2
-    assert "====> Epoch: 3" in log2, log2[-1500:]
+    log2 = open(os.path.join(mdir, "train.log")).read()[len(log):]          # what the second run appended
+    both = log2 + r2.stdout + r2.stderr
+    # a broken load (run() swallows load errors and restarts from epoch 1, like train.py:106-109) would ALSO reach epoch 3:
+    # require the load itself, no restart, and the step counter continued from the checkpoint's file name
+    assert "Loaded checkpoint" in both and "load old checkpoint failed" not in both, both[-2000:]
+    # (the epoch stored in the checkpoint is re-run, as in the reference: train.py:99,116)
+    assert "====> Epoch: 3" in log2 and "====> Epoch: 1," not in log2, log2[-1500:]
+    last = max(int(os.path.basename(p)[2:-4]) for p in ds)
+    steps2 = [int(l.split("step: ")[1].split(",")[0]) for l in log2.splitlines() if "Losses:" in l]
+    assert steps2 and steps2[0] == last + 1 and steps2 == list(range(last + 1, last + 1 + len(steps2))), (last, steps2)
+    # the optimizer state came back too: one AdamW step per iteration since step 0, across the restart (a run that failed to
+    # load the optimizer would count from the restart only)
+    newest = sorted(glob.glob(os.path.join(mdir, "G_*.pth")), key=lambda p: int(os.path.basename(p)[2:-4]))[-1]
+    n_new = int(os.path.basename(newest)[2:-4])
+    st = torch.load(newest, map_location="cpu")["optimizer"]["state"]
+    assert n_new > last and st and all(float(v["step"]) == n_new + 1 for v in st.values()), (n_new, sorted({float(v["step"]) for v in st.values()}))
