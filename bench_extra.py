@@ -226,6 +226,27 @@ def write_train_dataset(root, n_items, seed=4321, n_spk=4, ssl_dim=768, n_fft=20
     return fl
 
 
+class _TimedLoader:
+    """Wraps a DataLoader: records how long the training loop waited for each batch (host time not hidden behind the GPU)."""
+
+    def __init__(self, loader):
+        self.loader, self.waits = loader, []
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        while True:
+            t0 = time.perf_counter()
+            try:
+                batch = next(it)
+            except StopIteration:
+                return
+            self.waits.append(time.perf_counter() - t0)
+            yield batch
+
+
 def bench_train_loader(dev, hps_dict, n_items=96, epochs=3):
     """The training number THROUGH the entry point's loop: train.make_loaders (reference-format files,
     DataLoader workers, collate) -> train.train_and_evaluate -> TrainStep, on a synthetic data set of `n_items` utterances with
@@ -260,7 +281,7 @@ def bench_train_loader(dev, hps_dict, n_items=96, epochs=3):
             net_d.module.load_state_dict(W.make_mpd_state_dict(1235))
             step = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d).enable_graph(use_graph)
             loaders = TR.make_loaders(hps, 0, 1, use_graph)
-            shapes = set()
+            loaders = [_TimedLoader(loaders[0]), loaders[1]]
             TR.global_step = 1                       # nothing logs / evaluates / saves at these intervals
             times = []
             for epoch in range(1, epochs + 1):
@@ -272,7 +293,8 @@ def bench_train_loader(dev, hps_dict, n_items=96, epochs=3):
             n_steps = len(loaders[0])
             dt = sum(times[1:]) / (n_steps * (epochs - 1))
             out[name] = dict(ms_per_step=round(1e3 * dt, 2), steps_per_s=round(1.0 / dt, 3), first_epoch_s=round(times[0], 2),
-                             timed_steps=n_steps * (epochs - 1))
+                             timed_steps=n_steps * (epochs - 1),
+                             loader_wait_ms_per_step=round(1e3 * sum(loaders[0].waits[n_steps:]) / (n_steps * (epochs - 1)), 2))
             if use_graph:
                 out[name]["graphs"] = len(step._graphs)
                 out[name]["padded_frames"] = sorted({k[0][0][2] for k in step._graphs})

@@ -113,6 +113,14 @@ typedef struct svc_conv1d_args {
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
 
+/* n (1..16) INDEPENDENT convolutions — no output of one is an input, residual or output of another — with the same results as
+ * n calls of svc_conv1d_f32 in any order.  The three ResBlock chains of an MRF stage (vdecoder/hifigan/models.py:382-388:
+ * `xs += self.resblocks[i*num_kernels+j](x)`, kernel sizes 11 / 7 / 3) advance in lockstep, so the same step of the three
+ * chains is such a group: members that run on the strip kernel or on the 64 x 128 LDS-DMA tiling with 11, 7 and 3 taps are
+ * issued as ONE launch (heaviest workgroups first), the others one by one. */
+int svc_conv1d_multi_f32(const svc_conv1d_args* a, int n, void* stream);
+int svc_debug_conv_multi_merged(void);   /* merged launches of the tiled kernel so far (tests) */
+
 /* ------------------------------------------------------------------------------------------------
  * ConvTranspose1d (upsampling `ups[i]`, vdecoder/hifigan/models.py:340-342,378), lowered to `stride`
  * dense polyphase sub-convolutions on the same MFMA kernel:

@@ -20,7 +20,7 @@ void prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(hipStream_t s_, const char* name, double flop, double bytes) : s(s_), on(prof_on()) {
+  ProfScope(hipStream_t s_, const char* name, double flop, double bytes, bool enable = true) : s(s_), on(enable && prof_on()) {
     if (on) prof_begin(s, name, flop, bytes);
   }
   ~ProfScope() {

@@ -237,6 +237,13 @@ class DataParallel(nn.Module):
             self.reducer = GradReducer(self.arena, process_group, bucket_bytes, first_bucket_bytes)
             if broadcast:
                 self.reducer.broadcast_parameters(0)
+                # ... and the module's buffers, like DDP's constructor (`_sync_module_states`): the power-iteration vectors of
+                # spectral-norm discriminators (`weight_u` / `weight_v`, models.py:170,205) start from rank 0's everywhere.  They
+                # then evolve identically on every rank — each forward advances them from the (synchronised) weights by the same
+                # deterministic kernel — so DDP's per-forward re-broadcast (`broadcast_buffers`) is not needed.
+                for buf in module.buffers():
+                    if torch.is_tensor(buf) and buf.numel():
+                        dist.broadcast(buf, src=0, group=process_group)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -101,6 +101,7 @@ def lib():
         L.svc_pack_convt1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
+        L.svc_conv1d_multi_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_int, C.c_void_p]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
         L.svc_resblock_pair_f32.argtypes = [C.POINTER(ResblockPairArgs), C.c_void_p]
@@ -133,7 +134,8 @@ def lib():
 
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
-    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv_transpose1d_f32",
+    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
+    "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
@@ -248,8 +250,36 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.epi, a.post_act, a.res_mode, a.skip_from = epi, post_act, res_mode, skip_from
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
     a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
+    if _GROUP is not None:          # inside `with conv_group():` — issued with the rest of the group on exit
+        _GROUP.append((a, (x, wp, bias, cond, mask, premask, res, out, out2)))
+        return out
     check(lib().svc_conv1d_f32(C.byref(a), stream_ptr()), "conv1d")
     return out
+
+
+_GROUP = None
+
+
+class conv_group:
+    """`with conv_group(): ...` — every svc_hip.conv1d call inside the block is collected and the block's exit issues them
+    together through svc_conv1d_multi_f32.  The calls must be INDEPENDENT (no output of one is an input, residual or output of
+    another): the decoder uses it for the same step of the three ResBlock chains of an MRF stage, which then share one launch."""
+
+    def __enter__(self):
+        global _GROUP
+        if _GROUP is not None:
+            raise SvcError("conv_group does not nest")
+        _GROUP = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        items, _GROUP = _GROUP, None
+        if et is not None or not items:
+            return False
+        arr = (Conv1dArgs * len(items))(*[a for a, _ in items])
+        check(lib().svc_conv1d_multi_f32(arr, len(items), stream_ptr()), "conv1d_multi")
+        return False
 
 
 def conv_transpose1d(x, wp, Cout, KS, stride, padding, *, bias=None, pre_slope=1.0, res=None, out=None):

@@ -29,6 +29,7 @@ LRELU_SLOPE = 0.1
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
 _MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
+_MRF_MERGE = __import__("os").environ.get("SVC_MRF_MERGE", "1") != "0"       # A/B switch: the chains' same-step convs in one launch
 
 
 class ResBlock1(nn.Module):
@@ -179,6 +180,41 @@ class SourceModuleHnNSF(nn.Module):
         return har, None, None
 
 
+def _mergeable(blocks, x):
+    """ResBlock1 chains of equal depth on the two-launch path (the fused 16-channel pairs keep their own kernel)."""
+    if isinstance(x, S.FlipView) or not all(isinstance(b, ResBlock1) for b in blocks):
+        return False
+    if len({len(b.convs1) for b in blocks}) != 1 or not _POSTACT:
+        return False
+    C = x.shape[1]
+    return not (_FUSE_PAIR and C in S.RESBLOCK_PAIR_CHANNELS and all(b.convs1[0].kernel_size in S.RESBLOCK_PAIR_KERNELS for b in blocks))
+
+
+def _mrf_stage_merged(blocks, x, acc, kw):
+    """The chains of a stage advance in LOCKSTEP on one stream: step s of every chain is one svc_conv1d_multi_f32 group (one
+    launch when the convs share a kernel family: conv1d_strip3_kernel / conv1d_mfma3_kernel), i.e. 2*depth - 1 merged launches
+    per stage plus the chains' last convs one by one — those accumulate into the shared `acc` in the fixed order k = 3, 7, 11,
+    exactly like the sequential form, so the output is bit-identical to it."""
+    n, depth = len(blocks), len(blocks[0].convs1)
+    cur = [x] * n
+    xt = [torch.empty_like(x) for _ in range(n)]
+    ping = [torch.empty_like(x) for _ in range(n)]
+    pong = [torch.empty_like(x) for _ in range(n)]
+    for j in range(depth):
+        with S.conv_group():
+            for b, blk in enumerate(blocks):
+                blk.convs1[j].run(cur[b], pre_slope=LRELU_SLOPE, post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE, out=xt[b])
+        if j == depth - 1:
+            for b, blk in enumerate(blocks):
+                blk.convs2[j].run(xt[b], pre_slope=1.0, res=cur[b], res_mode=1, **kw(b))
+            return acc
+        dst = [ping[b] if cur[b] is not ping[b] else pong[b] for b in range(n)]
+        with S.conv_group():
+            for b, blk in enumerate(blocks):
+                blk.convs2[j].run(xt[b], pre_slope=1.0, res=cur[b], res_mode=1, out=dst[b])
+        cur = dst
+
+
 def mrf_stage(owner, blocks, x, acc, n_tmp=3):
     """acc = mean_j blocks[j](x) for the ResBlocks of one decoder stage (`xs += resblocks[j](x)`; `x = xs / num_kernels`,
     vdecoder/hifigan/models.py:382-388), the blocks accumulating into `acc` in order.
@@ -191,6 +227,8 @@ def mrf_stage(owner, blocks, x, acc, n_tmp=3):
     Capturable (torch.cuda.graph follows the fork / join)."""
     n = len(blocks)
     kw = lambda j: dict(out=acc, beta=0.0 if j == 0 else 1.0, out_div=float(n) if j == n - 1 else 1.0)
+    if _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x):
+        return _mrf_stage_merged(blocks, x, acc, kw)
     if not (_MRF_STREAMS and n > 1 and x.is_cuda):
         tmp = [torch.empty_like(x) for _ in range(n_tmp)]
         for j, blk in enumerate(blocks):

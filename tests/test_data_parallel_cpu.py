@@ -211,3 +211,197 @@ def test_param_arena_is_released_with_its_optimizer():
     assert ref2() is None
     a3 = optim.ParamArena(lin.parameters())
     assert optim.arena_for(lin.parameters()) is a3
+
+
+# ---- world size 4: the control flow of train.TrainStep._call_graph_dp (two graphs per iteration, all-reduces between them) -------
+class _FakeGraph:
+    """Stands in for torch.cuda.CUDAGraph on CPU: 'capture' remembers the segment that ran inside it, replay() re-runs it on the
+    same (static) input tensors — which is what a replayed hipGraph does."""
+    capturing = None
+
+    def __init__(self):
+        self.fn = None
+
+    def pool(self):
+        return None
+
+    def replay(self):
+        self.fn()
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def _dp4_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib
+        import data_parallel as DP
+        import svc_hip as S
+        import train as TR
+        from optim import arena_for
+
+        # -- device calls stubbed: streams / events / graphs are no-ops or _FakeGraph; the optimizers are plain SGD over the SAME
+        #    ParamArena class the fused AdamW uses (touched / collect / zero_grad bookkeeping is the real one)
+        torch.cuda.Stream = _Dummy
+        torch.cuda.Event = _Dummy
+        torch.cuda.current_stream = lambda *a, **k: _Dummy()
+        torch.cuda.stream = lambda s: contextlib.nullcontext()
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.CUDAGraph = _FakeGraph
+
+        @contextlib.contextmanager
+        def fake_capture(graph, pool=None):
+            _FakeGraph.capturing = graph
+            try:
+                yield
+            finally:
+                _FakeGraph.capturing = None
+        S.graph_capture = fake_capture
+
+        class SGD:
+            def __init__(self, params, lr=0.05):
+                self.arena, self.lr, self.steps = arena_for(list(params)), lr, 0
+
+            def zero_grad(self):
+                self.arena.zero_grad()
+
+            def snapshot(self):
+                return dict(param=self.arena.param.clone(), steps=self.steps)
+
+            def restore(self, snap, device=True):
+                self.steps = snap["steps"]
+                if device:
+                    with torch.no_grad():
+                        self.arena.param.copy_(snap["param"])
+
+            def step(self):
+                a = self.arena
+                a.collect()
+                with torch.no_grad():
+                    for s, e, _ in a.touched_runs():
+                        a.param[s:e] -= self.lr * a.grad[s:e]
+                self.steps += 1
+
+        class Step(TR.TrainStep):
+            log = []
+
+            def _dense_spec(self, items):          # (the real one densifies the loader's spectrogram slot)
+                return items
+
+            def _replayed(self, seg, *a):          # a replayed hipGraph runs the kernels only: no Python autograd hooks fire
+                with self.net_g.reducer.no_sync(), self.net_d.reducer.no_sync():
+                    return seg(*a)
+
+            def _seg_d(self, items, noise=None):
+                if _FakeGraph.capturing is not None:
+                    _FakeGraph.capturing.fn = lambda: self._replayed(self._seg_d, items, noise)
+                x, y = items
+                y_hat = self.net_g(x)
+                loss_d = ((self.net_d(y) - 1) ** 2).mean() + (self.net_d(y_hat.detach()) ** 2).mean()
+                self.optim_d.zero_grad()
+                loss_d.backward()
+                self.ctx = dict(y_hat=y_hat, loss_disc=loss_d.detach())
+                Step.log.append("D")
+                return self.ctx
+
+            def _seg_g(self, ctx):
+                if _FakeGraph.capturing is not None:
+                    _FakeGraph.capturing.fn = lambda: self._replayed(self._seg_g, self.ctx)
+                dmod = self.net_d.module
+                with DP.no_param_grads(dmod):
+                    loss_g = ((dmod(self.ctx["y_hat"]) - 1) ** 2).mean()
+                self.optim_g.zero_grad()
+                loss_g.backward()
+                Step.log.append("G")
+                return dict(loss_disc=self.ctx["loss_disc"], loss_gen=loss_g.detach())
+
+        torch.manual_seed(50 + rank)                      # different init per rank: the constructor's broadcast fixes it
+        G = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 5))
+        D = nn.Sequential(nn.Linear(5, 12), nn.Tanh(), nn.Linear(12, 1))
+        D.register_buffer("weight_u", torch.randn(12))    # a spectral-norm style buffer: rank 0's must reach everyone
+        og, od = SGD(G.parameters()), SGD(D.parameters())
+        net_g = DP.DataParallel(G, bucket_bytes=256, first_bucket_bytes=128)
+        net_d = DP.DataParallel(D, bucket_bytes=256, first_bucket_bytes=128)
+        assert len(net_g.reducer.buckets) >= 2 and net_g.reducer.world == 4
+        bufs = [None] * world
+        dist.all_gather_object(bufs, D.weight_u.clone())
+        assert all(torch.equal(bufs[0], b) for b in bufs), "buffers were not broadcast from rank 0"
+        hps = dict(data=dict(filter_length=8, n_mel_channels=2, sampling_rate=8, hop_length=2, win_length=8, mel_fmin=0, mel_fmax=4),
+                   train=dict(segment_size=4, c_mel=1, c_kl=1, fp16_run=False))
+        step = Step(hps, net_g, net_d, og, od).enable_graph(True)
+        # uneven shards: rank r holds r + 1 items (every rank captures its own shapes; only the arena is communicated)
+        gen = torch.Generator().manual_seed(3)
+        shards = [(torch.randn(r + 1, 6, generator=gen), torch.randn(r + 1, 5, generator=gen)) for r in range(world)]
+        p0 = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+        n_it = 3
+        for _ in range(n_it):
+            out = step(shards[rank])
+        assert step.dp_mode.startswith("two graphs") and len(step._graphs) == 1
+        # warm-up (2 eager iterations, undone) + capture + 3 replayed iterations, D segment always before G
+        assert Step.log == ["D", "G"] * (2 + 1 + n_it), Step.log
+        for red in (net_g.reducer, net_d.reducer):
+            assert red.stats["reduce_all_calls"] == n_it and red.stats["backward_passes"] == 2, red.stats      # hooks only during the warm-up
+            assert red.stats["launches"] == n_it * len(red.buckets) + 2 * len(red.buckets)
+        # every rank ends with the same parameters ...
+        flat = torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])
+        allp = [None] * world
+        dist.all_gather_object(allp, flat)
+        assert all(torch.equal(allp[0], a) for a in allp)
+        # ... the ones a single process gets by averaging the four shards' gradients by hand
+        Gr = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 5))
+        Dr = nn.Sequential(nn.Linear(5, 12), nn.Tanh(), nn.Linear(12, 1))
+        with torch.no_grad():
+            for p, v in zip(list(Gr.parameters()) + list(Dr.parameters()), p0):
+                p.copy_(v)
+        for _ in range(n_it):
+            gd = [torch.zeros_like(p) for p in Dr.parameters()]
+            for x, y in shards:
+                loss = ((Dr(y) - 1) ** 2).mean() + (Dr(Gr(x).detach()) ** 2).mean()
+                for a, g_ in zip(gd, torch.autograd.grad(loss, list(Dr.parameters()))):
+                    a += g_ / world
+            with torch.no_grad():
+                for p, g_ in zip(Dr.parameters(), gd):
+                    p -= 0.05 * g_
+            gg = [torch.zeros_like(p) for p in Gr.parameters()]
+            for x, y in shards:
+                loss = ((Dr(Gr(x)) - 1) ** 2).mean()
+                for a, g_ in zip(gg, torch.autograd.grad(loss, list(Gr.parameters()))):
+                    a += g_ / world
+            with torch.no_grad():
+                for p, g_ in zip(Gr.parameters(), gg):
+                    p -= 0.05 * g_
+        ref = torch.cat([p.detach().flatten() for p in list(Gr.parameters()) + list(Dr.parameters())])
+        assert torch.allclose(flat, ref, rtol=1e-5, atol=1e-6), (flat - ref).abs().max().item()
+        assert torch.isfinite(out["loss_gen"]) and not S.wgrad_slab.active
+        q.put((rank, "ok"))
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_graph_data_parallel_iteration_world4_gloo():
+    """train.TrainStep._call_graph_dp at world size 4 with the device calls stubbed — warm-up through the
+    bucket-overlapped hooks, capture under no_sync, then per iteration graph[D] -> reduce_all(D) -> step(D) -> graph[G] ->
+    reduce_all(G) -> step(G); uneven shards; buffers broadcast from rank 0; all ranks bit-identical and equal to hand-averaged
+    single-process training."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
