@@ -64,7 +64,14 @@ def main():
               f"{r['write_bytes_per_launch'] / 1e6:16.3f} {r['hbm_bytes_per_step'] / 1e6:10.2f}")
     if out:
         dom = next((r for r in rows if r["family"] == "conv1d_mfma"), None)
-        json.dump(dict(hbm_bytes_per_launch=dom["hbm_bytes_per_launch"] if dom else None, families=rows,
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("svc_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   "so-vits-svc_amd", "csrc", "build.py"))
+        bld = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bld)
+        json.dump(dict(hbm_bytes_per_launch=dom["hbm_bytes_per_launch"] if dom else None,
+                       hbm_bytes_per_step=dom["hbm_bytes_per_step"] if dom else None, steps=steps,
+                       csrc_sha=bld.source_hash(), families=rows,
                        note="read = FETCH_SIZE*1024*2 (gfx950 correction), write = WRITE_SIZE*1024 (uncalibrated); "
                             "separate --pmc passes"), open(out, "w"), indent=1)
 

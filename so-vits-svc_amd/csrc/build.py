@@ -25,6 +25,18 @@ def _headers():
     return hs
 
 
+def source_hash():
+    """sha256 over the kernel sources and headers (sorted by name): identifies the build a measurement was taken on — PMC
+    summaries are stamped with it and bench.py refuses to quote one taken on other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(HERE, s) for s in _sources()] + sorted(_headers()):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True, save_temps=False):
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = max(os.path.getmtime(h) for h in _headers())

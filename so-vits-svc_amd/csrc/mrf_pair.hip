@@ -18,6 +18,7 @@
 // Reduction order = the unfused kernels' (channel groups outer, taps inner; fp32 fmaf chains), epilogue arithmetic in the
 // same order: results are bit-identical to the two-launch path.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -190,6 +191,189 @@ __global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(Pai
   }
 }
 
+
+// ---- round 4: the 16-channel pair, second form --------------------------------------------------------------------------------
+// What the first form lost (ISA + counters): per MFMA one ds_read -> s_waitcnt lgkmcnt(0) -> 3 VALU of leaky-ReLU -> MFMA
+// on ONE accumulator, i.e. LDS latency, VALU and the matrix pipe never overlapped (43 TFLOP/s = 0.27 of peak); persistent
+// workgroups over 1724 tiles on 512 slots (3.37 tiles each, the slowest takes 4); three un-overlapped phases per tile.  Here:
+//   * a wave owns FOUR column tiles at a time (four independent accumulators sharing the weight operand): per (channel group,
+//     tap) four independent LDS reads feed four MFMAs, and the reads of the next tap are in flight under them;
+//   * the leaky-ReLU is applied ONCE, when the x tile is staged (the first form applied it to every operand read: K times per
+//     element); the residual is re-read from global memory in the epilogue (the tile is L2-resident: the workgroup loaded it a few
+//     microseconds earlier) and prefetched in front of the second conv's MFMA loop together with the accumulate operand;
+//   * BN = 240 outputs per workgroup: conv1 needs 240 + 2*H2 <= 250 columns = 16 tiles (4 per wave, none left over), conv2 15;
+//   * ONE tile per workgroup, 1839 workgroups for a 10 s clip, three resident per CU: the hardware dispatcher balances them and
+//     one workgroup's staging / store phases run under its neighbours' MFMA loops.
+// Same reduction order and epilogue expression as the first form: bit-identical results.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void mrf_pair16_kernel(PairP p) {
+  constexpr int C = 16, TS = 16, KPI = 4, NG = 4, BN = 240, NTW = 4;
+  constexpr int H2 = (KS - 1) / 2;
+  const svc_resblock_pair_args& a = p.a;
+  const int d = a.dil1, H1 = d * H2, HX = H1 + H2;
+  const int XW = p.XW, MW = p.MW;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                 // [C][XW]  lrelu(x), columns t0 - HX ...
+  float* ms = xs + C * XW;         // [C][MW]  lrelu(conv1 + b1), columns t0 - H2 ...
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lk = lane >> 4;
+  const float slope = a.slope;
+  const int tile = blockIdx.x;
+  const int b = tile / p.n_tiles;
+  const int t0 = (tile - b * p.n_tiles) * BN;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  float* yb = a.y + (long long)b * a.y_bs;
+
+  // ---- 1. stage lrelu(x): [C][BN + 2*HX] (zero outside the sequence), coalesced along time; all loads of a thread in flight ----
+  const int xcols = BN + 2 * HX;
+  {
+    float v[C][2];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = tid + 256 * h;
+        const int t = t0 - HX + col;
+        const int tc = min(max(t, 0), a.T - 1);
+        const float x = xb[(long long)c * a.x_cs + tc];
+        v[c][h] = (t >= 0 && t < a.T) ? x : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = tid + 256 * h;
+        if (col < xcols) xs[c * XW + col] = lrelu01(v[c][h], slope);
+      }
+  }
+  // weights and biases in registers while the tile lands
+  float w1r[NG][KS], w2r[NG][KS];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      w1r[g][k] = a.w1[((g * KPI + lk) * KS + k) * a.CP + ln];
+      w2r[g][k] = a.w2[((g * KPI + lk) * KS + k) * a.CP + ln];
+    }
+  float b1r[4], b2r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b1r[r] = a.b1 ? a.b1[4 * lk + r] : 0.f;
+    b2r[r] = a.b2 ? a.b2[4 * lk + r] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- 2. conv1 -> mid: this wave's four column tiles [64*wave, 64*wave + 64) of the 256 staged mid columns ----
+  {
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr = xs + lk * XW + 64 * wave + ln;
+    // operand reads one (channel group, tap) step ahead of their MFMAs, pinned with sched_barriers: left alone the compiler
+    // emits ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs on ONE reused register pair (read off the ISA)
+    float bv[2][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bv[0][j] = xr[j * TS];
+#pragma unroll
+    for (int st = 0; st < NG * KS; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < NG * KS) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bv[(st + 1) & 1][j] = xr[((st + 1) / KS) * KPI * XW + ((st + 1) % KS) * d + j * TS];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[st / KS][st % KS], bv[st & 1][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int col = 64 * wave + j * TS + ln;
+      const int t = t0 - H2 + col;
+      const bool ok = t >= 0 && t < a.T;     // conv2's zero padding pads lrelu(conv1(..)), not conv1 evaluated past the ends
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ms[(4 * lk + r) * MW + col] = ok ? lrelu01(acc[j][r] + b1r[r], slope) : 0.f;
+    }
+  }
+  // ---- 3. conv2 + residual -> out: column tiles 4*wave .. 4*wave + 3 of the 15 (the 16th is computed and dropped) ----
+  float xres[NTW][4], yold[NTW][4];
+  const bool accum = a.beta != 0.f;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int t = min(t0 + 64 * wave + j * TS + ln, a.T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xres[j][r] = xb[(long long)(4 * lk + r) * a.x_cs + t];
+      yold[j][r] = accum ? yb[(long long)(4 * lk + r) * a.y_cs + t] : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* mr = ms + lk * MW + 64 * wave + ln;
+    float bv[2][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bv[0][j] = mr[j * TS];
+#pragma unroll
+    for (int st = 0; st < NG * KS; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < NG * KS) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bv[(st + 1) & 1][j] = mr[((st + 1) / KS) * KPI * MW + ((st + 1) % KS) + j * TS];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[st / KS][st % KS], bv[st & 1][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int col = 64 * wave + j * TS + ln;
+      const int t = t0 + col;
+      if (col < BN && t < a.T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[j][r] + b2r[r];
+          v = v + xres[j][r];
+          if (accum) v = v + a.beta * yold[j][r];
+          if (a.out_div != 1.f) v = v / a.out_div;
+          yb[(long long)(4 * lk + r) * a.y_cs + t] = v;
+        }
+      }
+    }
+  }
+}
+
+int g_pair_v2 = -1;     // 16-channel pairs on mrf_pair16_kernel (environment SVC_PAIR_V2=0: the first form, A/B)
+
+template <int KS>
+int launch_pair16(const svc_resblock_pair_args& a, hipStream_t s) {
+  constexpr int H2 = (KS - 1) / 2, BN = 240;
+  const int H1 = a.dil1 * H2;
+  PairP p;
+  p.a = a;
+  p.n_tiles = svc::cdiv(a.T, BN);
+  auto pitch = [](int w) {
+    w = (w + 3) & ~3;
+    while ((w & 63) != 16 && (w & 63) != 48) w += 4;   // 4 channel rows x 16 lanes of one operand fetch on disjoint bank groups
+    return w;
+  };
+  p.XW = pitch(256 + 2 * H1);                          // the 256 mid columns of the four waves read up to 2*H1 columns further
+  p.MW = pitch(256 + 2 * H2 + 16);
+  const size_t lds = (size_t)16 * (p.XW + p.MW) * 4;
+  auto kern = mrf_pair16_kernel<KS>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long long)p.n_tiles * a.B)), dim3(256), lds, s, p);
+  return svc::check_launch("resblock_pair16");
+}
+
 int g_cus = 0;
 
 template <int C, int KS>
@@ -252,6 +436,17 @@ extern "C" int svc_resblock_pair_f32(const svc_resblock_pair_args* ap, void* str
   const double flop = 2.0 * 2.0 * a.B * (double)a.C * a.C * a.KS * a.T;
   const double bytes = 4.0 * a.B * (double)a.C * a.T * (a.beta != 0.f ? 3 : 2);
   svc::ProfScope prof(s, "resblock_pair", flop, bytes);
+  if (g_pair_v2 < 0) {
+    const char* e = getenv("SVC_PAIR_V2");
+    g_pair_v2 = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (a.C == 16 && g_pair_v2 && (long long)(240 + 2 * (a.dil1 + 1) * ((a.KS - 1) / 2)) <= 512) {
+    switch (a.KS) {
+      case 3: return launch_pair16<3>(a, s);
+      case 7: return launch_pair16<7>(a, s);
+      default: return launch_pair16<11>(a, s);
+    }
+  }
   if (a.C == 16) {
     switch (a.KS) {
       case 3: return launch_pair<16, 3>(a, s);

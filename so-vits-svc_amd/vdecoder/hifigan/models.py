@@ -29,7 +29,13 @@ LRELU_SLOPE = 0.1
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
 _MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
-_MRF_MERGE = __import__("os").environ.get("SVC_MRF_MERGE", "1") != "0"       # A/B switch: the chains' same-step convs in one launch
+# the chains' same-step convs in one launch (svc_conv1d_multi_f32): 0 never (default), 1 every stage, 2 only stages whose single
+# launches cannot fill the chip (fewer workgroups than CUs: the 256-channel stage, 216).  Measured on one box, 10 s clip
+# (profiles/r05b_infer_merge{0,1}.json, r05d_infer_merge_modes_realtime.txt): launches back to back on ONE stream the merged form
+# is faster — dense-conv family 6.85 -> 6.39 ms, 78.6 -> 84.3 TFLOP/s — but the three-stream schedule below already overlaps the
+# chains' fixed phases AND has no barrier between the steps of a stage: 7.51 ms per clip against 7.71 (merged) / 7.64 (mode 2).
+# The timed path and its roofline pass both run the default.
+_MRF_MERGE = int(__import__("os").environ.get("SVC_MRF_MERGE", "0"))
 
 
 class ResBlock1(nn.Module):
@@ -227,7 +233,7 @@ def mrf_stage(owner, blocks, x, acc, n_tmp=3):
     Capturable (torch.cuda.graph follows the fork / join)."""
     n = len(blocks)
     kw = lambda j: dict(out=acc, beta=0.0 if j == 0 else 1.0, out_div=float(n) if j == n - 1 else 1.0)
-    if _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x):
+    if _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x) and (_MRF_MERGE == 1 or x.shape[0] * x.shape[2] < 16384):
         return _mrf_stage_merged(blocks, x, acc, kw)
     if not (_MRF_STREAMS and n > 1 and x.is_cuda):
         tmp = [torch.empty_like(x) for _ in range(n_tmp)]

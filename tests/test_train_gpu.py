@@ -66,12 +66,13 @@ def test_training_step_matches_reference_and_oracle(dev):
     # D step gradients
     out["loss_disc"].backward(retain_graph=True)
     gd = {k: p.grad.detach().cpu() for k, p in net_d.named_parameters()}
+    report = []
     for k, n in zip([str(k) for k in z["gnorm_d_keys"]], z["gnorm_d"]):
-        assert abs(gd[k].norm().item() - n) <= 2e-3 * max(n, 1e-6), ("D", k, gd[k].norm().item(), n)
+        report.append(("D", k, abs(gd[k].norm().item() - n) / max(n, 1e-6), n))
     for name in z.files:
         if name.startswith("grad_d."):
             g = gd[name[7:]].numpy()
-            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
+            assert np.abs(g - z[name]).max() <= GRAD_ELEM_TOL * max(np.abs(z[name]).max(), 1e-6), name
     net_d.zero_grad()
     # G step gradients
     out["loss_gen_all"].backward()
@@ -80,11 +81,44 @@ def test_training_step_matches_reference_and_oracle(dev):
         if k.endswith("conv_k.bias"):
             continue
         assert k in gg, k
-        assert abs(gg[k].norm().item() - n) <= 2e-3 * max(n, 1e-5), ("G", k, gg[k].norm().item(), n)
+        report.append(("G", k, abs(gg[k].norm().item() - n) / max(n, 1e-5), n))
     for name in z.files:
         if name.startswith("grad_g."):
             g = gg[name[7:]].numpy()
-            assert np.abs(g - z[name]).max() <= 1e-3 * max(np.abs(z[name]).max(), 1e-6), name
+            assert np.abs(g - z[name]).max() <= GRAD_ELEM_TOL * max(np.abs(z[name]).max(), 1e-6), name
+    _check_grad_norms(report)
+
+
+# Gradient tolerances of an fp32 path against the fp32 reference (2e-3 on the norm would let a systematic
+# 0.1 % error of one conv's wgrad through).  Every parameter's gradient NORM agrees with the reference's to GRAD_NORM_TOL; the
+# tensors in GRAD_NORM_LOOSE are the measured exceptions, each with its reason.  What the fp32 round-off consists of here: the
+# time reduction of a weight gradient runs as 256 partial sums combined by atomics (order varies run to run), and the backward
+# chain re-associates every convolution's reduction (MFMA groups of 2 / 4 channels), where the CPU reference runs oneDNN's
+# blocked GEMMs — relative differences of ~1e-6 per op compound over the ~100-layer path, and cancel less in tensors whose
+# gradient is a small difference of large terms.
+GRAD_NORM_TOL = 1e-4          # measured worst: 7.7e-5 (dec.m_source.l_linear.bias), every other tensor <= 1.5e-5 (profiles/r05d_grad_norm_errors.txt)
+GRAD_ELEM_TOL = 1e-3          # sampled elements, relative to the tensor's largest: dominated by the same effects on small entries
+GRAD_NORM_LOOSE = {}          # name suffix -> (tolerance, reason): no tensor needs one (662 of 662 inside GRAD_NORM_TOL)
+
+
+def _check_grad_norms(report):
+    import os
+    report = sorted(report, key=lambda r: -r[2])
+    path = os.environ.get("SVC_GRAD_REPORT")
+    if path:
+        with open(path, "w") as f:
+            f.write("# |norm(grad HIP) - norm(grad reference)| / norm(reference), tests/golden/train_small.npz, worst first\n")
+            for net, k, e, n in report:
+                f.write(f"{net} {k:60s} rel_err {e:.3e}  ref_norm {n:.3e}\n")
+    bad = []
+    for net, k, e, n in report:
+        tol = GRAD_NORM_TOL
+        for suffix, (t, _why) in GRAD_NORM_LOOSE.items():
+            if k.endswith(suffix):
+                tol = t
+        if e > tol:
+            bad.append((net, k, f"{e:.2e}", f"{n:.2e}"))
+    assert not bad, bad[:12]
 
 
 def test_training_forward_with_vol_embedding_matches_oracle(dev):
@@ -398,9 +432,9 @@ def test_training_step_at_the_benchmarked_shapes(dev):
     out["loss_disc"].backward(retain_graph=True)
     pd = dict(net_d.named_parameters())
     for k, g in zip(probe_d, rg_d):
-        assert abs(pd[k].grad.norm().item() - g.norm().item()) <= 2e-3 * max(g.norm().item(), 1e-6), ("D", k)
+        assert abs(pd[k].grad.norm().item() - g.norm().item()) <= 5e-4 * max(g.norm().item(), 1e-6), ("D", k)
     net_d.zero_grad()
     out["loss_gen_all"].backward()
     pg = dict(net_g.named_parameters())
     for k, g in zip(probe_g, rg_g):
-        assert abs(pg[k].grad.norm().item() - g.norm().item()) <= 2e-3 * max(g.norm().item(), 1e-6), ("G", k, pg[k].grad.norm().item(), g.norm().item())
+        assert abs(pg[k].grad.norm().item() - g.norm().item()) <= 5e-4 * max(g.norm().item(), 1e-6), ("G", k, pg[k].grad.norm().item(), g.norm().item())
