@@ -102,12 +102,12 @@ TRAIN_B = 16
 TRAIN_SEG = 8192
 
 
-def train_hps(cfg):
+def train_hps(cfg, bf16=False):
     model = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
     return dict(data=dict(filter_length=2048, hop_length=HOP, win_length=2048, n_mel_channels=80, sampling_rate=44100,
                           mel_fmin=0.0, mel_fmax=22050),
                 train=dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
-                           fp16_run=False, batch_size=TRAIN_B),
+                           fp16_run=bool(bf16), half_type="bf16" if bf16 else "fp16", batch_size=TRAIN_B),
                 model=model)
 
 
@@ -160,15 +160,20 @@ def cpu_baseline_train(cfg, hps, items_cpu, max_items=4):
                        "(work is linear in the batch)")
 
 
-def run_train(args, dev, rank, world, dist):
-    """Time K training iterations; returns the result dict (rank 0) or None."""
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+
+
+def run_train(args, dev, rank, world, dist, bf16=False):
+    """Time K training iterations; returns the result dict (rank 0) or None.  bf16: the reference's `fp16_run: true,
+    half_type: bf16` configuration (bf16 matrix operands inside the autocast regions) — reported under its own key, never as
+    the headline."""
     import svc_hip as S
     import synthetic_data as W
     import train as TR
     cfg = W.full_config()
     if os.environ.get("SVC_BENCH_PDROP") is not None:      # determinism experiments only
         cfg["p_dropout"] = float(os.environ["SVC_BENCH_PDROP"])
-    hps = train_hps(cfg)
+    hps = train_hps(cfg, bf16=bf16)
     torch.manual_seed(1234)
     net_g, net_d, optim_g, optim_d = TR.build(hps, dev)
     net_g.module.load_state_dict(W.make_train_state_dict(cfg, 1234))
@@ -273,14 +278,24 @@ def run_train(args, dev, rank, world, dist):
                    buckets=dict(g=len(rg.buckets), d=len(rd.buckets)),
                    exposed_ms_per_iter=(rg.exposed_ms() + rd.exposed_ms()) / n_red)
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not bf16:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)
-    return dict(metric="train steps/sec (train.py D+G iteration)", value=steps / elapsed, unit="steps/s",
-                ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak", dtype="f32",
+    if bf16 and roof is not None:
+        # the step mixes bf16-operand launches (the LDS-DMA tilings of the batched convolutions, the 128 x 64 weight-gradient
+        # kernel) with fp32 ones (unaligned / narrow shapes, attention products): the fraction is quoted against the bf16 peak
+        roof["peak"] = PEAK_BF16_MFMA_TFLOPS
+        roof["frac"] = round(roof["achieved"] / PEAK_BF16_MFMA_TFLOPS, 4)
+        roof["whole_step"]["frac"] = round(roof["whole_step"]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
+        roof["note"] += "; bf16-operand and fp32 launches share these family rows, peak = dense bf16 MFMA"
+        roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
+    return dict(metric="train steps/sec (train.py D+G iteration)" + (", fp16_run + half_type bf16" if bf16 else ""),
+                value=steps / elapsed, unit="steps/s",
+                ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak",
+                dtype="bf16 matrix operands, f32 accumulate / storage" if bf16 else "f32",
                 items_per_s=world * TRAIN_B * steps / elapsed,
                 config=dict(workload="BASELINE configs[2]: config_template.json model + MultiPeriodDiscriminator, "
                                      f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
-                                     "4 speakers, fp32, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
+                                     f"4 speakers, {'fp16_run half_type=bf16' if bf16 else 'fp32'}, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
                             global_batch=TRAIN_B * world, frames=T,
                             launch=("hipGraph replay of the whole iteration" if world == 1 else
                                     "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph
@@ -303,6 +318,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=None)
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
     args = ap.parse_args()
@@ -352,7 +368,7 @@ def main():
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps
         args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
-        res = run_train(args, dev, rank, world, dist)
+        res = run_train(args, dev, rank, world, dist, bf16=args.bf16)
         if rank == 0:
             res.update(higher_is_better=True, vs_baseline=None, data="synthetic")
             print(json.dumps(res))
@@ -506,6 +522,12 @@ def main():
                 extras["diffusion_train"] = extras["diffusion_infer"] = dres
         train_res = run_train(args, dev, rank, world, dist)
         if rank == 0 and world == 1 and not args.no_extras and train_res is not None:
+            torch.cuda.empty_cache()
+            # the reference's reduced-precision mode (fp16_run + half_type bf16), under its own key
+            tb = X.guarded(run_train, args, dev, rank, world, dist, True)
+            if isinstance(tb, dict) and "ms_per_step" in tb:
+                tb["speedup_vs_f32"] = round(train_res["ms_per_step"] / tb["ms_per_step"], 3)
+            train_res["train_bf16"] = tb
             torch.cuda.empty_cache()
             # the same iteration driven through the entry point's loader loop (files on disk -> DataLoader -> bucketed collate)
             tl = X.guarded(X.bench_train_loader, dev, train_hps(cfg))

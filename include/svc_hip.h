@@ -109,7 +109,17 @@ typedef struct svc_conv1d_args {
   int n_phase, y_ts, y_t0, y_len;
   long long w_phase_stride;
   float pre_slope, post_slope, beta, out_div;
+  /* Matrix-pipe operand format (the reference's `fp16_run` / `half_type: bf16` autocast mode, train.py:114,143,166,187,198:
+   * convolutions take bf16 operands and accumulate in fp32).  SVC_MMA_F32 (0): fp32 operands, v_mfma_f32_32x32x2_f32 — the
+   * default and the only format of inference.  SVC_MMA_BF16 (1): activations and weights are rounded to bf16 (round to nearest
+   * even) as the operands are fetched and multiplied on v_mfma_f32_32x32x16_bf16; accumulation, bias, activation, residual and
+   * the stored result stay fp32 (tensors in HBM are fp32 in both modes, the master weights too).  Honoured by the LDS-DMA tilings
+   * of plain convolutions with 16-byte aligned rows and Cin a multiple of 16; every other shape runs in fp32 — never less
+   * precise than asked. */
+  int mma;
 } svc_conv1d_args;
+#define SVC_MMA_F32 0
+#define SVC_MMA_BF16 1
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
 
@@ -120,6 +130,8 @@ int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
  * issued as ONE launch (heaviest workgroups first), the others one by one. */
 int svc_conv1d_multi_f32(const svc_conv1d_args* a, int n, void* stream);
 int svc_debug_conv_multi_merged(void);   /* merged launches of the tiled kernel so far (tests) */
+int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */
+int svc_debug_wgrad_bf16_launches(void);
 
 /* ------------------------------------------------------------------------------------------------
  * ConvTranspose1d (upsampling `ups[i]`, vdecoder/hifigan/models.py:340-342,378), lowered to `stride`
@@ -335,6 +347,8 @@ typedef struct svc_wgrad_args {
   int B, Ca, Cb, TA, TB, KS, dil, pad, accumulate;
   float* dbias; /* optional [Ca]: also produces the bias gradient sum_{b,t} A[b,ca,t] (zeroed by the call unless
                    `accumulate`), from the A tiles already staged in LDS — saves a separate reduction pass over dy */
+  int mma;      /* SVC_MMA_F32 / SVC_MMA_BF16 (see svc_conv1d_args.mma): bf16 operands for the 128 x 64 tile kernel, fp32
+                   accumulation and bias gradient; the small-channel kernel (Ca, Cb <= 32) always runs fp32 */
 } svc_wgrad_args;
 int svc_conv1d_wgrad_f32(const svc_wgrad_args* a, void* stream);
 

@@ -62,6 +62,9 @@ struct ConvP {
 
 __device__ float4 g_zero_block[2];
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+
 // One LDS-DMA piece: every lane's 16 B at `g` land at LDS byte address lds_byte + lane*16 (wave-uniform base in M0).
 // Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (svc_vmcnt0 before the barrier).
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
@@ -382,7 +385,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, f32x16 (&ac
 }
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, bool BF16 = false>
 // (scalar-staging instantiations — unaligned rows, e.g. DiscriminatorP's period layout — keep 48 X + 64 W staging registers
 // in flight next to the accumulators: at two workgroups per CU they spilled 92..296 B/lane of scratch into the chunk loop
 // and ran 3.7x slower than their aligned twins; they get the whole register file of a SIMD instead)
@@ -647,7 +650,41 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
       //  channel pairs, operand ring, sched_barrier between groups — instead of restarting at every channel pair: slower on
       //  every shape, 1 x 1 convs included (profiles/r03z_trainconv.txt vs r03y_*): the per-pair restart is not what holds
       //  the short-reduction shapes back)
-      if constexpr (KSC > 0) {
+      if constexpr (BF16) {
+        // ---- bf16 operands (svc_conv1d_args.mma = SVC_MMA_BF16): v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The chunk sits in
+        // LDS exactly as for the fp32 loop (fp32, [ci][k][BM] weights and [ci][XW] activations, fetched by LDS-DMA); an
+        // instruction reduces 16 input channels of one tap, lane half lk supplying channels 8*lk .. 8*lk + 7 of the group: eight
+        // ds_read_b32 per fragment, rounded to bf16 in pairs (v_cvt_pk_bf16_f32, round to nearest even) on the way into the
+        // operand registers.  Same C layout as the fp32 instruction: the epilogues are shared.
+        static_assert(!BF16 || (DB && KSC == 0 && !M16), "bf16 operands: LDS-DMA tilings, run-time tap count");
+        const int dil = a.dil, n_g = BC >> 4, wrow = KS * BM;
+        for (int g = 0; g < n_g; ++g) {
+          const float* wa = wbuf + (g * 16 + 8 * lk) * wrow;
+          const float* xa = xbuf + (g * 16 + 8 * lk) * XW;
+          for (int k = 0; k < KS; ++k) {
+            bf16x8 af[MT], bq[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              f32x8v t;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) t[j] = wa[j * wrow + k * BM + i * TS];
+              af[i] = __builtin_convertvector(t, bf16x8);
+            }
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) {
+              f32x8v t;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) t[j] = xa[j * XW + k * dil + jn * TS];
+              bq[jn] = __builtin_convertvector(t, bf16x8);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int jn = 0; jn < NT; ++jn)
+                acc32[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[jn], acc32[i][jn], 0, 0, 0);
+          }
+        }
+      } else if constexpr (KSC > 0) {
         const int dil = a.dil;
         // ACT: leaky-ReLU applied to each B operand as it is read (1..3 taps, see above).  Instantiated twice: plain inputs
         // (slope 1: every training conv, the encoder / flow convs) must not pay its 3 VALU per operand — nor their effect on
@@ -909,9 +946,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
 }
 
 thread_local int t_row_phases = 1;  // set by svc_conv_transpose1d_f32 around its dispatch (see ConvP::row_phases)
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, bool BF16 = false>
 __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (XVEC || WK > 1) ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
-  conv1d_mfma_body<MT, NT, WM, WN, WK, M16, EPI, KSC, XVEC, DB>(p, blockIdx.x);
+  conv1d_mfma_body<MT, NT, WM, WN, WK, M16, EPI, KSC, XVEC, DB, BF16>(p, blockIdx.x);
 }
 
 // Up to three INDEPENDENT plain convolutions on the 64 x 128 LDS-DMA tiling in ONE launch: the same step of the 11- / 7- / 3-tap
@@ -941,6 +978,8 @@ thread_local std::vector<TileRec>* t_tile_rec = nullptr;
 int g_tile_merged = 0;
 
 thread_local int t_multi_depth = 0;
+int g_bf16_enabled = 1;    // svc_debug_bf16(0) forces fp32 operands whatever the calls ask for (A/B)
+int g_bf16_launches = 0;   // launches that ran with bf16 operands (tests ask through svc_debug_bf16(-1))
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
 int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
 int g_dbg = 0;         // debug: ConvP.dbg
@@ -1028,13 +1067,22 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     // (tried: 80 KiB for the 128x128 tiles, two per CU, half as many chunks / barriers: no measurable change)
     // (round 3: a 128 KiB budget — twice the chunk, half the hand-overs — for launches of at most one workgroup per CU: no
     //  change on any shape, profiles/r03y_trainconv_solo{64,128}.txt)
-    const size_t budget = std::max((size_t)(BM * BN >= 128 * 128 ? g_db_budget_kb : 64) * 1024, epi_bytes);
+    size_t budget = std::max((size_t)(BM * BN >= 128 * 128 ? g_db_budget_kb : 64) * 1024, epi_bytes);
+    // bf16 operands are built for the tilings the batched (training) convolutions take; anything else stays fp32
+    constexpr bool BF16_TILING = EPI == SVC_EPI_PLAIN && ((MT == 2 && NT == 2 && WM == 2 && WN == 2) || (MT == 2 && NT == 1 && WM == 1 && WN == 4) ||
+                                                          (MT == 1 && NT == 3 && WM == 2 && WN == 2) || (MT == 1 && NT == 5 && WM == 4 && WN == 1) ||
+                                                          (MT == 2 && NT == 2 && WM == 1 && WN == 4));
+    const bool want_bf16 = BF16_TILING && a.mma == SVC_MMA_BF16 && (a.Cin % 16) == 0 && g_bf16_enabled;
+    // a bf16 chunk is at least 16 channels (one instruction's reduction): 5..11 taps of them do not fit the 64 KiB the fp32
+    // chunks are sized for — they take up to 144 KiB (one workgroup per CU; the instruction stream is 16x shorter per chunk)
+    if (want_bf16) budget = std::max(budget, (size_t)144 * 1024);
     bool use_db = g_db_mode != 0 && xvec && a.pre_slope >= 0.f && a.pre_slope <= 1.f && (a.Cin % KG) == 0 &&
                   std::llabs((long long)a.x_cs) * 4 * 64 < (1ll << 31) && (long long)a.CoutP * a.KS * 4 * 64 < (1ll << 31);
     int bcd = 0, ni = 0;
     if (use_db) {
       // largest chunk (multiple of KG dividing Cin) whose two buffers fit the budget and 16 pieces per wave
-      constexpr int CQ = (KSC > 0 && ring_steps(KSC) > 0) ? KG * (ring_steps(KSC) / KSC) : KG;   // whole ring trips per chunk
+      constexpr int CQF = (KSC > 0 && ring_steps(KSC) > 0) ? KG * (ring_steps(KSC) / KSC) : KG;   // whole ring trips per chunk
+      const int CQ = want_bf16 ? 16 : CQF;                                                        // bf16: 16 channels per MFMA
       for (int c = std::min(a.Cin, 64) / CQ * CQ; c >= CQ; c -= CQ) {
         if (a.Cin % c) continue;
         const int tot4 = c * (a.KS * BM + xw) / 4;
@@ -1061,6 +1109,19 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       p.zero = zero;
       p.dump_off = 0;
       const size_t lds = std::max((size_t)2 * ni * NWV * 1024, epi_bytes);
+      if constexpr (BF16_TILING) {
+        if (want_bf16) {
+          auto kb = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, true>;
+          static bool doneb = false;
+          if (!doneb) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            doneb = true;
+          }
+          ++g_bf16_launches;
+          hipLaunchKernelGGL(kb, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+          return svc::check_launch("conv1d_mfma_bf16");
+        }
+      }
       auto kd = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true, true>;
       if (lds > 64 * 1024) {
         static bool done = false;
@@ -1534,6 +1595,12 @@ extern "C" int svc_conv1d_multi_f32(const svc_conv1d_args* ap, int n, void* stre
 }
 
 extern "C" int svc_debug_conv_multi_merged(void) { return g_tile_merged; }
+
+extern "C" int svc_debug_bf16(int mode) {
+  if (mode < 0) return g_bf16_launches;
+  g_bf16_enabled = mode ? 1 : 0;
+  return SVC_OK;
+}
 
 // ConvTranspose1d as `stride` dense polyphase sub-convolutions (vdecoder/hifigan/models.py:340-342,378):
 //   y[co, q*u + p - pad] = sum_ci sum_m x[ci, q - m] * W[ci, co, p + m*u],   m < M = ceil(KS/u)

@@ -43,7 +43,13 @@ struct WgP {
   int tiles_per_b, n_tiles, tiles_per_wg, PB, n_kgroups, splits;
 };
 
-template <int NK>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+
+// BF16 (svc_wgrad_args.mma = SVC_MMA_BF16): the staged fp32 tiles are multiplied on v_mfma_f32_32x32x16_bf16 — an instruction
+// reduces 16 time steps, lane half lk supplying steps 8*lk .. 8*lk + 7 of its channel row, rounded to bf16 (round to nearest
+// even) as they are read; fp32 accumulation, the bias gradient is summed from the fp32 tile as before.
+template <int NK, bool BF16 = false>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   extern __shared__ float lds[];
   float* As = lds;               // [CA_T][PA]
@@ -147,6 +153,30 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     // branch-merged accumulators were copied between AGPRs and VGPRs inside the loop (16 v_accvgpr moves per MFMA pair in
     // the NK = 5 ISA).  Unguarded, the loop body is 2 + NK ds_reads feeding 2*NK back-to-back MFMAs, software-pipelined
     // over the 4x unroll.
+    if constexpr (BF16) {
+      // ap / bp already carry the fp32 instruction's lane offset lk; the bf16 instruction's is 8 * lk
+      const float* ap8 = ap + 7 * lk;
+      const float* bp8 = bp + 7 * lk;
+#pragma unroll 2
+      for (int s = 0; s < TT; s += 16) {
+        f32x8v t0, t1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          t0[j] = ap8[s + j];
+          t1[j] = ap8[32 * PA + s + j];
+        }
+        const bf16x8 a0 = __builtin_convertvector(t0, bf16x8), a1 = __builtin_convertvector(t1, bf16x8);
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+          f32x8v tb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tb[j] = bp8[s + q * dil + j];
+          const bf16x8 bq = __builtin_convertvector(tb, bf16x8);
+          acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[q][0], 0, 0, 0);
+          acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[q][1], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll 4
     for (int s = 0; s < TT; s += 2) {
       const float a0 = ap[s], a1 = ap[32 * PA + s];
@@ -158,6 +188,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
         acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], acc[q][0], 0, 0, 0);
         acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], acc[q][1], 0, 0, 0);
       }
+    }
     }
   }
   if (do_bias) {
@@ -374,12 +405,21 @@ void launch_small(const WgSP& p, dim3 grid, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL((conv1d_wgrad_small_kernel<NKS, MA, NB>), grid, dim3(256), lds, s, p);
 }
 
+int g_wgrad_bf16_launches = 0;
+
 template <int NK>
-void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((conv1d_wgrad_kernel<NK>), grid, dim3(256), lds, s, p);
+void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, bool bf16) {
+  if (bf16) {
+    ++g_wgrad_bf16_launches;
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, true>), grid, dim3(256), lds, s, p);
+  } else {
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, false>), grid, dim3(256), lds, s, p);
+  }
 }
 
 }  // namespace
+
+extern "C" int svc_debug_wgrad_bf16_launches(void) { return g_wgrad_bf16_launches; }
 
 extern "C" int svc_debug_set_wgrad_target(int workgroups) {
   if (workgroups == 0) return SVC_ERR_BAD_ARG;
@@ -482,12 +522,13 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   size_t lds = sizeof(float) * ((size_t)CA_T * PA + (size_t)CB_T * pb);
   lds = std::max(lds, sizeof(float) * (size_t)4 * 16 * (32 * 5 + 1));     // epilogue transpose slabs
   dim3 grid(splits * p.n_kgroups, n_ca, n_cb);
+  const bool bf16 = a.mma == SVC_MMA_BF16;
   switch (nk) {
-    case 1: launch<1>(p, grid, lds, s); break;
-    case 2: launch<2>(p, grid, lds, s); break;
-    case 3: launch<3>(p, grid, lds, s); break;
-    case 4: launch<4>(p, grid, lds, s); break;
-    default: launch<5>(p, grid, lds, s); break;
+    case 1: launch<1>(p, grid, lds, s, bf16); break;
+    case 2: launch<2>(p, grid, lds, s, bf16); break;
+    case 3: launch<3>(p, grid, lds, s, bf16); break;
+    case 4: launch<4>(p, grid, lds, s, bf16); break;
+    default: launch<5>(p, grid, lds, s, bf16); break;
   }
   return svc::check_launch("conv1d_wgrad");
 }

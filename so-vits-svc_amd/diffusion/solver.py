@@ -6,7 +6,7 @@ crops of one run all have `duration` seconds: one graph, plus one for a short la
 when a process group is up (the reference's train_diff.py is single-GPU), rank 0 logs / validates / saves.
 `train()` takes the reference's argument list; an `torch.optim.AdamW` handed in by an unchanged `train_diff.py` is replaced
 by a FusedAdamW with the same hyper-parameters and state, and its StepLR keeps driving the learning rate.
-Not built: fp16/bf16 autocast (`train.amp_dtype` must be fp32 — raises otherwise)."""
+`train.amp_dtype: bf16` runs the model call with bf16 matrix operands (svc_hip.mma_mode); `fp16` raises (no fp16 kernels)."""
 import os
 import time
 
@@ -29,8 +29,12 @@ def build_optimizer(model, lr, weight_decay=0.0, gamma=0.5, decay_step=100000, i
 
 class TrainStep:
     def __init__(self, model, optimizer, gamma=0.5, decay_step=100000, initial_global_step=0, amp_dtype="fp32", scheduler=None):
-        if amp_dtype != "fp32":
-            raise NotImplementedError("amp_dtype fp16/bf16 is not implemented: the MI355X engine trains in fp32")
+        # solver.py:107-115,127-131: `amp_dtype` bf16 / fp16 runs the model call under torch.autocast.  bf16: the engine's form of
+        # that region — svc_hip.mma_mode(MMA_BF16): bf16 operands on the matrix pipe for the convolutions and their gradients,
+        # fp32 accumulation / storage / master weights, no GradScaler needed.  fp16 has no kernels here.
+        if amp_dtype not in ("fp32", "bf16"):
+            raise NotImplementedError("amp_dtype fp16 is not implemented: the MI355X engine has fp32 and bf16 (amp_dtype: bf16) kernels")
+        self.mma = S.MMA_BF16 if amp_dtype == "bf16" else S.MMA_F32
         self.model, self.opt = model, optimizer
         self.gamma, self.decay_step = gamma, decay_step
         self.scheduler = scheduler           # a torch lr_scheduler already attached to `optimizer`: it replaces the built-in StepLR
@@ -57,8 +61,9 @@ class TrainStep:
         self.opt.zero_grad()
         self.plan_sets.enter("fwd", self.model.parameters())     # every conv weight of the pass prepared in one launch
         try:
-            loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
-                              gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
+            with S.mma_mode(self.mma):
+                loss = self.model(data["units"].float(), data["f0"], data["volume"], data["spk_id"], aug_shift=data.get("aug_shift"),
+                                  gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
         finally:
             self.plan_sets.leave("fwd")
         loss.backward()

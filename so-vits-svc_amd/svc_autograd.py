@@ -37,7 +37,8 @@ class _Conv1dDense(Function):
         if tout is not None:
             Tout = tout if exact else min(Tout, tout)
         wp = S.pack_conv1d_weight(w.detach())
-        y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
+        ctx.mma = S.current_mma()      # the operand format of this forward is also the one of its backward (an autocast region's rule)
+        y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma)
         ctx.save_for_backward(x, w)
         ctx.cfg = (pad, dil, bias is not None)
         return y
@@ -51,14 +52,14 @@ class _Conv1dDense(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = S.pack_conv1d_weight_T(w)
-            dx = S.conv1d(dy, wt, Cin, KS, dil=dil, pad_left=dil * (KS - 1) - pad, Tout=x.shape[2])
+            dx = S.conv1d(dy, wt, Cin, KS, dil=dil, pad_left=dil * (KS - 1) - pad, Tout=x.shape[2], mma=ctx.mma)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:      # bias gradient from the dy tiles the wgrad kernel stages anyway
                 db, zeroed = S.wgrad_zeros((Cout,), dy.device)
                 if not zeroed and S.wgrad_slab.active:
                     db.zero_()
-            dw = S.conv1d_wgrad(dy, x, KS, dil, pad, dbias=db)
+            dw = S.conv1d_wgrad(dy, x, KS, dil, pad, dbias=db, mma=ctx.mma)
         elif want_db:
             db = S.reduce_bct(dy, 0)
         return dx, dw, db, None, None, None, None
@@ -85,12 +86,13 @@ class _ConvPlanned(Function):
         # of ONE column each launch fills 1/128 of a tile (0.3 TFLOP/s, 150 us per call at B = 16: profiles/r03w_*).  The batch
         # becomes the column axis instead: [1, C, B] — the same GEMM in one tile row.
         ctx.batch_cols = bool(Tin == 1 and Tout == 1 and plan.Kd == 1 and pad == 0 and x.shape[0] > 1)
+        ctx.mma = S.current_mma()
         if ctx.batch_cols:
             x = x.squeeze(2).t().contiguous().unsqueeze(0)                       # [1, Cin, B]
-            y = S.conv1d(x, wp, plan.Od, 1, bias=bias)                            # [1, Od, B]
+            y = S.conv1d(x, wp, plan.Od, 1, bias=bias, mma=ctx.mma)               # [1, Od, B]
             y = y.squeeze(0).t().contiguous().unsqueeze(2)                       # [B, Od, 1]
         else:
-            y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout)
+            y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma)
         ctx.save_for_backward(x, v, g)
         ctx.plan = plan
         ctx.cfg = (pad, dil, bias is not None)
@@ -106,7 +108,7 @@ class _ConvPlanned(Function):
             dy = dy.squeeze(2).t().contiguous().unsqueeze(0)                     # [1, Od, B]
         dx = dv = dg = db = None
         if ctx.needs_input_grad[0]:
-            dx = S.conv1d(dy, plan.wt, plan.Id, plan.Kd, dil=dil, pad_left=dil * (plan.Kd - 1) - pad, Tout=x.shape[2])
+            dx = S.conv1d(dy, plan.wt, plan.Id, plan.Kd, dil=dil, pad_left=dil * (plan.Kd - 1) - pad, Tout=x.shape[2], mma=ctx.mma)
             if ctx.batch_cols:
                 dx = dx.squeeze(0).t().contiguous().unsqueeze(2)                 # [B, Cin, 1]
         want_db = has_bias and ctx.needs_input_grad[3]
@@ -115,7 +117,7 @@ class _ConvPlanned(Function):
                 db, zeroed = S.wgrad_zeros((plan.Od,), dy.device)
                 if not zeroed and S.wgrad_slab.active:
                     db.zero_()
-            dwd = S.conv1d_wgrad(dy, x, plan.Kd, dil, pad, dbias=db)
+            dwd = S.conv1d_wgrad(dy, x, plan.Kd, dil, pad, dbias=db, mma=ctx.mma)
             gd = g.detach().reshape(-1) if g is not None else None
             dv, dgf = plan.grad(v.detach(), gd, dwd)
             dv = dv.view(v.shape)

@@ -35,6 +35,7 @@ class Conv1dArgs(C.Structure):
         ("n_phase", C.c_int), ("y_ts", C.c_int), ("y_t0", C.c_int), ("y_len", C.c_int),
         ("w_phase_stride", C.c_longlong),
         ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float),
+        ("mma", C.c_int),
     ]
 
 
@@ -102,6 +103,7 @@ def lib():
                                               C.c_void_p]
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
         L.svc_conv1d_multi_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_int, C.c_void_p]
+        L.svc_debug_bf16.argtypes = [C.c_int]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
         L.svc_resblock_pair_f32.argtypes = [C.POINTER(ResblockPairArgs), C.c_void_p]
@@ -135,6 +137,7 @@ def lib():
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
+    "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
@@ -212,7 +215,7 @@ def _bct_strides(t):
 
 def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=1.0, premask=None, cond=None,
            mask=None, post_act=ACT_NONE, post_slope=0.0, res=None, res_mode=0, out=None, beta=0.0, out_div=1.0,
-           epi=EPI_PLAIN, out2=None, skip_from=0):
+           epi=EPI_PLAIN, out2=None, skip_from=0, mma=None):
     """Fused conv1d (see include/svc_hip.h).  x/res/out are [B,C,T] views (channel stride may be negative: use
     flip_view()); wp is a packed weight from pack_conv1d_weight; cond is [B,C,1|T]; mask/premask are [B,1,T]."""
     require_gpu(x, wp, bias, cond, mask, premask, res, out, out2)
@@ -250,6 +253,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.epi, a.post_act, a.res_mode, a.skip_from = epi, post_act, res_mode, skip_from
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
     a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
+    a.mma = _MMA if mma is None else mma
     if _GROUP is not None:          # inside `with conv_group():` — issued with the rest of the group on exit
         _GROUP.append((a, (x, wp, bias, cond, mask, premask, res, out, out2)))
         return out
@@ -258,6 +262,34 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
 
 
 _GROUP = None
+
+# ---- matrix-pipe operand format of the convolutions (svc_conv1d_args.mma): the engine's form of the reference's autocast region
+MMA_F32, MMA_BF16 = 0, 1
+_MMA = MMA_F32
+
+
+def current_mma():
+    return _MMA
+
+
+class mma_mode:
+    """`with mma_mode(MMA_BF16): ...` — convolutions (and, through svc_autograd, their input / weight gradients) issued inside
+    the block take bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, where the shape has such a kernel: what
+    `torch.autocast(dtype=torch.bfloat16)` is to the reference's training step (train.py:166,187,198).  Tensors stay fp32.
+    Autograd ops record the mode of their forward and use it in their backward, whatever thread that runs on."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global _MMA
+        self.prev, _MMA = _MMA, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global _MMA
+        _MMA = self.prev
+        return False
 
 
 class conv_group:
@@ -652,7 +684,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("A", _f32p), ("Bm", _f32p), ("G", _f32p),
                 ("a_bs", C.c_longlong), ("a_cs", C.c_longlong), ("b_bs", C.c_longlong), ("b_cs", C.c_longlong),
                 ("B", C.c_int), ("Ca", C.c_int), ("Cb", C.c_int), ("TA", C.c_int), ("TB", C.c_int), ("KS", C.c_int),
-                ("dil", C.c_int), ("pad", C.c_int), ("accumulate", C.c_int), ("dbias", _f32p)]
+                ("dil", C.c_int), ("pad", C.c_int), ("accumulate", C.c_int), ("dbias", _f32p), ("mma", C.c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -1009,7 +1041,7 @@ def wgrad_zeros(shape, device):
     return torch.empty(tuple(shape), device=device, dtype=torch.float32), False
 
 
-def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None):
+def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None, mma=None):
     """G[ca,cb,k] = sum_{b,t} A[b,ca,t] * Bm[b,cb,t + k*dil - pad]; dbias (optional [Ca] buffer) also receives
     sum_{b,t} A[b,ca,t].  Without `out` the result lands in the pre-zeroed gradient slab when that is active; a dbias
     passed together with a slab-backed output must itself be zero-initialised (wgrad_zeros)."""
@@ -1025,6 +1057,7 @@ def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None):
     a.b_bs, a.b_cs = _bct_strides(Bm)
     a.B, a.Ca, a.Cb, a.TA, a.TB, a.KS, a.dil, a.pad, a.accumulate = B, Ca, Cb, TA, TB, KS, dil, pad, 1 if accumulate else 0
     a.dbias = ptr(dbias)
+    a.mma = _MMA if mma is None else mma
     check(tlib().svc_conv1d_wgrad_f32(C.byref(a), stream_ptr()), "conv1d_wgrad")
     return out
 

@@ -10,7 +10,8 @@ What is re-designed rather than mirrored:
   * no `.item()` host syncs inside the step: the losses come back as device scalars.
 `main()` / `run()` / `train_and_evaluate()` / `evaluate()` at the end of the file are the entry point behind the reference's CLI
 (`svc_run.py train.py -c ... -m ...`): same logs/<model> layout, checkpoints, epoch / warm-up / ExponentialLR bookkeeping.
-`fp16_run` configs are accepted but computed in fp32 (no reduced-precision kernels yet; a warning says so).
+`fp16_run` + `half_type: bf16` runs the reference's autocast regions with bf16 matrix operands (svc_hip.mma_mode);
+`half_type: fp16` is accepted and computed in fp32 (a warning says so).
 """
 import torch
 import torch.distributed as dist
@@ -71,13 +72,21 @@ class TrainStep:
         self.fmin, self.fmax = _get(d, "mel_fmin"), _get(d, "mel_fmax")
         self.segment_size = _get(t, "segment_size")
         self.c_mel, self.c_kl = _get(t, "c_mel"), _get(t, "c_kl")
+        # train.py:114,143,166,187,198: `fp16_run` wraps the generator forward, the mel of y_hat and both discriminator forwards
+        # in torch.autocast(dtype=half_type) and computes every loss in fp32.  The engine's form of that region is
+        # svc_hip.mma_mode: convolutions (forward, input- and weight-gradient) take bf16 operands on v_mfma_f32_32x32x16_bf16
+        # with fp32 accumulation; tensors and master weights stay fp32 — so no GradScaler is needed (bf16 has fp32's exponent
+        # range, and nothing is stored in it), the mel / attention products / element-wise maths keep fp32, and a shape without
+        # a bf16 kernel runs in fp32.  `half_type: fp16` has no kernels here: it trains in fp32 and says so.
+        self.mma = S.MMA_F32
         if _get(t, "fp16_run"):
-            # train.py:114,143,166: autocast + GradScaler are a speed option of the reference.  The engine has no reduced-
-            # precision kernels yet: the step runs in fp32 (at least the reference's precision, no loss scaling needed) and
-            # says so instead of refusing the config.
-            import warnings
-            warnings.warn("fp16_run / half_type: the MI355X engine has no fp16/bf16 kernels yet — training runs in fp32 "
-                          "(GradScaler is not needed and not applied)", stacklevel=2)
+            half = t.get("half_type", "fp16") if isinstance(t, dict) else getattr(t, "half_type", "fp16")
+            if half == "bf16":
+                self.mma = S.MMA_BF16
+            else:
+                import warnings
+                warnings.warn("fp16_run with half_type fp16: the MI355X engine has bf16 matrix kernels only (half_type: bf16) — this run "
+                              "trains in fp32 (GradScaler is not needed and not applied)", stacklevel=2)
 
         self.use_graph = False
         self._graphs = {}
@@ -222,8 +231,9 @@ class TrainStep:
         kw = dict(noise=noise) if noise is not None else {}
         self.plan_sets.enter("g", net_g.parameters())
         try:
-            y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
-                c, f0, uv, spec, g=spk, c_lengths=lengths, spec_lengths=lengths, vol=volume, **kw)        # :167-169
+            with S.mma_mode(self.mma):                                                                    # :166 autocast region
+                y_hat, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), pred_lf0, norm_lf0, lf0 = net_g(
+                    c, f0, uv, spec, g=spk, c_lengths=lengths, spec_lengths=lengths, vol=volume, **kw)    # :167-169
         finally:
             self.plan_sets.leave("g")
         y_mel = commons.slice_segments(mel, ids_slice, seg_frames)                                        # :171
@@ -234,7 +244,8 @@ class TrainStep:
         # ---- discriminator step (:184-195) ----
         self.plan_sets.enter("d", net_d.parameters())
         try:
-            y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+            with S.mma_mode(self.mma):                                                                    # :185, still inside :166's region
+                y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
         finally:
             self.plan_sets.leave("d")
         loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
@@ -251,7 +262,7 @@ class TrainStep:
         y, y_hat, y_mel, y_hat_mel = ctx["y"], ctx["y_hat"], ctx["y_mel"], ctx["y_hat_mel"]
         self.plan_sets.enter("d_gen", dmod.parameters())      # D's weights as its optimizer step just left them
         try:
-            with no_param_grads(dmod):
+            with no_param_grads(dmod), S.mma_mode(self.mma):                                              # :198-200
                 _, y_d_hat_g, fmap_r, fmap_g = dmod.forward_gen_step(y, y_hat)
         finally:
             self.plan_sets.leave("d_gen")

@@ -51,6 +51,24 @@ def _step(cs, net_g, net_d, dev):
                 loss_lf0=loss_lf0, loss_gen_all=loss_gen_all, y_hat=y_hat)
 
 
+def _bench_like_items(dev, n=2):
+    """-> f(fp16_run, half_type) -> (hps dict, items on the device): the first `n` items of bench.py's training batch on the
+    full template (what tests that drive train.TrainStep as an object need)."""
+    import bench
+    import synthetic_data as W
+    cfg = W.full_config()
+    (c, f0, spec, y, spk, lengths, uv, _), _ = bench.make_train_items(cfg, bench.TRAIN_B, 4321)
+    T = int(lengths[:n].max())
+    items = tuple(t.to(dev) if t is not None else None for t in
+                  (c[:n, :, :T], f0[:n, :T], spec[:n, :, :T], y[:n, :, :T * bench.HOP], spk[:n], lengths[:n], uv[:n, :T], None))
+
+    def make(fp16_run, half_type):
+        hps = bench.train_hps(cfg)
+        hps["train"] = dict(hps["train"], fp16_run=fp16_run, half_type=half_type)
+        return hps, items
+    return make
+
+
 def test_training_step_matches_reference_and_oracle(dev):
     cs = load_case()
     z = cs["z"]
