@@ -24,6 +24,12 @@ namespace {
 // (profiles/r02_u_wgrad_split_target_sweep.txt) 128 / 192 / 224 / 256 / 384 / 512 -> wgrad family 40.4 / 35.4 / 33.8 / 30.3 /
 // 37.2 / 34.9 ms per iteration (every split pays a prologue, an exposed first load and an atomic pass over G).
 int g_wgrad_target = 256;
+// 1- and 2-tap launches of the tile kernel (svc_debug_set_wgrad_target(100000 + n)).  Swept on the attention / WN 1 x 1 layers of the
+// B = 16, T = 768 batch (profiles/r05k_wgrad_k1_target_sweep.txt): 512 / 384 / 256 / 192 / 128 / 64 workgroups -> 36.7 / 37.1 /
+// 33.7 / 37.8 / 54.7 / 97.8 us at 192 x 192, 47.4 / 53.1 / 44.7 / 56.3 / 73.2 / 133 us at 384 x 192 — and the same with bf16
+// operands: these launches are bound by how the tiles are staged (0.5 TB/s of operand traffic), neither by the matrix pipe nor by
+// the atomics of the combine pass.
+int g_wgrad_k12_target = 256;
 int g_wgrad_small_target = 256;   // same for the small-channel kernel (negative argument of svc_debug_set_wgrad_target): 128 / 256 / 512 -> 128.3 / 127.1 / 126.9 ms per iteration
 
 constexpr int TT = 64;      // time steps per staged tile
@@ -423,7 +429,8 @@ extern "C" int svc_debug_wgrad_bf16_launches(void) { return g_wgrad_bf16_launche
 
 extern "C" int svc_debug_set_wgrad_target(int workgroups) {
   if (workgroups == 0) return SVC_ERR_BAD_ARG;
-  if (workgroups > 0) g_wgrad_target = workgroups;
+  if (workgroups > 100000) g_wgrad_k12_target = workgroups - 100000;   // the 1- / 2-tap launches of the tile kernel
+  else if (workgroups > 0) g_wgrad_target = workgroups;
   else g_wgrad_small_target = -workgroups;      // negative: the small-channel kernel's target
   return SVC_OK;
 }
@@ -510,7 +517,7 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   // enough time-splits to fill the chip (every split costs one prologue and one atomic pass over G), at least 2 tiles each so
   // the prefetch has something to hide.  The 1- and 2-tap instantiations fit two workgroups per CU (512 resident), the 3..5-tap
   // ones (96-160 accumulator registers) one: their target is tunable (svc_debug_set_wgrad_target)
-  const int target = nk >= 3 ? g_wgrad_target : 512;
+  const int target = nk >= 3 ? g_wgrad_target : g_wgrad_k12_target;
   int splits = std::max(1, target / (n_ca * n_cb * p.n_kgroups));
   splits = std::min(splits, std::max(1, p.n_tiles / 2));
   p.tiles_per_wg = svc::cdiv(p.n_tiles, splits);

@@ -102,15 +102,15 @@ __global__ __launch_bounds__(LN_TT* LN_CG) void add_layernorm_kernel(const float
 }
 
 // Short sequences (T = 500..862 frames: the unit encoder's 26 and the prior encoder's 12 launches per clip): ONE pass over memory.
-// 8 time steps x 32 channel groups per block; a thread keeps its NV = C / 32 values of x + r in registers between the mean, the
-// variance and the output pass (the <4, 64> form above re-reads x and r from L2 for each of the three: 16 us per call at
-// C = 768, T = 500, against ~3 us of HBM time for the 4.6 MB it touches), 32-byte row segments instead of 16.
+// 4 time steps x 64 channel groups per block (the block count of the <4, 64> form above: at T = 500 a coarser split leaves
+// most CUs without a block — 8 x 32 measured 21 us per call against 16); a thread keeps its NV = C / 64 values of x + r in
+// registers between the mean, the variance and the output pass instead of re-reading both tensors from L2 for each of them.
 template <int NV>
 __global__ __launch_bounds__(256) void add_layernorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ mask, float* __restrict__ y, int C,
                                                                 int T, float eps) {
-  constexpr int TT = 8, CG = 32;
+  constexpr int TT = 4, CG = 64;
   __shared__ float red[CG][TT];
   const int tl = threadIdx.x % TT, cg = threadIdx.x / TT;
   const int t = blockIdx.x * TT + tl, b = blockIdx.y;
@@ -323,6 +323,11 @@ extern "C" int svc_prenet_embed_f32(const float* xin, const float* uv, const flo
   return svc::check_launch("prenet_embed");
 }
 
+static bool ln_reg_on() {      // A/B switch: SVC_LN_REG=0 keeps the three-pass kernel
+  static const bool on = [] { const char* e = getenv("SVC_LN_REG"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 extern "C" int svc_add_layernorm_f32(const float* x, const float* r, const float* gamma, const float* beta,
                                      const float* mask, float* y, int B, int C, int T, float eps, void* stream) {
   SVC_REQUIRE(x && gamma && beta && y, "add_layernorm: null tensor");
@@ -332,10 +337,10 @@ extern "C" int svc_add_layernorm_f32(const float* x, const float* r, const float
   if ((long long)svc::cdiv(T, 32) * B >= 256)
     hipLaunchKernelGGL((add_layernorm_kernel<32, 8>), dim3(svc::cdiv(T, 32), B), dim3(256), 0, s, x, r, gamma, beta, mask, y,
                        C, T, eps);
-  else if (C <= 6 * 32)
-    hipLaunchKernelGGL((add_layernorm_reg_kernel<6>), dim3(svc::cdiv(T, 8), B), dim3(256), 0, s, x, r, gamma, beta, mask, y, C, T, eps);
-  else if (C <= 24 * 32)
-    hipLaunchKernelGGL((add_layernorm_reg_kernel<24>), dim3(svc::cdiv(T, 8), B), dim3(256), 0, s, x, r, gamma, beta, mask, y, C, T, eps);
+  else if (ln_reg_on() && C <= 3 * 64)
+    hipLaunchKernelGGL((add_layernorm_reg_kernel<3>), dim3(svc::cdiv(T, 4), B), dim3(256), 0, s, x, r, gamma, beta, mask, y, C, T, eps);
+  else if (ln_reg_on() && C <= 12 * 64)
+    hipLaunchKernelGGL((add_layernorm_reg_kernel<12>), dim3(svc::cdiv(T, 4), B), dim3(256), 0, s, x, r, gamma, beta, mask, y, C, T, eps);
   else
     hipLaunchKernelGGL((add_layernorm_kernel<4, 64>), dim3(svc::cdiv(T, 4), B), dim3(256), 0, s, x, r, gamma, beta, mask, y,
                        C, T, eps);

@@ -257,7 +257,9 @@ class Svc(object):
             cache[(src, dst)] = svc_audio.Resampler(src, dst)
         return cache[(src, dst)](wav.to(self.dev))
 
-    def get_unit_f0(self, wav, tran, cluster_infer_ratio, speaker, f0_filter, f0_predictor, cr_threshold=0.05):
+    def _f0_and_wav16k(self, wav, tran, f0_filter, f0_predictor, cr_threshold=0.05):
+        """The part of get_unit_f0 in front of the unit encoder (:206-222): f0 / uv from the configured predictor (CPU code of the
+        reference), the 16 kHz wave for the encoder."""
         if self.f0_predictor_object is None or f0_predictor != getattr(self.f0_predictor_object, "name", f0_predictor):
             self.f0_predictor_object = utils.get_f0_predictor(f0_predictor, hop_length=self.hop_size,
                                                               sampling_rate=self.target_sample, device=self.dev,
@@ -271,7 +273,15 @@ class Svc(object):
         uv = uv.unsqueeze(0)
         wav_t = torch.from_numpy(np.asarray(wav, dtype=np.float32)).to(self.dev)
         wav16k = self._resample(wav_t[None, :], self.target_sample, 16000)[0]
-        c = self._need("hubert_model").encoder(wav16k)
+        return f0, uv, wav16k
+
+    def get_unit_f0(self, wav, tran, cluster_infer_ratio, speaker, f0_filter, f0_predictor, cr_threshold=0.05, units=None):
+        """`units`: the encoder's output for this wave when the caller already has it (batched chunks), else it is computed."""
+        if units is None:
+            f0, uv, wav16k = self._f0_and_wav16k(wav, tran, f0_filter, f0_predictor, cr_threshold)
+            c = self._need("hubert_model").encoder(wav16k)
+        else:
+            c, f0, uv = units
         c = utils.repeat_expand_2d(c.squeeze(0), f0.shape[1], self.unit_interpolate_mode)
         if cluster_infer_ratio != 0:                                         # :227-253 (CPU retrieval of the reference)
             if self.feature_retrieval:
@@ -302,20 +312,27 @@ class Svc(object):
                                        predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol, seed=seed, noise=noise,
                                        lengths=lengths)
 
-    def _features(self, speaker, tran, raw_path, cluster_infer_ratio, f0_filter, f0_predictor, cr_threshold, frame, spk_mix):
-        """Everything of infer() in front of the synthesizer (:270-290): (wav, c, f0, uv, sid, n_frames)."""
+    def _load_at_target_rate(self, raw_path):
         wav, sr = self._load(raw_path)
         if sr != self.target_sample:
             wav = self._resample(torch.from_numpy(np.asarray(wav, dtype=np.float32))[None, :], sr,
                                  self.target_sample)[0].cpu().numpy()
+        return wav
+
+    def _features(self, speaker, tran, raw_path, cluster_infer_ratio, f0_filter, f0_predictor, cr_threshold, frame, spk_mix,
+                  wav=None, units=None):
+        """Everything of infer() in front of the synthesizer (:270-290): (wav, c, f0, uv, sid, n_frames).  `wav` / `units`:
+        what a batched caller computed already (the wave at the target rate; (encoder output, f0, uv))."""
+        if wav is None:
+            wav = self._load_at_target_rate(raw_path)
         if spk_mix:
-            c, f0, uv = self.get_unit_f0(wav, tran, 0, None, f0_filter, f0_predictor, cr_threshold=cr_threshold)
+            c, f0, uv = self.get_unit_f0(wav, tran, 0, None, f0_filter, f0_predictor, cr_threshold=cr_threshold, units=units)
             n_frames = f0.size(1)
             sid = speaker[:, frame:frame + n_frames].transpose(0, 1)
         else:
             sid = torch.LongTensor([self._speaker_id(speaker)]).to(self.dev).unsqueeze(0)
             c, f0, uv = self.get_unit_f0(wav, tran, cluster_infer_ratio, speaker, f0_filter, f0_predictor,
-                                         cr_threshold=cr_threshold)
+                                         cr_threshold=cr_threshold, units=units)
             n_frames = f0.size(1)
         return wav, c.float(), f0.float(), uv.float(), sid, n_frames
 
@@ -508,14 +525,27 @@ class Svc(object):
         item's samples within its receptive field of the padded tail differ from the serial run, but that region (< 0.25 s)
         lies inside the `pad_seconds` (0.5 s) of silence slice_inference adds to every chunk and trims again (:460,470).
         Fills j["audio"] exactly as the serial loop would."""
+        # front-ends: f0 chunk by chunk (CPU predictor), then the unit encoder over ALL chunks at once — encoder_batch runs waves
+        # of equal length (fixed-length clipping gives them) as one batch, the others one by one
+        voiced = [j for j in jobs if "silence" not in j]
+        pre = []
+        for j in voiced:
+            wav = self._load_at_target_rate((j["dat"], audio_sr))
+            pre.append((wav,) + self._f0_and_wav16k(wav, tran, False, kw["f0_predictor"], kw["cr_threshold"]))
+        enc = self._need("hubert_model")
+        batch = getattr(enc, "encoder_batch", None)
+        units = batch([p[3] for p in pre]) if batch is not None else [enc.encoder(p[3]) for p in pre]
         global_frame = 0
         feats = []
+        it = iter(zip(pre, units))
         for j in jobs:
             if "silence" in j:
                 global_frame += j["silence"] // self.hop_size
                 continue
-            wav, c, f0, uv, sid, n_frames = self._features(spk, tran, (j["dat"], audio_sr), kw["cluster_infer_ratio"], False,
-                                                           kw["f0_predictor"], kw["cr_threshold"], global_frame, kw["spk_mix"])
+            (wav, f0_, uv_, w16), c_ = next(it)
+            wav, c, f0, uv, sid, n_frames = self._features(spk, tran, None, kw["cluster_infer_ratio"], False, kw["f0_predictor"],
+                                                           kw["cr_threshold"], global_frame, kw["spk_mix"], wav=wav,
+                                                           units=(c_, f0_, uv_))
             global_frame += n_frames
             feats.append(dict(j=j, wav=wav, c=c, f0=f0, uv=uv, sid=sid, T=n_frames))
         groups = {}

@@ -5,7 +5,7 @@ output_layer=12)` (:28-36); here the same checkpoint file is mapped onto vencode
 (`load_fairseq_hubert`) and `Hubert.encode(wav, layer=12)` runs the stack in libsvc_hip.so."""
 import torch
 
-from vencoder.encoder import SpeechEncoder
+from vencoder.encoder import SpeechEncoder, batch_equal_lengths
 from vencoder.hubert import hubert_model
 
 
@@ -38,3 +38,10 @@ class ContentVec768L12(SpeechEncoder):
             if self.USE_FINAL_PROJ:
                 x = self.model.project(x)
         return x
+
+    def encoder_batch(self, wavs):
+        def run(x):
+            y, _ = self.model.encode(x.to(self.dev), layer=self.OUTPUT_LAYER)
+            return self.model.project(y) if self.USE_FINAL_PROJ else y
+        with torch.no_grad():
+            return batch_equal_lengths(wavs, run)

@@ -1,7 +1,7 @@
 """Mirror of vencoder/HubertSoft.py: the `hubertsoft` speech encoder (256-d soft units) on the MI355X engine."""
 import torch
 
-from vencoder.encoder import SpeechEncoder
+from vencoder.encoder import SpeechEncoder, batch_equal_lengths
 from vencoder.hubert import hubert_model
 
 
@@ -29,3 +29,7 @@ class HubertSoft(SpeechEncoder):
         with torch.no_grad():
             units = self.model.units(feats.to(self.dev))
             return units.transpose(1, 2)
+
+    def encoder_batch(self, wavs):
+        with torch.no_grad():
+            return batch_equal_lengths(wavs, lambda x: self.model.units(x.to(self.dev)).transpose(1, 2))

@@ -294,3 +294,36 @@ def test_contentvec_encoders_match_oracle(dev, tmp_path, cls_name, layer, proj):
     import utils
     import vencoder.ContentVec768L12 as M
     assert utils._SPEECH_ENCODERS["vec768l12"] == "ContentVec768L12" and M.ContentVec768L12.OUTPUT_LAYER == 12
+
+
+def test_slice_inference_batches_the_unit_encoder_over_equal_length_chunks(dev, tmp_path, monkeypatch, patched_factories):
+    """with batch_chunks=True the engine's HuBERT-based unit encoders take the chunks' 16 kHz waves through
+    `encoder_batch` — equal lengths (forced clipping) as ONE batch: every op of that stack is per item (GroupNorm(512, 512) over
+    the item's own time axis), so the batch equals the serial loop to fp32 round-off.  Real ContentVec768L12 mirror on a synthetic
+    fairseq-format checkpoint; the synthesizer is built for its 768-d units."""
+    import svc_audio
+    import utils
+    from inference.infer_tool import Svc
+    from vencoder.ContentVec768L12 import ContentVec768L12
+    cfg = dict(W.small_config(), ssl_dim=768)
+    patched_factories["ssl_dim"] = 768
+    monkeypatch.chdir(tmp_path)
+    ckpt = str(tmp_path / "checkpoint_best_legacy_500.pt")
+    torch.save({"model": HO.to_fairseq_state_dict(HO.make_state_dict(4)), "cfg": None, "args": None}, ckpt)
+    enc = ContentVec768L12(vec_path=ckpt, device=dev)
+    monkeypatch.setattr(utils, "get_speech_encoder", lambda name, device=None, **kw: enc)
+    net, ck, cj = _write_model(str(tmp_path), cfg, 9)
+    svc_audio.write_wav("song.wav", _song(seconds_voiced=(3.1,), gap=0.0), SR)
+    svc = Svc(ck, cj, "cuda:0", "")
+    sizes = []
+    orig = enc.model.encode
+    enc.model.encode = lambda x, layer=None: (sizes.append(x.shape[0]), orig(x, layer=layer))[1]
+    kw = dict(pad_seconds=0.3, clip_seconds=0.7, lg_num=0.1, lgr_num=0.75)
+    serial = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, **kw)
+    assert len(sizes) >= 4 and set(sizes) == {1}
+    n_serial = len(sizes)
+    sizes.clear()
+    batched = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, batch_chunks=True, **kw)
+    assert len(sizes) < n_serial and max(sizes) >= 3, sizes          # the equal-length clips went through the encoder together
+    assert serial.shape == batched.shape
+    assert np.abs(serial - batched).max() <= 5e-5 * max(1.0, np.abs(serial).max())
