@@ -321,6 +321,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the 200-replay steady_state look (profiling runs: keeps the step count exact)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -411,7 +412,7 @@ def main():
 
     # ---- a longer look at the same step (K = 20 steps are 0.15 s): >= 200 more replays, reported beside `value`, never as it ----
     steady = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_steady:
         ns = max(200, args.steps)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -138,9 +138,10 @@ def _worker3_eager(rank, world, port, q):
     _worker(rank, world, port, q, graph=None)
 
 
-def _worker_diffusion(rank, world, port, q):
+def _worker_diffusion(rank, world, port, q, graph=False):
     """BASELINE configs[4] (train_diff.py under data parallelism): each rank trains the shallow-diffusion model on its half
-    of a 4-item batch; the averaged-gradient result must equal single-process training on the whole batch."""
+    of a 4-item batch; the averaged-gradient result must equal single-process training on the whole batch.  graph=True: the
+    form `diffusion.solver.train` runs by default — graph[zero_grad, forward, backward] -> all-reduce(arena) -> AdamW."""
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -168,7 +169,7 @@ def _worker_diffusion(rank, world, port, q):
 
         def run(net_or_dp, sl):
             opt = solver.build_optimizer(net_or_dp.module if isinstance(net_or_dp, DataParallel) else net_or_dp, lr=2e-3)
-            step = solver.TrainStep(net_or_dp, opt)
+            step = solver.TrainStep(net_or_dp, opt).enable_graph(graph and isinstance(net_or_dp, DataParallel))
             for bt in batches:
                 d = {k: v[sl].to(dev) for k, v in bt.items()}
                 step(dict(units=d["units"], f0=d["f0"], volume=d["volume"], spk_id=d["spk_id"], mel=d["gt"]),
@@ -179,7 +180,10 @@ def _worker_diffusion(rank, world, port, q):
         net = fresh(7 + rank)                               # different init per rank: DataParallel's broadcast must fix it
         if rank == 0:
             net = fresh(7)
-        flat = run(DataParallel(net), slice(2 * rank, 2 * rank + 2))
+        dp = DataParallel(net)
+        flat = run(dp, slice(2 * rank, 2 * rank + 2))
+        if graph and dp.reducer.stats["reduce_all_calls"] != len(batches):
+            raise AssertionError(f"graph mode did not reduce between replays: {dp.reducer.stats}")
         parts = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(parts, flat)
         same = torch.equal(parts[0], parts[1])
@@ -196,11 +200,12 @@ def _worker_diffusion(rank, world, port, q):
         q.put((rank, traceback.format_exc(), None))
 
 
-def test_two_rank_diffusion_training_equals_full_batch():
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_diffusion_training_equals_full_batch(graph):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_diffusion, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_diffusion, args=(r, 2, port, q, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
