@@ -103,11 +103,12 @@ TRAIN_SEG = 8192
 
 
 def train_hps(cfg, bf16=False):
+    """bf16: False (fp32), True / "bf16" (fp16_run + half_type bf16) or "fp16" (fp16_run + half_type fp16)."""
     model = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
     return dict(data=dict(filter_length=2048, hop_length=HOP, win_length=2048, n_mel_channels=80, sampling_rate=44100,
                           mel_fmin=0.0, mel_fmax=22050),
                 train=dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
-                           fp16_run=bool(bf16), half_type="bf16" if bf16 else "fp16", batch_size=TRAIN_B),
+                           fp16_run=bool(bf16), half_type=("fp16" if bf16 == "fp16" else "bf16") if bf16 else "fp16", batch_size=TRAIN_B),
                 model=model)
 
 
@@ -288,18 +289,18 @@ def run_train(args, dev, rank, world, dist, bf16=False):
         roof["whole_step"]["frac"] = round(roof["whole_step"]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
         roof["note"] += "; bf16-operand and fp32 launches share these family rows, peak = dense bf16 MFMA"
         roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
-    return dict(metric="train steps/sec (train.py D+G iteration)" + (", fp16_run + half_type bf16" if bf16 else ""),
+    return dict(metric="train steps/sec (train.py D+G iteration)" + (f", fp16_run + half_type {'fp16' if bf16 == 'fp16' else 'bf16'}" if bf16 else ""),
                 value=steps / elapsed, unit="steps/s",
                 ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak",
-                dtype="bf16 matrix operands, f32 accumulate / storage" if bf16 else "f32",
+                dtype=f"{'fp16' if bf16 == 'fp16' else 'bf16'} matrix operands, f32 accumulate / storage" if bf16 else "f32",
                 items_per_s=world * TRAIN_B * steps / elapsed,
                 config=dict(workload="BASELINE configs[2]: config_template.json model + MultiPeriodDiscriminator, "
                                      f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
-                                     f"4 speakers, {'fp16_run half_type=bf16' if bf16 else 'fp32'}, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
+                                     f"4 speakers, {('fp16_run half_type=' + ('fp16' if bf16 == 'fp16' else 'bf16')) if bf16 else 'fp32'}, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
                             global_batch=TRAIN_B * world, frames=T,
-                            launch=("hipGraph replay of the whole iteration" if world == 1 else
-                                    "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph
-                            else "eager",
+                            launch="eager (fp16: the GradScaler rule decides every optimizer step on the host)" if bf16 == "fp16" else
+                            (("hipGraph replay of the whole iteration" if world == 1 else
+                              "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph else "eager"),
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU",
                             p_dropout=cfg["p_dropout"]),
                 losses={k: round(float(v), 4) for k, v in last.items()},
@@ -319,6 +320,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
+    ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
     ap.add_argument("--no-steady", action="store_true", help="skip the 200-replay steady_state look (profiling runs: keeps the step count exact)")
@@ -369,7 +371,7 @@ def main():
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps
         args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
-        res = run_train(args, dev, rank, world, dist, bf16=args.bf16)
+        res = run_train(args, dev, rank, world, dist, bf16="fp16" if args.fp16 else args.bf16)
         if rank == 0:
             res.update(higher_is_better=True, vs_baseline=None, data="synthetic")
             print(json.dumps(res))

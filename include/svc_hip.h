@@ -120,6 +120,7 @@ typedef struct svc_conv1d_args {
 } svc_conv1d_args;
 #define SVC_MMA_F32 0
 #define SVC_MMA_BF16 1
+#define SVC_MMA_F16 2  /* `half_type: fp16`: the same with fp16 operands (v_mfma_f32_32x32x16_f16); the caller scales the loss (GradScaler) */
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
 

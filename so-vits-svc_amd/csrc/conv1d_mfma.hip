@@ -63,7 +63,22 @@ struct ConvP {
 __device__ float4 g_zero_block[2];
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
+
+// 16-bit operand formats of the matrix pipe (svc_conv1d_args.mma): eight fp32 values -> one operand fragment (round to nearest
+// even: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), and the 32x32x16 instruction of that format.  fp32 accumulation either way.
+template <int MMA> struct Op16;
+template <> struct Op16<SVC_MMA_BF16> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, bf16x8); }
+  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Op16<SVC_MMA_F16> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, f16x8); }
+  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // One LDS-DMA piece: every lane's 16 B at `g` land at LDS byte address lds_byte + lane*16 (wave-uniform base in M0).
 // Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (svc_vmcnt0 before the barrier).
@@ -385,7 +400,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, f32x16 (&ac
 }
 
 // MT x NT MFMA tiles per wave; WM x WN x WK waves per workgroup (WK waves split the reduction).
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, bool BF16 = false>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, int MMA = SVC_MMA_F32>
 // (scalar-staging instantiations — unaligned rows, e.g. DiscriminatorP's period layout — keep 48 X + 64 W staging registers
 // in flight next to the accumulators: at two workgroups per CU they spilled 92..296 B/lane of scratch into the chunk loop
 // and ran 3.7x slower than their aligned twins; they get the whole register file of a SIMD instead)
@@ -650,38 +665,39 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
       //  channel pairs, operand ring, sched_barrier between groups — instead of restarting at every channel pair: slower on
       //  every shape, 1 x 1 convs included (profiles/r03z_trainconv.txt vs r03y_*): the per-pair restart is not what holds
       //  the short-reduction shapes back)
-      if constexpr (BF16) {
-        // ---- bf16 operands (svc_conv1d_args.mma = SVC_MMA_BF16): v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The chunk sits in
+      if constexpr (MMA != SVC_MMA_F32) {
+        // ---- 16-bit operands (svc_conv1d_args.mma = SVC_MMA_BF16 / SVC_MMA_F16): v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate.  The chunk sits in
         // LDS exactly as for the fp32 loop (fp32, [ci][k][BM] weights and [ci][XW] activations, fetched by LDS-DMA); an
         // instruction reduces 16 input channels of one tap, lane half lk supplying channels 8*lk .. 8*lk + 7 of the group: eight
-        // ds_read_b32 per fragment, rounded to bf16 in pairs (v_cvt_pk_bf16_f32, round to nearest even) on the way into the
-        // operand registers.  Same C layout as the fp32 instruction: the epilogues are shared.
-        static_assert(!BF16 || (DB && KSC == 0 && !M16), "bf16 operands: LDS-DMA tilings, run-time tap count");
+        // ds_read_b32 per fragment, rounded in pairs (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even) on the way
+        // into the operand registers.  Same C layout as the fp32 instruction: the epilogues are shared.
+        static_assert(MMA == SVC_MMA_F32 || (DB && KSC == 0 && !M16), "16-bit operands: LDS-DMA tilings, run-time tap count");
+        typedef Op16<MMA == SVC_MMA_F32 ? SVC_MMA_BF16 : MMA> OP;
         const int dil = a.dil, n_g = BC >> 4, wrow = KS * BM;
         for (int g = 0; g < n_g; ++g) {
           const float* wa = wbuf + (g * 16 + 8 * lk) * wrow;
           const float* xa = xbuf + (g * 16 + 8 * lk) * XW;
           for (int k = 0; k < KS; ++k) {
-            bf16x8 af[MT], bq[NT];
+            typename OP::frag af[MT], bq[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
               f32x8v t;
 #pragma unroll
               for (int j = 0; j < 8; ++j) t[j] = wa[j * wrow + k * BM + i * TS];
-              af[i] = __builtin_convertvector(t, bf16x8);
+              af[i] = OP::cvt(t);
             }
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) {
               f32x8v t;
 #pragma unroll
               for (int j = 0; j < 8; ++j) t[j] = xa[j * XW + k * dil + jn * TS];
-              bq[jn] = __builtin_convertvector(t, bf16x8);
+              bq[jn] = OP::cvt(t);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
               for (int jn = 0; jn < NT; ++jn)
-                acc32[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[jn], acc32[i][jn], 0, 0, 0);
+                acc32[i][jn] = OP::mfma(af[i], bq[jn], acc32[i][jn]);
           }
         }
       } else if constexpr (KSC > 0) {
@@ -946,9 +962,9 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
 }
 
 thread_local int t_row_phases = 1;  // set by svc_conv_transpose1d_f32 around its dispatch (see ConvP::row_phases)
-template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, bool BF16 = false>
+template <int MT, int NT, int WM, int WN, int WK, bool M16, int EPI, int KSC, bool XVEC, bool DB = false, int MMA = SVC_MMA_F32>
 __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (XVEC || WK > 1) ? 2 : 1)) void conv1d_mfma_kernel(ConvP p) {
-  conv1d_mfma_body<MT, NT, WM, WN, WK, M16, EPI, KSC, XVEC, DB, BF16>(p, blockIdx.x);
+  conv1d_mfma_body<MT, NT, WM, WN, WK, M16, EPI, KSC, XVEC, DB, MMA>(p, blockIdx.x);
 }
 
 // Up to three INDEPENDENT plain convolutions on the 64 x 128 LDS-DMA tiling in ONE launch: the same step of the 11- / 7- / 3-tap
@@ -1072,7 +1088,7 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     constexpr bool BF16_TILING = EPI == SVC_EPI_PLAIN && ((MT == 2 && NT == 2 && WM == 2 && WN == 2) || (MT == 2 && NT == 1 && WM == 1 && WN == 4) ||
                                                           (MT == 1 && NT == 3 && WM == 2 && WN == 2) || (MT == 1 && NT == 5 && WM == 4 && WN == 1) ||
                                                           (MT == 2 && NT == 2 && WM == 1 && WN == 4));
-    const bool want_bf16 = BF16_TILING && a.mma == SVC_MMA_BF16 && (a.Cin % 16) == 0 && g_bf16_enabled;
+    const bool want_bf16 = BF16_TILING && (a.mma == SVC_MMA_BF16 || a.mma == SVC_MMA_F16) && (a.Cin % 16) == 0 && g_bf16_enabled;
     // a bf16 chunk is at least 16 channels (one instruction's reduction): 5..11 taps of them do not fit the 64 KiB the fp32
     // chunks are sized for — they take up to 144 KiB (one workgroup per CU; the instruction stream is 16x shorter per chunk)
     if (want_bf16) budget = std::max(budget, (size_t)144 * 1024);
@@ -1111,15 +1127,18 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
       const size_t lds = std::max((size_t)2 * ni * NWV * 1024, epi_bytes);
       if constexpr (BF16_TILING) {
         if (want_bf16) {
-          auto kb = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, true>;
+          auto kb = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, SVC_MMA_BF16>;
+          auto kh = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, SVC_MMA_F16>;
           static bool doneb = false;
           if (!doneb) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             doneb = true;
           }
           ++g_bf16_launches;
-          hipLaunchKernelGGL(kb, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
-          return svc::check_launch("conv1d_mfma_bf16");
+          if (a.mma == SVC_MMA_F16) hipLaunchKernelGGL(kh, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+          else hipLaunchKernelGGL(kb, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+          return svc::check_launch("conv1d_mfma_16bit");
         }
       }
       auto kd = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true, true>;

@@ -50,12 +50,24 @@ struct WgP {
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
+template <int MMA> struct WOp16;
+template <> struct WOp16<SVC_MMA_BF16> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, bf16x8); }
+  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct WOp16<SVC_MMA_F16> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, f16x8); }
+  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
-// BF16 (svc_wgrad_args.mma = SVC_MMA_BF16): the staged fp32 tiles are multiplied on v_mfma_f32_32x32x16_bf16 — an instruction
-// reduces 16 time steps, lane half lk supplying steps 8*lk .. 8*lk + 7 of its channel row, rounded to bf16 (round to nearest
-// even) as they are read; fp32 accumulation, the bias gradient is summed from the fp32 tile as before.
-template <int NK, bool BF16 = false>
+// MMA (svc_wgrad_args.mma = SVC_MMA_BF16 / SVC_MMA_F16): the staged fp32 tiles are multiplied on v_mfma_f32_32x32x16_{bf16,f16} — an
+// instruction reduces 16 time steps, lane half lk supplying steps 8*lk .. 8*lk + 7 of its channel row, rounded to the 16-bit format
+// (round to nearest even) as they are read; fp32 accumulation, the bias gradient is summed from the fp32 tile as before.
+template <int NK, int MMA = SVC_MMA_F32>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   extern __shared__ float lds[];
   float* As = lds;               // [CA_T][PA]
@@ -159,8 +171,9 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     // branch-merged accumulators were copied between AGPRs and VGPRs inside the loop (16 v_accvgpr moves per MFMA pair in
     // the NK = 5 ISA).  Unguarded, the loop body is 2 + NK ds_reads feeding 2*NK back-to-back MFMAs, software-pipelined
     // over the 4x unroll.
-    if constexpr (BF16) {
-      // ap / bp already carry the fp32 instruction's lane offset lk; the bf16 instruction's is 8 * lk
+    if constexpr (MMA != SVC_MMA_F32) {
+      typedef WOp16<MMA == SVC_MMA_F32 ? SVC_MMA_BF16 : MMA> OP;
+      // ap / bp already carry the fp32 instruction's lane offset lk; the 16-bit instruction's is 8 * lk
       const float* ap8 = ap + 7 * lk;
       const float* bp8 = bp + 7 * lk;
 #pragma unroll 2
@@ -171,15 +184,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
           t0[j] = ap8[s + j];
           t1[j] = ap8[32 * PA + s + j];
         }
-        const bf16x8 a0 = __builtin_convertvector(t0, bf16x8), a1 = __builtin_convertvector(t1, bf16x8);
+        const typename OP::frag a0 = OP::cvt(t0), a1 = OP::cvt(t1);
 #pragma unroll
         for (int q = 0; q < NK; ++q) {
           f32x8v tb;
 #pragma unroll
           for (int j = 0; j < 8; ++j) tb[j] = bp8[s + q * dil + j];
-          const bf16x8 bq = __builtin_convertvector(tb, bf16x8);
-          acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq, acc[q][0], 0, 0, 0);
-          acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc[q][1], 0, 0, 0);
+          const typename OP::frag bq = OP::cvt(tb);
+          acc[q][0] = OP::mfma(a0, bq, acc[q][0]);
+          acc[q][1] = OP::mfma(a1, bq, acc[q][1]);
         }
       }
     } else {
@@ -414,12 +427,15 @@ void launch_small(const WgSP& p, dim3 grid, size_t lds, hipStream_t s) {
 int g_wgrad_bf16_launches = 0;
 
 template <int NK>
-void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, bool bf16) {
-  if (bf16) {
+void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma) {
+  if (mma == SVC_MMA_BF16) {
     ++g_wgrad_bf16_launches;
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, true>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_BF16>), grid, dim3(256), lds, s, p);
+  } else if (mma == SVC_MMA_F16) {
+    ++g_wgrad_bf16_launches;
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_F16>), grid, dim3(256), lds, s, p);
   } else {
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, false>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_F32>), grid, dim3(256), lds, s, p);
   }
 }
 
@@ -529,13 +545,12 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   size_t lds = sizeof(float) * ((size_t)CA_T * PA + (size_t)CB_T * pb);
   lds = std::max(lds, sizeof(float) * (size_t)4 * 16 * (32 * 5 + 1));     // epilogue transpose slabs
   dim3 grid(splits * p.n_kgroups, n_ca, n_cb);
-  const bool bf16 = a.mma == SVC_MMA_BF16;
   switch (nk) {
-    case 1: launch<1>(p, grid, lds, s, bf16); break;
-    case 2: launch<2>(p, grid, lds, s, bf16); break;
-    case 3: launch<3>(p, grid, lds, s, bf16); break;
-    case 4: launch<4>(p, grid, lds, s, bf16); break;
-    default: launch<5>(p, grid, lds, s, bf16); break;
+    case 1: launch<1>(p, grid, lds, s, a.mma); break;
+    case 2: launch<2>(p, grid, lds, s, a.mma); break;
+    case 3: launch<3>(p, grid, lds, s, a.mma); break;
+    case 4: launch<4>(p, grid, lds, s, a.mma); break;
+    default: launch<5>(p, grid, lds, s, a.mma); break;
   }
   return svc::check_launch("conv1d_wgrad");
 }

@@ -6,7 +6,8 @@ crops of one run all have `duration` seconds: one graph, plus one for a short la
 when a process group is up (the reference's train_diff.py is single-GPU), rank 0 logs / validates / saves.
 `train()` takes the reference's argument list; an `torch.optim.AdamW` handed in by an unchanged `train_diff.py` is replaced
 by a FusedAdamW with the same hyper-parameters and state, and its StepLR keeps driving the learning rate.
-`train.amp_dtype: bf16` runs the model call with bf16 matrix operands (svc_hip.mma_mode); `fp16` raises (no fp16 kernels)."""
+`train.amp_dtype: bf16 / fp16` run the model call with 16-bit matrix operands (svc_hip.mma_mode); fp16 adds the GradScaler rule
+(optim.LossScaler) and launches eagerly."""
 import os
 import time
 
@@ -15,7 +16,7 @@ import torch
 
 from data_parallel import DataParallel
 import svc_hip as S
-from optim import FusedAdamW
+from optim import FusedAdamW, LossScaler
 
 
 def build_optimizer(model, lr, weight_decay=0.0, gamma=0.5, decay_step=100000, initial_global_step=0):
@@ -30,11 +31,14 @@ def build_optimizer(model, lr, weight_decay=0.0, gamma=0.5, decay_step=100000, i
 class TrainStep:
     def __init__(self, model, optimizer, gamma=0.5, decay_step=100000, initial_global_step=0, amp_dtype="fp32", scheduler=None):
         # solver.py:107-115,127-131: `amp_dtype` bf16 / fp16 runs the model call under torch.autocast.  bf16: the engine's form of
-        # that region — svc_hip.mma_mode(MMA_BF16): bf16 operands on the matrix pipe for the convolutions and their gradients,
-        # fp32 accumulation / storage / master weights, no GradScaler needed.  fp16 has no kernels here.
-        if amp_dtype not in ("fp32", "bf16"):
-            raise NotImplementedError("amp_dtype fp16 is not implemented: the MI355X engine has fp32 and bf16 (amp_dtype: bf16) kernels")
-        self.mma = S.MMA_BF16 if amp_dtype == "bf16" else S.MMA_F32
+        # that region — svc_hip.mma_mode: 16-bit operands on the matrix pipe for the convolutions and their gradients, fp32
+        # accumulation / storage / master weights (bf16 needs no GradScaler: nothing is stored in it).
+        if amp_dtype not in ("fp32", "bf16", "fp16"):
+            raise ValueError(" [x] Unknown amp_dtype: " + str(amp_dtype))
+        self.mma = {"fp32": S.MMA_F32, "bf16": S.MMA_BF16, "fp16": S.MMA_F16}[amp_dtype]
+        # fp16 operands need the reference's GradScaler (solver.py:105,134-137): scale the loss, skip the step on overflow — a host
+        # decision per step, so this mode launches eagerly (no whole-iteration hipGraph)
+        self.scaler = LossScaler() if amp_dtype == "fp16" else None
         self.model, self.opt = model, optimizer
         self.gamma, self.decay_step = gamma, decay_step
         self.scheduler = scheduler           # a torch lr_scheduler already attached to `optimizer`: it replaces the built-in StepLR
@@ -66,13 +70,17 @@ class TrainStep:
                                   gt_spec=data["mel"].float(), infer=False, k_step=getattr(self._mod(), "k_step_max", None), noise=noise)
         finally:
             self.plan_sets.leave("fwd")
-        loss.backward()
+        (loss * self.scaler.scale if self.scaler is not None else loss).backward()
         return loss.detach()
 
     def _body(self, data, noise):
         try:
             loss = self._fwd_bwd(data, noise)
-            self.opt.step()
+            if self.scaler is None:
+                self.opt.step()
+            else:
+                self.scaler.step(self.opt)
+                self.scaler.update()
         finally:
             S.wgrad_slab.active = False  # also when the step raises: later backward passes must not get views of this slab
         return loss
@@ -97,7 +105,7 @@ class TrainStep:
     def __call__(self, data, noise=None):
         """data: dict(units [B,T,n_unit], f0 [B,T,1], volume [B,T,1], spk_id [B,1], mel [B,T,M], aug_shift [B,1,1] | None)
         on the device; noise: optional dict(t [B] long, noise [B,1,M,T]).  Returns the loss (0-dim device tensor)."""
-        if not self.use_graph:
+        if not self.use_graph or self.scaler is not None:
             loss = self._body(data, noise)
             self._sched_step()
             return loss

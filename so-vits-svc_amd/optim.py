@@ -303,6 +303,18 @@ class FusedAdamW(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(self.arena.params)
 
     @torch.no_grad()
+    def grads_finite(self):
+        """True when every gradient produced since the last zero_grad is finite (what GradScaler.unscale_ / step look at,
+        train.py:193-195,211-212).  Reads one device scalar: a host synchronisation, like the reference's `found_inf.item()`."""
+        a = self.arena
+        a.collect()
+        runs = a.touched_runs()
+        if not runs:
+            return True
+        ok = torch.stack([torch.isfinite(a.grad[s:e]).all() for s, e, _ in runs]).all()
+        return bool(ok)
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -354,3 +366,41 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._steps[i] = int(float(st["step"]))
         self._gstep = max(self._steps) if self._steps else 0
         self._hyper = {}
+
+
+class LossScaler:
+    """torch.cuda.amp.GradScaler's rule (train.py:143 `GradScaler(enabled=hps.train.fp16_run)`, :192-213) for the fp16 mode: the
+    loss is multiplied by `scale` before backward, the optimizer divides the gradients by it again (FusedAdamW.grad_scale: inside
+    the one AdamW launch) and skips its step when a gradient is not finite; `update()` — once per iteration, after both
+    optimizers — halves the scale if either of them skipped, doubles it after `growth_interval` clean iterations.  Defaults are
+    GradScaler's (65536, x2, x0.5, 2000).  Host-side: one device->host flag per optimizer step, as in the reference."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self._good, self._found_inf, self.skipped = 0, False, 0
+
+    def step(self, optimizer):
+        if not optimizer.grads_finite():
+            self._found_inf = True
+            self.skipped += 1
+            return False
+        optimizer.grad_scale = 1.0 / self.scale
+        optimizer.step()
+        return True
+
+    def update(self):
+        if self._found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+        self._found_inf = False
+
+    def state_dict(self):
+        return dict(scale=self.scale, growth_tracker=self._good)
+
+    def load_state_dict(self, d):
+        self.scale, self._good = float(d["scale"]), int(d.get("growth_tracker", 0))

@@ -264,7 +264,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
 _GROUP = None
 
 # ---- matrix-pipe operand format of the convolutions (svc_conv1d_args.mma): the engine's form of the reference's autocast region
-MMA_F32, MMA_BF16 = 0, 1
+MMA_F32, MMA_BF16, MMA_F16 = 0, 1, 2
 _MMA = MMA_F32
 
 

@@ -10,8 +10,8 @@ What is re-designed rather than mirrored:
   * no `.item()` host syncs inside the step: the losses come back as device scalars.
 `main()` / `run()` / `train_and_evaluate()` / `evaluate()` at the end of the file are the entry point behind the reference's CLI
 (`svc_run.py train.py -c ... -m ...`): same logs/<model> layout, checkpoints, epoch / warm-up / ExponentialLR bookkeeping.
-`fp16_run` + `half_type: bf16` runs the reference's autocast regions with bf16 matrix operands (svc_hip.mma_mode);
-`half_type: fp16` is accepted and computed in fp32 (a warning says so).
+`fp16_run` runs the reference's autocast regions with 16-bit matrix operands (svc_hip.mma_mode): `half_type: bf16` on
+v_mfma_f32_32x32x16_bf16, `half_type: fp16` on v_mfma_f32_32x32x16_f16 with the GradScaler rule (LossScaler; eager launches).
 """
 import torch
 import torch.distributed as dist
@@ -25,7 +25,7 @@ import svc_hip as S
 from data_parallel import DataParallel, no_param_grads
 from modules.losses import discriminator_loss, feature_loss, generator_loss, kl_loss
 from modules.mel_processing import mel_spectrogram_torch, spec_to_mel_torch
-from optim import FusedAdamW
+from optim import FusedAdamW, LossScaler
 
 
 def _get(h, name):
@@ -77,16 +77,17 @@ class TrainStep:
         # svc_hip.mma_mode: convolutions (forward, input- and weight-gradient) take bf16 operands on v_mfma_f32_32x32x16_bf16
         # with fp32 accumulation; tensors and master weights stay fp32 — so no GradScaler is needed (bf16 has fp32's exponent
         # range, and nothing is stored in it), the mel / attention products / element-wise maths keep fp32, and a shape without
-        # a bf16 kernel runs in fp32.  `half_type: fp16` has no kernels here: it trains in fp32 and says so.
-        self.mma = S.MMA_F32
+        # a 16-bit kernel runs in fp32.  `half_type: fp16`: the same with fp16 operands plus the GradScaler rule (LossScaler).
+        self.mma, self.scaler = S.MMA_F32, None
         if _get(t, "fp16_run"):
             half = t.get("half_type", "fp16") if isinstance(t, dict) else getattr(t, "half_type", "fp16")
             if half == "bf16":
                 self.mma = S.MMA_BF16
             else:
-                import warnings
-                warnings.warn("fp16_run with half_type fp16: the MI355X engine has bf16 matrix kernels only (half_type: bf16) — this run "
-                              "trains in fp32 (GradScaler is not needed and not applied)", stacklevel=2)
+                # fp16 operands (v_mfma_f32_32x32x16_f16) need the reference's loss scaling: a gradient below 6e-8 rounds to zero
+                # as an fp16 operand.  The scaler's skip-on-overflow is a host decision per optimizer step (as in the reference:
+                # GradScaler reads found_inf back), so this mode launches eagerly — no whole-iteration hipGraph.
+                self.mma, self.scaler = S.MMA_F16, LossScaler()
 
         self.use_graph = False
         self._graphs = {}
@@ -108,7 +109,7 @@ class TrainStep:
     def __call__(self, items, noise=None):
         """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
         returns a dict of 0-dim device tensors."""
-        if self.use_graph:
+        if self.use_graph and self.scaler is None:
             items = self._dense_spec(items)
             if all(r is not None for r in self._reducers()):
                 return self._call_graph_dp(items, noise)
@@ -204,9 +205,16 @@ class TrainStep:
     def _step_body(self, items, noise=None):
         try:
             ctx = self._seg_d(items, noise)
-            self.optim_d.step()
-            out = self._seg_g(ctx)
-            self.optim_g.step()
+            if self.scaler is None:
+                self.optim_d.step()
+                out = self._seg_g(ctx)
+                self.optim_g.step()
+            else:                                    # train.py:192-213: scale -> backward -> unscale -> step (or skip) -> update
+                self.scaler.step(self.optim_d)
+                out = self._seg_g(ctx)
+                self.scaler.step(self.optim_g)
+                self.scaler.update()
+                out["loss_scale"] = self.scaler.scale
         finally:
             # gradients consumed (or the step raised): later backward passes in this process must not receive views of a
             # slab that the next reset() zeroes
@@ -250,7 +258,7 @@ class TrainStep:
             self.plan_sets.leave("d")
         loss_disc, _, _ = discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
-        loss_disc.backward()
+        (loss_disc * self.scaler.scale if self.scaler is not None else loss_disc).backward()
         return dict(y=y, y_hat=y_hat, y_mel=y_mel, y_hat_mel=y_hat_mel, z_p=z_p, logs_q=logs_q, m_p=m_p, logs_p=logs_p,
                     z_mask=z_mask, pred_lf0=pred_lf0, lf0=lf0, loss_disc=loss_disc)
 
@@ -276,7 +284,7 @@ class TrainStep:
             loss_lf0 = 0
         loss_gen_all = loss_gen + loss_fm + loss_mel + loss_kl + loss_lf0
         self.optim_g.zero_grad()
-        loss_gen_all.backward()
+        (loss_gen_all * self.scaler.scale if self.scaler is not None else loss_gen_all).backward()
         loss_disc = ctx["loss_disc"]
         return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
                     loss_mel=loss_mel.detach(), loss_kl=loss_kl.detach(),

@@ -70,3 +70,36 @@ def test_transposed_conv_map(Cin, Cout, KS, u):
     wd = torch.nn.functional.pad(w, (0, M * u - KS)).view(Cin, Cout, M, u).flip(2).permute(3, 1, 0, 2).reshape(u * Cout, Cin, M)
     a, b = emulate(plan, w.numpy()), operands(wd, plan)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_loss_scaler_follows_gradscaler_rule():
+    """optim.LossScaler = torch.cuda.amp.GradScaler's bookkeeping (train.py:143,192-213): skip + halve on a non-finite gradient of
+    EITHER optimizer of an iteration, double after `growth_interval` clean iterations, 1/scale handed to the optimizer."""
+    from optim import LossScaler
+
+    class Opt:
+        def __init__(self):
+            self.finite, self.steps, self.grad_scale = True, 0, None
+
+        def grads_finite(self):
+            return self.finite
+
+        def step(self):
+            self.steps += 1
+
+    sc = LossScaler(init_scale=1024.0, growth_interval=3)
+    d, g = Opt(), Opt()
+    assert sc.step(d) and sc.step(g) and d.grad_scale == 1 / 1024.0
+    sc.update()
+    assert sc.scale == 1024.0
+    d.finite = False                                   # D overflows: its step is skipped, G's is not, the scale halves ONCE
+    assert not sc.step(d) and sc.step(g)
+    sc.update()
+    assert sc.scale == 512.0 and d.steps == 1 and g.steps == 2 and sc.skipped == 1
+    d.finite = True
+    for i in range(3):                                 # three clean iterations (the counter restarted at the overflow) -> x2
+        sc.step(d); sc.step(g); sc.update()
+    assert sc.scale == 1024.0 and g.grad_scale == 1 / 512.0
+    sc2 = LossScaler()
+    sc2.load_state_dict(sc.state_dict())
+    assert sc2.scale == sc.scale and LossScaler().scale == 65536.0
