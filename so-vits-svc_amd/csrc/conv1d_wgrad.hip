@@ -64,20 +64,61 @@ template <> struct WOp16<SVC_MMA_F16> {
   static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+// ---- LDS-DMA staging (DMA = true) -------------------------------------------------------------------------------------
+// The register-staged tile hand-over above costs a launch more than its MFMAs when a tap group is short: per 64-step tile a
+// thread issues 64 global loads, waits for them behind the MFMA loop, writes 64 LDS words and passes two barriers — 4.3 us per
+// tile against 1.9 us of matrix work at one tap (profiles/r05k_wgrad_k1_target_sweep.txt: 97.8 / 54.7 / 33.7 us at 20 / 10 / 5
+// tiles per workgroup), the same with 16-bit operands.  With DMA = true the tiles go from global memory / L2 straight into LDS
+// (global_load_lds_dword: one instruction = one 64-step row piece, 256 B, written at an M0-given LDS address — so the ODD row
+// pitch of the operand fetch survives, which the 16 B form's lane-linear image would not allow), double-buffered: the pieces of
+// tile i + 1 are issued BETWEEN the MFMAs of tile i (one piece behind each of the first MFMAs of a macro-step, pinned with
+// sched_barrier: the ~13 scalar / vector instructions of a piece run in the shadow of the 64-cycle matrix instruction), no
+// staging registers, no LDS writes, ONE barrier per tile.  Zero padding (time steps outside [0, TB), the tail of the last
+// tile) = the lane reads a zero word instead; rows past Ca / Cb are clamped (their accumulators are never written out).
+__device__ float g_wgrad_zero[4];
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) — the macro-step schedules below index registers and DMA
+// pieces by it (a `#pragma unroll` loop whose body differs per iteration was peeled instead: the remaining iterations became a
+// run-time loop over the accumulator array, 80 v_accvgpr copies per tile)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// tile buffers of the LDS-DMA form (taps per workgroup, 32-row MFMA tiles per wave along ca): host and device agree on this
+constexpr __host__ __device__ int wgrad_nbuf(int nk, int mt) { return mt == 1 ? 3 : 2; }
+
+__device__ __forceinline__ void glds4(const void* g, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_byte));
+}
+__device__ __forceinline__ void wg_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // MMA (svc_wgrad_args.mma = SVC_MMA_BF16 / SVC_MMA_F16): the staged fp32 tiles are multiplied on v_mfma_f32_32x32x16_{bf16,f16} — an
 // instruction reduces 16 time steps, lane half lk supplying steps 8*lk .. 8*lk + 7 of its channel row, rounded to the 16-bit format
 // (round to nearest even) as they are read; fp32 accumulation, the bias gradient is summed from the fp32 tile as before.
-template <int NK, int MMA = SVC_MMA_F32>
+template <int NK, int MMA = SVC_MMA_F32, bool DMA = false, int MT = 2>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
+  // MT: 32-row MFMA tiles per wave along ca (workgroup block 64*MT x 64).  MT = 1 halves the block a workgroup adds into G —
+  // the launch's atomic volume is (workgroups x block), and the combine pass is bound by L2's one-dword-per-clock-per-channel
+  // atomic rate: ~7.5 us per tap plane of a 128 x 64 block at 256 workgroups (profiles/r05q_wgrad_dma_sweep.txt: a launch costs
+  // ~8 us + 7.5 us x NK on top of its tiles) — at the price of twice as many, half as long tiles per workgroup.
+  static_assert(MT == 2 || (MT == 1 && DMA), "wgrad: 64-row blocks exist in the LDS-DMA form only");
+  constexpr int CAT = 64 * MT;
   extern __shared__ float lds[];
-  float* As = lds;               // [CA_T][PA]
-  float* Bs = lds + CA_T * PA;   // [CB_T][PB]
+  float* As = lds;               // [CAT][PA]
+  float* Bs = lds + CAT * PA;   // [CB_T][PB]
   const int PB = p.PB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): row pointers below stay scalar
   const int ln = lane & 31, lk = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ca0 = blockIdx.y * CA_T, cb0 = blockIdx.z * CB_T;
+  const int ca0 = blockIdx.y * CAT, cb0 = blockIdx.z * CB_T;
   const int kg = blockIdx.x % p.n_kgroups;
   const int split = blockIdx.x / p.n_kgroups;
   const int k0 = kg * NK;
@@ -88,16 +129,16 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
   const int XWB = TT + halo;
   const int boff = k0 * p.dil - p.pad;             // Bm index = t + boff + q*dil
 
-  f32x16 acc[NK][2];
+  f32x16 acc[NK][MT];
 #pragma unroll
   for (int q = 0; q < NK; ++q)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
 
   // staging maps: A slot i -> row i*4 + wave, column lane;  B slot (j,cj) -> row j*4 + wave, column cj*64 + lane
-  float areg[CA_T / 4];
+  float areg[CAT / 4];
   float breg[(CB_T / 4) * BCOLS];
 
   auto load_tile = [&](int tile) {
@@ -108,7 +149,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     // addresses = wave-uniform row pointer (SGPRs) + one 32-bit lane offset: no per-slot 64-bit address registers
     const int ta = min(t0 + lane, p.TA - 1);
 #pragma unroll
-    for (int i = 0; i < CA_T / 4; ++i) {
+    for (int i = 0; i < CAT / 4; ++i) {
       const int ca = min(ca0 + i * 4 + wave, p.Ca - 1);
       areg[i] = (ab + (long long)ca * p.a_cs)[ta];
     }
@@ -128,7 +169,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     const int t0 = (tile - b * p.tiles_per_b) * TT;
     const bool ta_ok = t0 + lane < p.TA;
 #pragma unroll
-    for (int i = 0; i < CA_T / 4; ++i) {
+    for (int i = 0; i < CAT / 4; ++i) {
       const int r = i * 4 + wave;
       As[r * PA + lane] = (ta_ok && ca0 + r < p.Ca) ? areg[i] : 0.f;
     }
@@ -147,12 +188,158 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
 
   // bias gradient (optional): row sums of the A tiles, taken by the workgroups of the first cb tile / tap group
   const bool do_bias = p.dbias != nullptr && blockIdx.z == 0 && kg == 0;
-  float bsum = 0.f;                       // thread tid: row tid >> 1, columns (tid & 1) * 32 .. + 32
-  const float* brow_sum = As + (tid >> 1) * PA + (tid & 1) * 32;
+  constexpr int TPR = 256 / CAT, BSC = TT / TPR;   // threads per A row (2 / 4), columns each sums
+  float bsum = 0.f;                       // thread tid: row tid / TPR, columns (tid % TPR) * BSC .. + BSC
+  const float* brow_sum = As + (tid / TPR) * PA + (tid % TPR) * BSC;
 
-  const float* ap = As + (wm * 64 + ln) * PA + lk;
+  const float* ap = As + (wm * (32 * MT) + ln) * PA + lk;
   const float* bp = Bs + (wn * 32 + ln) * PB + lk;
   const int dil = p.dil;
+  if constexpr (DMA) {
+    // ---- LDS-DMA multi-buffered tiles (see glds4 above) ----
+    // NBUF tile buffers, pieces issued NBUF - 1 tiles ahead, one behind each of the first MFMAs of every macro-step.  Three for the
+    // 64-row blocks (50 KiB each): a piece then has a whole tile's MFMA loop to land whichever MFMA it was issued behind — with two
+    // the last pieces of a tile had no time to land before the next tile's wait (one memory round trip exposed per tile: 5.8 us
+    // per 2.8 us tile at 3 taps, profiles/r05r_*; three buffers: 768 x 192 x 3 taps 163 -> 149 us, 128 x 128 x 11 122 -> 116 us,
+    // profiles/r05s_*).  Two for the 128-row blocks (66 KiB each at 2..5 taps; a third buffer for their one-tap form measured
+    // slower, 29.7 -> 32.8 us: two more tiles of pieces per workgroup of five tiles), whose tiles are long enough to cover most of
+    // it (10.4 us per 9.3 us tile at 5 taps); issuing their pieces behind the FIRST MFMAs of the tile instead was slower still
+    // (384 x 192 x 5: 129 -> 138 us — a piece's ~12 instructions do not fit under every consecutive MFMA).
+    constexpr int NBUF = wgrad_nbuf(NK, MT), AHEAD = NBUF - 1;
+    constexpr int BC = NK == 1 ? 1 : 2;            // 64-column pieces per Bm row (PB = 65 / 129: set by the launcher)
+    constexpr int NP = CAT / 4 + (CB_T / 4) * BC; // pieces per wave and tile: A rows i*4 + wave, then Bm rows j*4 + wave x BC
+    const int BUF_F = CAT * PA + CB_T * PB;       // floats per buffer
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const char* zsrc = reinterpret_cast<const char*>(g_wgrad_zero);
+    const long long a_csb = p.a_cs * 4, b_csb = p.b_cs * 4;
+    // lane state of the tile whose pieces are being issued
+    const char* n_ab = nullptr;
+    const char* n_bb = nullptr;
+    unsigned n_lds = 0, n_aoff = 0, n_boff[BC];
+    bool n_aok = false, n_bok[BC];
+    auto set_next = [&](int tile, int nbuf) {
+      const bool live = tile < tile1;              // past the range: every lane reads the zero word (no branches in the loop)
+      const int tl = live ? tile : tile0;
+      const int b = tl / p.tiles_per_b;
+      const int t0 = (tl - b * p.tiles_per_b) * TT;
+      n_ab = reinterpret_cast<const char*>(p.A + (long long)b * p.a_bs);
+      n_bb = reinterpret_cast<const char*>(p.Bm + (long long)b * p.b_bs);
+      const int ta = t0 + lane;
+      n_aok = live && ta < p.TA;
+      n_aoff = (unsigned)ta * 4u;
+#pragma unroll
+      for (int cj = 0; cj < BC; ++cj) {
+        const int tb = t0 + boff + cj * 64 + lane;
+        n_bok[cj] = live && tb >= 0 && tb < p.TB;
+        n_boff[cj] = (unsigned)tb * 4u;
+      }
+      n_lds = lds0 + (unsigned)(nbuf * BUF_F) * 4u;
+    };
+    auto dma_piece = [&](int pi) {                 // pi: compile-time after unrolling
+      if (pi < CAT / 4) {
+        const int r = pi * 4 + wave;
+        const char* row = n_ab + (long long)min(ca0 + r, p.Ca - 1) * a_csb;
+        const char* src = n_aok ? row + n_aoff : zsrc;
+        glds4(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(n_lds + (unsigned)(r * PA) * 4u)));
+      } else {
+        const int j = (pi - CAT / 4) / BC, cj = (pi - CAT / 4) % BC;
+        const int r = j * 4 + wave;
+        const char* row = n_bb + (long long)min(cb0 + r, p.Cb - 1) * b_csb;
+        const char* src = n_bok[cj] ? row + n_boff[cj] : zsrc;
+        glds4(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(n_lds + (unsigned)(CAT * PA + r * PB + cj * 64) * 4u)));
+      }
+    };
+    static_assert(NBUF == 2 || NP <= 63, "wgrad dma: s_waitcnt vmcnt holds 6 bits");
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {      // (past the range: zero-source pieces — every tile slot issues exactly NP pieces)
+      set_next(tile0 + a, a);
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) dma_piece(pi);
+    }
+    int buf = 0;
+    for (int tile = tile0; tile < tile1; ++tile, buf = buf + 1 == NBUF ? 0 : buf + 1) {
+      // this wave's pieces of `tile` have landed (LDS-DMA loads complete in order: the NP pieces of tile + 1 may still fly)
+      if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else wg_vmcnt0();
+      __syncthreads();   // ... everyone's have; everyone is done reading the buffer of tile - 1
+      set_next(tile + AHEAD, buf + AHEAD >= NBUF ? buf + AHEAD - NBUF : buf + AHEAD);
+      const float* apb = ap + buf * BUF_F;
+      const float* bpb = bp + buf * BUF_F;
+      if (do_bias) {
+        const float* bs = brow_sum + buf * BUF_F;
+#pragma unroll
+        for (int c = 0; c < BSC; ++c) bsum += bs[c];
+      }
+      if constexpr (MMA != SVC_MMA_F32) {
+        // 4 macro-steps of 16 time steps; operands of macro-step g + 1 are read (and rounded) in front of the MFMAs of g
+        typedef WOp16<MMA == SVC_MMA_F32 ? SVC_MMA_BF16 : MMA> OP;
+        constexpr int G = TT / 16, PPG = NP / G, PPM = (PPG + MT * NK - 1) / (MT * NK);   // pieces per group / behind each MFMA
+        static_assert(NP % G == 0, "wgrad dma: pieces per macro-step");
+        const float* ap8 = apb + 7 * lk;
+        const float* bp8 = bpb + 7 * lk;
+        typename OP::frag fa[2][MT], fb[2][NK];
+        auto load16 = [&](int slot, int s) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            f32x8v t0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t0[j] = ap8[i * 32 * PA + s + j];
+            fa[slot][i] = OP::cvt(t0);
+          }
+#pragma unroll
+          for (int q = 0; q < NK; ++q) {
+            f32x8v tb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tb[j] = bp8[s + q * dil + j];
+            fb[slot][q] = OP::cvt(tb);
+          }
+        };
+        load16(0, 0);
+        static_for<0, G>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          if constexpr (g + 1 < G) load16((g + 1) & 1, 16 * (g + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, NK * MT>([&](auto ec) {
+            constexpr int e = decltype(ec)::value, q = e / MT, i = e % MT;
+            acc[q][i] = OP::mfma(fa[g & 1][i], fb[g & 1][q], acc[q][i]);
+            static_for<0, PPM>([&](auto xc) {
+              constexpr int d = e * PPM + decltype(xc)::value;
+              if constexpr (d < PPG && g * PPG + d < NP) dma_piece(g * PPG + d);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      } else {
+        // 16 macro-steps of 4 time steps (two MFMA steps s, s + 2 per operand pair: ds_read2_b32); operands of macro-step
+        // m + 1 are read in front of the MFMAs of m
+        constexpr int G = TT / 4, PPG = NP / G;
+        static_assert(NP % G == 0 && PPG <= 2 * MT * NK, "wgrad dma: pieces per macro-step");
+        float oa[2][MT][2], ob[2][NK][2];         // [slot][row tile | tap][step]
+        auto load32 = [&](int slot, int s) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) oa[slot][i][h] = apb[i * 32 * PA + s + 2 * h];
+#pragma unroll
+            for (int q = 0; q < NK; ++q) ob[slot][q][h] = bpb[s + q * dil + 2 * h];
+          }
+        };
+        load32(0, 0);
+        static_for<0, G>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          if constexpr (m + 1 < G) load32((m + 1) & 1, 4 * (m + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, 2 * NK * MT>([&](auto ec) {
+            constexpr int e = decltype(ec)::value, h = e / (NK * MT), q = (e / MT) % NK, i = e % MT;
+            acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[m & 1][i][h], ob[m & 1][q][h], acc[q][i], 0, 0, 0);
+            if constexpr (e < PPG && m * PPG + e < NP) dma_piece(m * PPG + e);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      }
+    }
+    wg_vmcnt0();   // the zero-source pieces issued during the last tile: landed before the epilogue reuses the buffers
+  } else {
   if (tile0 < tile1) load_tile(tile0);
   for (int tile = tile0; tile < tile1; ++tile) {
     __syncthreads();   // previous tile fully consumed
@@ -210,10 +397,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     }
     }
   }
+  }
   if (do_bias) {
     bsum += __shfl_xor(bsum, 1);
-    const int ca = ca0 + (tid >> 1);
-    if ((tid & 1) == 0 && ca < p.Ca) atomicAdd(p.dbias + ca, bsum);
+    if (TPR == 4) bsum += __shfl_xor(bsum, 2);
+    const int ca = ca0 + tid / TPR;
+    if (tid % TPR == 0 && ca < p.Ca) atomicAdd(p.dbias + ca, bsum);
   }
   // combine: G[ca][cb][k0..k0+nk) += acc.  The MFMA C layout has one cb column per lane (addresses KS floats apart), so
   // each wave first transposes 16 ca rows at a time through LDS into G's own [cb][k] order: consecutive lanes then
@@ -230,7 +419,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
     float* Wt = lds + wave * 16 * (32 * NK + 1);
     const int cbw = cb0 + wn * 32;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -246,7 +435,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
         }
         __syncthreads();   // slab written (uniform trip counts: every wave reaches the barriers)
         // rows of this half: MFMA row (r&3) + 8*(r>>2) + 4*lk with r in [8hf, 8hf+8) -> 16*hf + rl
-        const int ca_base = ca0 + wm * 64 + i * 32 + 16 * hf;
+        const int ca_base = ca0 + wm * (32 * MT) + i * 32 + 16 * hf;
         for (int rl = 0; rl < 16; ++rl) {
           const int ca = ca_base + rl;
           if (ca >= p.Ca) break;              // wave-uniform
@@ -426,17 +615,39 @@ void launch_small(const WgSP& p, dim3 grid, size_t lds, hipStream_t s) {
 
 int g_wgrad_bf16_launches = 0;
 
-template <int NK>
-void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma) {
-  if (mma == SVC_MMA_BF16) {
-    ++g_wgrad_bf16_launches;
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_BF16>), grid, dim3(256), lds, s, p);
-  } else if (mma == SVC_MMA_F16) {
-    ++g_wgrad_bf16_launches;
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_F16>), grid, dim3(256), lds, s, p);
-  } else {
-    hipLaunchKernelGGL((conv1d_wgrad_kernel<NK, SVC_MMA_F32>), grid, dim3(256), lds, s, p);
+// staging form of the tile kernel: 0 register-staged, 1 LDS-DMA double buffer, 2 (default) by rule
+// (svc_debug_set_wgrad_target(200000 + v), SVC_WGRAD_DMA)
+int g_wgrad_dma = -1;
+
+// block rows of the LDS-DMA form: 0 = by rule (see svc_conv1d_wgrad_f32), 1 = 64, 2 = 128 (svc_debug_set_wgrad_target(300000 + v))
+int g_wgrad_mt = 0;
+
+template <int NK, int MMA, bool DMA, int MT>
+void launch_one(const WgP& p, dim3 grid, size_t lds, hipStream_t s) {
+  auto k = conv1d_wgrad_kernel<NK, MMA, DMA, MT>;
+  if constexpr (DMA) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
   }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, p);
+}
+
+template <int NK, bool DMA, int MT>
+void launch_fmt(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma) {
+  if (mma == SVC_MMA_BF16) launch_one<NK, SVC_MMA_BF16, DMA, MT>(p, grid, lds, s);
+  else if (mma == SVC_MMA_F16) launch_one<NK, SVC_MMA_F16, DMA, MT>(p, grid, lds, s);
+  else launch_one<NK, SVC_MMA_F32, DMA, MT>(p, grid, lds, s);
+}
+
+template <int NK>
+void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma, bool dma, int mt) {
+  if (mma == SVC_MMA_BF16 || mma == SVC_MMA_F16) ++g_wgrad_bf16_launches;
+  if (dma && mt == 1) launch_fmt<NK, true, 1>(p, grid, lds, s, mma);
+  else if (dma) launch_fmt<NK, true, 2>(p, grid, lds, s, mma);
+  else launch_fmt<NK, false, 2>(p, grid, lds, s, mma);
 }
 
 }  // namespace
@@ -445,7 +656,9 @@ extern "C" int svc_debug_wgrad_bf16_launches(void) { return g_wgrad_bf16_launche
 
 extern "C" int svc_debug_set_wgrad_target(int workgroups) {
   if (workgroups == 0) return SVC_ERR_BAD_ARG;
-  if (workgroups > 100000) g_wgrad_k12_target = workgroups - 100000;   // the 1- / 2-tap launches of the tile kernel
+  if (workgroups >= 300000) g_wgrad_mt = workgroups - 300000;            // block rows of the LDS-DMA form (0: rule)
+  else if (workgroups >= 200000) g_wgrad_dma = workgroups - 200000;      // staging form of the tile kernel: 0 registers, 1 LDS-DMA, 2 rule
+  else if (workgroups > 100000) g_wgrad_k12_target = workgroups - 100000;   // the 1- / 2-tap launches of the tile kernel
   else if (workgroups > 0) g_wgrad_target = workgroups;
   else g_wgrad_small_target = -workgroups;      // negative: the small-channel kernel's target
   return SVC_OK;
@@ -529,28 +742,55 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   p.n_kgroups = svc::cdiv(a.KS, nk);
   p.tiles_per_b = svc::cdiv(a.TA, TT);
   p.n_tiles = p.tiles_per_b * a.B;
-  const int n_ca = svc::cdiv(a.Ca, CA_T), n_cb = svc::cdiv(a.Cb, CB_T);
+  if (g_wgrad_dma < 0) {
+    const char* e = getenv("SVC_WGRAD_DMA");
+    g_wgrad_dma = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+  }
+  const int n_cb = svc::cdiv(a.Cb, CB_T);
   // enough time-splits to fill the chip (every split costs one prologue and one atomic pass over G), at least 2 tiles each so
-  // the prefetch has something to hide.  The 1- and 2-tap instantiations fit two workgroups per CU (512 resident), the 3..5-tap
-  // ones (96-160 accumulator registers) one: their target is tunable (svc_debug_set_wgrad_target)
-  const int target = nk >= 3 ? g_wgrad_target : g_wgrad_k12_target;
-  int splits = std::max(1, target / (n_ca * n_cb * p.n_kgroups));
-  splits = std::min(splits, std::max(1, p.n_tiles / 2));
-  p.tiles_per_wg = svc::cdiv(p.n_tiles, splits);
-  splits = svc::cdiv(p.n_tiles, p.tiles_per_wg);
+  // the prefetch has something to hide: the target is tunable (svc_debug_set_wgrad_target)
+  // (1- and 2-tap register-staged workgroups fit two per CU: a launch of >= 128 blocks — DiscriminatorP's 1024 x 1536 x 2 taps,
+  //  192 blocks — runs as 384 co-resident workgroups of half the tiles: 658 -> 526 us, 16-bit operands 357 -> 214 us,
+  //  profiles/r05r_*; the few-block 1 x 1 layers stay at one round of 256, profiles/r05k_*)
+  int target = nk >= 3 ? g_wgrad_target : g_wgrad_k12_target;
+  if (nk < 3 && g_wgrad_k12_target == 256 && svc::cdiv(a.Ca, CA_T) * n_cb * p.n_kgroups >= 128) target = 512;
+  auto plan = [&](int rows, int& n_ca, int& splits, int& tiles_per_wg) {
+    n_ca = svc::cdiv(a.Ca, rows);
+    splits = std::max(1, target / (n_ca * n_cb * p.n_kgroups));
+    splits = std::min(splits, std::max(1, p.n_tiles / 2));
+    tiles_per_wg = svc::cdiv(p.n_tiles, splits);
+    splits = svc::cdiv(p.n_tiles, tiles_per_wg);
+  };
+  // Staging form and block rows (kernel header).  Measured on the training step's shapes (profiles/r05s_wgrad_dma_triple_buffer_sweep.txt,
+  // 256 workgroups, register-staged 128 x 64 -> LDS-DMA 64 x 64): 64-row blocks win wherever the launch is split over time many
+  // times — 6 blocks x 42 splits (192 x 192): 5 taps 91.8 -> 73.7 us, 3 taps 66.7 -> 51.2, 1 tap 32.9 -> 24.7; 128 x 128 x 11 taps
+  // 147 -> 116; 9 blocks x 28 splits (384 x 192 x 5) 130 -> 121 (16-bit operands 72 -> 58) — or 128 rows would be padding (Ca = 192:
+  // 192 x 768 x 3 taps 197 -> 148); they change nothing at 18 blocks x 14 splits (768 x 192 x 3: 145 / 149) and lose where the
+  // tile loop is all there is (128 blocks x 2 splits, 1024 x 1024 x 5 taps: 611 -> 705).  One tap with few splits: LDS-DMA on
+  // 128-row blocks (384 x 192: 43.3 -> 38.1 us, 16-bit 42.9 -> 28.3).
+  int n_ca, splits, tiles_per_wg;
+  plan(CA_T, n_ca, splits, tiles_per_wg);
+  const int ca_rem = a.Ca % CA_T;
+  int mt = 2;
+  if (g_wgrad_mt == 1 || (g_wgrad_mt == 0 && g_wgrad_dma != 0 && (splits >= 16 || (ca_rem > 0 && ca_rem <= CA_T / 2 && splits >= 4)))) mt = 1;
+  const bool dma = g_wgrad_dma == 1 || mt == 1 || (g_wgrad_dma == 2 && nk == 1);
+  if (mt == 1) plan(CA_T / 2, n_ca, splits, tiles_per_wg);
+  p.tiles_per_wg = tiles_per_wg;
   p.splits = splits;
+  // the DMA pieces are 4-byte loads at (row base + 4 * t): any row / batch stride, any time offset
   int pb = TT + (nk - 1) * a.dil;
   if ((pb & 1) == 0) ++pb;
+  if (dma) pb = nk == 1 ? TT + 1 : 2 * TT + 1;     // whole 64-column pieces per row (one / two), odd pitch
   p.PB = pb;
-  size_t lds = sizeof(float) * ((size_t)CA_T * PA + (size_t)CB_T * pb);
+  size_t lds = sizeof(float) * ((size_t)(32 * mt * 2) * PA + (size_t)CB_T * pb) * (dma ? wgrad_nbuf(nk, mt) : 1);
   lds = std::max(lds, sizeof(float) * (size_t)4 * 16 * (32 * 5 + 1));     // epilogue transpose slabs
   dim3 grid(splits * p.n_kgroups, n_ca, n_cb);
   switch (nk) {
-    case 1: launch<1>(p, grid, lds, s, a.mma); break;
-    case 2: launch<2>(p, grid, lds, s, a.mma); break;
-    case 3: launch<3>(p, grid, lds, s, a.mma); break;
-    case 4: launch<4>(p, grid, lds, s, a.mma); break;
-    default: launch<5>(p, grid, lds, s, a.mma); break;
+    case 1: launch<1>(p, grid, lds, s, a.mma, dma, mt); break;
+    case 2: launch<2>(p, grid, lds, s, a.mma, dma, mt); break;
+    case 3: launch<3>(p, grid, lds, s, a.mma, dma, mt); break;
+    case 4: launch<4>(p, grid, lds, s, a.mma, dma, mt); break;
+    default: launch<5>(p, grid, lds, s, a.mma, dma, mt); break;
   }
   return svc::check_launch("conv1d_wgrad");
 }

@@ -49,6 +49,46 @@ def test_conv1d_dense_fwd_bwd(dev, B, Cin, Cout, T, K, dil, pad):
               t, dev)
 
 
+@pytest.mark.parametrize("B,Ca,Cb,T,K,dil,pad", [
+    (3, 100, 70, 333, 7, 2, 6), (2, 192, 192, 768, 1, 1, 0), (2, 384, 192, 770, 5, 1, 2), (4, 130, 65, 129, 3, 1, 1),
+    (2, 256, 128, 132, 5, 11, 22), (1, 64, 200, 1000, 2, 11, 11), (2, 96, 96, 63, 4, 3, 0), (1, 128, 64, 4096, 11, 1, 5)])
+def test_conv1d_wgrad_lds_dma_and_register_staged_tiles(dev, B, Ca, Cb, T, K, dil, pad):
+    """The tile kernel's forms (LDS-DMA double buffer with 64- / 128-row blocks, register-staged tiles; svc_debug_set_wgrad_target
+    200000 + form / 300000 + block) against torch's float64 weight gradient: tail tiles, channel tails, left / right zero padding, several time splits,
+    non-contiguous channel strides (a channel slice of a wider tensor), the bias gradient."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(B * 7 + Ca + Cb + T + K)
+    Tout = T + 2 * pad - dil * (K - 1)          # A = dy over Tout steps, Bm = x over T
+    dy_w = torch.randn(B, Ca + 5, Tout, generator=g)
+    x = torch.randn(B, Cb, T, generator=g)
+    dy = dy_w[:, 3:3 + Ca]                      # channel slice: batch stride (Ca + 5) * Tout
+    w = torch.zeros(Ca, Cb, K, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(x.double(), w, dilation=dil, padding=pad)
+    assert y.shape[-1] == Tout
+    (ref,) = torch.autograd.grad(y, w, dy.double())
+    scale = ref.abs().max().item()
+    outs = []
+    try:
+        for dma, mt in ((1, 1), (1, 2), (0, 2), (2, 0)):      # LDS-DMA 64 / 128-row blocks, register-staged, the dispatcher's rule
+            S.tlib().svc_debug_set_wgrad_target(200000 + dma)
+            S.tlib().svc_debug_set_wgrad_target(300000 + mt)
+            for tg in (256, 24):
+                S.tlib().svc_debug_set_wgrad_target(tg)
+                S.tlib().svc_debug_set_wgrad_target(100000 + tg)
+                db = torch.zeros(Ca, device=dev)
+                G = S.conv1d_wgrad(dy_w.to(dev)[:, 3:3 + Ca], x.to(dev), K, dil, pad, out=torch.zeros(Ca, Cb, K, device=dev),
+                                   accumulate=True, dbias=db)
+                torch.cuda.synchronize()
+                assert (G.cpu().double() - ref).abs().max().item() <= 2e-5 * scale, (dma, mt, tg)
+                assert (db.cpu() - dy.sum((0, 2))).abs().max().item() <= 1e-4 * max(dy.sum((0, 2)).abs().max().item(), 1.0)
+                outs.append(G)
+    finally:
+        S.tlib().svc_debug_set_wgrad_target(200002)
+        S.tlib().svc_debug_set_wgrad_target(300000)
+        S.tlib().svc_debug_set_wgrad_target(256)
+        S.tlib().svc_debug_set_wgrad_target(100256)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,s,pad", [(2, 1, 32, 2731, 5, 3, 2), (2, 32, 128, 911, 5, 3, 2),
                                                   (1, 1, 64, 8192, 128, 64, 32), (2, 1, 16, 4096, 4, 2, 1),
                                                   (2, 8, 8, 100, 16, 8, 4)])
