@@ -753,7 +753,7 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   //  192 blocks — runs as 384 co-resident workgroups of half the tiles: 658 -> 526 us, 16-bit operands 357 -> 214 us,
   //  profiles/r05r_*; the few-block 1 x 1 layers stay at one round of 256, profiles/r05k_*)
   int target = nk >= 3 ? g_wgrad_target : g_wgrad_k12_target;
-  if (nk < 3 && g_wgrad_k12_target == 256 && svc::cdiv(a.Ca, CA_T) * n_cb * p.n_kgroups >= 128) target = 512;
+  if ((nk == 2 || (nk == 1 && g_wgrad_dma == 0)) && g_wgrad_k12_target == 256 && svc::cdiv(a.Ca, CA_T) * n_cb * p.n_kgroups >= 128) target = 512;
   auto plan = [&](int rows, int& n_ca, int& splits, int& tiles_per_wg) {
     n_ca = svc::cdiv(a.Ca, rows);
     splits = std::max(1, target / (n_ca * n_cb * p.n_kgroups));

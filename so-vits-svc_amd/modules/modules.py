@@ -7,6 +7,8 @@ parameter names (state_dict compatible); every forward is a sequence of libsvc_h
     Flip                     modules/modules.py:232-239  -> folded into channel strides by ResidualCouplingBlock
     ResBlock1 / ResBlock2    modules/modules.py:149-218  (masked variants; the decoder uses vdecoder.hifigan's)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -16,6 +18,8 @@ from modules.commons import get_padding, init_weights
 from svc_nn import Conv1d, DepthwiseSeparableConv1d, mask2d, training_call
 
 LRELU_SLOPE = 0.1
+# training-time WN layers with fused epilogues (WN.forward_train); SVC_WN_FUSED=0: one autograd op per reference op
+WN_FUSED = os.environ.get("SVC_WN_FUSED", "1") != "0"
 
 _use_depthwise_conv = False
 
@@ -81,18 +85,30 @@ class WN(nn.Module):
         H = self.hidden_channels
         gc = self.cond_layer.forward_train(g) if g is not None else None          # [B, 2H*L, 1|T]
         output = None
+        # fused form (default; SVC_WN_FUSED=0 = one autograd op per reference op): the conditioning add in in_layer's epilogue,
+        # res / skip / mask in res_skip_layer's (the inference path's epilogues, with their adjoints in svc_autograd)
+        fused = WN_FUSED and all(l.fused_train_ok() for l in self.res_skip_layers) and \
+            all(getattr(l, "fused_train_ok", lambda: False)() for l in self.in_layers)
         for i in range(self.n_layers):
+            last = i == self.n_layers - 1
+            if fused:
+                cond = gc[:, i * 2 * H:(i + 1) * 2 * H] if gc is not None else None
+                acts = A.gate(self.in_layers[i].forward_train(x, cond=cond))
+                x, output = self.res_skip_layers[i].forward_train_res_skip(acts, x, output, x_mask, last)
+                continue
             x_in = self.in_layers[i].forward_train(x)
             if gc is not None:
                 x_in = A.add_bcast(x_in, gc[:, i * 2 * H:(i + 1) * 2 * H])
             acts = A.gate(x_in)
             rs = self.res_skip_layers[i].forward_train(acts)
-            if i < self.n_layers - 1:
+            if not last:
                 res, skip = A.chunk_channels(rs, 2)     # one gradient buffer in the backward (no zero-fill + add per half)
                 x = A.mul_bcast(A.add(x, res), x_mask)
             else:
                 skip = rs
             output = skip if output is None else A.add(output, skip)
+        if fused:
+            return output
         return A.mul_bcast(output, x_mask)
 
     def forward(self, x, x_mask, g=None, **kwargs):

@@ -73,7 +73,9 @@ class _ConvPlanned(Function):
     F.pad / permute / copy + pack (+ pack_T, the adjoint copies and weight_norm_bwd in the backward): 4-9 launches -> 2."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, plan, pad, dil, tout, exact):
+    def forward(ctx, x, v, g, bias, plan, pad, dil, tout, exact, cond=None):
+        """`cond` [B, Od, 1|T]: added in the conv's epilogue (WN's `x_in + g_l`, modules/modules.py:123-128 — one launch and
+        one pass over the 2H-channel tensor less than a separate broadcast add)."""
         x = _c(x)
         vd = v.detach()
         gd = g.detach().reshape(-1) if g is not None else None
@@ -92,7 +94,10 @@ class _ConvPlanned(Function):
             y = S.conv1d(x, wp, plan.Od, 1, bias=bias, mma=ctx.mma)               # [1, Od, B]
             y = y.squeeze(0).t().contiguous().unsqueeze(2)                       # [B, Od, 1]
         else:
-            y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma)
+            y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma, cond=cond)
+        if cond is not None and ctx.batch_cols:
+            raise S.SvcError("conv1d_planned: cond with a [B, C, 1] input is not on the path")
+        ctx.cond_shape = tuple(cond.shape) if cond is not None else None
         ctx.save_for_backward(x, v, g)
         ctx.plan = plan
         ctx.cfg = (pad, dil, bias is not None)
@@ -125,7 +130,97 @@ class _ConvPlanned(Function):
                 dg = dgf.view(g.shape)
         elif want_db:
             db = S.reduce_bct(dy, 0)
-        return dx, dv, dg, db, None, None, None, None, None
+        dc = _reduce_to(dy, ctx.cond_shape) if ctx.cond_shape is not None and ctx.needs_input_grad[9] else None
+        return dx, dv, dg, db, None, None, None, None, None, dc
+
+
+class _WNResSkip(Function):
+    """One WN layer's `res_skip_layers[i](acts)` with what follows it (modules/modules.py:130-137) in the conv's epilogue —
+    the inference path's SVC_EPI_RES_SKIP launch:
+        x_new  = (x + rs[:, :H]) * x_mask          (not the last layer)
+        output = output + rs[:, H:]                (in place; the last layer: output = (output + rs) * x_mask, :138)
+    instead of chunk + add + mask-multiply + add (three element-wise launches forward).  Backward: the gradient of the conv
+    output is [dx_new * x_mask ; d_output] written into ONE buffer (two launches instead of the chunk / mask / add adjoints),
+    then dgrad / wgrad / plan.grad as _ConvPlanned.  `output` is None for the first layer."""
+
+    @staticmethod
+    def forward(ctx, acts, x, output, x_mask, v, g, bias, plan, last):
+        acts = _c(acts)
+        B, H, T = acts.shape
+        vd = v.detach()
+        gd = g.detach().reshape(-1) if g is not None else None
+        wp, _ = plan.prepare(vd, gd)
+        first = output is None
+        if first:
+            output = torch.empty((B, H, T), device=acts.device, dtype=torch.float32)
+        else:
+            ctx.mark_dirty(output)
+        ctx.mma = S.current_mma()
+        m = x_mask.detach()
+        if last:
+            # every row is a skip row; res_mode 1 applies the final `output * x_mask`
+            S.conv1d(acts, wp, H, 1, bias=bias, epi=S.EPI_RES_SKIP, res=acts, out=acts, out2=output, skip_from=0, mask=m,
+                     beta=0.0 if first else 1.0, res_mode=1, mma=ctx.mma)
+            x_new = None
+        else:
+            x = _c(x)
+            x_new = torch.empty_like(x)
+            S.conv1d(acts, wp, 2 * H, 1, bias=bias, epi=S.EPI_RES_SKIP, res=x, out=x_new, out2=output, skip_from=H, mask=m,
+                     beta=0.0 if first else 1.0, mma=ctx.mma)
+        ctx.save_for_backward(acts, m, v, g)
+        ctx.plan = plan
+        ctx.cfg = (last, first, bias is not None, H)
+        if last:
+            return output
+        return x_new, output
+
+    @staticmethod
+    def backward(ctx, *grads):
+        acts, m, v, g = ctx.saved_tensors
+        plan = ctx.plan
+        last, first, has_bias, H = ctx.cfg
+        B, _, T = acts.shape
+        if last:
+            (dout,) = grads
+            d_rs = S.ew_bct(S.EW_MUL, _c(dout), m)                  # gradient of (output + rs) * x_mask
+            d_x, d_prev = None, (None if first else d_rs)
+        else:
+            dxn, dout = grads
+            d_rs = torch.empty((B, 2 * H, T), device=acts.device, dtype=torch.float32)
+            if dxn is None:
+                d_rs[:, :H].zero_()
+            else:
+                S.ew_bct(S.EW_MUL, dxn if dxn.stride(2) == 1 else _c(dxn), m, out=d_rs[:, :H])   # (a batch-strided view is fine)
+            if dout is None:
+                d_rs[:, H:].zero_()
+            else:
+                S.copy_bct(_c(dout), out=d_rs[:, H:])
+            d_x = d_rs[:, :H] if ctx.needs_input_grad[1] else None
+            d_prev = None if first else dout
+        d_acts = dv = dg = db = None
+        if ctx.needs_input_grad[0]:
+            d_acts = S.conv1d(d_rs, plan.wt, plan.Id, 1, Tout=T, mma=ctx.mma)
+        want_db = has_bias and ctx.needs_input_grad[6]
+        if ctx.needs_input_grad[4]:
+            if want_db:
+                db, zeroed = S.wgrad_zeros((plan.Od,), acts.device)
+                if not zeroed and S.wgrad_slab.active:
+                    db.zero_()
+            dwd = S.conv1d_wgrad(d_rs, acts, 1, 1, 0, dbias=db, mma=ctx.mma)
+            gd = g.detach().reshape(-1) if g is not None else None
+            dv, dgf = plan.grad(v.detach(), gd, dwd)
+            dv = dv.view(v.shape)
+            dg = dgf.view(g.shape) if g is not None else None
+        elif want_db:
+            db = S.reduce_bct(d_rs, 0)
+        return d_acts, d_x, d_prev, None, dv, dg, db, None, None
+
+
+def wn_res_skip(acts, x, output, x_mask, plan, v, g, bias, last):
+    """See _WNResSkip: returns (x_new, output) — x_new is None for the last layer."""
+    if last:
+        return None, _WNResSkip.apply(acts, x, output, x_mask, v, g, bias, plan, True)
+    return _WNResSkip.apply(acts, x, output, x_mask, v, g, bias, plan, False)
 
 
 class _Decimate(Function):
@@ -570,7 +665,7 @@ def conv_plan(weight_shape, stride=1, padding=0, transposed=False):
 
 
 def conv1d_planned(x, plan, v, g=None, bias=None, stride=1, padding=0, dilation=1, inner=1, lp=None, out_blocks=None,
-                   causal=False):
+                   causal=False, cond=None):
     """conv1d() on a module's parameters through its ConvWeightPlan (groups == 1): v is weight / weight_v, g weight_g or
     None.  causal: left padding (K-1)*dilation only, output length == input length."""
     KS = plan.K
@@ -578,6 +673,11 @@ def conv1d_planned(x, plan, v, g=None, bias=None, stride=1, padding=0, dilation=
         if stride != 1 or inner != 1:
             raise S.SvcError("causal padding with a stride is not on the so-vits-svc path")
         return _ConvPlanned.apply(x, v, g, bias, plan, (KS - 1) * dilation, dilation, x.shape[2], False)
+
+    if cond is not None:
+        if causal or stride != 1 or inner != 1 or lp is not None or out_blocks is not None:
+            raise S.SvcError("conv1d_planned: the cond epilogue exists for plain stride-1 convolutions")
+        return _ConvPlanned.apply(x, v, g, bias, plan, padding, dilation, None, False, cond)
 
     def dense(xx, pad, dil, tout=None, exact=False, strided=None):
         return _ConvPlanned.apply(xx, v, g, bias, plan, pad, dil, tout, exact)

@@ -107,6 +107,15 @@ class Conv1d(nn.Module, _PackedMixin):
         """The [Cout,Cin,KS] weight on the autograd tape (weight-norm folded by svc_weight_norm_fwd_f32)."""
         return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
 
+    def fused_train_ok(self):
+        """Training-time fused epilogues (cond add, WN res / skip) exist for planned stride-1 dense convolutions."""
+        return bool(WEIGHT_PLANS) and self.stride == 1 and not self._is_direct()
+
+    def forward_train_res_skip(self, acts, x, output, x_mask, last):
+        """WN layer tail (svc_autograd._WNResSkip): (x_new, output)."""
+        v, g = (self.weight_v, self.weight_g) if self.is_weight_norm else (self.weight, None)
+        return A.wn_res_skip(acts, x, output, x_mask, self._plan(), v, g, self.bias, last)
+
     def _plan(self):
         """The layer's svc_hip.ConvWeightPlan (index map + persistent operand buffers), built on first use."""
         plan = self.__dict__.get("_svc_plan")
@@ -115,12 +124,15 @@ class Conv1d(nn.Module, _PackedMixin):
             self.__dict__["_svc_plan"] = plan
         return plan
 
-    def forward_train(self, x, causal=False, padding=None):
-        """Autograd form of the plain convolution (no fused prologue/epilogue); `padding` overrides self.padding."""
+    def forward_train(self, x, causal=False, padding=None, cond=None):
+        """Autograd form of the plain convolution; `padding` overrides self.padding; `cond` [B, Cout, 1|T] is added in the
+        epilogue (weight plans only: callers check `fused_train_ok`)."""
         if WEIGHT_PLANS and (padding is None or self.stride == 1):
             v, g = (self.weight_v, self.weight_g) if self.is_weight_norm else (self.weight, None)
             return A.conv1d_planned(x, self._plan(), v, g, self.bias, self.stride,
-                                    self.padding if padding is None else padding, self.dilation, causal=causal)
+                                    self.padding if padding is None else padding, self.dilation, causal=causal, cond=cond)
+        if cond is not None:
+            raise S.SvcError("forward_train: the cond epilogue needs weight plans")
         if padding is not None and not causal:
             return A.conv1d(x, self.effective_weight(), self.bias, self.stride, padding, self.dilation)
         if causal and self.kernel_size > 1:

@@ -89,6 +89,37 @@ def test_conv1d_wgrad_lds_dma_and_register_staged_tiles(dev, B, Ca, Cb, T, K, di
         S.tlib().svc_debug_set_wgrad_target(100256)
 
 
+@pytest.mark.parametrize("gin,n_layers", [(0, 3), (24, 4), (24, 1)])
+def test_wn_fused_training_layers_match_the_op_by_op_form(dev, gin, n_layers):
+    """WN.forward_train with the conditioning add / res / skip / mask in the conv epilogues (default) against the same layers
+    run one autograd op per reference op (modules/modules.py:110-138): output and every gradient."""
+    import modules.modules as M
+    torch.manual_seed(11)
+    B, H, T = 3, 64, 333
+    wn = M.WN(H, 5, 2, n_layers, gin_channels=gin).to(dev)
+    for p_ in wn.parameters():
+        p_.data.normal_(0, 0.2)
+    lens = torch.tensor([T, T - 77, T - 200])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).to(dev)
+    x0 = torch.randn(B, H, T, device=dev)
+    g0 = torch.randn(B, gin, 1, device=dev) if gin else None
+    go = torch.randn(B, H, T, device=dev)
+    res = {}
+    for fused in (True, False):
+        M.WN_FUSED = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            g = g0.clone().requires_grad_(True) if gin else None
+            wn.zero_grad(set_to_none=True)
+            y = wn.forward_train(x, x_mask, g=g)
+            y.backward(go)
+            res[fused] = [y.detach(), x.grad] + ([g.grad] if gin else []) + [p_.grad.clone() for p_ in wn.parameters()]
+        finally:
+            M.WN_FUSED = True
+    for a, b in zip(res[True], res[False]):
+        _close(a, b, 2e-5, "fused vs op-by-op")
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,s,pad", [(2, 1, 32, 2731, 5, 3, 2), (2, 32, 128, 911, 5, 3, 2),
                                                   (1, 1, 64, 8192, 128, 64, 32), (2, 1, 16, 4096, 4, 2, 1),
                                                   (2, 8, 8, 100, 16, 8, 4)])
