@@ -6,6 +6,7 @@ fused qkv projection (one MFMA conv, Cout = 3C), flash-style attention with the 
 output projection, residual+LayerNorm, FFN conv1 (+mask+ReLU), FFN conv2 (+masks), residual+LayerNorm (+final mask).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -16,6 +17,8 @@ from svc_nn import Conv1d, _no_grad_guard, mask2d, training_call
 from modules.modules import LayerNorm
 
 MASK_NONE, MASK_PADDING, MASK_CAUSAL = 0, 1, 2
+# training-time epilogue fusions (FFN: ReLU and masks in the conv epilogues); SVC_FUSED_TRAIN=0: one autograd op per reference op
+FUSED_TRAIN = os.environ.get("SVC_FUSED_TRAIN", "1") != "0"
 
 
 class MultiHeadAttention(nn.Module):
@@ -139,10 +142,17 @@ class FFN(nn.Module):
         k = self.kernel_size
         if k % 2 == 0 and not self.causal:
             raise NotImplementedError("even FFN kernel sizes with 'same' padding are not on the so-vits-svc path")
-        h = self.conv_1.forward_train(A.mul_bcast(x, x_mask), causal=self.causal, padding=(k - 1) // 2)
-        h = A.relu(h)
         if drop is None:
             drop = DropoutDraws(self.p_dropout, self.training)
+        if FUSED_TRAIN and self.conv_1.fused_train_ok() and self.conv_2.fused_train_ok():
+            # ReLU and the `* x_mask` in front of conv_2 (:343-345) in conv_1's epilogue — the mask commutes with the dropout
+            # between them (both multiply element-wise, the mask by 0 / 1) —, the final mask in conv_2's
+            h = self.conv_1.forward_train(A.mul_bcast(x, x_mask), causal=self.causal, padding=(k - 1) // 2, mask=x_mask,
+                                          post_act=S.ACT_RELU)
+            h = drop(h)
+            return self.conv_2.forward_train(h, causal=self.causal, padding=(k - 1) // 2, mask=x_mask)
+        h = self.conv_1.forward_train(A.mul_bcast(x, x_mask), causal=self.causal, padding=(k - 1) // 2)
+        h = A.relu(h)
         h = drop(h)                                                             # :344
         h = self.conv_2.forward_train(A.mul_bcast(h, x_mask), causal=self.causal, padding=(k - 1) // 2)
         return A.mul_bcast(h, x_mask)

@@ -26,6 +26,8 @@ from .env import AttrDict  # noqa: F401
 from .utils import get_padding, init_weights
 
 LRELU_SLOPE = 0.1
+# training-time epilogue fusions (the ResBlock sums in the conv epilogues); SVC_FUSED_TRAIN=0: one autograd op per reference op
+FUSED_TRAIN = __import__("os").environ.get("SVC_FUSED_TRAIN", "1") != "0"
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
 _MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
@@ -53,8 +55,11 @@ class ResBlock1(nn.Module):
         """Reference vdecoder/hifigan/models.py:60-67."""
         for c1, c2 in zip(self.convs1, self.convs2):
             xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE))
-            xt = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE))
-            x = A.add(xt, x)
+            if FUSED_TRAIN and c2.fused_train_ok():
+                x = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE), res=x)       # `xt + x` in c2's epilogue
+            else:
+                xt = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE))
+                x = A.add(xt, x)
         return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
@@ -113,7 +118,10 @@ class ResBlock2(nn.Module):
     def forward_train(self, x):
         """Reference vdecoder/hifigan/models.py:88-93."""
         for c in self.convs:
-            x = A.add(c.forward_train(A.leaky_relu(x, LRELU_SLOPE)), x)
+            if FUSED_TRAIN and c.fused_train_ok():
+                x = c.forward_train(A.leaky_relu(x, LRELU_SLOPE), res=x)
+            else:
+                x = A.add(c.forward_train(A.leaky_relu(x, LRELU_SLOPE)), x)
         return x
 
     def forward(self, x, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):

@@ -120,6 +120,49 @@ def test_wn_fused_training_layers_match_the_op_by_op_form(dev, gin, n_layers):
         _close(a, b, 2e-5, "fused vs op-by-op")
 
 
+def _grads_of(mod, fn, inputs, go):
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    mod.zero_grad(set_to_none=True)
+    y = fn(*ins)
+    y.backward(go)
+    return [y.detach()] + [t.grad for t in ins] + [p_.grad.clone() for p_ in mod.parameters()]
+
+
+def test_ffn_and_resblock_fused_epilogues_match_the_op_by_op_form(dev):
+    """FFN (ReLU + masks in the conv epilogues, modules/attentions.py:337-345) and the HiFi-GAN ResBlocks (`xt + x` in the second
+    conv's epilogue, vdecoder/hifigan/models.py:60-67,88-93) in their fused training form against one autograd op per
+    reference op: outputs and all gradients."""
+    import modules.attentions as AT
+    import vdecoder.hifigan.models as HM
+    torch.manual_seed(12)
+    B, C, T = 3, 64, 257
+    lens = torch.tensor([T, T - 60, T - 130])
+    x_mask = (torch.arange(T)[None, :] < lens[:, None]).float().unsqueeze(1).to(dev)
+    x0 = torch.randn(B, C, T, device=dev)
+    go = torch.randn(B, C, T, device=dev)
+    for causal in (False, True):
+        ffn = AT.FFN(C, C, 160, 3, p_dropout=0.0, causal=causal).to(dev)
+        res = {}
+        for fused in (True, False):
+            AT.FUSED_TRAIN = fused
+            try:
+                res[fused] = _grads_of(ffn, lambda x: ffn.forward_train(x, x_mask), [x0], go)
+            finally:
+                AT.FUSED_TRAIN = True
+        for a, b in zip(res[True], res[False]):
+            _close(a, b, 2e-5, f"ffn causal={causal}")
+    for blk in (HM.ResBlock1(None, C, 3, (1, 3, 5)).to(dev), HM.ResBlock2(None, C, 3, (1, 3)).to(dev)):
+        res = {}
+        for fused in (True, False):
+            HM.FUSED_TRAIN = fused
+            try:
+                res[fused] = _grads_of(blk, blk.forward_train, [x0], go)
+            finally:
+                HM.FUSED_TRAIN = True
+        for a, b in zip(res[True], res[False]):
+            _close(a, b, 2e-5, type(blk).__name__)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,s,pad", [(2, 1, 32, 2731, 5, 3, 2), (2, 32, 128, 911, 5, 3, 2),
                                                   (1, 1, 64, 8192, 128, 64, 32), (2, 1, 16, 4096, 4, 2, 1),
                                                   (2, 8, 8, 100, 16, 8, 4)])
