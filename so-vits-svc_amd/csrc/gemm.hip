@@ -8,6 +8,7 @@
 // odd pitch so both the staging writes (lanes along whichever operand dimension is contiguous in memory) and the
 // MFMA operand reads (lanes along m / n) are bank-conflict free.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstdint>
 
@@ -68,6 +69,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
       *cp = v;
     }
   }
+}
+
+// ---- thin-M variant: M <= 16 rows, a long reduction ------------------------------------------------------------------------
+// The relative-position gradients of the training graph (d emb_rel_v: [2w+1 = 9] x [96] per head, reduced over T = 768 frames,
+// modules/attentions.py:259-303) are 9 x 96 x 768 products: on the 64 x 64 MFMA tile above 64 workgroups walk the whole
+// reduction behind 48 barriers with 86 % of every tile padding — 131 us for 42 MFLOP (0.3 TFLOP/s), 1.6 ms per training
+// iteration (profiles/r06a_train_shapes_f32.txt).  Here the REDUCTION is split over workgroups (grid = k-ranges x n-tiles x batch,
+// ~400 workgroups), a workgroup stages 64-step chunks of both operands in LDS and its threads own <= 8 outputs each (plain
+// FMAs: the product is bound by reading B once, 9 MB); partial sums meet in C through fp32 atomics (C scaled by beta first).
+constexpr int TK = 64, TN = 128, TM = 16, TOUT = TM * TN / 256;
+
+__global__ __launch_bounds__(256) void gemm_thin_scale_kernel(svc_gemm_args a) {
+  const long long n = (long long)a.batch * a.M * a.N;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int nn = (int)(i % a.N), m = (int)((i / a.N) % a.M), b = (int)(i / ((long long)a.N * a.M));
+    float* cp = a.C + (long long)b * a.c_bs + (long long)m * a.c_ms + (long long)nn * a.c_ns;
+    *cp = a.beta == 0.f ? 0.f : a.beta * (*cp);
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_thin_kernel(GemmP p, int k_per_wg) {
+  const svc_gemm_args& a = p.a;
+  __shared__ float As[TK * (TM + 1)];
+  __shared__ float Bs[TK * (TN + 1)];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.y * TN, b = blockIdx.z;
+  const int nt = min(TN, a.N - n0);
+  const int k_lo = blockIdx.x * k_per_wg, k_hi = min(a.K, k_lo + k_per_wg);
+  const float* Ab = a.A + (long long)b * a.a_bs;
+  const float* Bb = a.B + (long long)b * a.b_bs;
+  int om[TOUT], on[TOUT];
+  float acc[TOUT];
+#pragma unroll
+  for (int j = 0; j < TOUT; ++j) {
+    const int o = tid + 256 * j;
+    om[j] = o / nt;
+    on[j] = o - om[j] * nt;
+    if (om[j] >= a.M) om[j] = -1;
+    acc[j] = 0.f;
+  }
+  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+    __syncthreads();
+    for (int idx = tid; idx < a.M * TK; idx += 256) {
+      int m, k;
+      if (p.a_m_fast) { m = idx % a.M; k = idx / a.M; } else { k = idx % TK; m = idx / TK; }
+      As[k * (TM + 1) + m] = k0 + k < k_hi ? Ab[(long long)m * a.a_ms + (long long)(k0 + k) * a.a_ks] : 0.f;
+    }
+    for (int idx = tid; idx < nt * TK; idx += 256) {
+      int n, k;
+      if (p.b_n_fast) { n = idx % nt; k = idx / nt; } else { k = idx % TK; n = idx / TK; }
+      Bs[k * (TN + 1) + n] = k0 + k < k_hi ? Bb[(long long)(k0 + k) * a.b_ks + (long long)(n0 + n) * a.b_ns] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TOUT; ++j) {
+      if (om[j] < 0) continue;
+      const float* ap = As + om[j];
+      const float* bp = Bs + on[j];
+      float s = 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < TK; ++kk) s = fmaf(ap[kk * (TM + 1)], bp[kk * (TN + 1)], s);
+      acc[j] += s;
+    }
+  }
+  float* Cb = a.C + (long long)b * a.c_bs;
+#pragma unroll
+  for (int j = 0; j < TOUT; ++j)
+    if (om[j] >= 0) atomicAdd(Cb + (long long)om[j] * a.c_ms + (long long)(n0 + on[j]) * a.c_ns, a.alpha * acc[j]);
 }
 
 // ---- 128 x 128 tile variant: 2 x 2 waves, each wave a 64 x 64 block (2 x 2 MFMA tiles: every A / B operand fetched
@@ -283,6 +352,7 @@ int launch_reg(const svc_gemm_args& a, hipStream_t s) {
   return go(gemm_f32_reg_kernel<A_KC, B_KC, 1, 3>, 1, 3);
 }
 
+int g_gemm_thin = -1;  // A/B switch: SVC_GEMM_THIN=0 keeps thin-M products on the MFMA tiles
 int g_gemm_reg = -1;   // A/B switch: SVC_GEMM_REG=0 keeps every product on the LDS-staged kernels
 
 // operands as the register-fed kernel needs them; everything else stays on the LDS-staged kernels
@@ -314,12 +384,31 @@ extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
   SVC_REQUIRE(a.A && a.B && a.C, "gemm: null tensor");
   SVC_REQUIRE(a.batch > 0 && a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty shape");
   hipStream_t s = (hipStream_t)stream;
-  svc::ProfScope prof(s, "gemm_f32", 2.0 * a.batch * (double)a.M * a.N * a.K,
+  char pname[128];
+  if (svc::prof_on() && svc::prof_shapes())   // SVC_PROF_SHAPES=1: one profile row per shape and operand layout (k-contiguous A / B)
+    snprintf(pname, sizeof(pname), "gemm_f32[b%d,M%d,N%d,K%d,a%c,b%c]", a.batch, a.M, a.N, a.K, a.a_ks == 1 ? 'k' : (a.a_ms == 1 ? 'm' : 's'),
+             a.b_ks == 1 ? 'k' : (a.b_ns == 1 ? 'n' : 's'));
+  else
+    snprintf(pname, sizeof(pname), "gemm_f32");
+  svc::ProfScope prof(s, pname, 2.0 * a.batch * (double)a.M * a.N * a.K,
                       4.0 * a.batch * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N));
   GemmP p;
   p.a = a;
   p.a_m_fast = (a.a_ms == 1 || (a.a_ks != 1 && llabs(a.a_ms) < llabs(a.a_ks))) ? 1 : 0;
   p.b_n_fast = (a.b_ns == 1 || (a.b_ks != 1 && llabs(a.b_ns) < llabs(a.b_ks))) ? 1 : 0;
+  if (g_gemm_thin < 0) {
+    const char* e = getenv("SVC_GEMM_THIN");
+    g_gemm_thin = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (g_gemm_thin && a.M <= TM && a.K >= 4 * TK) {
+    const int n_tiles = svc::cdiv(a.N, TN);
+    int ksplits = std::max(1, std::min(svc::cdiv(a.K, TK), 512 / std::max(1, n_tiles * a.batch)));
+    const int k_per_wg = svc::cdiv(svc::cdiv(a.K, ksplits), TK) * TK;
+    ksplits = svc::cdiv(a.K, k_per_wg);
+    hipLaunchKernelGGL(gemm_thin_scale_kernel, dim3(std::min(1024, svc::cdiv(a.batch * a.M * a.N, 256))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_thin_kernel, dim3(ksplits, n_tiles, a.batch), dim3(256), 0, s, p, k_per_wg);
+    return svc::check_launch("gemm_thin");
+  }
   if (reg_ok(a)) {
     const bool a_kc = a.a_ks == 1, b_kc = a.b_ks == 1;
     if (a_kc && b_kc) return launch_reg<true, true>(a, s);

@@ -73,11 +73,12 @@ class _ConvPlanned(Function):
     F.pad / permute / copy + pack (+ pack_T, the adjoint copies and weight_norm_bwd in the backward): 4-9 launches -> 2."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, plan, pad, dil, tout, exact, cond=None, res=None, mask=None, post_act=0):
+    def forward(ctx, x, v, g, bias, plan, pad, dil, tout, exact, cond=None, res=None, mask=None, post_act=0, post_slope=0.0):
         """Epilogue fusions (each one launch and one pass over the output less than the separate op; the kernel's order:
         bias + cond, activation, mask, residual — include/svc_hip.h):
           cond [B, Od, 1|T]  added before the activation (WN's `x_in + g_l`, modules/modules.py:123-128)
-          post_act           S.ACT_RELU: FFN's `torch.relu(conv_1(x))` (modules/attentions.py:342)
+          post_act           S.ACT_RELU: FFN's `torch.relu(conv_1(x))` (modules/attentions.py:342); S.ACT_LRELU (post_slope > 0):
+                             `F.leaky_relu(c1(..))` in front of a ResBlock's second conv (vdecoder/hifigan/models.py:64-65)
           mask [B, 1, T]     `y * x_mask` after a conv
           res [B, Od, T]     `conv(x) + res` (the ResBlock sums, vdecoder/hifigan/models.py:66,92); not with post_act"""
         x = _c(x)
@@ -99,15 +100,16 @@ class _ConvPlanned(Function):
             y = y.squeeze(0).t().contiguous().unsqueeze(2)                       # [B, Od, 1]
         else:
             y = S.conv1d(x, wp, plan.Od, plan.Kd, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma, cond=cond,
-                         mask=None if mask is None else mask.detach(), post_act=post_act,
+                         mask=None if mask is None else mask.detach(), post_act=post_act, post_slope=post_slope,
                          res=None if res is None else _c(res), res_mode=0 if res is None else 1)
         fused = cond is not None or res is not None or mask is not None or post_act != 0
         if fused and ctx.batch_cols:
             raise S.SvcError("conv1d_planned: epilogue fusions with a [B, C, 1] input are not on the path")
-        if post_act not in (0, S.ACT_RELU) or (post_act and res is not None):
-            raise S.SvcError("conv1d_planned: the fused activation is ReLU, without a residual")
+        if post_act not in (0, S.ACT_RELU, S.ACT_LRELU) or (post_act and res is not None) or (post_act == S.ACT_LRELU and not
+                                                                                            (post_slope > 0.0 and mask is None)):
+            raise S.SvcError("conv1d_planned: the fused activation is ReLU or leaky ReLU (slope > 0, no mask), without a residual")
         ctx.cond_shape = tuple(cond.shape) if cond is not None else None
-        ctx.epi = (res is not None, mask is not None, post_act)
+        ctx.epi = (res is not None, mask is not None, post_act, float(post_slope))
         ctx.save_for_backward(x, v, g, y if post_act else None, mask.detach() if (mask is not None and not post_act) else None)
         ctx.plan = plan
         ctx.cfg = (pad, dil, bias is not None)
@@ -119,9 +121,11 @@ class _ConvPlanned(Function):
         plan = ctx.plan
         pad, dil, has_bias = ctx.cfg
         dy = _c(dy)
-        has_res, has_mask, post_act = ctx.epi
+        has_res, has_mask, post_act, post_slope = ctx.epi
         d_res = dy if (has_res and ctx.needs_input_grad[10]) else None
-        if post_act:
+        if post_act == S.ACT_LRELU:
+            dy = S.ew(S.EW_LRELU_BWD, dy, y_act, alpha=post_slope)      # sign(y) == sign(v) for slope > 0
+        elif post_act:
             dy = S.ew(S.EW_RELU_BWD, dy, y_act)         # y = relu(v) * mask: y > 0 <=> v > 0 inside the mask
         elif has_mask:
             dy = S.ew_bct(S.EW_MUL, dy, m)
@@ -147,7 +151,7 @@ class _ConvPlanned(Function):
         elif want_db:
             db = S.reduce_bct(dy, 0)
         dc = _reduce_to(dy, ctx.cond_shape) if ctx.cond_shape is not None and ctx.needs_input_grad[9] else None
-        return dx, dv, dg, db, None, None, None, None, None, dc, d_res, None, None
+        return dx, dv, dg, db, None, None, None, None, None, dc, d_res, None, None, None
 
 
 class _WNResSkip(Function):
@@ -681,19 +685,19 @@ def conv_plan(weight_shape, stride=1, padding=0, transposed=False):
 
 
 def conv1d_planned(x, plan, v, g=None, bias=None, stride=1, padding=0, dilation=1, inner=1, lp=None, out_blocks=None,
-                   causal=False, cond=None, res=None, mask=None, post_act=0):
+                   causal=False, cond=None, res=None, mask=None, post_act=0, post_slope=0.0):
     """conv1d() on a module's parameters through its ConvWeightPlan (groups == 1): v is weight / weight_v, g weight_g or
     None.  causal: left padding (K-1)*dilation only, output length == input length."""
     KS = plan.K
     if causal:
         if stride != 1 or inner != 1:
             raise S.SvcError("causal padding with a stride is not on the so-vits-svc path")
-        return _ConvPlanned.apply(x, v, g, bias, plan, (KS - 1) * dilation, dilation, x.shape[2], False, cond, res, mask, post_act)
+        return _ConvPlanned.apply(x, v, g, bias, plan, (KS - 1) * dilation, dilation, x.shape[2], False, cond, res, mask, post_act, post_slope)
 
     if cond is not None or res is not None or mask is not None or post_act:
         if stride != 1 or inner != 1 or lp is not None or out_blocks is not None:
             raise S.SvcError("conv1d_planned: the fused epilogues exist for plain stride-1 convolutions")
-        return _ConvPlanned.apply(x, v, g, bias, plan, padding, dilation, None, False, cond, res, mask, post_act)
+        return _ConvPlanned.apply(x, v, g, bias, plan, padding, dilation, None, False, cond, res, mask, post_act, post_slope)
 
     def dense(xx, pad, dil, tout=None, exact=False, strided=None):
         return _ConvPlanned.apply(xx, v, g, bias, plan, pad, dil, tout, exact)

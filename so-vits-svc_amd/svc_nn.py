@@ -124,14 +124,14 @@ class Conv1d(nn.Module, _PackedMixin):
             self.__dict__["_svc_plan"] = plan
         return plan
 
-    def forward_train(self, x, causal=False, padding=None, cond=None, res=None, mask=None, post_act=0):
+    def forward_train(self, x, causal=False, padding=None, cond=None, res=None, mask=None, post_act=0, post_slope=0.0):
         """Autograd form of the plain convolution; `padding` overrides self.padding; cond / res / mask / post_act: epilogue
         fusions of svc_autograd._ConvPlanned (weight plans only: callers check `fused_train_ok`)."""
         if WEIGHT_PLANS and (padding is None or self.stride == 1):
             v, g = (self.weight_v, self.weight_g) if self.is_weight_norm else (self.weight, None)
             return A.conv1d_planned(x, self._plan(), v, g, self.bias, self.stride,
                                     self.padding if padding is None else padding, self.dilation, causal=causal, cond=cond,
-                                    res=res, mask=mask, post_act=post_act)
+                                    res=res, mask=mask, post_act=post_act, post_slope=post_slope)
         if cond is not None or res is not None or mask is not None or post_act:
             raise S.SvcError("forward_train: the fused epilogues need weight plans")
         if padding is not None and not causal:

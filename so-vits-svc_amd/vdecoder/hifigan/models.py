@@ -54,10 +54,12 @@ class ResBlock1(nn.Module):
     def forward_train(self, x):
         """Reference vdecoder/hifigan/models.py:60-67."""
         for c1, c2 in zip(self.convs1, self.convs2):
-            xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE))
-            if FUSED_TRAIN and c2.fused_train_ok():
-                x = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE), res=x)       # `xt + x` in c2's epilogue
+            if FUSED_TRAIN and c1.fused_train_ok() and c2.fused_train_ok():
+                # the leaky ReLU in front of c2 in c1's epilogue (c1's raw output has no other reader), `xt + x` in c2's
+                xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE), post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE)
+                x = c2.forward_train(xt, res=x)
             else:
+                xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE))
                 xt = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE))
                 x = A.add(xt, x)
         return x

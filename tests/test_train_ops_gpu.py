@@ -534,6 +534,32 @@ def _vg(m):
     return (m.weight_v, m.weight_g) if hasattr(m, "weight_g") else (m.weight, None)
 
 
+@pytest.mark.parametrize("BH,M,N,K", [(32, 9, 96, 768), (3, 16, 200, 1000), (2, 1, 40, 257), (4, 9, 96, 300)])
+def test_gemm_thin_m_products(dev, BH, M, N, K):
+    """The thin-M form of svc_gemm_f32 (M <= 16, reduction split over workgroups, csrc/gemm.hip: gemm_thin_kernel) — the
+    relative-position gradients' 9 x 96 x T products (modules/attentions.py:259-303) — in both operand layouts, with
+    alpha / beta and a strided output."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(M * N + K)
+    A_mk = torch.randn(BH, K, M, generator=g)          # m contiguous: element (m, k) at k * M + m
+    B_nk = torch.randn(BH, N, K, generator=g)          # k contiguous: element (k, n) at n * K + k
+    ref = A_mk.transpose(1, 2) @ B_nk.transpose(1, 2)
+
+    def close(got, want, what):
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 2e-5 * max(1.0, want.abs().max().item()), (what, err)
+
+    close(S.gemm(A_mk.to(dev), B_nk.to(dev), (K * M, 1, M), (N * K, 1, K), BH, M, N, K, alpha=0.5), 0.5 * ref, "m-fast A, k-fast B")
+    A_km = A_mk.transpose(1, 2).contiguous()           # k contiguous
+    B_kn = B_nk.transpose(1, 2).contiguous()           # n contiguous
+    acc = torch.randn(BH, M, N + 3, generator=g)
+    out = acc.to(dev)
+    S.gemm(A_km.to(dev), B_kn.to(dev), (M * K, K, 1), (K * N, N, 1), BH, M, N, K, out=out, c_strides=(M * (N + 3), N + 3, 1), alpha=2.0, beta=1.0)
+    want = acc.clone()
+    want[:, :, :N] += 2.0 * ref
+    close(out, want, "k-fast A, n-fast B, strided accumulate")
+
+
 @pytest.mark.parametrize("T,dk,BH", [(256, 96, 4), (320, 96, 2), (128, 96, 2), (288, 64, 3), (96, 40, 2)])
 def test_gemm_attention_forms(dev, T, dk, BH):
     """svc_gemm_f32 on the six operand layouts of the training graph's attention products (svc_autograd.py:658-706): q / k / v /
