@@ -1429,9 +1429,15 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     if (a.Cout <= 16) cfg = cols >= 16384 ? 0 : 6;   // few columns (DiscriminatorP's 1024 -> 1 conv_post): split the reduction instead
     else if (a.Cout <= 32) cfg = cols >= 16384 ? 1 : 6;
     else if (cols >= 16384) cfg = a.Cout <= 64 ? 2 : 3;
+    // rows of at most 64 columns (the last layers of the discriminators: 1024 -> 1024 x 5 taps on T = 32, 2048 -> 512 x 2 taps on
+    // T = 16, B = 16 / 32 rows): a 128-column tile is >= 50 % padding there however many workgroups the launch has — 64 x 32 /
+    // 32 x 32 split-K instead: 192 -> 66 us, 340 -> 137 us (B = 32), 168 -> 38 us (profiles/r06c_train_small_conv_sweep.txt)
+    else if (m64 && a.Tout <= 64) cfg = wg64x32 >= 200 ? 5 : 6;
     else if (m64 && wg64x128 >= 128) cfg = 4;   // measured (768 -> 2304/3072, T=500): 64x128 at 144..192 workgroups beats
                                                 // the 64x32 split-K tiling by 1.5x (4x the operand reuse per LDS byte)
-    else if (m64 && wg64x32 >= 200) cfg = 5;
+    // (more than 7 taps run on the LDS-staged split-K tiles, where 32 x 32 beats 64 x 32 until the launch is large:
+    //  256 -> 256 x 11 taps, T = 128, B = 16: 79 -> 65 us)
+    else if (m64 && wg64x32 >= (a.KS > 7 ? 512 : 200)) cfg = 5;
     else cfg = 6;
     // Wide outputs (Cout > 64) with enough columns to fill the chip: pick among 128x128, 64x128 and 128x224 by modelled
     // time = (rounds of 256 CUs) * tile area.  Two effects it captures, both measured: (1) the decoder's lengths are
