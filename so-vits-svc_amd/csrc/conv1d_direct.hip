@@ -35,27 +35,45 @@ __global__ __launch_bounds__(DT) void conv1d_direct_kernel(DirectP p) {
 #pragma unroll
   for (int i = 0; i < COT; ++i) acc[i] = 0.f;
 
+  // polyphase position (i % s, i / s) of staged sample i and (k*dil % s, k*dil / s) of tap k, advanced incrementally: the
+  // integer divisions by the run-time stride were most of this kernel's instructions (two per staged sample and two per tap
+  // and channel — ~30 VALU instructions each against ONE fma of useful work per tap: conv_post 59 us for a 24 MB read,
+  // profiles/r05m_infer_T862_kernel_stats_serialised.txt)
+  const int dq = DT / s, dr = DT - dq * s;
+  const int q0 = tid / s, r0 = tid - q0 * s;
   for (int c0 = 0; c0 < a.Cin; c0 += p.bci) {
     const int nc = min(p.bci, a.Cin - c0);
     for (int r = 0; r < nc; ++r) {
       const float* xr = xb + (long long)(c0 + r) * a.x_cs;
+      int iq = q0, ir = r0;
       for (int i = tid; i < p.win; i += DT) {
         const int ti = in0 + i;
         float v = 0.f;
         if (ti >= 0 && ti < a.Tin) v = svc_lrelu(xr[ti], a.pre_slope);
-        xs[r * rowsz + (i % s) * p.Qp + i / s] = v;
+        xs[r * rowsz + ir * p.Qp + iq] = v;
+        iq += dq;
+        ir += dr;
+        if (ir >= s) {
+          ir -= s;
+          ++iq;
+        }
       }
     }
     __syncthreads();
     for (int r = 0; r < nc; ++r) {
       const float* wr = a.w + (long long)(c0 + r) * a.KS * a.CoutP + co0;
       const float* xr = xs + r * rowsz + tid;
+      int kr = 0, kq = 0;       // (k*dil) % s, (k*dil) / s
       for (int k = 0; k < a.KS; ++k) {
-        const int kd = k * a.dil;
-        const float xv = xr[(kd % s) * p.Qp + kd / s];
+        const float xv = xr[kr * p.Qp + kq];
         const float* wk = wr + (long long)k * a.CoutP;
 #pragma unroll
         for (int i = 0; i < COT; ++i) acc[i] = fmaf(wk[i], xv, acc[i]);
+        kr += a.dil;
+        while (kr >= s) {
+          kr -= s;
+          ++kq;
+        }
       }
     }
     __syncthreads();

@@ -29,47 +29,64 @@ struct ScanRec {
   double W;  // number of wraps detected before the frame
 };
 
-// one workgroup per batch item: f0[b,:] is staged in LDS once (the sequential scan below would otherwise pay a global
-// load latency per frame), thread h < H runs the T-step recurrence for its harmonic out of LDS
-constexpr int SCAN_CHUNK = 1024;   // frames staged per pass
-__global__ __launch_bounds__(64) void nsf_frame_scan_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
-                                                            ScanRec* __restrict__ rec, int B, int T, int upp, int H,
-                                                            float sr) {
-  __shared__ float f0s[SCAN_CHUNK];
+// one workgroup per batch item.  The recurrence over frames is sequential per harmonic, but only through ONE double-precision
+// fma (A += upp * rad): everything else of a step — the fp32 `(f0 * h / sr) % 1` (a multiply, a divide and an fmodf), the wrap
+// count and the carried rounding error — hangs off it.  So the 256 threads first fill LDS with rad for a chunk of frames and
+// all harmonics (the expensive, fully parallel part), then thread h walks its row four frames at a time (the LDS reads of a
+// group are issued together).  (With rad computed inside the loop a step cost ~400 cycles: 159 us for the 862 frames of a 10 s
+// clip, 2 % of the synthesis — profiles/r05m_infer_T862_kernel_stats_serialised.txt.)  Same arithmetic per step as before.
+constexpr int SCAN_CHUNK = 512;   // frames staged per pass
+constexpr int SCAN_PITCH = SCAN_CHUNK + 1;
+__global__ __launch_bounds__(256) void nsf_frame_scan_kernel(const float* __restrict__ f0, const float* __restrict__ rand_ini,
+                                                             ScanRec* __restrict__ rec, int B, int T, int upp, int H,
+                                                             float sr) {
+  __shared__ float rads[MAXH * SCAN_PITCH];
   const int b = blockIdx.x, h = threadIdx.x;
-  const float hm = (float)(h + 1);
   const float ri = (h == 0 || h >= H) ? 0.f : rand_ini[b * H + h];
   double A = 0.0, E = 0.0, W = 0.0;
   double base = 0.0;  // floor(float(S1(0)))
+  const double dupp = (double)upp;
   for (int c0 = 0; c0 < T; c0 += SCAN_CHUNK) {
     const int nc = min(SCAN_CHUNK, T - c0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nc; i += 64) f0s[i] = f0[(long long)b * T + c0 + i];
+    for (int idx = threadIdx.x; idx < H * nc; idx += 256) {
+      const int hh = idx / nc, i = idx - hh * nc;
+      const float fn = f0[(long long)b * T + c0 + i] * (float)(hh + 1);
+      rads[hh * SCAN_PITCH + i] = fmodf(fn / sr, 1.0f);
+    }
     __syncthreads();
     if (h < H) {
-      for (int i = 0; i < nc; ++i) {
-        const int f = c0 + i;
-        const float fn = f0s[i] * hm;
-        const float rad = fmodf(fn / sr, 1.0f);
+      const float* rp = rads + h * SCAN_PITCH;
+      ScanRec* rr = rec + ((long long)b * H + h) * T + c0;
+      auto step = [&](int i, float rad) {
         ScanRec r;
         r.A = A;
         r.E = E;
         r.W = W;
-        rec[((long long)b * H + h) * T + f] = r;
+        rr[i] = r;
         double s_end;
-        if (f == 0) {
+        if (c0 + i == 0) {
           const float rad0 = rad + ri;  // fp32 add, models.py:149
           base = floor((double)(float)(double)rad0);
           s_end = (double)rad0 + (double)(upp - 1) * (double)rad;
         } else {
-          s_end = A + (double)upp * (double)rad;
+          s_end = A + dupp * (double)rad;
         }
         const double w_end = floor((double)(float)s_end) - base;
         const double eps = (double)(rad - 1.0f) - ((double)rad - 1.0);
         E += (w_end - W) * eps;
         W = w_end;
         A = s_end;
+      };
+      int i = 0;
+      for (; i + 4 <= nc; i += 4) {
+        const float r0 = rp[i], r1 = rp[i + 1], r2 = rp[i + 2], r3 = rp[i + 3];
+        step(i, r0);
+        step(i + 1, r1);
+        step(i + 2, r2);
+        step(i + 3, r3);
       }
+      for (; i < nc; ++i) step(i, rp[i]);
     }
   }
 }
@@ -187,7 +204,7 @@ static int nsf_source_impl(const float* f0, const float* rand_ini, const float* 
   ScanRec* rec = reinterpret_cast<ScanRec*>(scratch);
   const long long L = (long long)T * upp;
   svc::ProfScope prof(s, "nsf_source", 0.0, 4.0 * B * L * (H + 1));
-  hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(B), dim3(64), 0, s, f0, rand_ini, rec, B, T, upp, H,
+  hipLaunchKernelGGL(nsf_frame_scan_kernel, dim3(B), dim3(256), 0, s, f0, rand_ini, rec, B, T, upp, H,
                      sampling_rate);
   hipLaunchKernelGGL(nsf_sample_kernel, dim3((unsigned)svc::cdivll(L, 256), B), dim3(256), 0, s, f0, rand_ini, noise,
                      lin_w, lin_b, rec, har, waves, B, T, upp, H, sampling_rate, sine_amp, noise_std);
