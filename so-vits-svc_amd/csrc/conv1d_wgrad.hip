@@ -766,14 +766,15 @@ extern "C" int svc_conv1d_wgrad_f32(const svc_wgrad_args* ap, void* stream) {
   // times — 6 blocks x 42 splits (192 x 192): 5 taps 91.8 -> 73.7 us, 3 taps 66.7 -> 51.2, 1 tap 32.9 -> 24.7; 128 x 128 x 11 taps
   // 147 -> 116; 9 blocks x 28 splits (384 x 192 x 5) 130 -> 121 (16-bit operands 72 -> 58) — or 128 rows would be padding (Ca = 192:
   // 192 x 768 x 3 taps 197 -> 148); they change nothing at 18 blocks x 14 splits (768 x 192 x 3: 145 / 149) and lose where the
-  // tile loop is all there is (128 blocks x 2 splits, 1024 x 1024 x 5 taps: 611 -> 705).  One tap with few splits: LDS-DMA on
-  // 128-row blocks (384 x 192: 43.3 -> 38.1 us, 16-bit 42.9 -> 28.3).
+  // tile loop is all there is (128 blocks x 2 splits, 1024 x 1024 x 5 taps: 611 -> 705).  128-row blocks keep the register-staged
+  // tiles, except one tap with 16-bit operands, where the LDS-DMA form is ahead (384 x 192: 43.7 -> 38.7 us; fp32 44.4 / 49.7,
+  // profiles/r05v_wgrad_sweep_targets.txt).
   int n_ca, splits, tiles_per_wg;
   plan(CA_T, n_ca, splits, tiles_per_wg);
   const int ca_rem = a.Ca % CA_T;
   int mt = 2;
   if (g_wgrad_mt == 1 || (g_wgrad_mt == 0 && g_wgrad_dma != 0 && (splits >= 16 || (ca_rem > 0 && ca_rem <= CA_T / 2 && splits >= 4)))) mt = 1;
-  const bool dma = g_wgrad_dma == 1 || mt == 1 || (g_wgrad_dma == 2 && nk == 1);
+  const bool dma = g_wgrad_dma == 1 || mt == 1 || (g_wgrad_dma == 2 && nk == 1 && a.mma != SVC_MMA_F32);
   if (mt == 1) plan(CA_T / 2, n_ca, splits, tiles_per_wg);
   p.tiles_per_wg = tiles_per_wg;
   p.splits = splits;
