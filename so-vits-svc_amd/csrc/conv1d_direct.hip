@@ -6,6 +6,7 @@
 // polyphase order (index i -> row i % stride) so a strided read is bank-conflict free; weights are wave-uniform
 // and come through the scalar cache.  HBM-bound by design (<= 0.2 % of the path's FLOPs).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -14,6 +15,7 @@ struct DirectP {
   int win;   // input samples staged per channel
   int Qp;    // polyphase row pitch (odd)
   int bci;   // channels per LDS chunk
+  int wlds;  // 1: the chunk's weights [bci][KS][COT] are staged in LDS behind the input window (else read through the scalar cache)
 };
 
 constexpr int DT = 256;  // outputs (threads) per block
@@ -36,27 +38,59 @@ __global__ __launch_bounds__(DT) void conv1d_direct_kernel(DirectP p) {
   for (int i = 0; i < COT; ++i) acc[i] = 0.f;
 
   // polyphase position (i % s, i / s) of staged sample i and (k*dil % s, k*dil / s) of tap k, advanced incrementally: the
-  // integer divisions by the run-time stride were most of this kernel's instructions (two per staged sample and two per tap
-  // and channel — ~30 VALU instructions each against ONE fma of useful work per tap: conv_post 59 us for a 24 MB read,
-  // profiles/r05m_infer_T862_kernel_stats_serialised.txt)
+  // integer divisions by the run-time stride cost two per staged sample and two per tap and channel (~30 VALU instructions each
+  // against ONE fma of useful work per tap).  conv_post (16 -> 1, 7 taps, a 24 MB read) step by step: 59 us -> 53 us without
+  // the divisions -> 46 us with the loads of a staging group issued together -> 38 us with its weights in LDS
+  // (profiles/r05m_*, r06f_*, r07a_*, r07b_infer_T862_kernel_stats_serialised.txt)
   const int dq = DT / s, dr = DT - dq * s;
   const int q0 = tid / s, r0 = tid - q0 * s;
   for (int c0 = 0; c0 < a.Cin; c0 += p.bci) {
     const int nc = min(p.bci, a.Cin - c0);
-    for (int r = 0; r < nc; ++r) {
-      const float* xr = xb + (long long)(c0 + r) * a.x_cs;
-      int iq = q0, ir = r0;
-      for (int i = tid; i < p.win; i += DT) {
-        const int ti = in0 + i;
-        float v = 0.f;
-        if (ti >= 0 && ti < a.Tin) v = svc_lrelu(xr[ti], a.pre_slope);
-        xs[r * rowsz + ir * p.Qp + iq] = v;
-        iq += dq;
-        ir += dr;
-        if (ir >= s) {
-          ir -= s;
-          ++iq;
+    // staging with the global loads of a group issued together (RU rows x SU column slots per pass): one row and one slot at a
+    // time every load waited for the previous one's LDS write — 16 exposed round trips per block for conv_post's 16 channels
+    auto stage = [&](auto ru_tag, auto su_tag) {
+      constexpr int RU = decltype(ru_tag)::value, SU = decltype(su_tag)::value;
+      for (int rb = 0; rb < nc; rb += RU) {
+        int iq = q0, ir = r0;
+        for (int i = tid; i < p.win; i += SU * DT) {
+          float v[RU][SU];
+          int pos[SU];
+#pragma unroll
+          for (int j = 0; j < SU; ++j) {
+            const int ii = i + j * DT;
+            const int ti = in0 + ii;
+            const bool ok = ii < p.win && ti >= 0 && ti < a.Tin;
+            pos[j] = ii < p.win ? ir * p.Qp + iq : -1;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+              const float* xr = xb + (long long)(c0 + min(rb + u, nc - 1)) * a.x_cs;
+              v[u][j] = ok ? xr[ti] : 0.f;
+            }
+            iq += dq;
+            ir += dr;
+            if (ir >= s) {
+              ir -= s;
+              ++iq;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < SU; ++j)
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+              if (pos[j] >= 0 && rb + u < nc) xs[(rb + u) * rowsz + pos[j]] = svc_lrelu(v[u][j], a.pre_slope);
         }
+      }
+    };
+    if (nc == 1) stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+    else stage(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+    // the chunk's weights into LDS: read wave-uniformly through the scalar cache inside the tap loop, every tap waited for its own
+    // s_load (a run-time trip count: nothing to batch) — conv_post's 16 x 7 taps = 112 exposed scalar-load latencies per block
+    float* ws = xs + p.bci * rowsz;
+    if (p.wlds) {
+      const int nw = nc * a.KS * COT;
+      for (int i = tid; i < nw; i += DT) {
+        const int rk = i / COT, c = i - rk * COT;
+        ws[i] = a.w[(long long)c0 * a.KS * a.CoutP + (long long)rk * a.CoutP + co0 + c];
       }
     }
     __syncthreads();
@@ -64,9 +98,10 @@ __global__ __launch_bounds__(DT) void conv1d_direct_kernel(DirectP p) {
       const float* wr = a.w + (long long)(c0 + r) * a.KS * a.CoutP + co0;
       const float* xr = xs + r * rowsz + tid;
       int kr = 0, kq = 0;       // (k*dil) % s, (k*dil) / s
+      const float* wl = ws + r * a.KS * COT;
       for (int k = 0; k < a.KS; ++k) {
         const float xv = xr[kr * p.Qp + kq];
-        const float* wk = wr + (long long)k * a.CoutP;
+        const float* wk = p.wlds ? wl + k * COT : wr + (long long)k * a.CoutP;
 #pragma unroll
         for (int i = 0; i < COT; ++i) acc[i] = fmaf(wk[i], xv, acc[i]);
         kr += a.dil;
@@ -100,9 +135,13 @@ __global__ __launch_bounds__(DT) void conv1d_direct_kernel(DirectP p) {
 }
 
 template <int COT>
-int launch(const DirectP& p, hipStream_t s) {
+int launch(DirectP p, hipStream_t s) {
+  // (16 output channels per thread read their 16 weights of a tap with ONE s_load_dwordx16: the scalar path is the better one
+  //  there — noise_convs 23.6 us against 26.1 us with the slab, profiles/r07a_* / r07b_*)
+  p.wlds = (COT < 16 && (size_t)p.bci * p.a.KS * COT * 4 <= 48 * 1024) ? 1 : 0;
   const svc_conv1d_direct_args& a = p.a;
-  const size_t lds = (size_t)p.bci * a.stride * p.Qp * 4;
+  size_t lds = (size_t)p.bci * a.stride * p.Qp * 4;
+  if (p.wlds) lds += (size_t)p.bci * a.KS * COT * 4;
   auto kern = conv1d_direct_kernel<COT>;
   if (lds > 64 * 1024) {
     static bool done = false;
