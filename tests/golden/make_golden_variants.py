@@ -2,6 +2,8 @@
   snake_T40   small config with vocoder_name="nsf-snake-hifigan" (vdecoder/hifiganwithsnake, SnakeAlias activations)
   tiny_T40    small config with the tiny template's switches (configs_template/config_tiny_template.json:
               use_depthwise_conv, flow_share_parameter, odd decoder widths 100/50/25/12/6)
+  tinyfull_T24  configs_template/config_tiny_template.json:42-71 at its REAL widths (filter 512, upsample_initial_channel
+              400 -> decoder 200/100/50/25/12 channels, depthwise WN, one WN shared by the four flows): BASELINE configs[0]
   mixvol_T40  small config with vol_embedding=True, infer(..., vol=...) after EnableCharacterMix(4) with a per-frame
               speaker-mix matrix g [T, 4] (models.py:456-461,505-509,517)
 
@@ -56,6 +58,7 @@ def main():
     snake["vocoder_name"] = "nsf-snake-hifigan"
     run_case(models, "snake_T40", snake, B=2, T=40, seed=13)
     run_case(models, "tiny_T40", W.small_tiny_config(), B=2, T=40, seed=14)
+    run_case(models, "tinyfull_T24", W.tiny_config(), B=2, T=24, seed=16)
     run_mixvol(models)
 
 

@@ -96,6 +96,39 @@ def test_snake_long_form_matches_oracle_on_full_clips(dev):
     _check(o, ref)
 
 
+def test_tiny_template_at_its_true_widths_matches_oracle(dev):
+    """BASELINE configs[0] / SURVEY §8(d) cfg1: configs_template/config_tiny_template.json:42-71 at its REAL widths — filter 512,
+    upsample_initial_channel 400 -> decoder 200/100/50/25/12 channels (none a multiple of 32: every MRF conv takes the generic
+    tiled kernel's odd-width paths, at T*512 columns in the last stage), depthwise-separable WN (modules/DSConv.py:5-32), one WN
+    shared by the four flows (models.py:37,42) — on its own 2 x 5 s clips (T = 431), eager and hipGraph, against the CPU oracle
+    (itself pinned to the real reference at these widths by tests/golden/infer_tinyfull_T24.npz)."""
+    cfg = W.tiny_config()
+    net, sd = _build(cfg, 16, dev)
+    B, T = 2, 431
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=31)
+    noise = W.make_noise(cfg, B, T, seed=32)
+    with torch.no_grad():
+        ref = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4, return_all=True)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert o.shape == ref["o"].shape == (B, 1, T * 512)
+    mse, mx = _check(o, ref["o"])
+    print(f"tiny template true widths B={B} T={T}: mse {mse:.3e} max|err| {mx:.3e} max|ref| {ref['o'].abs().max().item():.3f}")
+    net.enable_graph(True)
+    o2, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    o3, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert torch.equal(o2, o) and torch.equal(o3, o)
+    # a second shape of the same model: B = 1, T not a multiple of 4 or 32
+    net.enable_graph(False)
+    c1, f01, uv1, sid1 = W.make_inputs(cfg, 1, 219, seed=33)
+    n1 = W.make_noise(cfg, 1, 219, seed=34)
+    with torch.no_grad():
+        r1, _ = O.synth_infer(sd, cfg, c1, f01, uv1, sid1, n1, noice_scale=0.4)
+    o1, _ = net.infer(c1.to(dev), f01.to(dev), uv1.to(dev), g=sid1.to(dev), noice_scale=0.4,
+                      noise={k: v.to(dev) for k, v in n1.items()})
+    _check(o1, r1)
+
+
 @pytest.mark.parametrize("B,T", [(1, 97), (2, 33)])
 def test_infer_matches_oracle_full_config(dev, B, T):
     cfg = W.full_config()

@@ -141,18 +141,20 @@ def test_f0_to_coarse_vs_reference_golden(dev):
     f0 = torch.from_numpy(z["f0"])
     gold = torch.from_numpy(z["coarse"])
     out = S.f0_to_coarse(f0.to(dev)).cpu()
-    # integer path: bit-exact except where libm logf differences land on a rounding boundary (none on this grid;
-    # if that ever changes the mismatch must stay a single adjacent bin on < 0.1 % of the inputs)
-    diff = (out - gold).abs()
-    assert diff.max().item() <= 1
-    assert (diff != 0).float().mean().item() < 1e-3
+    # integer path: bit-exact on the reference's golden grid (dense sweep incl. both clamp edges)
+    assert torch.equal(out, gold), f"{int((out != gold).sum())} of {gold.numel()} bins differ from the reference"
     g = torch.Generator().manual_seed(0)
     f0r = 1200 * torch.rand(200000, generator=g)
     mine, ref = S.f0_to_coarse(f0r.to(dev)).cpu(), O.f0_to_coarse(f0r)
-    # the reference maps bin 256+ to 0 (utils.py:77-79), so at the 255|256 boundary "adjacent" is 255 <-> 0
+    # random sweep against the oracle (torch CPU logf): a differing bin may only be an adjacent one at a rounding boundary of the
+    # fp32 logarithm; the reference maps bin 256+ to 0 (utils.py:77-79), so at the 255|256 boundary "adjacent" is 255 <-> 0
     unwrap = lambda c: torch.where((c == 0) & (f0r > 1000), torch.full_like(c, 256), c)
     d2 = (unwrap(mine) - unwrap(ref)).abs()
-    assert d2.max().item() <= 1 and (d2 != 0).float().mean().item() < 1e-3
+    n_bad = int((d2 != 0).sum())
+    bad = (d2 != 0).nonzero().flatten()[:8]
+    print(f"f0_to_coarse random sweep: {n_bad} of {f0r.numel()} bins differ from torch-CPU:",
+          [(f0r[i].item().hex(), int(mine[i]), int(ref[i])) for i in bad])
+    assert d2.max().item() <= 1 and n_bad <= 4
 
 
 def test_prenet_embed_layernorm_reparam(dev):

@@ -244,6 +244,64 @@ def test_tiny_template_training_matches_oracle(dev):
         assert (gh - gr).abs().max().item() <= 2e-3 * max(gr.abs().max().item(), 1e-6), k
 
 
+def test_tiny_template_true_widths_training_step_matches_oracle(dev):
+    """config_tiny_template.json:42-71 at its real widths in the TRAINING graph (hidden 192, filter 512, decoder 200/100/50/25/12,
+    spec 1025, segment 16 frames = 8192 samples): forward vectors and the gradients of a loss that reaches every branch — y_hat
+    through the odd-width MRF stages, z_p through the depthwise posterior WN and the shared flow WN, pred_lf0 through the F0
+    decoder — against the oracle's torch-CPU autograd."""
+    import models
+    import svc_autograd as A
+    from oracle import train_oracle as TO
+    from oracle import weights as W
+    cfg = dict(W.tiny_config(), p_dropout=0.0)
+    B, T, seed = 2, 40, 61
+    sd = W.make_train_state_dict(cfg, seed)
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    c, f0, uv, spec, y, sid, lengths = W.make_train_batch(cfg, B, T, seed)
+    noise = W.make_train_noise(cfg, B, T, lengths, seed + 2)
+    leaves, sg = {}, {}
+    for k, v in sd.items():                              # the shared WN appears under five prefixes: one leaf per storage
+        key = v.data_ptr()
+        if key not in leaves:
+            leaves[key] = v.clone().requires_grad_(True)
+        sg[k] = leaves[key]
+    ref = TO.synth_forward(sg, cfg, c, f0, uv, spec, sid, lengths, lengths, noise)
+    out = net(c.to(dev), f0.to(dev), uv.to(dev), spec.to(dev), g=sid.to(dev), c_lengths=lengths.to(dev),
+              spec_lengths=lengths.to(dev), noise={k: v.to(dev) for k, v in noise.items()})
+    yh, yr = out[0], ref[0]
+    zh, zr = out[3][1], ref[3][1]
+    ph, pr = out[4], ref[4]
+    assert yh.shape == yr.shape == (B, 1, 16 * 512)
+    for name, h, r in (("y_hat", yh, yr), ("z_p", zh, zr), ("pred_lf0", ph, pr), ("m_p", out[3][2], ref[3][2])):
+        err = (h.detach().cpu() - r.detach()).abs().max().item()
+        assert err <= 2e-4 * max(1.0, r.detach().abs().max().item()), (name, err)
+    (A.sum_sq(yh) / yh.numel() + A.sum_sq(zh) / zh.numel() + A.sum_sq(ph) / ph.numel()).backward()
+    (yr.pow(2).mean() + zr.pow(2).mean() + pr.pow(2).mean()).backward()
+    named = net.state_dict(keep_vars=True)
+    checked = 0
+    for k, p in named.items():
+        gr = sg[k].grad
+        if gr is None or not p.requires_grad or k.endswith("conv_k.bias"):      # softmax is shift-invariant: d/d(k bias) == 0
+            continue
+        assert p.grad is not None, k
+        gh = p.grad.cpu()
+        # element-wise 5e-3 of the tensor's largest entry, norm-wise 2e-3: the late decoder stages' bias gradients are sums of
+        # 16 k signed terms that cancel to ~1e-4 of their absolute sum (measured worst: dec.resblocks.3.convs1.0.bias, one element
+        # 2.6e-3 of the largest, every other element of that tensor <= 4e-5)
+        assert (gh - gr).abs().max().item() <= 5e-3 * max(gr.abs().max().item(), 1e-6), k
+        assert (gh - gr).norm().item() <= 2e-3 * max(gr.norm().item(), 1e-6), k
+        checked += 1
+    # every decoder stage (odd widths), the depthwise / pointwise pairs and the shared WN are among the checked tensors
+    for k in ("dec.resblocks.14.convs2.2.weight_v", "dec.resblocks.9.convs1.0.weight_g", "dec.ups.4.weight_v", "dec.ups.0.weight_g",
+              "dec.noise_convs.3.weight", "flow.wn.in_layers.0.depth_conv.weight_v", "flow.wn.in_layers.3.point_conv.weight_g",
+              "enc_q.enc.in_layers.15.depth_conv.weight_v", "enc_q.pre.weight", "f0_decoder.proj.weight"):
+        assert named[k].grad is not None and sg[k].grad is not None, k
+    assert checked > 400, checked
+
+
 def test_training_forward_with_dropout_matches_reference(dev):
     """p_dropout = 0.1 (configs_template/config_template.json:49): the HIP training graph with the keep decisions made
     inside svc_attn_softmax_fwd_f32 (attention probabilities, modules/attentions.py:232) and SVC_EW_DROPOUT (attention /

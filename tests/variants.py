@@ -7,6 +7,8 @@ def variant_config(name):
         return W.full_config()
     if name == "tiny":
         return W.small_tiny_config()
+    if name == "tinyfull":
+        return W.tiny_config()                          # config_tiny_template.json:42-71 at its real widths
     cfg = W.small_config()
     if name == "snake":
         cfg["vocoder_name"] = "nsf-snake-hifigan"      # vdecoder/hifiganwithsnake (SnakeAlias activations)
@@ -20,5 +22,6 @@ def variant_config(name):
 
 
 INFER_GOLDENS = [("infer_small_T40.npz", "small"), ("infer_small_T40_predf0.npz", "small"), ("infer_full_T24.npz", "full"),
-                 ("infer_snake_T40.npz", "snake"), ("infer_tiny_T40.npz", "tiny"), ("infer_transflow_T40.npz", "transflow"),
+                 ("infer_snake_T40.npz", "snake"), ("infer_tiny_T40.npz", "tiny"),
+                 ("infer_tinyfull_T24.npz", "tinyfull"), ("infer_transflow_T40.npz", "transflow"),
                  ("infer_transflow_shared_T40.npz", "transflow_shared")]
