@@ -182,9 +182,10 @@ def run_train(args, dev, rank, world, dist, bf16=False):
     net_g.train()
     net_d.train()
     step_fn = TR.TrainStep(hps, net_g, net_d, optim_g, optim_d)
-    # N = 1: the whole iteration is ONE hipGraph.  N > 1: two hipGraphs per iteration (D segment, G segment) with the
-    # gradient all-reduces and optimizer launches between them (train.TrainStep._call_graph_dp); SVC_TRAIN_GRAPH=0 selects the
-    # eager, bucket-overlapped path instead.
+    # N = 1: the whole iteration is ONE hipGraph.  N > 1: each phase (D, G) is a sequence of hipGraphs cut at the gradient-bucket
+    # boundaries of its backward pass, a bucket's all-reduce issued behind the graph that completed it and overlapped with the
+    # next graph (train.TrainStep._call_graph_dp; SVC_DP_SPLIT=0: two monolithic graphs, reductions between them);
+    # SVC_TRAIN_GRAPH=0 selects the eager, hook-driven bucket-overlapped path instead.
     use_graph = (not args.no_graph) and os.environ.get("SVC_TRAIN_GRAPH", "1") != "0"
     step_fn.enable_graph(use_graph)
     items_cpu, T = make_train_items(cfg, TRAIN_B, 4321 + rank)
@@ -206,6 +207,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                   file=sys.stderr)
             use_graph = False
             step_fn.enable_graph(False)
+            step_fn.dp_ordered = True              # keep issuing the bucket-ordered collectives the other ranks' replays issue
     trace = [] if os.environ.get("SVC_BENCH_TRACE") else None      # determinism experiments: per-iteration losses
     for _ in range(warm):
         last = step_fn(items)
@@ -269,15 +271,21 @@ def run_train(args, dev, rank, world, dist, bf16=False):
         rg, rd = net_g.reducer, net_d.reducer
         # every iteration reduces each network's gradients once: per-iteration figures = totals / number of reductions
         # (reduce_all calls between graph replays, or hooked backward passes in the eager mode; warm-up iterations included)
+        def n_iter(r):      # one reduction of a network's gradients per iteration, whichever of the three forms issued it
+            return max(r.stats["wait_all_calls"] + r.stats["reduce_all_calls"] + r.stats["backward_passes"], 1)
+
         def per_it(r, key):
-            return r.stats[key] / max(r.stats["reduce_all_calls"] or r.stats["backward_passes"], 1)
-        n_red = max(rg.stats["reduce_all_calls"] or rg.stats["backward_passes"], 1)
+            return r.stats[key] / n_iter(r)
+        n_red = n_iter(rg)
         red = dict(backend=rg.backend, ranks=world,
                    mode=getattr(step_fn, "dp_mode", "eager launches, per-bucket all-reduce overlapped with backward (autograd hooks)"),
                    bytes_per_iter=per_it(rg, "reduced_bytes") + per_it(rd, "reduced_bytes"),
                    launches_per_iter=per_it(rg, "launches") + per_it(rd, "launches"),
                    buckets=dict(g=len(rg.buckets), d=len(rd.buckets)),
-                   exposed_ms_per_iter=(rg.exposed_ms() + rd.exposed_ms()) / n_red)
+                   exposed_ms=(rg.exposed_ms() + rd.exposed_ms()) / n_red, bytes=per_it(rg, "reduced_bytes") + per_it(rd, "reduced_bytes"),
+                   launches=per_it(rg, "launches") + per_it(rd, "launches"),
+                   note="per iteration; exposed_ms = time the compute stream stalled on all-reduces (hipEvents around the waits)")
+        red["exposed_ms_per_iter"] = red["exposed_ms"]
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not bf16:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)
@@ -300,7 +308,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                             global_batch=TRAIN_B * world, frames=T,
                             launch="eager (fp16: the GradScaler rule decides every optimizer step on the host)" if bf16 == "fp16" else
                             (("hipGraph replay of the whole iteration" if world == 1 else
-                              "two hipGraphs per iteration (D / G segments), all-reduce + AdamW between them") if use_graph else "eager"),
+                              "hipGraphs cut at the gradient-bucket boundaries, bucket all-reduces overlapped with the backward passes, AdamW per phase") if use_graph else "eager"),
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU",
                             p_dropout=cfg["p_dropout"]),
                 losses={k: round(float(v), 4) for k, v in last.items()},

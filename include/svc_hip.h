@@ -363,6 +363,10 @@ typedef struct svc_gemm_args {
   long long a_bs, a_ms, a_ks, b_bs, b_ks, b_ns, c_bs, c_ms, c_ns;
   int batch, M, N, K;
   float alpha, beta;
+  int split_k_atomic; /* 1: the caller accepts a reduction split over workgroups and combined with fp32 atomics (thin-M products,
+                         M <= 16 and K >= 256: ~10x faster, sum order and thus the last bits vary run to run).  Set by the
+                         training backward of the relative-position embeddings only; 0 (everything else, all of inference): every
+                         element is one deterministic accumulation chain */
 } svc_gemm_args;
 int svc_gemm_f32(const svc_gemm_args* a, void* stream);
 

@@ -400,7 +400,7 @@ extern "C" int svc_gemm_f32(const svc_gemm_args* ap, void* stream) {
     const char* e = getenv("SVC_GEMM_THIN");
     g_gemm_thin = (e && e[0] == '0') ? 0 : 1;
   }
-  if (g_gemm_thin && a.M <= TM && a.K >= 4 * TK) {
+  if (g_gemm_thin && a.split_k_atomic && a.M <= TM && a.K >= 4 * TK) {
     const int n_tiles = svc::cdiv(a.N, TN);
     int ksplits = std::max(1, std::min(svc::cdiv(a.K, TK), 512 / std::max(1, n_tiles * a.batch)));
     const int k_per_wg = svc::cdiv(svc::cdiv(a.K, ksplits), TK) * TK;

@@ -114,8 +114,10 @@ class GradReducer:
         self._pending = None        # per-bucket count of members still waiting for a gradient in this backward
         self._works = []
         self._launched = None
-        self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0, reduce_all_calls=0)
+        self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0, reduce_all_calls=0, wait_all_calls=0)
         self._exposed = []          # (start, end) event pairs around reduce_all on the compute stream
+        self._seg_cb = None         # segmented(): callback(bucket) instead of a collective (hipGraph capture of a backward pass)
+        self.seg_next = 0           # ... first bucket (index order) not yet handed to the callback
         arena.add_listener(self._on_grad)
 
     # -- construction-time parameter sync ----------------------------------------------------------------------
@@ -132,6 +134,9 @@ class GradReducer:
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _on_grad(self, i):
+        if self._seg_cb is not None:
+            self._on_grad_segmented(i)
+            return
         if not self.enabled or self.single:
             return
         if self._pending is None:
@@ -149,7 +154,8 @@ class GradReducer:
         else:       # gloo has no AVG: sum, then scale when the work completes
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._works.append((w, buf))
-        self._launched[b] = True
+        if self._launched is not None:
+            self._launched[b] = True
         self.stats["reduced_bytes"] += buf.numel() * 4
         self.stats["launches"] += 1
 
@@ -168,6 +174,60 @@ class GradReducer:
                 buf.mul_(1.0 / self.world)
         self._works = []
         self._pending = None
+
+    # -- bucket-ordered mode: the replayed-graph iteration (train.TrainStep._call_graph_dp) ---------------------------------
+    # Every rank issues the SAME collectives in the SAME order on every iteration — bucket 0, 1, ..., n-1 of an optimizer —
+    # whatever it does locally (replays split graphs, captures a new batch shape, or launches eagerly past the graph cap), so
+    # ranks whose shards produce different padded shapes on an iteration stay in step.
+    @contextlib.contextmanager
+    def segmented(self, on_ready):
+        """Run a backward pass (being captured into hipGraphs) WITHOUT collectives: `on_ready(b)` is called from the gradient
+        hook that completes bucket b — strictly in bucket index order (a bucket that completes early waits for its
+        predecessors), on the thread that runs backward.  The caller ends the current capture there, notes "all-reduce
+        bucket b", and begins the next graph; buckets not completed when backward returns (`seg_next` .. n-1: parameters without
+        a gradient in this pass) are reduced after the last graph."""
+        self._seg_cb, self._pending, self.seg_next = on_ready, None, 0
+        try:
+            yield self
+        finally:
+            self._seg_cb, self._pending = None, None
+
+    def _on_grad_segmented(self, i):
+        if self._pending is None:
+            self._pending = [len(b["members"]) for b in self.buckets]
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        while self.seg_next < len(self.buckets) and self._pending[self.seg_next] == 0:
+            nb = self.seg_next
+            self.seg_next += 1
+            self._seg_cb(nb)
+
+    def launch_bucket(self, b):
+        """Asynchronous all-reduce (mean) of bucket b, ordered after the work queued on the current stream so far (RCCL's
+        stream waits for an event recorded here); the current stream is NOT blocked: what is enqueued next overlaps it."""
+        if self.single:
+            return
+        self._launch(b)
+
+    def wait_all(self, time_it=True):
+        """The current stream waits for every all-reduce issued by launch_bucket since the last call.  The time the stream
+        stalls here is the iteration's EXPOSED communication (`exposed_ms()`)."""
+        if self.single:
+            return
+        self.stats["wait_all_calls"] += 1
+        ev = None
+        if time_it and self.arena.grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for w, buf in self._works:
+            w.wait()
+            if self.backend != "nccl":
+                buf.mul_(1.0 / self.world)
+        self._works = []
+        self._launched = None
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
 
     def reduce_all(self, time_it=True):
         """All-reduce (mean) of the whole flat gradient buffer, ordered after the work already queued on the current stream:

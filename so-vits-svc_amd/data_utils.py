@@ -156,7 +156,10 @@ class TextAudioSpeakerLoader(torch.utils.data.Dataset):
         return len(self.audiopaths)
 
 
-FRAME_BUCKETS = (320, 448, 576, 672, 736, 800)     # padded frame counts of a bucketed batch; beyond the last: multiples of 128
+# padded frame counts of a bucketed batch; beyond the last: multiples of 128.  The entries below 320 serve data sets of short
+# clips and the short last batch of an epoch (padding a 100-frame batch to 320 tripled its step time); with
+# drop_last=False they can add captured shapes, which TrainStep's graph cache bounds (least-recently-used eviction).
+FRAME_BUCKETS = (128, 192, 256, 320, 448, 576, 672, 736, 800)
 
 
 def bucket_frames(n_frames, buckets=FRAME_BUCKETS):

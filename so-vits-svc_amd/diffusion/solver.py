@@ -122,8 +122,11 @@ class TrainStep:
             snap = self.opt.snapshot()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):                   # warm-up (with a reducer: real, bucket-overlapped all-reduces on every rank)
+            import contextlib
+            # warm-up WITHOUT collectives: ranks read their own shards, so only this rank may be meeting this shape now (its
+            # results are discarded anyway); the replay below issues the one bucket-ordered reduction every rank issues per step
+            with torch.cuda.stream(side), (red.no_sync() if red is not None else contextlib.nullcontext()):
+                for _ in range(2):
                     self._body(sdata, snoise)
             torch.cuda.current_stream().wait_stream(side)
             self.opt.restore(snap)
@@ -257,6 +260,14 @@ def train(args, initial_global_step, model, optimizer, scheduler, vocoder, loade
                      initial_global_step=initial_global_step, amp_dtype=args.train.amp_dtype, scheduler=scheduler)
     step.enable_graph(os.environ.get("SVC_TRAIN_GRAPH", "1") == "1")
     core = net.module if isinstance(net, DataParallel) else net
+    # rank 0 validates and checkpoints alone (reference :170-189) while the others would run into the next step's all-reduce and
+    # sit there until RCCL's watchdog (10 min) aborts the job on a long validation set: they wait at a barrier of a side group
+    # with a long timeout instead
+    val_group = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        val_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=12))
     num_batches = len(loader_train)
     core.train()
     info("======= start training =======")
@@ -294,6 +305,9 @@ def train(args, initial_global_step, model, optimizer, scheduler, vocoder, loade
                 info(" --- <validation> --- \nloss: {:.3f}. ".format(test_loss))
                 saver.log_value({"validation/loss": test_loss})
                 core.train()
+            if global_step % args.train.interval_val == 0 and val_group is not None:
+                import torch.distributed as dist
+                dist.barrier(group=val_group)
             if max_steps and global_step - initial_global_step >= max_steps:
                 return global_step
     return global_step

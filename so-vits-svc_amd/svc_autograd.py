@@ -818,7 +818,7 @@ class _Attention(Function):
             ev = _c(emb_v.view(-1, dk))
             dpband = S.gemm(dO, ev, (dk * T, 1, T), (0, 1, dk), BH, T, nrel, dk)
             S.band_scatter_add(dP, dpband, BH * T, T, window)
-            dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T)      # [BH, nrel, dk]
+            dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, split_k_atomic=True)      # [BH, nrel, dk]
             dEv = S.reduce_bct(dEv_b.view(BH, nrel * dk, 1), 0).view(emb_v.shape)
         S.attn_softmax_bwd(P, dP, B, H, T, drop_u, p_drop, mask, mask_mode)          # dP(d) -> dS in place
         dS = dP
@@ -830,7 +830,7 @@ class _Attention(Function):
             drel = S.band_gather(dS, BH * T, T, window)
             S.gemm(ek, drel, (0, 1, dk), (T * nrel, 1, nrel), BH, dk, T, nrel, out=dQ, c_strides=(dk * T, T, 1), alpha=sc,
                    beta=1.0)
-            dEk_b = S.gemm(drel, q, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, alpha=sc)
+            dEk_b = S.gemm(drel, q, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, alpha=sc, split_k_atomic=True)
             dEk = S.reduce_bct(dEk_b.view(BH, nrel * dk, 1), 0).view(emb_k.shape)
         return dQ, dK, dV, dEk, dEv, None, None, None, None, None, None
 

@@ -693,7 +693,7 @@ class GemmArgs(C.Structure):
                 ("b_bs", C.c_longlong), ("b_ks", C.c_longlong), ("b_ns", C.c_longlong),
                 ("c_bs", C.c_longlong), ("c_ms", C.c_longlong), ("c_ns", C.c_longlong),
                 ("batch", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("alpha", C.c_float), ("beta", C.c_float)]
+                ("alpha", C.c_float), ("beta", C.c_float), ("split_k_atomic", C.c_int)]
 
 
 class ConvWeightArgs(C.Structure):
@@ -1062,9 +1062,10 @@ def conv1d_wgrad(A, Bm, KS, dil, pad, out=None, accumulate=False, dbias=None, mm
     return out
 
 
-def gemm(A, Bmat, a_strides, b_strides, batch, M, N, K, out=None, c_strides=None, alpha=1.0, beta=0.0):
+def gemm(A, Bmat, a_strides, b_strides, batch, M, N, K, out=None, c_strides=None, alpha=1.0, beta=0.0, split_k_atomic=False):
     """C[b,m,n] = alpha*sum_k A[b,m,k]*B[b,k,n] + beta*C.  a_strides = (bs, ms, ks), b_strides = (bs, ks, ns),
-    c_strides = (bs, ms, ns) (default contiguous [batch,M,N]).  A/Bmat/out are tensors used as base pointers."""
+    c_strides = (bs, ms, ns) (default contiguous [batch,M,N]).  A/Bmat/out are tensors used as base pointers.
+    split_k_atomic: allow the thin-M split-reduction kernel (fp32 atomics: not bit-reproducible) — gradient products only."""
     require_gpu(A, Bmat, out)
     if out is None:
         out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
@@ -1076,6 +1077,7 @@ def gemm(A, Bmat, a_strides, b_strides, batch, M, N, K, out=None, c_strides=None
     a.b_bs, a.b_ks, a.b_ns = b_strides
     a.c_bs, a.c_ms, a.c_ns = c_strides
     a.batch, a.M, a.N, a.K, a.alpha, a.beta = batch, M, N, K, alpha, beta
+    a.split_k_atomic = 1 if split_k_atomic else 0
     check(tlib().svc_gemm_f32(C.byref(a), stream_ptr()), "gemm")
     return out
 
@@ -1369,6 +1371,31 @@ def graph_capture(graph, pool=None):
     if dist.is_available() and dist.is_initialized():
         kw["capture_error_mode"] = "thread_local"
     return torch.cuda.graph(graph, **kw)
+
+
+def capture_error_mode():
+    """hipStreamCaptureMode of this engine's captures (see graph_capture)."""
+    import torch.distributed as dist
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
+class capture_stream:
+    """What torch.cuda.graph does around capture_begin / capture_end, for captures that are begun and ended by hand (the
+    data-parallel iteration is cut into several graphs inside one backward pass): device idle, cached blocks released,
+    a side stream current for the duration."""
+    _stream = None
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if capture_stream._stream is None:
+            capture_stream._stream = torch.cuda.Stream()
+        self.ctx = torch.cuda.stream(capture_stream._stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
 
 
 def lrelu_tail_fwd(x, valid, slope):

@@ -90,7 +90,10 @@ class TrainStep:
                 self.mma, self.scaler = S.MMA_F16, LossScaler()
 
         self.use_graph = False
-        self._graphs = {}
+        import collections
+        self._graphs = collections.OrderedDict()      # batch shape -> captured iteration, least recently used first
+        self.graph_evictions, self._cap_logged = 0, False
+        self.dp_ordered = False       # eager launches with the replayed form's collective order (a rank whose capture failed)
         # every captured shape keeps its own ~10 GB tape alive: bound the count (bucketed batches need 2-4; a data set of
         # odd batch sizes falls back to eager launches for the shapes beyond the cap instead of growing without limit)
         self.max_graphs = int(os.environ.get("SVC_TRAIN_GRAPH_MAX", "8"))
@@ -114,6 +117,8 @@ class TrainStep:
             if all(r is not None for r in self._reducers()):
                 return self._call_graph_dp(items, noise)
             return self._call_graph(items, noise)
+        if self.dp_ordered and all(r is not None for r in self._reducers()):
+            return self._step_body_dp_eager(items, noise)
         return self._step_body(items, noise)
 
     def _dense_spec(self, items):
@@ -138,9 +143,9 @@ class TrainStep:
         nkeys = sorted(noise) if noise is not None else []
         items = list(items) + [noise[k] for k in nkeys]
         key = tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
-        ent = self._graphs.get(key)
+        ent = self._graph_get(key)
         n_in = len(items) - len(nkeys)
-        if ent is None and len(self._graphs) >= self.max_graphs:
+        if ent is None and self._graph_cap_reached():
             self.eager_fallbacks += 1
             return self._step_body(items[:n_in], dict(zip(nkeys, items[n_in:])) if nkeys else None)
         if ent is None:
@@ -296,22 +301,33 @@ class TrainStep:
         return getattr(self.net_g, "reducer", None), getattr(self.net_d, "reducer", None)
 
     def _call_graph_dp(self, items, noise=None):
-        """With a process group the iteration is replayed as TWO hipGraphs (D segment, G segment) with the gradient
-        all-reduces and the two (one-launch) optimizer steps issued eagerly between them:
-            graph[G forward, D forward, D backward] -> all-reduce(D grads) -> AdamW(D)
-            -> graph[D forward (frozen), losses, G backward] -> all-reduce(G grads) -> AdamW(G)
-        Collectives are not captured (RCCL inside a graph needs capture-aware streams and watchdog handling; the two
-        all-reduces move 0.2 + 0.4 GB per iteration, a few ms over xGMI) and the Python autograd hooks that drive the
-        overlapped per-bucket path do not run in a replay, so each optimizer's gradients are reduced in one call."""
+        """With a process group the iteration is replayed as a SEQUENCE of hipGraphs per optimizer, split where a gradient bucket
+        becomes complete, with that bucket's all-reduce issued right behind the graph that completed it:
+            D phase: graph[G forward, D forward, D backward up to bucket 0] -> all-reduce(b0) ‖ graph[... up to bucket 1] ->
+                     all-reduce(b1) ‖ ... -> wait -> AdamW(D)
+            G phase: graph[D forward (frozen), losses, G backward up to bucket 0] -> all-reduce(b0) ‖ ... -> wait -> AdamW(G)
+        Each all-reduce runs on RCCL's stream behind an event of the compute stream, which goes straight on to the next graph:
+        communication overlaps the rest of that backward pass (north_star's schedule: train.py:57,89-90 = DDP's bucketed
+        overlap), and only the LAST bucket's transfer is exposed.  The split points come from the reducer's gradient hooks
+        firing DURING capture (`GradReducer.segmented`: the backward pass runs on the capturing thread —
+        `torch.autograd.set_multithreading_enabled(False)` — so a hook can end one capture and begin the next); nothing is
+        captured of the collectives themselves.  SVC_DP_SPLIT=0 keeps the two monolithic graphs with both reductions between
+        them (round-2 form); SVC_DP_CAPTURE_COLLECTIVES=1 records the collectives inside two graphs instead.
+
+        Rank consistency: ranks read different shards, so on one iteration rank A may replay a cached shape while
+        rank B meets a new one (warm-up + capture) and rank C is past the graph cap (eager launches).  All three issue the
+        same collectives — D's buckets 0..n-1, then G's — because (1) warm-up iterations run under `no_sync` (their results
+        are discarded anyway), (2) a capture records no collective and is followed by a replay of what it captured, (3) the
+        eager fallback runs its two segments under `no_sync` and reduces with `reduce_all` (same buckets, same order)."""
         red_g, red_d = self._reducers()
         nkeys = sorted(noise) if noise is not None else []
         items = list(items) + [noise[k] for k in nkeys]
         key = ("dp",) + tuple((tuple(t.shape), str(t.dtype)) if t is not None else None for t in items) + tuple(nkeys)
-        ent = self._graphs.get(key)
+        ent = self._graph_get(key)
         n_in = len(items) - len(nkeys)
-        if ent is None and len(self._graphs) >= self.max_graphs:     # same decision on every rank: the shapes are the loader's
+        if ent is None and self._graph_cap_reached():
             self.eager_fallbacks += 1
-            return self._step_body(items[:n_in], dict(zip(nkeys, items[n_in:])) if nkeys else None)
+            return self._step_body_dp_eager(items[:n_in], dict(zip(nkeys, items[n_in:])) if nkeys else None)
         if ent is None:
             commons.DEVICE_RNG = True
             static = [t.clone() if t is not None else None for t in items]
@@ -322,8 +338,8 @@ class TrainStep:
             sn_saved = [b.clone() for b in sn]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):                       # warm-up (real, bucket-overlapped all-reduces: every rank runs it)
+            with torch.cuda.stream(side), red_g.no_sync(), red_d.no_sync():
+                for _ in range(2):                       # warm-up WITHOUT collectives: only this rank may be here (see above)
                     self._step_body(s_items, s_noise)
             torch.cuda.current_stream().wait_stream(side)
             self.optim_g.restore(snaps[0])               # also invalidates every packed-weight cache (version bump)
@@ -331,46 +347,55 @@ class TrainStep:
             for b, v in zip(sn, sn_saved):
                 b.copy_(v)
             torch.cuda.synchronize()
-            # SVC_DP_CAPTURE_COLLECTIVES=1 (opt-in, RCCL only): let the autograd hooks fire DURING capture, so the per-bucket
-            # all-reduces are recorded on RCCL's stream inside the two graphs and overlap the rest of the captured backward
-            # (north_star's schedule, replayed without host work).  Not the default: collectives inside hipGraphs have never run
-            # on this code base's hardware (single-GPU boxes only), and a mis-captured collective hangs instead of raising.
             captured = os.environ.get("SVC_DP_CAPTURE_COLLECTIVES", "0") == "1" and red_g.backend == "nccl"
-            import contextlib
-            guard = contextlib.ExitStack()
-            if not captured:
-                guard.enter_context(red_g.no_sync())     # hooks must not launch collectives inside a capture
-                guard.enter_context(red_d.no_sync())
-            with guard:
-                g1 = torch.cuda.CUDAGraph()
-                with S.graph_capture(g1):
-                    ctx = self._seg_d(s_items, s_noise)
+            split = not captured and os.environ.get("SVC_DP_SPLIT", "1") == "1"
+            if split:
+                prog_d, ctx, pool = self._capture_split(lambda: self._seg_d(s_items, s_noise), red_d, None)
                 touched_d = list(self.optim_d.arena.touched)
                 # what optim_d.step() does to the host view of the weights: the G segment must re-pack D's weights
                 torch.autograd.graph.increment_version(self.optim_d.arena.params)
-                g2 = torch.cuda.CUDAGraph()
-                with S.graph_capture(g2, pool=g1.pool()):
-                    out = self._seg_g(ctx)
+                prog_g, out, _ = self._capture_split(lambda: self._seg_g(ctx), red_g, pool)
                 touched_g = list(self.optim_g.arena.touched)
                 torch.autograd.graph.increment_version(self.optim_g.arena.params)
-            ent = (g1, g2, static, out, touched_d, touched_g, ctx, captured)
-            self._graphs[key] = ent
-            self.dp_mode = "collectives captured in the graphs (bucket-overlapped)" if captured else \
-                "two graphs, bucketed all-reduce between them (exposed)"
-        g1, g2, static, out, touched_d, touched_g, _, captured = ent
+                self.dp_mode = (f"split graphs ({sum(1 for o, _ in prog_d if o == 'graph')} + "
+                                f"{sum(1 for o, _ in prog_g if o == 'graph')}), bucket all-reduces overlapped with the backward passes")
+            else:
+                # SVC_DP_CAPTURE_COLLECTIVES=1 (opt-in, RCCL only): let the autograd hooks fire DURING capture, so the per-bucket
+                # all-reduces are recorded on RCCL's stream inside the two graphs.  Not the default: collectives inside hipGraphs
+                # have never run on this code base's hardware (single-GPU boxes only), a mis-captured collective hangs instead of
+                # raising, and every rank must then capture on the SAME iteration (a capture executes no collective).
+                import contextlib
+                guard = contextlib.ExitStack()
+                if not captured:
+                    guard.enter_context(red_g.no_sync())     # hooks must not launch collectives inside a capture
+                    guard.enter_context(red_d.no_sync())
+                with guard:
+                    g1 = torch.cuda.CUDAGraph()
+                    with S.graph_capture(g1):
+                        ctx = self._seg_d(s_items, s_noise)
+                    touched_d = list(self.optim_d.arena.touched)
+                    torch.autograd.graph.increment_version(self.optim_d.arena.params)
+                    g2 = torch.cuda.CUDAGraph()
+                    with S.graph_capture(g2, pool=g1.pool()):
+                        out = self._seg_g(ctx)
+                    touched_g = list(self.optim_g.arena.touched)
+                    torch.autograd.graph.increment_version(self.optim_g.arena.params)
+                tail = lambda red: [] if captured else [("reduce", b) for b in range(len(red.buckets))]
+                prog_d, prog_g = [("graph", g1)] + tail(red_d), [("graph", g2)] + tail(red_g)
+                self.dp_mode = "collectives captured in the graphs (bucket-overlapped)" if captured else \
+                    "two graphs, bucketed all-reduce between them (exposed)"
+            ent = (prog_d, prog_g, static, out, touched_d, touched_g, ctx)
+            self._graph_put(key, ent)
+        prog_d, prog_g, static, out, touched_d, touched_g, _ = ent
         self._serialize_replays()
         for s, t in zip(static, items):
             if s is not None:
                 s.copy_(t, non_blocking=True)
         try:
-            g1.replay()
-            if not captured:
-                red_d.reduce_all()
+            self._run_program(prog_d, red_d)
             self.optim_d.arena.touched = list(touched_d)
             self.optim_d.step()
-            g2.replay()
-            if not captured:
-                red_g.reduce_all()
+            self._run_program(prog_g, red_g)
             self.optim_g.arena.touched = list(touched_g)
             self.optim_g.step()
         finally:
@@ -378,6 +403,98 @@ class TrainStep:
         res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
         self._mark_replay()
         return res
+
+    @staticmethod
+    def _run_program(prog, red):
+        for op, x in prog:
+            if op == "graph":
+                x.replay()
+            else:
+                red.launch_bucket(x)
+        red.wait_all()
+
+    def _capture_split(self, fn, red, pool):
+        """Capture `fn` (a forward + backward segment) into a sequence of hipGraphs sharing one memory pool, cut wherever
+        `red` reports a completed gradient bucket -> ([("graph", g) | ("reduce", bucket), ...], fn's result, pool)."""
+        prog = []
+        st = dict(g=None, pool=pool)
+        mode = S.capture_error_mode()
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            args = () if st["pool"] is None else (st["pool"],)
+            g.capture_begin(*args, capture_error_mode=mode)
+            st["g"] = g
+
+        def end():
+            g, st["g"] = st["g"], None
+            g.capture_end()
+            prog.append(("graph", g))
+            if st["pool"] is None:
+                st["pool"] = g.pool()
+
+        def ready(b):
+            end()
+            prog.append(("reduce", b))
+            begin()
+
+        with S.capture_stream(), torch.autograd.set_multithreading_enabled(False), red.segmented(ready):
+            begin()
+            try:
+                out = fn()
+            finally:
+                if st["g"] is not None:
+                    end()
+            nb = red.seg_next
+        prog += [("reduce", b) for b in range(nb, len(red.buckets))]     # buckets without a (complete set of) gradient(s)
+        return prog, out, st["pool"]
+
+    def _step_body_dp_eager(self, items, noise=None):
+        """The iteration launched eagerly (past the graph cap) with the SAME collective sequence as the replayed form: both
+        segments under no_sync, each followed by the bucket-ordered reduction."""
+        red_g, red_d = self._reducers()
+        try:
+            with red_g.no_sync(), red_d.no_sync():
+                ctx = self._seg_d(items, noise)
+            red_d.reduce_all()
+            self.optim_d.step()
+            with red_g.no_sync(), red_d.no_sync():
+                out = self._seg_g(ctx)
+            red_g.reduce_all()
+            self.optim_g.step()
+        finally:
+            S.wgrad_slab.active = False
+        return out
+
+    # -- graph cache: least-recently-used eviction at the cap ---------------------------------------------------------------------
+    def _graph_get(self, key):
+        ent = self._graphs.get(key)
+        if ent is not None:
+            self._graphs.move_to_end(key)
+        return ent
+
+    def _graph_cap_reached(self):
+        """Every captured shape keeps its own ~10 GB tape alive, so the count is bounded (SVC_TRAIN_GRAPH_MAX).  At the cap the
+        least recently used graph is dropped (SVC_TRAIN_GRAPH_EVICT=0: launch unseen shapes eagerly from then on); either way the
+        event is logged once and counted (`graph_evictions` / `eager_fallbacks`), ADVICE r4 medium."""
+        if len(self._graphs) < self.max_graphs:
+            return False
+        evict = os.environ.get("SVC_TRAIN_GRAPH_EVICT", "1") == "1"
+        if not self._cap_logged:
+            self._cap_logged = True
+            import logging
+            logging.getLogger("train").warning(
+                "TrainStep: %d batch shapes captured (SVC_TRAIN_GRAPH_MAX) — %s; bucket the loader's frame counts or raise the cap",
+                len(self._graphs), "dropping the least recently used graph for each new shape" if evict
+                else "unseen shapes launch eagerly from now on")
+        if not evict:
+            return True
+        self._graphs.popitem(last=False)
+        self.graph_evictions += 1
+        return False
+
+    def _graph_put(self, key, ent):
+        self._graphs[key] = ent
 
 
 def init_distributed(rank, world, device):

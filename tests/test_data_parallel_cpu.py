@@ -223,10 +223,19 @@ class _FakeGraph:
         self.fn = None
 
     def pool(self):
-        return None
+        return "pool"
+
+    def capture_begin(self, *pool, capture_error_mode="global"):
+        assert _FakeGraph.capturing is None, "nested capture"
+        _FakeGraph.capturing = self
+
+    def capture_end(self):
+        assert _FakeGraph.capturing is self
+        _FakeGraph.capturing = None
 
     def replay(self):
-        self.fn()
+        if self.fn is not None:          # a graph begun inside a gradient hook holds the REST of a backward pass: the fake's first
+            self.fn()                    # graph re-runs the whole segment, the later ones have nothing left to do
 
 
 class _Dummy:
@@ -237,7 +246,7 @@ class _Dummy:
         return lambda *a, **k: None
 
 
-def _dp4_worker(rank, world, port, q):
+def _dp4_worker(rank, world, port, q, scenario="same_shapes"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -265,6 +274,8 @@ def _dp4_worker(rank, world, port, q):
             finally:
                 _FakeGraph.capturing = None
         S.graph_capture = fake_capture
+        S.capture_stream = contextlib.nullcontext
+        S.capture_error_mode = lambda: "global"
 
         class SGD:
             def __init__(self, params, lr=0.05):
@@ -303,7 +314,7 @@ def _dp4_worker(rank, world, port, q):
             def _seg_d(self, items, noise=None):
                 if _FakeGraph.capturing is not None:
                     _FakeGraph.capturing.fn = lambda: self._replayed(self._seg_d, items, noise)
-                x, y = items
+                x, y = items[:2]
                 y_hat = self.net_g(x)
                 loss_d = ((self.net_d(y) - 1) ** 2).mean() + (self.net_d(y_hat.detach()) ** 2).mean()
                 self.optim_d.zero_grad()
@@ -337,33 +348,65 @@ def _dp4_worker(rank, world, port, q):
         hps = dict(data=dict(filter_length=8, n_mel_channels=2, sampling_rate=8, hop_length=2, win_length=8, mel_fmin=0, mel_fmax=4),
                    train=dict(segment_size=4, c_mel=1, c_kl=1, fp16_run=False))
         step = Step(hps, net_g, net_d, og, od).enable_graph(True)
-        # uneven shards: rank r holds r + 1 items (every rank captures its own shapes; only the arena is communicated)
-        gen = torch.Generator().manual_seed(3)
-        shards = [(torch.randn(r + 1, 6, generator=gen), torch.randn(r + 1, 5, generator=gen)) for r in range(world)]
         p0 = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
-        n_it = 3
-        for _ in range(n_it):
-            out = step(shards[rank])
-        assert step.dp_mode.startswith("two graphs") and len(step._graphs) == 1
-        # warm-up (2 eager iterations, undone) + capture + 3 replayed iterations, D segment always before G
-        assert Step.log == ["D", "G"] * (2 + 1 + n_it), Step.log
-        for red in (net_g.reducer, net_d.reducer):
-            assert red.stats["reduce_all_calls"] == n_it and red.stats["backward_passes"] == 2, red.stats      # hooks only during the warm-up
-            assert red.stats["launches"] == n_it * len(red.buckets) + 2 * len(red.buckets)
+        gen = torch.Generator().manual_seed(3)
+        if scenario == "same_shapes":
+            # uneven shards: rank r holds r + 1 items (every rank captures its own shapes; only the arena is communicated)
+            shards = [(torch.randn(r + 1, 6, generator=gen), torch.randn(r + 1, 5, generator=gen)) for r in range(world)]
+            n_it = 3
+            sched = [[shards[r]] * n_it for r in range(world)]
+            for it in range(n_it):
+                out = step(sched[rank][it])
+            assert step.dp_mode.startswith("split graphs") and len(step._graphs) == 1
+            # warm-up (2 eager iterations, undone) + capture + 3 replayed iterations, D segment always before G
+            assert Step.log == ["D", "G"] * (2 + 1 + n_it), Step.log
+            for red in (net_g.reducer, net_d.reducer):
+                # no collective in the warm-up or the capture: exactly one all-reduce per bucket and replayed iteration, none through
+                # the autograd hooks
+                assert red.stats["reduce_all_calls"] == 0 and red.stats["backward_passes"] == 0, red.stats
+                assert red.stats["launches"] == n_it * len(red.buckets), red.stats
+            prog_d, prog_g = next(iter(step._graphs.values()))[:2]
+            for prog, red in ((prog_d, net_d.reducer), (prog_g, net_g.reducer)):
+                assert [x for o, x in prog if o == "reduce"] == list(range(len(red.buckets)))      # canonical order on every rank
+                assert prog[0][0] == "graph" and sum(1 for o, _ in prog if o == "graph") >= 2        # the backward pass WAS cut
+                first_reduce = [o for o, _ in prog].index("reduce")
+                assert "graph" in [o for o, _ in prog[first_reduce:]], "no graph left to overlap the first all-reduce with"
+        else:
+            # every rank meets ITS batch shapes in ITS order (rank-local shards pad to different buckets), with a
+            # graph cap of 2 — so on the same iteration one rank replays, another warms up + captures, a third is past the cap and
+            # launches eagerly (rank 1: eviction off) or evicts (the others).  The collective sequence must still line up.
+            os.environ["SVC_TRAIN_GRAPH_EVICT"] = "0" if rank == 1 else "1"
+            step.max_graphs = 2
+            sizes = {0: [2, 2, 3, 2, 4, 3], 1: [1, 2, 3, 4, 1, 2], 2: [3, 3, 3, 3, 3, 3], 3: [4, 1, 4, 2, 2, 1]}
+            n_it = len(sizes[0])
+            batches = {n: (torch.randn(n, 6, generator=gen), torch.randn(n, 5, generator=gen)) for n in (1, 2, 3, 4)}
+            sched = [[batches[n] for n in sizes[r]] for r in range(world)]
+            for it in range(n_it):
+                out = step(sched[rank][it])
+            for red in (net_g.reducer, net_d.reducer):
+                assert red.stats["backward_passes"] == 0, red.stats            # the hook-driven path never ran (warm-ups are no_sync)
+                assert red.stats["launches"] == n_it * len(red.buckets), red.stats
+            if rank == 1:
+                assert step.eager_fallbacks == 2 and step.graph_evictions == 0 and len(step._graphs) == 2
+            elif rank == 2:
+                assert step.eager_fallbacks == 0 and step.graph_evictions == 0 and len(step._graphs) == 1
+            else:
+                assert step.eager_fallbacks == 0 and step.graph_evictions >= 1 and len(step._graphs) == 2
         # every rank ends with the same parameters ...
         flat = torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])
         allp = [None] * world
         dist.all_gather_object(allp, flat)
         assert all(torch.equal(allp[0], a) for a in allp)
-        # ... the ones a single process gets by averaging the four shards' gradients by hand
+        # ... the ones a single process gets by averaging the four ranks' gradients by hand
         Gr = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 5))
         Dr = nn.Sequential(nn.Linear(5, 12), nn.Tanh(), nn.Linear(12, 1))
         with torch.no_grad():
             for p, v in zip(list(Gr.parameters()) + list(Dr.parameters()), p0):
                 p.copy_(v)
-        for _ in range(n_it):
+        for it in range(n_it):
             gd = [torch.zeros_like(p) for p in Dr.parameters()]
-            for x, y in shards:
+            for r in range(world):
+                x, y = sched[r][it]
                 loss = ((Dr(y) - 1) ** 2).mean() + (Dr(Gr(x).detach()) ** 2).mean()
                 for a, g_ in zip(gd, torch.autograd.grad(loss, list(Dr.parameters()))):
                     a += g_ / world
@@ -371,7 +414,8 @@ def _dp4_worker(rank, world, port, q):
                 for p, g_ in zip(Dr.parameters(), gd):
                     p -= 0.05 * g_
             gg = [torch.zeros_like(p) for p in Gr.parameters()]
-            for x, y in shards:
+            for r in range(world):
+                x, y = sched[r][it]
                 loss = ((Dr(Gr(x)) - 1) ** 2).mean()
                 for a, g_ in zip(gg, torch.autograd.grad(loss, list(Gr.parameters()))):
                     a += g_ / world
@@ -389,15 +433,18 @@ def _dp4_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_graph_data_parallel_iteration_world4_gloo():
-    """train.TrainStep._call_graph_dp at world size 4 with the device calls stubbed — warm-up through the
-    bucket-overlapped hooks, capture under no_sync, then per iteration graph[D] -> reduce_all(D) -> step(D) -> graph[G] ->
-    reduce_all(G) -> step(G); uneven shards; buffers broadcast from rank 0; all ranks bit-identical and equal to hand-averaged
-    single-process training."""
+@pytest.mark.parametrize("scenario", ["same_shapes", "rank_local_shapes"])
+def test_split_graph_data_parallel_iteration_world4_gloo(scenario):
+    """train.TrainStep._call_graph_dp at world size 4 with the device calls stubbed: warm-up
+    under no_sync, each phase captured as a SEQUENCE of graphs cut at the gradient-bucket boundaries by the reducer's hooks, then
+    per iteration graph -> all-reduce(bucket 0) ‖ graph -> ... -> wait -> step for D and for G; buffers broadcast from rank 0; all
+    ranks bit-identical and equal to hand-averaged single-process training.  `rank_local_shapes`: the ranks meet different batch
+    shapes on the same iteration (replay / warm-up + capture / eviction / eager fallback mixed) and still issue the same
+    collective sequence."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q)) for r in range(4)]
+    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q, scenario)) for r in range(4)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

@@ -23,11 +23,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False):
+def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False, env=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.update(env or {})
         if capture:
             os.environ["SVC_DP_CAPTURE_COLLECTIVES"] = "1"
         root = os.path.dirname(HERE)
@@ -72,9 +73,10 @@ def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False):
         dist.all_gather(parts, flat_dev)                    # (device tensors: valid for gloo and nccl alike)
         parts = [t.cpu() for t in parts]
         flat = flat_dev.cpu()
-        same = torch.equal(parts[0], parts[1])
+        same = all(torch.equal(parts[0], p) for p in parts)
         fin = all(torch.isfinite(v).all().item() for v in out.values() if torch.is_tensor(v))
-        stats = (dict(net_g.reducer.stats), dict(net_d.reducer.stats))
+        stats = (dict(net_g.reducer.stats, mode=getattr(step, "dp_mode", "eager"),
+                      exposed_ms=net_g.reducer.exposed_ms() if graph else 0.0), dict(net_d.reducer.stats))
         dist.destroy_process_group()
         q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats, flat if rank == 0 else None))
     except Exception:      # noqa: BLE001
@@ -82,11 +84,11 @@ def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False):
         q.put((rank, traceback.format_exc(), None, None))
 
 
-def _run_two_ranks(graph, backend="gloo", capture=False):
+def _run_two_ranks(graph, backend="gloo", capture=False, world=2, env=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph, backend, capture)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph, backend, capture, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -104,10 +106,15 @@ def test_two_rank_training_keeps_parameters_identical():
 
 
 def test_two_rank_training_graph_segments():
-    """train.TrainStep with a process group AND enable_graph(): two hipGraphs per iteration (D segment, G segment) with
-    whole-arena all-reduces and the AdamW launches between them.  Ranks stay bit-identical, the un-captured warm-up leaves no
-    trace (3 replayed iterations == 3 training steps: compared against 3 eager data-parallel iterations)."""
+    """train.TrainStep with a process group AND enable_graph(): each phase of the iteration is a sequence of hipGraphs cut at
+    the gradient-bucket boundaries DURING the captured backward pass (real capture_end / capture_begin inside the reducer's
+    hooks), a bucket's all-reduce issued behind the graph that completed it, AdamW after the last.  Ranks stay bit-identical,
+    the un-captured warm-up leaves no trace (3 replayed iterations == 3 training steps: compared against 3 eager data-parallel
+    iterations)."""
     res_g = _run_two_ranks(True)
+    g_stats = res_g[0][2][0]
+    assert g_stats["mode"].startswith("split graphs"), g_stats
+    assert g_stats["backward_passes"] == 0 and g_stats["launches"] % 3 == 0, g_stats     # no collective outside the 3 replays
     flat_g = next(f for r, _, _, f in res_g if f is not None)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -215,6 +222,29 @@ def test_two_rank_diffusion_training_equals_full_batch(graph):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+def test_split_graph_iteration_over_rccl_world1():
+    """What ONE GPU can exercise of the default N > 1 mode over the real transport: process group "nccl" (RCCL) at world size 1
+    with SVC_DP_FORCE=1 — reducers built, hipGraph captures cut inside the backward pass under ProcessGroupNCCL's watchdog
+    thread (capture_error_mode thread_local), every bucket's all-reduce really issued on RCCL's stream between the graph
+    replays.  Three replayed iterations must equal three eager hook-driven iterations of the same process group to the weight
+    gradients' atomics noise, and the two monolithic graphs of SVC_DP_SPLIT=0 likewise."""
+    env = {"SVC_DP_FORCE": "1"}
+    split = _run_two_ranks(True, backend="nccl", world=1, env=env)
+    st = split[0][2][0]
+    assert st["mode"].startswith("split graphs") and st["launches"] > 0, st
+    eager = _run_two_ranks(None, backend="nccl", world=1, env=env)
+    mono = _run_two_ranks(True, backend="nccl", world=1, env=dict(env, SVC_DP_SPLIT="0"))
+    assert mono[0][2][0]["mode"].startswith("two graphs"), mono[0][2][0]
+    lr, steps = 2e-4, 3
+    for other in (eager, mono):
+        d = (split[0][3] - other[0][3]).abs()
+        assert d.max().item() <= 2.5 * lr * steps and d.mean().item() <= 0.02 * lr, (d.max().item(), d.mean().item())
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "dp_split_rccl_world1.txt"), "w") as f:
+            f.write(repr(dict(split=split[0][2], mono=mono[0][2])) + "\n")
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 
 
@@ -226,7 +256,7 @@ def test_two_rank_training_over_rccl():
     kernels on the same gradients and must agree with each other to fp32 atomics' noise.  Skipped on one-GPU boxes — it runs
     the moment the suite sees a multi-GPU node."""
     _run_two_ranks(False, backend="nccl")
-    two = next(f for r, _, _, f in _run_two_ranks(True, backend="nccl") if f is not None)
+    two = next(f for r, _, _, f in _run_two_ranks(True, backend="nccl") if f is not None)      # split graphs, overlapped buckets
     cap = next(f for r, _, _, f in _run_two_ranks(True, backend="nccl", capture=True) if f is not None)
     d = (two - cap).abs()
     assert d.max().item() <= 2.5 * 2e-4 * 3 and d.mean().item() <= 0.02 * 2e-4, (d.max().item(), d.mean().item())

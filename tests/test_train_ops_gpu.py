@@ -549,12 +549,19 @@ def test_gemm_thin_m_products(dev, BH, M, N, K):
         err = (got.cpu() - want).abs().max().item()
         assert err <= 2e-5 * max(1.0, want.abs().max().item()), (what, err)
 
-    close(S.gemm(A_mk.to(dev), B_nk.to(dev), (K * M, 1, M), (N * K, 1, K), BH, M, N, K, alpha=0.5), 0.5 * ref, "m-fast A, k-fast B")
+    close(S.gemm(A_mk.to(dev), B_nk.to(dev), (K * M, 1, M), (N * K, 1, K), BH, M, N, K, alpha=0.5, split_k_atomic=True), 0.5 * ref,
+          "m-fast A, k-fast B")
+    # without the opt-in the same product takes a deterministic kernel (inference / forward products never use atomics)
+    d1 = S.gemm(A_mk.to(dev), B_nk.to(dev), (K * M, 1, M), (N * K, 1, K), BH, M, N, K, alpha=0.5)
+    d2 = S.gemm(A_mk.to(dev), B_nk.to(dev), (K * M, 1, M), (N * K, 1, K), BH, M, N, K, alpha=0.5)
+    close(d1, 0.5 * ref, "deterministic form")
+    assert torch.equal(d1, d2)
     A_km = A_mk.transpose(1, 2).contiguous()           # k contiguous
     B_kn = B_nk.transpose(1, 2).contiguous()           # n contiguous
     acc = torch.randn(BH, M, N + 3, generator=g)
     out = acc.to(dev)
-    S.gemm(A_km.to(dev), B_kn.to(dev), (M * K, K, 1), (K * N, N, 1), BH, M, N, K, out=out, c_strides=(M * (N + 3), N + 3, 1), alpha=2.0, beta=1.0)
+    S.gemm(A_km.to(dev), B_kn.to(dev), (M * K, K, 1), (K * N, N, 1), BH, M, N, K, out=out, c_strides=(M * (N + 3), N + 3, 1), alpha=2.0, beta=1.0,
+           split_k_atomic=True)
     want = acc.clone()
     want[:, :, :N] += 2.0 * ref
     close(out, want, "k-fast A, n-fast B, strided accumulate")
