@@ -286,10 +286,17 @@ typedef struct svc_attention_args {
   float* out;
   long long q_bs, q_cs, k_bs, k_cs, v_bs, v_cs, o_bs, o_cs, mask_bs;
   int B, H, dk, T, window, mask_mode;
+  void* ws;           /* optional scratch (device memory, caller-owned, contents undefined before and after the call) ... */
+  long long ws_bytes; /* ... of at least svc_attention_ws_bytes(a): with it a short sequence with few heads (one utterance:
+                         27 query tiles x 2 heads at T = 862) also splits its KEYS over workgroups and merges them in a second
+                         small launch; NULL / too small: one workgroup per (query tile, head) walks all keys */
 } svc_attention_args;
 
 int svc_attention_f32(const svc_attention_args* a, void* stream);
-/* Tuning aid (A/B on one box): force the 8- or 16-wave workgroup variant of svc_attention_f32; 0 = automatic. */
+/* Scratch bytes the key-split form wants for this shape (0: the shape does not take it).  Reads B, H, dk, T only. */
+long long svc_attention_ws_bytes(const svc_attention_args* a);
+/* Tuning aid (A/B on one box): force the 8- or 16-wave workgroup variant of svc_attention_f32; 0 = automatic; 100 / 101: key-split
+ * form off / automatic. */
 int svc_debug_set_attention_waves(int nw);
 
 

@@ -12,7 +12,8 @@ for (B, H, dk, T, w) in ((1, 2, 96, 862, 4), (1, 2, 96, 2584, 4), (8, 2, 96, 862
     ek = torch.randn(2 * w + 1, dk, device=dev) * 0.1 if w else None
     ev = torch.randn(2 * w + 1, dk, device=dev) * 0.1 if w else None
     outs = {}
-    for nw in (8, 16):
+    for nw in (8, 16, 0):          # 0: automatic + the key-split form (two launches) where the shape takes it
+        S.lib().svc_debug_set_attention_waves(100 + (1 if nw == 0 else 0))
         S.lib().svc_debug_set_attention_waves(nw)
         fn = lambda: S.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H, emb_rel_k=ek, emb_rel_v=ev, window=w)
         outs[nw] = fn().clone()
@@ -25,6 +26,7 @@ for (B, H, dk, T, w) in ((1, 2, 96, 862, 4), (1, 2, 96, 2584, 4), (8, 2, 96, 862
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / (2 * N) * 1e3
-        print(f"B={B} H={H} dk={dk} T={T} w={w}: {nw:2d} waves {us:7.1f} us  {4.0*B*H*T*T*dk/us/1e6:5.1f} TF")
-    print("   max |diff| 8 vs 16 waves:", (outs[8] - outs[16]).abs().max().item())
+        print(f"B={B} H={H} dk={dk} T={T} w={w}: {'split/auto' if nw == 0 else str(nw) + ' waves'} {us:7.1f} us  {4.0*B*H*T*T*dk/us/1e6:5.1f} TF")
+    print("   max |diff| 8 vs 16 waves:", (outs[8] - outs[16]).abs().max().item(), " split vs 16:", (outs[0] - outs[16]).abs().max().item())
 S.lib().svc_debug_set_attention_waves(0)
+S.lib().svc_debug_set_attention_waves(101)

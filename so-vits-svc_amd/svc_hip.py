@@ -77,6 +77,7 @@ class AttentionArgs(C.Structure):
         ("v_bs", C.c_longlong), ("v_cs", C.c_longlong), ("o_bs", C.c_longlong), ("o_cs", C.c_longlong),
         ("mask_bs", C.c_longlong),
         ("B", C.c_int), ("H", C.c_int), ("dk", C.c_int), ("T", C.c_int), ("window", C.c_int), ("mask_mode", C.c_int),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
     ]
 
 
@@ -115,6 +116,8 @@ def lib():
         L.svc_add_layernorm_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_reparam_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_attention_f32.argtypes = [C.POINTER(AttentionArgs), C.c_void_p]
+        L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
+        L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
         L.svc_lf0_to_f0_f32.argtypes = [_f32p, _f32p, C.c_longlong, C.c_void_p]
         L.svc_copy_bct_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 5 + [C.c_int] * 3 + [C.c_void_p]
@@ -140,7 +143,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -509,6 +512,11 @@ def attention(q, k, v, n_heads, *, emb_rel_k=None, emb_rel_v=None, window=0, mas
     if mask is not None:
         a.mask_bs = mask.stride(0)
     a.B, a.H, a.dk, a.T, a.window, a.mask_mode = B, n_heads, dk, T, window, mask_mode
+    nws = lib().svc_attention_ws_bytes(C.byref(a))       # > 0: a short sequence whose keys are split over workgroups too
+    ws = None
+    if nws > 0:
+        ws = torch.empty(nws // 4, device=q.device, dtype=torch.float32)
+        a.ws, a.ws_bytes = ptr(ws), nws
     check(lib().svc_attention_f32(C.byref(a), stream_ptr()), "attention")
     return out
 

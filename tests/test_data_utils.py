@@ -227,7 +227,7 @@ def test_bucketed_collate_is_the_plain_collate_zero_padded(tmp_path):
     items = [ds[i] for i in range(6)]
     a, b = plain(items), bucketed(items)
     T, Tb = a[0].shape[2], b[0].shape[2]
-    assert Tb == data_utils.bucket_frames(T) == 320 and b[3].shape[2] == Tb * HOP
+    assert Tb == data_utils.bucket_frames(T) and Tb in data_utils.FRAME_BUCKETS and Tb >= T and b[3].shape[2] == Tb * HOP
     assert torch.equal(a[5], b[5]) and torch.equal(a[4], b[4])                       # lengths, speaker ids: same order
     for x, y in zip(a, b):
         if torch.is_tensor(x) and x.dim() >= 2 and x.shape[-1] in (T, a[3].shape[2]):
@@ -240,7 +240,8 @@ def test_bucketed_collate_is_the_plain_collate_zero_padded(tmp_path):
     items2 = [ds2[i] for i in range(4)]
     a2, b2 = plain2(items2), bucketed(items2)
     assert isinstance(b2[2], data_utils.SpecContextBatch) and torch.equal(a2[2].n_frames, b2[2].n_frames)
-    assert b2[2].ext.shape[1] == 320 * HOP + (NFFT - HOP) and torch.equal(a2[2].ext, b2[2].ext[:, :a2[2].ext.shape[1]])
-    assert [data_utils.bucket_frames(n) for n in (1, 320, 321, 790, 800, 801, 1000)] == [320, 320, 448, 800, 800, 896, 1024]
+    Tb2 = data_utils.bucket_frames(int(a2[2].n_frames.max()))
+    assert b2[2].ext.shape[1] == Tb2 * HOP + (NFFT - HOP) and torch.equal(a2[2].ext, b2[2].ext[:, :a2[2].ext.shape[1]])
+    assert [data_utils.bucket_frames(n) for n in (1, 128, 129, 200, 320, 321, 790, 800, 801, 1000)] == [128, 128, 192, 256, 320, 448, 800, 800, 896, 1024]
     with pytest.raises(ValueError):
         data_utils.TextAudioCollate(buckets=(64,))

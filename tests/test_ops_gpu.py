@@ -190,11 +190,17 @@ def test_prenet_embed_layernorm_reparam(dev):
 @pytest.mark.parametrize("B,H,dk,T,window,mode", [
     (1, 2, 96, 50, 4, 0), (2, 2, 96, 131, 4, 1), (1, 2, 96, 862, 4, 0), (1, 2, 32, 40, 4, 1), (2, 2, 96, 77, 0, 2),
     (1, 2, 32, 300, 0, 2), (1, 4, 64, 33, 4, 0), (1, 2, 96, 3, 4, 0), (1, 2, 96, 7, 4, 1),
+    # one utterance: the key-split form (workgroup = query tile x head x key split, merged by a second launch) — every mask mode,
+    # a ragged last tile, the unit encoder's 12 x 64 heads, two masked items, the capped split count (T = 1500: two tiles per wave)
+    (1, 2, 96, 862, 4, 1), (1, 2, 96, 861, 4, 2), (1, 12, 64, 500, 0, 0), (2, 2, 96, 500, 4, 1), (1, 2, 128, 257, 4, 0), (1, 4, 64, 300, 0, 0),
+    (1, 2, 96, 1500, 4, 1),
 ])
-def test_attention(dev, B, H, dk, T, window, mode):
+@pytest.mark.parametrize("split", [1, 0])
+def test_attention(dev, B, H, dk, T, window, mode, split):
     """MultiHeadAttention.attention (modules/attentions.py:207-239): window-4 relative positions (Encoder),
-    padding mask (-1e4 fill), causal mask (FFT)."""
+    padding mask (-1e4 fill), causal mask (FFT).  split = 0: the key-split form switched off (one workgroup per query tile)."""
     import svc_hip as S
+    S.lib().svc_debug_set_attention_waves(100 + split)
     g = torch.Generator().manual_seed(T + dk)
     C = H * dk
     q = torch.randn(B, C, T, generator=g) * 1.5
@@ -215,6 +221,7 @@ def test_attention(dev, B, H, dk, T, window, mode):
     out = S.attention(q.to(d), k.to(d), v.to(d), H, emb_rel_k=e_k.to(d) if window else None,
                       emb_rel_v=e_v.to(d) if window else None, window=window, mask=m.to(d) if mode == 1 else None,
                       mask_mode=mode)
+    S.lib().svc_debug_set_attention_waves(101)
     assert _rel(out.cpu(), ref) < 5e-6
 
 
