@@ -519,6 +519,10 @@ def main():
         extras["device"] = X.guarded(X.device_info, dev)
         net.enable_graph(not args.no_graph)
         extras["e2e"] = X.guarded(X.bench_e2e, dev, net, (c, f0, uv, sid), T_FRAMES)
+        ih = X.guarded(X.bench_infer_half, dev, net, (c, f0, uv, sid), T_FRAMES)
+        if isinstance(ih, dict) and "ms_per_step" in ih:
+            ih["speedup_vs_f32"] = round(1e3 * elapsed / args.steps / ih["ms_per_step"], 3)
+        extras["infer_half"] = ih
 
     train_res = None
     if args.mode == "both":

@@ -3,6 +3,7 @@
   device           what this box is (name, CUs, clocks / power cap when rocm-smi answers) + one calibration launch — the
                    128-channel k=11 MRF conv in a hipGraph — so a run-to-run difference can be attributed to the box
   e2e              configs[1] end to end: 16 kHz wave -> ContentVec768L12 units (HuBERT-base stack) -> SynthesizerTrn.infer
+  infer_half       configs[1] in the reference's half-precision mode (`net_g_ms.half()`): the generator's 16-bit pipeline
   snake_b8         configs[3]: nsf-snake-hifigan decoder, 30 s clips (T = 2584 frames), batch 8
   diffusion_train  configs[4]: WaveNet unit2mel training step, 20 x 512, B = 48 crops of 172 frames, fp32
   diffusion_infer  the same model sampling a 10 s clip: 100 DDIM steps (timesteps 1000, speedup 10)
@@ -128,6 +129,47 @@ def bench_e2e(dev, net, inputs, frames):
                 note="unit encoder and synthesizer each replayed from a hipGraph; repeat_expand_2d (utils.py:396-424) is a device "
                      "gather through an index cached per (source, target) length pair",
                 unit_encoder_families=fam)
+
+
+def bench_infer_half(dev, net, inputs, frames, steps=20):
+    """The headline clip through the reference's half-precision inference mode (inference/infer_tool.py:196-198 `net_g_ms.half()`
+    on a compress_model.py checkpoint) = SynthesizerTrn.half(): the generator's 16-bit pipeline (fp16 activations in HBM and LDS,
+    fp16 weights, v_mfma_f32_32x32x16_f16 with fp32 accumulation).  Own key, own roofline against the dense 16-bit MFMA peak;
+    never the headline.  The waveform's distance to the fp32 path on the same noise is measured here, on the spot."""
+    import svc_hip as S
+    c, f0, uv, sid = inputs
+    noise = dict(enc_p=torch.randn(1, net.inter_channels, frames, device=dev), rand_ini=torch.rand(1, 9, device=dev),
+                 sine=torch.randn(1, frames * net.dec.upp, 9, device=dev))
+    was_graph = net.use_graph
+    net.enable_graph(False)
+    o32, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+    net.half()
+    try:
+        oh, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+        mse = (oh - o32).pow(2).mean().item()
+        mx = (oh - o32).abs().max().item()
+        fams = _families(lambda: net.infer(c, f0, uv, g=sid, noice_scale=0.4), n=3)
+        net.enable_graph(True)
+        step = lambda: net.infer(c, f0, uv, g=sid, noice_scale=0.4)
+        dt = _timeit(step, steps, warm=3)
+    finally:
+        net.float()
+        net.enable_graph(was_graph)
+    samples = frames * HOP
+    h = {k: v for k, v in fams.items() if k.endswith("_h")}
+    hms = sum(v["ms_per_step"] for v in h.values())
+    hflop = sum(v["tflops"] * v["ms_per_step"] * 1e9 for v in h.values())
+    peak = 2500.0
+    ach = hflop / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
+    return dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.half().infer)", value=samples / dt, unit="samples/s",
+                ms_per_step=round(1e3 * dt, 4), steps=steps, dtype="fp16 activations + weights in the generator, f32 accumulate; "
+                "encoder / flow / harmonic source f32", launch="hipGraph replay",
+                waveform_vs_f32_path=dict(mse=mse, max_abs=mx, bar="north_star: MSE < 1e-4"),
+                roofline=dict(bound="mfma", kernel="+".join(sorted(h)), achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
+                              frac=round(ach / peak, 4), kernel_ms_per_step=round(hms, 4), traffic=None,
+                              note="16-bit conv launches of the generator (serialised eager pass, hipEvents per launch) against "
+                                   "the dense f16 MFMA peak"),
+                families=fams)
 
 
 def bench_snake_b8(dev, steps=3):

@@ -300,6 +300,44 @@ long long svc_attention_ws_bytes(const svc_attention_args* a);
 int svc_debug_set_attention_waves(int nw);
 
 
+/* ------------------------------------------------------------------------------------------------
+ * 16-bit inference pipeline of the NSF-HiFiGAN generator (csrc/conv1d_h.hip): the engine's form of the reference's
+ * half-precision inference — inference/infer_tool.py:196-198 (`"half" in net_g_path` -> `net_g_ms.half()`), checkpoints written
+ * by compress_model.py:21-48.  Activations are fp16 in HBM and LDS in the BLOCKED layout [B][C/8][T][8] (8 channels of a time step
+ * = 16 contiguous bytes), weights fp16 packed once, products on v_mfma_f32_32x32x16_f16 with fp32 accumulation; bias / activation
+ * / residual / accumulate arithmetic in fp32 before the one rounding of the stored result.
+ *
+ * svc_pack_conv1d_h: dense fp32 weight (weight norm already folded) -> [taps][Cin/16][RP][16] fp16.  u == 1: Conv1d weight
+ *   [Cout][Cin][K], taps = K.  u > 1: ConvTranspose1d weight [Cin][Cout][K], rows = u*Cout (row = phase*Cout + co),
+ *   taps = ceil(K/u) (vdecoder/hifigan/models.py:340-342).  RP: row count rounded up to a multiple of 128.
+ * svc_conv1d_h: y = epilogue(conv(lrelu(x, pre_slope))): + bias[co], post_act (NONE | LRELU), + res (blocked fp16, y-shaped),
+ *   y = (beta*y_old + v) / out_div (the MRF mean of :382-389 accumulated in place).  u > 1: transposed form, Tq = number of input
+ *   positions q that reach an output, y index = q*u + phase + y_t0 (y_t0 = -padding), KS = taps, pad_left = taps - 1.
+ * svc_cvt_to_h / svc_cvt_from_h: fp32 [B,C,T] (strided; optional second addend) <-> blocked fp16.
+ * svc_conv_post_h: leaky_relu(pre_slope) -> Conv1d(C -> 1, KS) -> act (SVC_ACT_TANH | NONE) with fp32 arithmetic and fp32 output
+ *   [B,1,T] (:390-392); w = dense fp32 [C][KS] (weight norm folded).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svc_conv1d_h_args {
+  const void* x;     /* fp16 [B][Cin/8][Tin][8] */
+  const void* w;     /* svc_pack_conv1d_h output */
+  const float* bias; /* [Cout] fp32 or NULL */
+  const void* res;   /* fp16 blocked [B][Cout/8][Ty][8] or NULL */
+  void* y;           /* fp16 blocked [B][Cout/8][Ty][8] */
+  int B, Cin, Cout, Tin, Tq, Ty;
+  int KS, dil, pad_left;
+  int u, y_t0, RP;
+  int post_act;
+  float pre_slope, post_slope, beta, out_div;
+} svc_conv1d_h_args;
+int svc_pack_conv1d_h(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
+int svc_conv1d_h(const svc_conv1d_h_args* a, void* stream);
+int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
+                 int B, int C, int T, void* stream);
+int svc_cvt_from_h(const void* x, float* y, int B, int C, int T, void* stream);
+int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
+                    float pre_slope, int act, void* stream);
+
+
 /* ================================================================================================
  * TRAINING path.  Backward of the convolutions above plus the small ops of the
  * GAN step (train.py:150-213).  Same conventions; every gradient is fp32.

@@ -1,0 +1,363 @@
+// conv1d_h.hip — the decoder's convolutions as a 16-bit pipeline: fp16 activations in HBM AND in LDS, fp16 weights packed once,
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation.  This is the engine's form of the reference's half-precision inference
+// (inference/infer_tool.py:196-198: a checkpoint whose name contains "half" — compress_model.py:21-48 — runs `net_g_ms.half()`):
+// there every tensor of the model is fp16; here the NSF-HiFiGAN generator (94 % of the FLOPs: ResBlock1 convs
+// vdecoder/hifigan/models.py:41-67, ups :340-342,378, conv_post :390-392) stores and multiplies in fp16 while the encoder / flow /
+// harmonic source keep the fp32 kernels (they are latency-bound at 6 % of the FLOPs; the source's phase integration is not
+// representable in fp16 at all — the reference's own half mode loses 8e-4 MSE there).
+//
+// Layout.  An activation tensor is [B][C/8][T][8] fp16 ("blocked": 8 channels of one time step are 16 contiguous bytes).  Why: the
+// 32x32x16 instruction reduces 16 input channels of ONE tap per issue, lane (n = lane & 31, kh = lane >> 5) supplying channels
+// 8*kh .. 8*kh+7 of column n — in this layout that B operand is ONE ds_read_b128 at [(2g + kh)][t + tap*dil] (a dilated tap is an
+// address offset, consecutive lanes read consecutive 16-byte words: conflict-free), a tile row is staged by 16-byte loads that
+// are contiguous along time, and the C layout (lane holds rows 8i + 4kh .. +3 of column n) stores 8-byte groups of 4 channels.
+// A whole input-channel extent fits LDS at once (256 channels x 178 columns = 91 KB): no chunk loop, one barrier per launch.
+// The A operand (weights, [tap][Cin/16][rows][16] fp16) is read straight from L2 into registers, one 16-byte load per lane per
+// (tap, channel group, row tile), double-buffered one channel group ahead; a wave owns a (32 MT) x (32 NT) tile so that every
+// B fragment feeds MT instructions (the LDS port delivers one 1 KB fragment per 8 clocks, the matrix pipe eats one per
+// 32 clocks per SIMD: with MT = 1 four SIMDs would run the port at 100 %).
+//
+// ConvTranspose1d (ups) = the same kernel on "phases as rows": row = phase * Cout + co, M = ceil(K / u) taps, the epilogue writes
+// row (phase, co), column q to y[co][q * u + phase - padding].
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct HP {
+  svc_conv1d_h_args a;
+  int XW;  // columns of the staged tile: BN + (KS - 1) * dil
+  int G;   // Cin / 16
+  int R;   // valid rows: Cout (conv) or u * Cout (transposed)
+};
+
+__device__ __forceinline__ h8 lrelu8(h8 v, _Float16 s) {
+  const h8 sv = v * s;
+  return __builtin_elementwise_max(v, sv);
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  const svc_conv1d_h_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  h8* xs = reinterpret_cast<h8*>(smem_h);       // [Cin/8][XW]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int t0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
+  const int CB = a.Cin >> 3, XW = p.XW, G = p.G;
+
+  // ---- weights of channel group 0 first: they depend on nothing (L2 latency runs under the staging below)
+  const h8* wp = reinterpret_cast<const h8*>(a.w);          // h8 index = ((tap * G + g) * RP + row) * 2 + kh
+  const long long rowoff = ((long long)(r0 + wm * MT * 32 + li)) * 2 + kh;
+  auto wload = [&](h8 (&af)[KS][MT], int g) {
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[tap][mt] = wp[((long long)(tap * G + g) * a.RP + mt * 32) * 2 + rowoff];
+  };
+  h8 a0[KS][MT], a1[KS][MT];
+  wload(a0, 0);
+
+  // ---- stage the activation tile: 16-byte words, contiguous along time within a channel block; pre-activation applied once
+  {
+    const h8* xg = reinterpret_cast<const h8*>(a.x) + (long long)b * CB * a.Tin;
+    const _Float16 ps = (_Float16)a.pre_slope;
+    const bool act = a.pre_slope != 1.f;
+    const int total = CB * XW;
+    for (int base = tid; base < total; base += 256 * 4) {
+      h8 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * 256;
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[j] = z;
+        if (idx < total) {
+          const int cb = idx / XW, tl = idx - cb * XW;
+          const int tin = t0 - a.pad_left + tl;
+          if (tin >= 0 && tin < a.Tin) v[j] = xg[(long long)cb * a.Tin + tin];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * 256;
+        if (idx < total) xs[idx] = act ? lrelu8(v[j], ps) : v[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- matrix loop: per 16-channel group, KS taps x (MT x NT) instructions; weights of group g + 1 in flight meanwhile
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  const int colbase = wn * NT * 32 + li;
+  const int dil = a.dil;
+  auto step = [&](const h8 (&af)[KS][MT], int g) {
+    const h8* xr = xs + (2 * g + kh) * XW + colbase;
+#pragma unroll
+    for (int tap = 0; tap < KS; ++tap) {
+      h8 bq[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bq[nt] = xr[tap * dil + nt * 32];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap][mt], bq[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  for (int g = 0; g < G; g += 2) {
+    if (g + 1 < G) wload(a1, g + 1);
+    step(a0, g);
+    if (g + 1 < G) {
+      if (g + 2 < G) wload(a0, g + 2);
+      step(a1, g + 1);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators: bias, activation, residual, accumulate / divide, fp16, 8-byte stores
+  _Float16* yb = reinterpret_cast<_Float16*>(a.y) + (long long)b * a.Cout * a.Ty;
+  const _Float16* rb = a.res ? reinterpret_cast<const _Float16*>(a.res) + (long long)b * a.Cout * a.Ty : nullptr;
+  const bool lre = a.post_act == SVC_ACT_LRELU;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int q = t0 + wn * NT * 32 + nt * 32 + li;
+      if (q >= a.Tq) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row8 = r0 + (wm * MT + mt) * 32 + 8 * i;      // this lane holds rows row8 + 4 kh + (0..3) of column q
+        if (row8 >= p.R) continue;
+        int ph = 0, co8 = row8;
+        if (a.u > 1) {
+          ph = row8 / a.Cout;
+          co8 = row8 - ph * a.Cout;
+        }
+        const int t = a.u > 1 ? q * a.u + ph + a.y_t0 : q;
+        if (t < 0 || t >= a.Ty) continue;
+        const long long off = ((long long)(co8 >> 3) * a.Ty + t) * 8 + 4 * kh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mt][nt][4 * i + e] + (a.bias ? a.bias[co8 + 4 * kh + e] : 0.f);
+          if (lre) v[e] = svc_lrelu(v[e], a.post_slope);
+        }
+        if (rb) {
+          const h4 rv = *reinterpret_cast<const h4*>(rb + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        if (a.beta != 0.f) {
+          const h4 ov = *reinterpret_cast<const h4*>(yb + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(a.beta, (float)ov[e], v[e]);
+        }
+        if (a.out_div != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] /= a.out_div;
+        }
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+        *reinterpret_cast<h4*>(yb + off) = o;
+      }
+    }
+  }
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+int launch_h(const svc_conv1d_h_args& a, int R, hipStream_t s) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  HP p;
+  p.a = a;
+  p.XW = BN + (a.KS - 1) * a.dil;
+  p.G = a.Cin / 16;
+  p.R = R;
+  const size_t lds = (size_t)(a.Cin / 8) * p.XW * 16;
+  SVC_REQUIRE(lds <= 160 * 1024, "conv1d_h: tile of %zu bytes does not fit LDS (Cin %d, KS %d, dil %d)", lds, a.Cin, a.KS, a.dil);
+  auto kern = conv1d_h_kernel<KS, MT, NT, WM, WN>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  dim3 grid(svc::cdiv(a.Tq, BN), svc::cdiv(R, BM), a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  return svc::check_launch("conv1d_h");
+}
+
+template <int KS>
+int launch_h_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
+  if (R >= 128) return launch_h<KS, 2, 2, 2, 2>(a, R, s);   // 128 rows x 128 columns
+  if (R > 32) return launch_h<KS, 2, 2, 1, 4>(a, R, s);     //  64 rows x 256 columns
+  return launch_h<KS, 1, 2, 1, 4>(a, R, s);                 //  32 rows x 256 columns
+}
+
+// ---- weight pack: dense fp32 (weight norm already folded) -> [tap][Cin/16][RP][16] fp16.
+// conv (u == 1): w [Cout][Cin][KS], row = co, tap = k.   transposed (u > 1): w [Cin][Cout][K], row = ph * Cout + co, tap mr of
+// M = ceil(K / u): k = ph + (M - 1 - mr) * u (taps time-reversed: each phase is a plain correlation, as pack_convt1d_kernel).
+__global__ void pack_h_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int K, int taps, int RP,
+                              int u, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int j = (int)(idx & 15);
+  long long r = idx >> 4;
+  const int row = (int)(r % RP);
+  r /= RP;
+  const int G = Cin >> 4;
+  const int g = (int)(r % G), tap = (int)(r / G);
+  const int ci = g * 16 + j;
+  float v = 0.f;
+  if (u <= 1) {
+    if (row < Cout) v = w[((long long)row * Cin + ci) * K + tap];
+  } else if (row < u * Cout) {
+    const int ph = row / Cout, co = row - ph * Cout;
+    const int k = ph + (taps - 1 - tap) * u;
+    if (k < K) v = w[((long long)ci * Cout + co) * K + k];
+  }
+  dst[idx] = (_Float16)v;
+}
+
+// ---- fp32 [B,C,T] (strided) (+ a second fp32 tensor) -> blocked fp16, and back
+__global__ void cvt_to_h_kernel(const float* __restrict__ x, const float* __restrict__ add, h8* __restrict__ y, long long x_bs,
+                                long long x_cs, long long a_bs, long long a_cs, int B, int C, int T) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = C >> 3;
+  if (idx >= (long long)B * CB * T) return;
+  const int t = (int)(idx % T);
+  const long long r = idx / T;
+  const int cb = (int)(r % CB), b = (int)(r / CB);
+  h8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = x[(long long)b * x_bs + (long long)(cb * 8 + j) * x_cs + t];
+    if (add) v += add[(long long)b * a_bs + (long long)(cb * 8 + j) * a_cs + t];
+    o[j] = (_Float16)v;
+  }
+  y[idx] = o;
+}
+
+__global__ void cvt_from_h_kernel(const h8* __restrict__ x, float* __restrict__ y, int B, int C, int T) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = C >> 3;
+  if (idx >= (long long)B * CB * T) return;
+  const int t = (int)(idx % T);
+  const long long r = idx / T;
+  const int cb = (int)(r % CB), b = (int)(r / CB);
+  const h8 v = x[idx];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[((long long)b * C + cb * 8 + j) * T + t] = (float)v[j];
+}
+
+// ---- conv_post (vdecoder/hifigan/models.py:390-392): leaky_relu(0.01) -> Conv1d(C, 1, KS) -> tanh, fp16 blocked in, fp32 out.
+// One thread per output sample; fp32 arithmetic (the waveform itself is never rounded to 16 bits).
+__global__ __launch_bounds__(256) void conv_post_h_kernel(const h8* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int B, int C, int T, int KS, int pad, float pre_slope,
+                                                          int act) {
+  extern __shared__ float wsh[];       // [C][KS]
+  for (int i = threadIdx.x; i < C * KS; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * T) return;
+  const int t = (int)(idx % T), b = (int)(idx / T);
+  const int CB = C >> 3;
+  float acc = bias ? bias[0] : 0.f;
+  for (int cb = 0; cb < CB; ++cb) {
+    const h8* xr = x + ((long long)b * CB + cb) * T;
+    for (int k = 0; k < KS; ++k) {
+      const int tin = t - pad + k;
+      if (tin < 0 || tin >= T) continue;
+      const h8 v = xr[tin];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(svc_lrelu((float)v[j], pre_slope), wsh[(cb * 8 + j) * KS + k], acc);
+    }
+  }
+  y[idx] = act == SVC_ACT_TANH ? tanhf(acc) : acc;
+}
+
+}  // namespace
+
+extern "C" int svc_pack_conv1d_h(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream) {
+  SVC_REQUIRE(w && dst, "pack_conv1d_h: null tensor");
+  SVC_REQUIRE(Cout > 0 && Cin > 0 && (Cin % 16) == 0 && K >= 1 && u >= 1, "pack_conv1d_h: bad shape (Cin must be a multiple of 16)");
+  const int taps = u > 1 ? (K + u - 1) / u : K;
+  const int R = u > 1 ? u * Cout : Cout;
+  SVC_REQUIRE(RP >= R && (RP % 128) == 0, "pack_conv1d_h: RP must be a multiple of 128 >= the row count %d", R);
+  const long long n = (long long)taps * (Cin / 16) * RP * 16;
+  hipLaunchKernelGGL(pack_h_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<_Float16*>(dst), Cout, Cin, K, taps, RP, u, n);
+  return svc::check_launch("pack_conv1d_h");
+}
+
+extern "C" int svc_conv1d_h(const svc_conv1d_h_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "conv1d_h: null args");
+  const svc_conv1d_h_args& a = *ap;
+  SVC_REQUIRE(a.x && a.w && a.y, "conv1d_h: null tensor");
+  SVC_REQUIRE(a.B > 0 && a.Cin > 0 && a.Cout > 0 && a.Tin > 0 && a.Tq > 0 && a.Ty > 0, "conv1d_h: empty shape");
+  SVC_REQUIRE((a.Cin % 16) == 0 && (a.Cout % 8) == 0, "conv1d_h: Cin must be a multiple of 16 and Cout of 8 (got %d, %d)", a.Cin, a.Cout);
+  SVC_REQUIRE(a.dil >= 1 && a.u >= 1 && (a.RP % 128) == 0, "conv1d_h: bad dil / u / RP");
+  SVC_REQUIRE(a.post_act == SVC_ACT_NONE || a.post_act == SVC_ACT_LRELU, "conv1d_h: post_act must be none or leaky_relu");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.y) |
+                reinterpret_cast<uintptr_t>(a.res)) & 15) == 0, "conv1d_h: tensors must be 16-byte aligned");
+  const int R = a.u > 1 ? a.u * a.Cout : a.Cout;
+  SVC_REQUIRE(a.RP >= R, "conv1d_h: RP %d below the row count %d", a.RP, R);
+  SVC_REQUIRE(a.u == 1 || (a.Cout % 8) == 0, "conv1d_h: transposed form needs Cout %% 8 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  const double flop = 2.0 * a.B * (double)R * a.Cin * a.KS * a.Tq;
+  const double bytes = 2.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Ty * (a.res ? 2 : 1));
+  char pname[96];
+  if (svc::prof_on() && svc::prof_shapes())   // SVC_PROF_SHAPES=1: one profile row per shape (tuning aid)
+    snprintf(pname, sizeof(pname), "%s[B%d,Ci%d,Co%d,K%d,d%d,T%d]", a.u > 1 ? "convt1d_h" : "conv1d_h", a.B, a.Cin, a.Cout, a.KS, a.dil, a.Tq);
+  else
+    snprintf(pname, sizeof(pname), "%s", a.u > 1 ? "convt1d_h" : "conv1d_h");
+  svc::ProfScope prof(s, pname, flop, bytes);
+  switch (a.KS) {
+    case 1: return launch_h_ks<1>(a, R, s);
+    case 2: return launch_h_ks<2>(a, R, s);
+    case 3: return launch_h_ks<3>(a, R, s);
+    case 7: return launch_h_ks<7>(a, R, s);
+    case 11: return launch_h_ks<11>(a, R, s);
+    default: SVC_REQUIRE(false, "conv1d_h: tap count %d not built (1, 2, 3, 7, 11)", a.KS);
+  }
+  return SVC_OK;
+}
+
+extern "C" int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs,
+                            long long add_cs, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "cvt_to_h: bad args (C must be a multiple of 8)");
+  const long long n = (long long)B * (C / 8) * T;
+  hipLaunchKernelGGL(cvt_to_h_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, x, add,
+                     reinterpret_cast<h8*>(y), x_bs, x_cs, add_bs, add_cs, B, C, T);
+  return svc::check_launch("cvt_to_h");
+}
+
+extern "C" int svc_cvt_from_h(const void* x, float* y, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "cvt_from_h: bad args");
+  const long long n = (long long)B * (C / 8) * T;
+  hipLaunchKernelGGL(cvt_from_h_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), y, B, C, T);
+  return svc::check_launch("cvt_from_h");
+}
+
+extern "C" int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
+                               float pre_slope, int act, void* stream) {
+  SVC_REQUIRE(x && w && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0 && KS >= 1, "conv_post_h: bad args");
+  SVC_REQUIRE((size_t)C * KS * 4 <= 48 * 1024, "conv_post_h: weight does not fit LDS");
+  const long long n = (long long)B * T;
+  svc::ProfScope prof((hipStream_t)stream, "conv_post_h", 2.0 * n * C * KS, 2.0 * n * C + 4.0 * n);
+  hipLaunchKernelGGL(conv_post_h_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), (size_t)C * KS * 4, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), w, bias, y, B, C, T, KS, pad, pre_slope, act);
+  return svc::check_launch("conv_post_h");
+}

@@ -213,9 +213,18 @@ class Svc(object):
         self.net_g_ms = SynthesizerTrn(self.hps_ms.data.filter_length // 2 + 1,
                                        self.hps_ms.train.segment_size // self.hps_ms.data.hop_length, **model_kw)
         utils.load_checkpoint(self.net_g_path, self.net_g_ms, None)
-        # the engine computes in fp32: a "half" checkpoint (compress_model.py) is up-cast at load
+        # A "half" checkpoint (compress_model.py:21-48) is up-cast at load (utils.load_checkpoint: the fp32 masters then hold the
+        # fp16 values exactly) and, as in the reference (:196-198), switches the model to half-precision inference: the generator's
+        # 16-bit pipeline (SynthesizerTrn.half).  Generators without one (snake variant, the tiny template's odd widths) compute in fp32.
         self.dtype = torch.float32
         self.net_g_ms.float().eval().to(self.dev)
+        self.half_mode = False
+        if "half" in str(self.net_g_path) and os.environ.get("SVC_INFER_HALF", "1") != "0":
+            try:
+                self.net_g_ms.half()
+                self.half_mode = True
+            except NotImplementedError:
+                pass
         if spk_mix_enable:
             self.net_g_ms.EnableCharacterMix(len(self.spk2id), self.dev)
 

@@ -311,6 +311,25 @@ class SynthesizerTrn(nn.Module):
         self.use_graph = False          # hipGraph replay of the infer path (enable_graph())
         self._graphs = {}
 
+    # -- half-precision inference (reference inference/infer_tool.py:196-198: `net_g_ms.half()`) ----------------------------------
+    def half(self):
+        """The reference's `.half()` makes every tensor of the model fp16.  Here it switches the NSF-HiFiGAN generator (94 % of the
+        FLOPs) to the 16-bit pipeline — fp16 activations and weights, fp32 accumulation (vdecoder.hifigan.models.Generator.set_half)
+        — and leaves the fp32 master parameters, the encoder / flow kernels and the harmonic source as they are: nothing is
+        LESS precise than the reference's half mode, and `list(net.parameters())[0].dtype` stays float32 (Svc casts its inputs to
+        that).  Generators without a 16-bit form (the snake variant, odd stage widths) raise NotImplementedError."""
+        if not hasattr(self.dec, "set_half"):
+            raise NotImplementedError(f"half-precision inference is not built for the {type(self.dec).__module__} generator")
+        self.dec.set_half(True)
+        self._graphs.clear()
+        return self
+
+    def float(self):
+        if hasattr(self.dec, "set_half"):
+            self.dec.set_half(False)
+        self._graphs.clear()
+        return super().float()
+
     def EnableCharacterMix(self, n_speakers_map, device):
         self.speaker_map = torch.zeros((n_speakers_map, 1, 1, self.gin_channels)).to(device)
         for i in range(n_speakers_map):

@@ -69,6 +69,14 @@ class ResblockPairArgs(C.Structure):
                 ("slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
 
 
+class Conv1dHArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", _f32p), ("res", C.c_void_p), ("y", C.c_void_p),
+                ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tq", C.c_int), ("Ty", C.c_int),
+                ("KS", C.c_int), ("dil", C.c_int), ("pad_left", C.c_int),
+                ("u", C.c_int), ("y_t0", C.c_int), ("RP", C.c_int), ("post_act", C.c_int),
+                ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
+
+
 class AttentionArgs(C.Structure):
     _fields_ = [
         ("q", _f32p), ("k", _f32p), ("v", _f32p), ("emb_rel_k", _f32p), ("emb_rel_v", _f32p), ("mask", _f32p),
@@ -116,6 +124,13 @@ def lib():
         L.svc_add_layernorm_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_reparam_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
         L.svc_attention_f32.argtypes = [C.POINTER(AttentionArgs), C.c_void_p]
+        L.svc_pack_conv1d_h.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svc_conv1d_h.argtypes = [C.POINTER(Conv1dHArgs), C.c_void_p]
+        L.svc_cvt_to_h.argtypes = [_f32p, _f32p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p]
+        L.svc_cvt_from_h.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svc_conv_post_h.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                      C.c_void_p]
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
@@ -143,7 +158,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -385,6 +400,124 @@ def resblock_pair(x, w1p, b1, w2p, b2, KS, dil1, *, slope=0.1, out=None, beta=0.
     a.B, a.C, a.T, a.KS, a.dil1, a.CP = B, Cc, T, KS, dil1, w1p.shape[2]
     a.slope, a.beta, a.out_div = slope, beta, out_div
     check(lib().svc_resblock_pair_f32(C.byref(a), stream_ptr()), "resblock_pair")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 16-bit decoder pipeline (csrc/conv1d_h.hip): fp16 activations in the blocked layout [B, C/8, T, 8]
+# --------------------------------------------------------------------------------------------------------------
+def _hptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu_h(*tensors):
+    """require_gpu for the 16-bit pipeline's calls: every tensor on the GPU, fp16 (blocked activations / packs) or fp32 (bias,
+    dense weights, plain tensors being converted)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SvcError("svc_hip ops need tensors on the GPU (cuda:N on ROCm); there is no CPU fallback")
+        if t is not None and t.dtype not in (torch.float16, torch.float32):
+            raise SvcError(f"svc_hip 16-bit ops take fp16 / fp32 tensors; got {t.dtype}")
+
+
+def _check_h(t, what):
+    if t.dtype != torch.float16 or t.dim() != 4 or t.shape[3] != 8 or not t.is_contiguous():
+        raise SvcError(f"{what}: expected a contiguous fp16 [B, C/8, T, 8] tensor, got {t.dtype} {tuple(t.shape)}")
+
+
+def pack_conv1d_h(w, u=1):
+    """Dense fp32 weight (weight norm folded) -> the fp16 operand pack of svc_conv1d_h.  u == 1: Conv1d [Cout, Cin, K];
+    u > 1: ConvTranspose1d [Cin, Cout, K] with stride u (phases as rows)."""
+    _require_gpu_h(w)
+    w = w.detach().float().contiguous()
+    if u > 1:
+        Cin, Cout, K = w.shape
+        taps, R = (K + u - 1) // u, u * Cout
+    else:
+        Cout, Cin, K = w.shape
+        taps, R = K, Cout
+    RP = round_up(R, 128)
+    dst = torch.empty((taps, Cin // 16, RP, 16), device=w.device, dtype=torch.float16)
+    check(lib().svc_pack_conv1d_h(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
+    return dst
+
+
+def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=1.0, post_slope=None, res=None, out=None, beta=0.0,
+             out_div=1.0):
+    """Conv1d on the 16-bit pipeline: x / res / out are blocked fp16 [B, C/8, T, 8]; wp from pack_conv1d_h."""
+    _require_gpu_h(x, wp, bias, res, out)
+    _check_h(x, "conv1d_h")
+    B, CB, Tin, _ = x.shape
+    KS = wp.shape[0]
+    if wp.shape[1] * 16 != CB * 8:
+        raise SvcError(f"conv1d_h: packed weight {tuple(wp.shape)} does not match Cin={CB * 8}")
+    if Tout is None:
+        Tout = Tin
+    if out is None:
+        out = torch.empty((B, Cout // 8, Tout, 8), device=x.device, dtype=torch.float16)
+    _check_h(out, "conv1d_h out")
+    a = Conv1dHArgs()
+    a.x, a.w, a.bias, a.res, a.y = _hptr(x), _hptr(wp), ptr(bias), _hptr(res), _hptr(out)
+    if res is not None:
+        _check_h(res, "conv1d_h res")
+    a.B, a.Cin, a.Cout, a.Tin, a.Tq, a.Ty = B, CB * 8, Cout, Tin, Tout, Tout
+    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = KS, dil, pad_left, 1, 0, wp.shape[2]
+    a.post_act = ACT_LRELU if post_slope is not None else ACT_NONE
+    a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope or 0.0, beta, out_div
+    check(lib().svc_conv1d_h(C.byref(a), stream_ptr()), "conv1d_h")
+    return out
+
+
+def conv_transpose1d_h(x, wp, Cout, K, stride, padding, *, bias=None, pre_slope=1.0, res=None, out=None):
+    """ConvTranspose1d on the 16-bit pipeline (phases as rows); wp from pack_conv1d_h(w, u=stride)."""
+    _require_gpu_h(x, wp, bias, res, out)
+    _check_h(x, "conv_transpose1d_h")
+    B, CB, Tin, _ = x.shape
+    M = wp.shape[0]
+    Lout = (Tin - 1) * stride - 2 * padding + K
+    if out is None:
+        out = torch.empty((B, Cout // 8, Lout, 8), device=x.device, dtype=torch.float16)
+    a = Conv1dHArgs()
+    a.x, a.w, a.bias, a.res, a.y = _hptr(x), _hptr(wp), ptr(bias), _hptr(res), _hptr(out)
+    a.B, a.Cin, a.Cout, a.Tin, a.Ty = B, CB * 8, Cout, Tin, Lout
+    a.Tq = (Lout - 1 + padding) // stride + 1
+    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = M, 1, M - 1, stride, -padding, wp.shape[2]
+    a.post_act, a.pre_slope, a.post_slope, a.beta, a.out_div = ACT_NONE, pre_slope, 0.0, 0.0, 1.0
+    check(lib().svc_conv1d_h(C.byref(a), stream_ptr()), "conv_transpose1d_h")
+    return out
+
+
+def to_h(x, add=None, out=None):
+    """fp32 [B, C, T] (time-contiguous view) (+ add) -> blocked fp16 [B, C/8, T, 8]."""
+    _require_gpu_h(x, add, out)
+    B, Cc, T = x.shape
+    if out is None:
+        out = torch.empty((B, Cc // 8, T, 8), device=x.device, dtype=torch.float16)
+    xb, xc = _bct_strides(x)
+    ab, ac = _bct_strides(add) if add is not None else (0, 0)
+    check(lib().svc_cvt_to_h(ptr(x), ptr(add), _hptr(out), xb, xc, ab, ac, B, Cc, T, stream_ptr()), "cvt_to_h")
+    return out
+
+
+def from_h(xh):
+    """Blocked fp16 [B, C/8, T, 8] -> fp32 [B, C, T]."""
+    _require_gpu_h(xh)
+    _check_h(xh, "from_h")
+    B, CB, T, _ = xh.shape
+    out = torch.empty((B, CB * 8, T), device=xh.device, dtype=torch.float32)
+    check(lib().svc_cvt_from_h(_hptr(xh), ptr(out), B, CB * 8, T, stream_ptr()), "cvt_from_h")
+    return out
+
+
+def conv_post_h(xh, w, bias, KS, pad, pre_slope=0.01, act=None):
+    """leaky_relu -> Conv1d(C -> 1) -> act on a blocked fp16 input; fp32 arithmetic and output [B, 1, T]."""
+    _require_gpu_h(xh, w, bias)
+    _check_h(xh, "conv_post_h")
+    B, CB, T, _ = xh.shape
+    out = torch.empty((B, 1, T), device=xh.device, dtype=torch.float32)
+    w = w.detach().float().contiguous()
+    check(lib().svc_conv_post_h(_hptr(xh), ptr(w), ptr(bias), ptr(out), B, CB * 8, T, KS, pad, pre_slope,
+                                ACT_TANH if act is None else act, stream_ptr()), "conv_post_h")
     return out
 
 

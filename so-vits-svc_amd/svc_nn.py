@@ -96,6 +96,22 @@ class Conv1d(nn.Module, _PackedMixin):
         self.weight = nn.Parameter(w)
         self.is_weight_norm = False
 
+    # -- the 16-bit decoder pipeline (svc_conv1d_h): fp16 operand pack of the weight-norm-folded fp32 weight ------------
+    def dense_weight(self):
+        """[Cout, Cin, K] fp32 with weight norm folded (svc_weight_norm_fwd_f32), no tape."""
+        with torch.no_grad():
+            if self.is_weight_norm:
+                return S.weight_norm_fwd(self.weight_v.detach(), self.weight_g.detach().reshape(-1))[0]
+            return self.weight.detach()
+
+    def packed_h(self):
+        return self._get_packed(("h",), lambda: S.pack_conv1d_h(self.dense_weight()))
+
+    def run_h(self, xh, **kw):
+        """Stride-1 dense conv on blocked fp16 activations; keyword arguments are the epilogue options of svc_hip.conv1d_h."""
+        _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
+        return S.conv1d_h(xh, self.packed_h(), self.out_channels, bias=self.bias, dil=self.dilation, pad_left=self.padding, **kw)
+
     # -- compute ------------------------------------------------------------------------------------------
     def _is_direct(self):
         return self.stride != 1 or self.in_channels == 1 or self.out_channels == 1
@@ -292,6 +308,22 @@ class ConvTranspose1d(nn.Module, _PackedMixin):
 
     def effective_weight(self):
         return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
+
+    def packed_h(self):
+        """fp16 operand pack (phases as rows) of the weight-norm-folded weight for svc_conv1d_h's transposed form."""
+        def fn():
+            with torch.no_grad():
+                if self.is_weight_norm:       # norm over (Cout, K) per input channel: rows of the [Cin, Cout*K] matrix
+                    w = S.weight_norm_fwd(self.weight_v.detach(), self.weight_g.detach().reshape(-1))[0]
+                else:
+                    w = self.weight.detach()
+                return S.pack_conv1d_h(w, u=self.stride)
+        return self._get_packed(("cth",), fn)
+
+    def run_h(self, xh, **kw):
+        _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
+        return S.conv_transpose1d_h(xh, self.packed_h(), self.out_channels, self.kernel_size, self.stride, self.padding,
+                                    bias=self.bias, **kw)
 
     def forward_train(self, x):
         if WEIGHT_PLANS:

@@ -104,6 +104,24 @@ class ResBlock1(nn.Module):
             c2.run(xt, pre_slope=ps2, res=cur, res_mode=1, out=dst)
             cur = dst
 
+    def forward_h(self, xh, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
+        """The same block on the 16-bit pipeline (blocked fp16 tensors, svc_conv1d_h): out = (beta * out + resblock(x)) / out_div."""
+        n = len(self.convs1)
+        cur = xh
+        xt, ping, pong = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(3)]
+        for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            # the second leaky_relu (:64) once, in the epilogue of the conv that produces xt (no other reader)
+            c1.run_h(cur, pre_slope=LRELU_SLOPE, post_slope=LRELU_SLOPE, out=xt)
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
+                c2.run_h(xt, res=cur, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c2.run_h(xt, res=cur, out=dst)
+            cur = dst
+
     def remove_weight_norm(self):
         for l in list(self.convs1) + list(self.convs2):
             l.remove_weight_norm()
@@ -363,6 +381,8 @@ class Generator(nn.Module):
         earlier start_source(f0, noise) call (same f0 / noise), else the source is computed here."""
         if training_call(self.conv_post.bias) or (torch.is_grad_enabled() and getattr(x, "requires_grad", False)):
             return self.forward_train(x, f0, g=g, noise=noise)
+        if getattr(self, "half_mode", False):
+            return self.forward_h(x, f0, g=g, noise=noise, source=source)
         _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
         if source is None:
             har, _, _ = self.m_source(f0, self.upp, noise=noise)
@@ -377,6 +397,54 @@ class Generator(nn.Module):
             x = mrf_stage(self, [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)], x, xs)
         # F.leaky_relu default slope 0.01 (:390), conv_post, tanh
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
+
+    # -- half-precision inference: the reference's `net_g_ms.half()` (inference/infer_tool.py:196-198) -----------------------
+    def set_half(self, on=True):
+        """Run the generator's convolution stack as the 16-bit pipeline of csrc/conv1d_h.hip: fp16 activations (HBM and LDS) and
+        fp16 weights from the first MRF stage on, fp32 accumulation.  What stays fp32, and why: the harmonic source (its phase
+        integration needs > 16 bits — the reference's own half mode loses it there), conv_pre and ups[0] on the 862-frame input
+        (latency-bound launches, 1.5 % of the FLOPs) and the waveform that conv_post + tanh emit."""
+        if on and not (self.h["resblock"] == '1' and all(c % 16 == 0 for c in self._stage_channels()[1:]) and
+                       all(k in (3, 7, 11) for k in self.h["resblock_kernel_sizes"]) and
+                       all(-(-k // u) in (1, 2, 3) for u, k in zip(self.h["upsample_rates"], self.h["upsample_kernel_sizes"]))):
+            raise NotImplementedError("half-precision generator: needs ResBlock1 with kernel sizes in {3, 7, 11}, stage widths that are "
+                                      "multiples of 16 and upsample kernels of at most 3 taps per phase (both templates' decoders except "
+                                      "the tiny template's 200/100/50/25/12 widths)")
+        self.half_mode = bool(on)
+        return self
+
+    def _stage_channels(self):
+        c0 = self.h["upsample_initial_channel"]
+        return [c0] + [c0 // (2 ** (i + 1)) for i in range(self.num_upsamples)]
+
+    def forward_h(self, x, f0, g=None, noise=None, source=None):
+        """forward() with the MRF stages, ups[1:] and conv_post on blocked fp16 tensors (one chain: the stage's three ResBlocks run
+        back to back on the caller's stream, each accumulating into the stage mean)."""
+        _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
+        if source is None:
+            har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        gc = self.cond(g) if g is not None else None
+        x = self.conv_pre.run(x, cond=gc)                                           # fp32 (:373-374)
+        if source is not None:
+            torch.cuda.current_stream().wait_event(source[1])
+        xh = None
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            xs = source[0][i] if source is not None else self.noise_convs[i](har)     # fp32 [B, C_i, L_i] (:379)
+            if i == 0:
+                x = self.ups[0].run(x, pre_slope=LRELU_SLOPE, res=xs)                 # fp32: lrelu + ConvT + add (:377-381)
+                xh = S.to_h(x)
+            else:
+                xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs))
+            acc = torch.empty_like(xh)
+            tmp = [torch.empty_like(xh) for _ in range(3)]
+            for j in range(nk):
+                self.resblocks[i * nk + j].forward_h(xh, out=acc, beta=0.0 if j == 0 else 1.0,
+                                                     out_div=float(nk) if j == nk - 1 else 1.0, tmp=tmp)
+            xh = acc
+        cp = self.conv_post
+        return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,
+                             pre_slope=0.01, act=S.ACT_TANH)
 
     def remove_weight_norm(self):
         for l in self.ups:

@@ -1,0 +1,191 @@
+"""The 16-bit inference pipeline (csrc/conv1d_h.hip; the engine's form of the reference's `net_g_ms.half()`,
+inference/infer_tool.py:196-198, on checkpoints of compress_model.py:21-48).
+
+Kernel level: svc_conv1d_h / its transposed form / conv_post against torch's fp32 convolution of the SAME fp16-rounded operands —
+what remains is fp32 accumulation order plus ONE rounding of the stored result to fp16 (2^-11 relative), so the bound is
+1e-3 of the output's largest value.  Model level: the full template through SynthesizerTrn.half() against (a) the fp32 oracle —
+north_star's waveform bar, MSE < 1e-4 — and (b) the REAL reference's own half-precision output (tests/golden/infer_full_T24_half.npz):
+the engine must be closer to the fp32 result than the reference's half mode is."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import svc_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _h(t):
+    """fp32 tensor rounded to fp16 values."""
+    return t.half().float()
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def test_blocked_layout_round_trip(dev):
+    import svc_hip as S
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 24, 301, generator=g)
+    add = torch.randn(2, 24, 301, generator=g)
+    xh = S.to_h(x.to(dev))
+    assert xh.shape == (2, 3, 301, 8) and xh.dtype == torch.float16
+    assert torch.equal(xh.cpu(), x.view(2, 3, 8, 301).permute(0, 1, 3, 2).half())        # [B, C/8, T, 8]: channel c = 8 cb + j
+    assert torch.equal(S.from_h(xh).cpu(), _h(x))
+    assert torch.equal(S.from_h(S.to_h(x.to(dev), add=add.to(dev))).cpu(), _h(x + add))
+    view = torch.randn(2, 40, 301, generator=g).to(dev)[:, 8:32]                          # channel-offset view: explicit strides
+    assert torch.equal(S.from_h(S.to_h(view)).cpu(), _h(view.cpu()))
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, KS, dil       (tile forms: >= 128 rows, 64 rows, <= 32 rows; ragged T; every tap count / dilation of the MRF)
+    (1, 256, 256, 300, 11, 5), (1, 128, 128, 1000, 7, 3), (2, 64, 64, 515, 3, 1), (1, 32, 32, 2100, 11, 1), (1, 16, 16, 4099, 7, 5),
+    (1, 16, 16, 37, 3, 3), (2, 128, 128, 129, 3, 5), (1, 256, 256, 6896, 7, 1), (1, 64, 64, 55168, 11, 3), (1, 32, 16, 700, 1, 1),
+    (1, 48, 80, 260, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,dil", CONV_CASES)
+def test_conv1d_h_vs_torch(dev, B, Cin, Cout, T, KS, dil):
+    """ResBlock1's convs (vdecoder/hifigan/models.py:41-67) on blocked fp16 tensors: plain, with leaky_relu on both sides, with the
+    residual and the accumulate / divide epilogue of the MRF mean (:382-389)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T + KS)
+    x = _h(torch.randn(B, Cin, T, generator=g))
+    w = _h(torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    pad = (KS * dil - dil) // 2
+    xh = S.to_h(x.to(dev))
+    wp = S.pack_conv1d_h(w.to(dev))
+    ref = F.conv1d(x, w, b, dilation=dil, padding=pad)
+    y = S.from_h(S.conv1d_h(xh, wp, Cout, bias=b.to(dev), dil=dil, pad_left=pad)).cpu()
+    assert y.shape == ref.shape
+    assert _rel(y, ref) < 1e-3, "plain"
+    # leaky_relu in front (applied to the fp16 operand, rounded to fp16 as the reference's half mode does) and behind
+    xa = _h(torch.where(x > 0, x, _h(x * _h(torch.tensor(0.1)))))
+    ref2 = F.leaky_relu(F.conv1d(xa, w, b, dilation=dil, padding=pad), 0.1)
+    y2 = S.from_h(S.conv1d_h(xh, wp, Cout, bias=b.to(dev), dil=dil, pad_left=pad, pre_slope=0.1, post_slope=0.1)).cpu()
+    assert _rel(y2, ref2) < 1e-3, "lrelu both sides"
+    if Cin == Cout:
+        old = _h(torch.randn(B, Cout, T, generator=g))
+        out = S.to_h(old.to(dev))
+        S.conv1d_h(xh, wp, Cout, bias=b.to(dev), dil=dil, pad_left=pad, res=xh, out=out, beta=1.0, out_div=3.0)
+        ref3 = (old + ref + x) / 3
+        assert _rel(S.from_h(out).cpu(), ref3) < 1e-3, "residual + accumulate"
+
+
+@pytest.mark.parametrize("B,Cin,L,K,u", [(1, 256, 300, 16, 8), (2, 128, 515, 4, 2), (1, 64, 1000, 4, 2), (1, 32, 2077, 4, 2),
+                                         (1, 256, 6896, 16, 8), (1, 32, 97, 8, 4)])
+def test_conv_transpose1d_h_vs_torch(dev, B, Cin, L, K, u):
+    """ups[i] (vdecoder/hifigan/models.py:340-342,377-381): leaky_relu + ConvTranspose1d(C -> C/2, K, u, (K-u+1)//2) + the noise-conv
+    addend, phases as rows of one 16-bit convolution."""
+    import svc_hip as S
+    Cout = Cin // 2
+    g = torch.Generator().manual_seed(Cin + L + K)
+    x = _h(torch.randn(B, Cin, L, generator=g))
+    w = _h(torch.randn(Cin, Cout, K, generator=g) / (Cin * K / u) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    pad = (K - u + 1) // 2
+    ref = F.conv_transpose1d(x, w, b, stride=u, padding=pad)
+    add = _h(torch.randn(ref.shape, generator=g))
+    xa = _h(torch.where(x > 0, x, _h(x * _h(torch.tensor(0.1)))))
+    ref2 = F.conv_transpose1d(xa, w, b, stride=u, padding=pad) + add
+    wp = S.pack_conv1d_h(w.to(dev), u=u)
+    xh = S.to_h(x.to(dev))
+    y = S.from_h(S.conv_transpose1d_h(xh, wp, Cout, K, u, pad, bias=b.to(dev))).cpu()
+    assert y.shape == ref.shape
+    assert _rel(y, ref) < 1e-3
+    y2 = S.from_h(S.conv_transpose1d_h(xh, wp, Cout, K, u, pad, bias=b.to(dev), pre_slope=0.1, res=S.to_h(add.to(dev)))).cpu()
+    assert _rel(y2, ref2) < 1e-3
+
+
+def test_conv_post_h_vs_torch(dev):
+    import svc_hip as S
+    g = torch.Generator().manual_seed(5)
+    B, Cc, T = 2, 16, 3001
+    x = _h(torch.randn(B, Cc, T, generator=g) * 2)
+    w = torch.randn(1, Cc, 7, generator=g) / (Cc * 7) ** 0.5
+    b = torch.randn(1, generator=g) * 0.1
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, b, padding=3))
+    y = S.conv_post_h(S.to_h(x.to(dev)), w.to(dev).reshape(Cc, 7), b.to(dev), 7, 3, pre_slope=0.01).cpu()
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    assert (y - ref).abs().max().item() < 2e-6
+
+
+def _build(cfg, seed, dev):
+    import models
+    kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    net = models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw)
+    sd = W.make_state_dict(cfg, seed)
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval(), sd
+
+
+def test_half_inference_is_closer_to_fp32_than_the_references_half_mode(dev):
+    """Full template, T = 24, the case of infer_full_T24.npz: SynthesizerTrn.half() against the reference's fp32 output and against
+    what the REAL reference produces after `net_g_ms.half()` (make_golden_half.py)."""
+    z = np.load(os.path.join(G, "infer_full_T24.npz"))
+    zh = np.load(os.path.join(G, "infer_full_T24_half.npz"))
+    meta = json.loads(str(zh["meta"]))
+    net, _ = _build(W.full_config(), meta["seed"], dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    noise = dict(enc_p=t("noise_enc_p"), rand_ini=t("noise_rand_ini"), sine=t("noise_sine"))
+    o32, _ = net.infer(t("c"), t("f0"), t("uv"), g=t("sid"), noice_scale=meta["noice_scale"], noise=noise)
+    net.half()
+    assert net.dec.half_mode and next(net.parameters()).dtype == torch.float32
+    oh, _ = net.infer(t("c"), t("f0"), t("uv"), g=t("sid"), noice_scale=meta["noice_scale"], noise=noise)
+    assert oh.dtype == torch.float32 and oh.shape == o32.shape
+    ref32 = torch.from_numpy(z["o"])
+    mse_engine = (oh.cpu() - ref32).pow(2).mean().item()
+    mse_ref_half = meta["mse_half_vs_fp32"]
+    ref_half = torch.from_numpy(zh["o_half"]).float()
+    print(f"half inference, full template T=24: engine vs fp32 reference MSE {mse_engine:.3e} (max {(oh.cpu() - ref32).abs().max().item():.3e}); "
+          f"reference .half() vs its fp32 MSE {mse_ref_half:.3e}; engine vs reference .half() MSE {(oh.cpu() - ref_half).pow(2).mean().item():.3e}")
+    assert mse_engine < 1e-4 and mse_engine < mse_ref_half, (mse_engine, mse_ref_half)
+    assert (o32.cpu() - ref32).abs().max().item() <= 2e-4 * ref32.abs().max().item()     # (the fp32 path of the same object, before)
+    # back to fp32: bit-identical to the first fp32 call
+    net.float()
+    o32b, _ = net.infer(t("c"), t("f0"), t("uv"), g=t("sid"), noice_scale=meta["noice_scale"], noise=noise)
+    assert torch.equal(o32b, o32)
+
+
+def test_half_inference_at_the_benchmarked_shape(dev):
+    """BASELINE configs[1] (full template, B = 1, T = 862) in half mode against the fp32 CPU oracle: waveform MSE < 1e-4
+    (north_star's bar), eager and hipGraph replay bit-equal."""
+    import bench
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    B, T = 1, bench.T_FRAMES
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=1234)
+    noise = W.make_noise(cfg, B, T, seed=99)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    net.half()
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    mse = (o.cpu() - ref).pow(2).mean().item()
+    mx = (o.cpu() - ref).abs().max().item()
+    print(f"half inference, T=862: MSE vs fp32 oracle {mse:.3e}, max|err| {mx:.3e}, max|ref| {ref.abs().max().item():.3f}")
+    assert mse < 1e-4, mse
+    net.enable_graph(True)
+    o2, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    o3, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert torch.equal(o2, o) and torch.equal(o3, o)
+
+
+def test_half_mode_refuses_generators_without_a_16_bit_form(dev):
+    net, _ = _build(W.small_config(), 3, dev)          # stage widths 64 / 32 / 16 / 8 / 4
+    with pytest.raises(NotImplementedError):
+        net.half()
+    cfg = W.small_config()
+    cfg["vocoder_name"] = "nsf-snake-hifigan"
+    net2, _ = _build(cfg, 3, dev)
+    with pytest.raises(NotImplementedError):
+        net2.half()
