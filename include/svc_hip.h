@@ -307,7 +307,7 @@ int svc_debug_set_attention_waves(int nw);
  * = 16 contiguous bytes), weights fp16 packed once, products on v_mfma_f32_32x32x16_f16 with fp32 accumulation; bias / activation
  * / residual / accumulate arithmetic in fp32 before the one rounding of the stored result.
  *
- * svc_pack_conv1d_h: dense fp32 weight (weight norm already folded) -> [taps][Cin/16][RP][16] fp16.  u == 1: Conv1d weight
+ * svc_pack_conv1d_h: dense fp32 weight (weight norm already folded) -> [Cin/16][taps][RP][16] fp16.  u == 1: Conv1d weight
  *   [Cout][Cin][K], taps = K.  u > 1: ConvTranspose1d weight [Cin][Cout][K], rows = u*Cout (row = phase*Cout + co),
  *   taps = ceil(K/u) (vdecoder/hifigan/models.py:340-342).  RP: row count rounded up to a multiple of 128.
  * svc_conv1d_h: y = epilogue(conv(lrelu(x, pre_slope))): + bias[co], post_act (NONE | LRELU), + res (blocked fp16, y-shaped),
@@ -331,6 +331,7 @@ typedef struct svc_conv1d_h_args {
 } svc_conv1d_h_args;
 int svc_pack_conv1d_h(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
 int svc_conv1d_h(const svc_conv1d_h_args* a, void* stream);
+int svc_debug_set_conv_h(int cfg); /* tuning aid: 0 automatic tile choice, 1 no 64 x 128 tile, 2 four column tiles per wave where they fit */
 int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                  int B, int C, int T, void* stream);
 int svc_cvt_from_h(const void* x, float* y, int B, int C, int T, void* stream);

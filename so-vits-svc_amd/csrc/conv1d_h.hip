@@ -12,10 +12,13 @@
 // address offset, consecutive lanes read consecutive 16-byte words: conflict-free), a tile row is staged by 16-byte loads that
 // are contiguous along time, and the C layout (lane holds rows 8i + 4kh .. +3 of column n) stores 8-byte groups of 4 channels.
 // A whole input-channel extent fits LDS at once (256 channels x 178 columns = 91 KB): no chunk loop, one barrier per launch.
-// The A operand (weights, [tap][Cin/16][rows][16] fp16) is read straight from L2 into registers, one 16-byte load per lane per
-// (tap, channel group, row tile), double-buffered one channel group ahead; a wave owns a (32 MT) x (32 NT) tile so that every
-// B fragment feeds MT instructions (the LDS port delivers one 1 KB fragment per 8 clocks, the matrix pipe eats one per
-// 32 clocks per SIMD: with MT = 1 four SIMDs would run the port at 100 %).
+// The A operand (weights, [Cin/16][tap][rows][16] fp16: one linear index per (channel group, tap) step) is read straight from
+// L2 into registers, one 16-byte load per lane per (step, row tile), through a ring of two 4-step chunks: the loads of chunk c + 1
+// are issued in front of the instructions of chunk c.  A wave owns a (32 MT) x (32 NT) tile: every B fragment feeds MT
+// instructions (the LDS port delivers one 1 KB fragment per 8 clocks, the matrix pipe eats one per 32 clocks per SIMD: with
+// MT = 1 four SIMDs would run the port at 100 %) and every A fragment NT of them — first measurements (profiles/r08a_*: 181 TFLOP/s
+// with 32 x 64 / 64 x 64 wave tiles) were bound by the weight stream (every workgroup pulls its rows' whole weight slab through
+// L1: bytes per FLOP = 1 / tile width), hence NT = 4 wherever the sequence is long enough to still fill the chip.
 //
 // ConvTranspose1d (ups) = the same kernel on "phases as rows": row = phase * Cout + co, M = ceil(K / u) taps, the epilogue writes
 // row (phase, co), column q to y[co][q * u + phase - padding].
@@ -40,8 +43,9 @@ __device__ __forceinline__ h8 lrelu8(h8 v, _Float16 s) {
 }
 
 template <int KS, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
+__global__ __launch_bounds__(256, 2) void conv1d_h_kernel(HP p) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  constexpr int CH = 4;                         // steps per chunk of the weight ring
   static_assert(WM * WN == 4, "four waves per workgroup");
   const svc_conv1d_h_args& a = p.a;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
@@ -49,30 +53,36 @@ __global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w / WN, wn = w - wm * WN;
   const int t0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
-  const int CB = a.Cin >> 3, XW = p.XW, G = p.G;
+  const int CB = a.Cin >> 3, XW = p.XW;
+  const int S = p.G * KS;                       // (channel group, tap) steps, group-major
 
-  // ---- weights of channel group 0 first: they depend on nothing (L2 latency runs under the staging below)
-  const h8* wp = reinterpret_cast<const h8*>(a.w);          // h8 index = ((tap * G + g) * RP + row) * 2 + kh
-  const long long rowoff = ((long long)(r0 + wm * MT * 32 + li)) * 2 + kh;
-  auto wload = [&](h8 (&af)[KS][MT], int g) {
+  // ---- the first weight chunk now: it depends on nothing (L2 latency runs under the staging below)
+  const h8* wp = reinterpret_cast<const h8*>(a.w) + ((long long)(r0 + wm * MT * 32 + li)) * 2 + kh;   // + (step * RP + mt * 32) * 2
+  const long long sstride = (long long)a.RP * 2;
+  auto wload = [&](h8 (&af)[CH][MT], int s0) {
 #pragma unroll
-    for (int tap = 0; tap < KS; ++tap)
+    for (int j = 0; j < CH; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[tap][mt] = wp[((long long)(tap * G + g) * a.RP + mt * 32) * 2 + rowoff];
+      for (int mt = 0; mt < MT; ++mt) {
+        const int sidx = min(s0 + j, S - 1);    // (a chunk may reach past the last step: re-read it, never use it)
+        af[j][mt] = wp[sidx * sstride + mt * 64];
+      }
   };
-  h8 a0[KS][MT], a1[KS][MT];
+  h8 a0[CH][MT], a1[CH][MT];
   wload(a0, 0);
 
-  // ---- stage the activation tile: 16-byte words, contiguous along time within a channel block; pre-activation applied once
+  // ---- stage the activation tile: 16-byte words, contiguous along time within a channel block; pre-activation applied once;
+  // 8 loads in flight per thread
   {
     const h8* xg = reinterpret_cast<const h8*>(a.x) + (long long)b * CB * a.Tin;
     const _Float16 ps = (_Float16)a.pre_slope;
     const bool act = a.pre_slope != 1.f;
     const int total = CB * XW;
-    for (int base = tid; base < total; base += 256 * 4) {
-      h8 v[4];
+    constexpr int LD = 8;
+    for (int base = tid; base < total; base += 256 * LD) {
+      h8 v[LD];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < LD; ++j) {
         const int idx = base + j * 256;
         h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         v[j] = z;
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < LD; ++j) {
         const int idx = base + j * 256;
         if (idx < total) xs[idx] = act ? lrelu8(v[j], ps) : v[j];
       }
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
   }
   __syncthreads();
 
-  // ---- matrix loop: per 16-channel group, KS taps x (MT x NT) instructions; weights of group g + 1 in flight meanwhile
+  // ---- matrix loop over the steps, four at a time; the weights of the next four are in flight meanwhile
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -99,28 +109,32 @@ __global__ __launch_bounds__(256) void conv1d_h_kernel(HP p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-  const int colbase = wn * NT * 32 + li;
+  const h8* xw = xs + kh * XW + wn * NT * 32 + li;
   const int dil = a.dil;
-  auto step = [&](const h8 (&af)[KS][MT], int g) {
-    const h8* xr = xs + (2 * g + kh) * XW + colbase;
+  auto chunk = [&](const h8 (&af)[CH][MT], int s0) {
 #pragma unroll
-    for (int tap = 0; tap < KS; ++tap) {
-      h8 bq[NT];
+    for (int j = 0; j < CH; ++j) {
+      const int sidx = s0 + j;
+      if (sidx < S) {
+        const int g = sidx / KS, tap = sidx - g * KS;
+        const h8* xr = xw + 2 * g * XW + tap * dil;
+        h8 bq[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bq[nt] = xr[tap * dil + nt * 32];
+        for (int nt = 0; nt < NT; ++nt) bq[nt] = xr[nt * 32];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap][mt], bq[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt], bq[nt], acc[mt][nt], 0, 0, 0);
+      }
     }
   };
-  for (int g = 0; g < G; g += 2) {
-    if (g + 1 < G) wload(a1, g + 1);
-    step(a0, g);
-    if (g + 1 < G) {
-      if (g + 2 < G) wload(a0, g + 2);
-      step(a1, g + 1);
+  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
+    if (s0 + CH < S) wload(a1, s0 + CH);
+    chunk(a0, s0);
+    if (s0 + CH < S) {
+      if (s0 + 2 * CH < S) wload(a0, s0 + 2 * CH);
+      chunk(a1, s0 + CH);
     }
   }
 
@@ -198,14 +212,33 @@ int launch_h(const svc_conv1d_h_args& a, int R, hipStream_t s) {
   return svc::check_launch("conv1d_h");
 }
 
+int g_h_cfg = 0;   // svc_debug_set_conv_h(cfg): 0 automatic; 1 never the 64 x 128 tile; 2 the wide wave tiles (NT = 4) where they fit
+
 template <int KS>
 int launch_h_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
-  if (R >= 128) return launch_h<KS, 2, 2, 2, 2>(a, R, s);   // 128 rows x 128 columns
-  if (R > 32) return launch_h<KS, 2, 2, 1, 4>(a, R, s);     //  64 rows x 256 columns
-  return launch_h<KS, 1, 2, 1, 4>(a, R, s);                 //  32 rows x 256 columns
+  // Measured per shape (profiles/r08b_conv_h_shapes.txt, one clip's MRF convs): the wave tiles with FOUR column tiles (128 x 256,
+  // 64 x 512, 32 x 512: half the weight stream per FLOP, one workgroup per CU) lose to the ones with two on every shape — 17..41
+  // against 17..34 us at 128 channels, 14..30 against 14..24 us at 64 — because a workgroup's phases (stage the tile, matrix loop,
+  // store) only overlap with those of a co-resident workgroup, and the narrow forms keep two or three per CU.  They stay behind
+  // the debug switch.  The 256-channel stage has 6 896 columns: 128 x 128 tiles are 108 workgroups for 256 CUs, 64 x 128 tiles 216.
+  const long long cols = (long long)a.Tq * a.B;
+  const bool wide = g_h_cfg == 2;
+  if (R >= 128) {
+    const long long wgs128 = (long long)svc::cdiv(R, 128) * svc::cdiv(a.Tq, 128) * a.B;
+    const size_t lds_wide = (size_t)(a.Cin / 8) * (256 + (a.KS - 1) * a.dil) * 16;
+    if (wide && wgs128 >= 320 && lds_wide <= 160 * 1024) return launch_h<KS, 2, 4, 2, 2>(a, R, s);   // 128 rows x 256 columns
+    if (g_h_cfg != 1 && wgs128 < 200) return launch_h<KS, 2, 1, 1, 4>(a, R, s);                       //  64 rows x 128 columns
+    return launch_h<KS, 2, 2, 2, 2>(a, R, s);                                                         // 128 rows x 128 columns
+  }
+  if (R > 32) {
+    if (wide && cols >= 160 * 512) return launch_h<KS, 2, 4, 1, 4>(a, R, s);                          //  64 rows x 512 columns
+    return launch_h<KS, 2, 2, 1, 4>(a, R, s);                                                         //  64 rows x 256 columns
+  }
+  if (wide && cols >= 160 * 512) return launch_h<KS, 1, 4, 1, 4>(a, R, s);                            //  32 rows x 512 columns
+  return launch_h<KS, 1, 2, 1, 4>(a, R, s);                                                           //  32 rows x 256 columns
 }
 
-// ---- weight pack: dense fp32 (weight norm already folded) -> [tap][Cin/16][RP][16] fp16.
+// ---- weight pack: dense fp32 (weight norm already folded) -> [Cin/16][tap][RP][16] fp16.
 // conv (u == 1): w [Cout][Cin][KS], row = co, tap = k.   transposed (u > 1): w [Cin][Cout][K], row = ph * Cout + co, tap mr of
 // M = ceil(K / u): k = ph + (M - 1 - mr) * u (taps time-reversed: each phase is a plain correlation, as pack_convt1d_kernel).
 __global__ void pack_h_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int K, int taps, int RP,
@@ -216,8 +249,7 @@ __global__ void pack_h_kernel(const float* __restrict__ w, _Float16* __restrict_
   long long r = idx >> 4;
   const int row = (int)(r % RP);
   r /= RP;
-  const int G = Cin >> 4;
-  const int g = (int)(r % G), tap = (int)(r / G);
+  const int tap = (int)(r % taps), g = (int)(r / taps);        // [Cin/16][tap][RP][16]: (group, tap) steps linear, group-major
   const int ci = g * 16 + j;
   float v = 0.f;
   if (u <= 1) {
@@ -331,6 +363,11 @@ extern "C" int svc_conv1d_h(const svc_conv1d_h_args* ap, void* stream) {
     case 11: return launch_h_ks<11>(a, R, s);
     default: SVC_REQUIRE(false, "conv1d_h: tap count %d not built (1, 2, 3, 7, 11)", a.KS);
   }
+  return SVC_OK;
+}
+
+extern "C" int svc_debug_set_conv_h(int cfg) {
+  g_h_cfg = cfg;
   return SVC_OK;
 }
 

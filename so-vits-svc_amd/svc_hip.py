@@ -158,7 +158,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -437,7 +437,7 @@ def pack_conv1d_h(w, u=1):
         Cout, Cin, K = w.shape
         taps, R = K, Cout
     RP = round_up(R, 128)
-    dst = torch.empty((taps, Cin // 16, RP, 16), device=w.device, dtype=torch.float16)
+    dst = torch.empty((Cin // 16, taps, RP, 16), device=w.device, dtype=torch.float16)
     check(lib().svc_pack_conv1d_h(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
     return dst
 
@@ -448,8 +448,8 @@ def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=
     _require_gpu_h(x, wp, bias, res, out)
     _check_h(x, "conv1d_h")
     B, CB, Tin, _ = x.shape
-    KS = wp.shape[0]
-    if wp.shape[1] * 16 != CB * 8:
+    KS = wp.shape[1]
+    if wp.shape[0] * 16 != CB * 8:
         raise SvcError(f"conv1d_h: packed weight {tuple(wp.shape)} does not match Cin={CB * 8}")
     if Tout is None:
         Tout = Tin
@@ -473,7 +473,7 @@ def conv_transpose1d_h(x, wp, Cout, K, stride, padding, *, bias=None, pre_slope=
     _require_gpu_h(x, wp, bias, res, out)
     _check_h(x, "conv_transpose1d_h")
     B, CB, Tin, _ = x.shape
-    M = wp.shape[0]
+    M = wp.shape[1]
     Lout = (Tin - 1) * stride - 2 * padding + K
     if out is None:
         out = torch.empty((B, Cout // 8, Lout, 8), device=x.device, dtype=torch.float16)

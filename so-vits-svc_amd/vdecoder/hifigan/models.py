@@ -249,7 +249,7 @@ def _mrf_stage_merged(blocks, x, acc, kw):
         cur = dst
 
 
-def mrf_stage(owner, blocks, x, acc, n_tmp=3):
+def mrf_stage(owner, blocks, x, acc, n_tmp=3, half=False):
     """acc = mean_j blocks[j](x) for the ResBlocks of one decoder stage (`xs += resblocks[j](x)`; `x = xs / num_kernels`,
     vdecoder/hifigan/models.py:382-388), the blocks accumulating into `acc` in order.
 
@@ -261,12 +261,13 @@ def mrf_stage(owner, blocks, x, acc, n_tmp=3):
     Capturable (torch.cuda.graph follows the fork / join)."""
     n = len(blocks)
     kw = lambda j: dict(out=acc, beta=0.0 if j == 0 else 1.0, out_div=float(n) if j == n - 1 else 1.0)
-    if _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x) and (_MRF_MERGE == 1 or x.shape[0] * x.shape[2] < 16384):
+    run = (lambda blk, *a, **k: blk.forward_h(*a, **k)) if half else (lambda blk, *a, **k: blk(*a, **k))   # half: blocked fp16 tensors
+    if not half and _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x) and (_MRF_MERGE == 1 or x.shape[0] * x.shape[2] < 16384):
         return _mrf_stage_merged(blocks, x, acc, kw)
     if not (_MRF_STREAMS and n > 1 and x.is_cuda):
         tmp = [torch.empty_like(x) for _ in range(n_tmp)]
         for j, blk in enumerate(blocks):
-            blk(x, tmp=tmp, **kw(j))
+            run(blk, x, tmp=tmp, **kw(j))
         return acc
     main = torch.cuda.current_stream()
     side = owner.__dict__.setdefault("_mrf_streams", {})
@@ -285,7 +286,7 @@ def mrf_stage(owner, blocks, x, acc, n_tmp=3):
             if j:
                 st.wait_event(fork)
             hook = (lambda jj=j, ss=st: ss.wait_event(done[jj - 1])) if j else None
-            blk(x, tmp=tmps[j], before_last=hook, **kw(j))
+            run(blk, x, tmp=tmps[j], before_last=hook, **kw(j))
             done[j].record(st)
     main.wait_event(done[-1])      # chain j's last launch waited for chain j-1's: the last event covers all of them
     return acc
@@ -418,8 +419,8 @@ class Generator(nn.Module):
         return [c0] + [c0 // (2 ** (i + 1)) for i in range(self.num_upsamples)]
 
     def forward_h(self, x, f0, g=None, noise=None, source=None):
-        """forward() with the MRF stages, ups[1:] and conv_post on blocked fp16 tensors (one chain: the stage's three ResBlocks run
-        back to back on the caller's stream, each accumulating into the stage mean)."""
+        """forward() with the MRF stages, ups[1:] and conv_post on blocked fp16 tensors; a stage's three ResBlock chains run on
+        concurrent streams and accumulate into the stage mean in order, as in the fp32 form (mrf_stage)."""
         _no_grad_guard(self.conv_pre.weight_v if self.conv_pre.is_weight_norm else self.conv_pre.weight)
         if source is None:
             har, _, _ = self.m_source(f0, self.upp, noise=noise)
@@ -436,12 +437,7 @@ class Generator(nn.Module):
                 xh = S.to_h(x)
             else:
                 xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs))
-            acc = torch.empty_like(xh)
-            tmp = [torch.empty_like(xh) for _ in range(3)]
-            for j in range(nk):
-                self.resblocks[i * nk + j].forward_h(xh, out=acc, beta=0.0 if j == 0 else 1.0,
-                                                     out_div=float(nk) if j == nk - 1 else 1.0, tmp=tmp)
-            xh = acc
+            xh = mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), half=True)
         cp = self.conv_post
         return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,
                              pre_slope=0.01, act=S.ACT_TANH)
