@@ -490,6 +490,11 @@ enum {
 int svc_reduce_scalar_f64(int op, const float* a, const float* b, const float* c, const float* d, long long n,
                           double* out, double scale, void* stream);
 int svc_f64_to_f32(const double* in, float* out, int n, void* stream);
+/* Guard of a hipGraph-replayed training iteration (no host sync per step): counter[2] += 1, counter[0] += number of non-finite
+ * values among the n (<= 8) device scalars, counter[1] = the (1-based) launch number when any was seen.  `scalars`: HOST array of n
+ * device pointers (read at call / capture time); counter: int[3] in device memory, zeroed by the caller.  The counters are sticky;
+ * the caller reads them back every N steps (train.TrainStep). */
+int svc_nonfinite_guard_f32(const float* const* scalars, int n, int* counter, void* stream);
 
 /* Fused AdamW step over one flat parameter buffer (train.py:79-88; torch.optim.AdamW semantics).  The hyper-parameters
  * are read from DEVICE memory: hyper = float[7] {lr, beta1, beta2, eps, weight_decay, step (>= 1), grad_scale}

@@ -621,6 +621,27 @@ __global__ void sn_bwd_kernel(const float* __restrict__ g, const float* __restri
 
 }  // namespace
 
+struct GuardP {
+  const float* p[8];
+};
+__global__ void nonfinite_guard_kernel(GuardP gp, int n, int* __restrict__ counter) {
+  const int i = threadIdx.x;
+  int bad = 0;
+  if (i < n) {
+    const float v = *gp.p[i];
+    bad = !(v == v) || v == INFINITY || v == -INFINITY;
+  }
+  const unsigned long long m = __ballot(bad);
+  if (i == 0) {
+    const int it = counter[2] + 1;
+    counter[2] = it;
+    if (m) {
+      counter[0] += __popcll(m);
+      counter[1] = it;
+    }
+  }
+}
+
 extern "C" {
 
 int svc_kl_fwd_f64(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p, const float* mask,
@@ -732,6 +753,19 @@ int svc_spectral_norm_bwd_f32(const float* W, const float* u, const float* v, co
   hipLaunchKernelGGL(sn_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, g, u, v, sigma,
                      dot_ws, dW, R, K);
   return svc::check_launch("spectral_norm_bwd");
+}
+
+
+/* Device-side guard of a replayed training iteration: counter[2] += 1 (launches so far), counter[0] += number of non-finite values
+ * among the n (<= 8) scalars, counter[1] = the launch number (1-based) of the LAST launch that saw one (0 = never).  The counters
+ * are sticky; the host reads them every few hundred steps instead of synchronising on every loss. */
+int svc_nonfinite_guard_f32(const float* const* scalars, int n, int* counter, void* stream) {
+  SVC_REQUIRE(scalars && counter && n > 0 && n <= 8, "nonfinite_guard: 1..8 scalars");
+  GuardP gp;
+  for (int i = 0; i < 8; ++i) gp.p[i] = i < n ? scalars[i] : nullptr;
+  for (int i = 0; i < n; ++i) SVC_REQUIRE(gp.p[i] != nullptr, "nonfinite_guard: null scalar %d", i);
+  hipLaunchKernelGGL(nonfinite_guard_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gp, n, counter);
+  return svc::check_launch("nonfinite_guard");
 }
 
 }  // extern "C"

@@ -848,7 +848,7 @@ TRAIN_EXPORTS = [
     "svc_gemm_f32", "svc_reduce_bct_f32", "svc_reduce_c_f32", "svc_ew_f32", "svc_ew_bct_f32", "svc_gate_fwd_f32",
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
     "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_adamw_advance", "svc_debug_set_conv_cfg",
-    "svc_debug_set_wgrad_target", "svc_debug_set_conv_strip", "svc_debug_set_gconv_version",
+    "svc_debug_set_wgrad_target", "svc_debug_set_conv_strip", "svc_debug_set_gconv_version", "svc_nonfinite_guard_f32",
 ]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
@@ -869,6 +869,7 @@ def tlib():
         L.svc_conv_weight_prep_multi_f32.argtypes = [C.POINTER(ConvWeightArgs), vp, vp, vp, i, vp]
         L.svc_conv_weight_prep_blocks.argtypes = [i, i, i]
         L.svc_gemm_f32.argtypes = [C.POINTER(GemmArgs), vp]
+        L.svc_nonfinite_guard_f32.argtypes = [vp, i, vp, vp]
         L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
         L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
         L.svc_ew_f32.argtypes = [i, _f32p, _f32p, _f32p, ll, f, f, vp]
@@ -1305,6 +1306,16 @@ def reduce_scalar(op, a, b=None, c=None, d=None, scale=1.0, acc=None):
     check(tlib().svc_reduce_scalar_f64(op, ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), ts[0].numel(),
                                        C.c_void_p(acc.data_ptr()), float(scale), stream_ptr()), "reduce_scalar")
     return acc
+
+
+def nonfinite_guard(scalars, counter):
+    """counter (int32[3] on the device, zeroed once): [0] += non-finite values among the 0-dim fp32 device tensors `scalars`
+    (at most 8), [1] = launch number that last saw one, [2] += 1.  No host sync; capturable."""
+    require_gpu(*scalars)
+    if counter.dtype != torch.int32 or counter.numel() < 3 or not counter.is_cuda:
+        raise SvcError("nonfinite_guard: counter must be an int32[3] device tensor")
+    arr = (C.c_void_p * len(scalars))(*[t.data_ptr() for t in scalars])
+    check(tlib().svc_nonfinite_guard_f32(arr, len(scalars), C.c_void_p(counter.data_ptr()), stream_ptr()), "nonfinite_guard")
 
 
 def f64_to_f32(acc):

@@ -94,6 +94,8 @@ class TrainStep:
         self._graphs = collections.OrderedDict()      # batch shape -> captured iteration, least recently used first
         self.graph_evictions, self._cap_logged = 0, False
         self.dp_ordered = False       # eager launches with the replayed form's collective order (a rank whose capture failed)
+        self._guard, self._since_check = None, 0
+        self.finite_every = max(1, int(os.environ.get("SVC_TRAIN_FINITE_EVERY", "200")))
         # every captured shape keeps its own ~10 GB tape alive: bound the count (bucketed batches need 2-4; a data set of
         # odd batch sizes falls back to eager launches for the shapes beyond the cap instead of growing without limit)
         self.max_graphs = int(os.environ.get("SVC_TRAIN_GRAPH_MAX", "8"))
@@ -112,6 +114,11 @@ class TrainStep:
     def __call__(self, items, noise=None):
         """items = (c, f0, spec, y, spk, lengths, uv, volume) as the reference's collate returns them (train.py:151);
         returns a dict of 0-dim device tensors."""
+        out = self._dispatch(items, noise)
+        self.check_finite()
+        return out
+
+    def _dispatch(self, items, noise=None):
         if self.use_graph and self.scaler is None:
             items = self._dense_spec(items)
             if all(r is not None for r in self._reducers()):
@@ -291,10 +298,38 @@ class TrainStep:
         self.optim_g.zero_grad()
         (loss_gen_all * self.scaler.scale if self.scaler is not None else loss_gen_all).backward()
         loss_disc = ctx["loss_disc"]
-        return dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
-                    loss_mel=loss_mel.detach(), loss_kl=loss_kl.detach(),
-                    loss_lf0=loss_lf0.detach() if torch.is_tensor(loss_lf0) else loss_lf0,
-                    loss_gen_all=loss_gen_all.detach())
+        out = dict(loss_disc=loss_disc.detach(), loss_gen=loss_gen.detach(), loss_fm=loss_fm.detach(),
+                   loss_mel=loss_mel.detach(), loss_kl=loss_kl.detach(),
+                   loss_lf0=loss_lf0.detach() if torch.is_tensor(loss_lf0) else loss_lf0,
+                   loss_gen_all=loss_gen_all.detach())
+        self._guard_losses(out)
+        return out
+
+    # -- non-finite guard ------------------------------------------------------------------------------------------------------
+    def _guard_losses(self, out):
+        """One one-thread kernel per iteration (captured with the rest of it) counts non-finite values among the seven losses
+        into sticky device counters; the host looks at them every SVC_TRAIN_FINITE_EVERY iterations (default 200) — the replayed
+        iteration never synchronises on a loss, so without this a divergence (or a recurrence of the round-2 replay corruption,
+        DESIGN §5 (d)) would run on silently for hours."""
+        vals = [v for v in out.values() if torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 and v.dim() == 0]
+        if not vals:
+            return
+        if self._guard is None or self._guard.device != vals[0].device:
+            self._guard = torch.zeros(3, dtype=torch.int32, device=vals[0].device)
+        S.nonfinite_guard(vals[:8], self._guard)
+
+    def check_finite(self, force=False):
+        """Raise FloatingPointError if an iteration since the last check produced a non-finite loss.  Called from __call__ every
+        `finite_every` iterations (one device read-back); `force` reads now."""
+        self._since_check += 1
+        if self._guard is None or (not force and self._since_check < self.finite_every):
+            return
+        self._since_check = 0
+        bad, last, n = self._guard.tolist()
+        if bad:
+            self._guard.zero_()
+            raise FloatingPointError(f"training diverged: {bad} non-finite loss value(s), last in iteration {last} of {n} "
+                                     f"(counted on the device by svc_nonfinite_guard_f32; SVC_TRAIN_FINITE_EVERY={self.finite_every})")
 
     # -- data-parallel hipGraph mode ---------------------------------------------------------------------------------------
     def _reducers(self):

@@ -68,6 +68,40 @@ def test_train_loop_matches_reference_loop(dev, graph):
     assert torch.equal(optim_g.exp_avg, m0) and set(optim_g._steps) == {meta["n_iter"]}
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_nonfinite_losses_are_caught_without_a_sync_per_step(dev, graph):
+    """TrainStep's device-side guard (svc_nonfinite_guard_f32, one thread per iteration, captured with it): finite iterations leave
+    the counters clean; once a weight is poisoned the replayed iterations keep running without any host read-back, and the next
+    periodic check raises with the device's own count of what it saw."""
+    import train as T
+    cs = load_case()
+    hps = _hps(cs, 2e-4)
+    net_g, net_d, optim_g, optim_d = T.build(hps, dev)
+    net_g.module.load_state_dict(cs["sd_g"], strict=True)
+    net_d.module.load_state_dict(cs["sd_d"], strict=True)
+    net_g.train()
+    net_d.train()
+    step = T.TrainStep(hps, net_g, net_d, optim_g, optim_d).enable_graph(graph)
+    step.finite_every = 1000                      # no periodic read-back inside this test: only the forced ones below
+    c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
+    noise = {k: v.to(dev) for k, v in cs["noise"].items()}
+    items = (c, f0, spec, y, sid, lengths, uv, None)
+    for _ in range(3):
+        step(items, noise=noise)
+    step.check_finite(force=True)                 # clean so far (warm-up and capture launches included)
+    n_before = int(step._guard[2])
+    with torch.no_grad():
+        net_g.module.dec.conv_post.bias.fill_(float("nan"))
+        torch.autograd.graph.increment_version(net_g.module.dec.conv_post.bias)
+    out = step(items, noise=noise)                # runs to completion: nothing synchronises on the losses
+    step(items, noise=noise)
+    assert not torch.isfinite(out["loss_mel"])
+    with pytest.raises(FloatingPointError) as e:
+        step.check_finite(force=True)
+    assert "non-finite" in str(e.value)
+    assert int(step._guard[2]) == n_before + 2 and int(step._guard[0]) == 0     # counted 2 more launches; cleared after raising
+
+
 def test_fused_adamw_matches_torch(dev):
     from optim import FusedAdamW
     torch.manual_seed(3)
