@@ -68,13 +68,37 @@ class Unit2Mel(nn.Module):
                     x = S.ew_bct(S.EW_ADD, x, e, alpha=1.0, beta=float(v))
             else:
                 if spk_id.shape[1] > 1:
-                    raise NotImplementedError("per-frame speaker mix tracks (speaker_map) are not mirrored for Unit2Mel")
-                e = self.spk_embed(spk_id.long()).detach().transpose(1, 2).contiguous()           # [B, H, 1] lookup
-                x = S.ew_bct(S.EW_ADD, x, e, alpha=1.0, beta=1.0)
+                    # per-frame speaker tracks (:150-156): spk_id is the [n_frames, n_spk] mix matrix Svc builds
+                    # (infer_tool.py:275-279), x[:, :, t] += sum_s mix[t, s] * spk_embed[s] — one [H x S] x [S x T] product
+                    if getattr(self, "speaker_map", None) is None:
+                        raise S.SvcError("per-frame speaker mix needs init_spkmix(n_spk) first (Svc(spk_mix_enable=True))")
+                    mix = spk_id.float().contiguous()                                             # [T, S]
+                    if mix.shape[0] != T or mix.shape[1] != self.speaker_map.shape[0]:
+                        raise S.SvcError(f"speaker mix {tuple(mix.shape)} does not match {T} frames x {self.speaker_map.shape[0]} speakers")
+                    Sn = mix.shape[1]
+                    g = S.gemm(self.speaker_map, mix, (0, 1, H), (0, 1, Sn), 1, H, T, Sn)        # [1, H, T]
+                    x = S.ew(S.EW_ADD, x, g if B == 1 else g.expand(B, H, T).contiguous(), alpha=1.0, beta=1.0)
+                else:
+                    e = self.spk_embed(spk_id.long()).detach().transpose(1, 2).contiguous()       # [B, H, 1] lookup
+                    x = S.ew_bct(S.EW_ADD, x, e, alpha=1.0, beta=1.0)
         if self.aug_shift_embed is not None and aug_shift is not None:
             sh = (aug_shift.float() / 5).reshape(B, 1, 1).expand(B, 1, T).contiguous()
             x = S.ew(S.EW_ADD, x, S.conv1d_direct(sh, pk(self.aug_shift_embed.weight.unsqueeze(-1)), H, 1), alpha=1.0, beta=1.0)
         return x
+
+    def init_spkmix(self, n_spk):
+        """Reference :119-130 (called by Svc(spk_mix_enable=True) with a diffusion model, infer_tool.py:157-158): build the
+        `speaker_map` that forward's per-frame branch (:150-156) multiplies the [n_frames, n_spk] mix matrix with.  As written the
+        reference's method cannot run — init_spkembed reads `self.hidden_size`, an attribute Unit2Mel never sets (AttributeError;
+        checked against the reference tree), and forward then adds a [B, H, N] term to the [B, N, H] embedding sum.  What both
+        evidently mean — and what SynthesizerTrn.EnableCharacterMix (models.py:456-461) does for the main model — is
+        speaker_map[s] = spk_embed(s) and x[:, t] += sum_s mix[t, s] * speaker_map[s]: that is what is built here, as the
+        [n_spk, n_hidden] matrix the mix product reads (row s = spk_embed.weight[s])."""
+        if self.n_spk is None or self.n_spk <= 1:
+            raise S.SvcError("init_spkmix: the model has no speaker embedding (n_spk <= 1)")
+        if n_spk > self.spk_embed.weight.shape[0]:
+            raise S.SvcError(f"init_spkmix: {n_spk} speakers but the embedding has {self.spk_embed.weight.shape[0]} rows")
+        self.speaker_map = self.spk_embed.weight.detach()[:n_spk].float().contiguous().clone()
 
     def _condition_train(self, units, f0, volume, spk_id, aug_shift):
         """The conditioning sum on the autograd ops (HIP forward + backward): gradients reach every embedding."""

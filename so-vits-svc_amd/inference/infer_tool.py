@@ -172,7 +172,7 @@ class Svc(object):
                     self.speech_encoder = self.diffusion_args.data.encoder
                     self.unit_interpolate_mode = self.diffusion_args.data.unit_interpolate_mode or "left"
                 if spk_mix_enable:
-                    raise NotImplementedError("speaker-mix tracks for the diffusion model (Unit2Mel.init_spkmix) are not mirrored")
+                    self.diffusion_model.init_spkmix(len(self.spk2id))                     # :157-158
             else:
                 print("No diffusion model or config found. Shallow diffusion mode will False")
                 self.shallow_diffusion = self.only_diffusion = False

@@ -82,6 +82,50 @@ def test_unit2mel_matches_reference_golden(dev, name, method, speedup, shallow, 
     assert err <= 1e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.gpu
+def test_unit2mel_per_frame_speaker_mix(dev):
+    """Unit2Mel.init_spkmix + the per-frame branch of forward (reference diffusion/unit2mel.py:119-130,150-156; reached by
+    Svc(spk_mix_enable=True, shallow_diffusion=True), inference/infer_tool.py:157-158,275-279).  The reference's own init_spkmix
+    raises AttributeError (`self.hidden_size`), so there is no golden: the evidently intended semantics are pinned through the
+    paths the reference CAN run — a mix that is one-hot in speaker k at every frame must equal spk_id = k, a constant mix must
+    equal the spk_mix_dict branch (:143-147) with the same weights, and the conditioning is linear in the mix."""
+    z, meta = _load()
+    c = DO.small_cfg()
+    net = _mirror(c, meta["seed"], dev)
+    t = lambda k: torch.from_numpy(z[k])[:1].to(dev)
+    units, f0, vol = t("units"), t("f0"), t("volume")
+    T, Sn = units.shape[1], c["n_spk"]
+    with pytest.raises(Exception):
+        net._condition(units, f0, vol, torch.ones(T, Sn, device=dev) / Sn, None, None)      # before init_spkmix
+    net.init_spkmix(Sn)
+    with torch.no_grad():
+        for k in range(Sn):
+            onehot = torch.zeros(T, Sn, device=dev)
+            onehot[:, k] = 1.0
+            a = net._condition(units, f0, vol, onehot, None, None)
+            b = net._condition(units, f0, vol, torch.tensor([[k]], device=dev), None, None)
+            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k
+        w = torch.tensor([0.5, 0.3, 0.2], device=dev)[:Sn]
+        w = w / w.sum()
+        const = net._condition(units, f0, vol, w.view(1, Sn).expand(T, Sn).contiguous(), None, None)
+        viadict = net._condition(units, f0, vol, None, {k: float(w[k]) for k in range(Sn)}, None)
+        assert (const - viadict).abs().max().item() <= 2e-6 * max(1.0, viadict.abs().max().item())
+        # a time-varying track: frame t mixes speakers 0 and 1 with weight t / (T - 1)
+        ramp = torch.zeros(T, Sn, device=dev)
+        ramp[:, 1] = torch.linspace(0, 1, T, device=dev)
+        ramp[:, 0] = 1 - ramp[:, 1]
+        got = net._condition(units, f0, vol, ramp, None, None)
+        e0 = net._condition(units, f0, vol, torch.tensor([[0]], device=dev), None, None)
+        e1 = net._condition(units, f0, vol, torch.tensor([[1]], device=dev), None, None)
+        want = e0 * ramp[:, 0].view(1, 1, T) + e1 * ramp[:, 1].view(1, 1, T)
+        assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+        # and the whole sampler runs with it
+        noise = dict(x_T=t("x_T"), steps=[s[:1].to(dev) for s in torch.from_numpy(z["steps"])])
+        mel = net(units, f0, vol, spk_id=ramp, gt_spec=None, infer=True, infer_speedup=10, method="ddim", k_step=300, use_tqdm=False,
+                  noise=noise)
+        assert torch.isfinite(mel).all() and mel.shape[:2] == (1, T)
+
+
 # ---- training (train_diff.py / diffusion/solver.py:116-147) ------------------------------------------------------------
 def _train_golden():
     z = np.load(os.path.join(G, "diffusion_train_small.npz"))
