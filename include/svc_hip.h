@@ -235,6 +235,11 @@ int svc_snake_alias_bwd_f32(const float* x, const float* dy, const float* alpha,
  * (b, c) row (biased variance, like torch).  x, y:[B,C,T] contiguous. */
 int svc_channel_norm_gelu_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                               float eps, int apply_gelu, void* stream);
+/* The same for a batch of items of DIFFERENT lengths zero-padded to T (Svc.slice_inference's chunks through the unit encoder,
+ * inference/infer_tool.py:446-495 + :220-224): item b's statistics run over its own lens[b] (int32, device) steps — what it gets
+ * when processed alone — and its columns t >= lens[b] are written as 0. */
+int svc_channel_norm_gelu_len_f32(const float* x, const float* gamma, const float* beta, const int* lens, float* y, int B, int C,
+                                  int T, float eps, int apply_gelu, void* stream);
 /* Windowed-sinc polyphase resampling, the conversion in front of the unit encoder (inference/infer_tool.py:219-222:
  * torchaudio.transforms.Resample(target_sample, 16000); :271-274 for inputs at another rate).  orig/nw are the two rates
  * divided by their gcd; kern:[K, nw] is the filter bank (tap-major: kern[k*nw + j] = torchaudio's kernels[j, 0, k],

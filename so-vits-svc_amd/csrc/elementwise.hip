@@ -262,6 +262,43 @@ __global__ __launch_bounds__(256) void channel_norm_gelu_kernel(const float* __r
   }
 }
 
+// The same with per-item valid lengths (a batch of utterances of DIFFERENT lengths, zero-padded to T): item b's statistics run over
+// its own lens[b] steps — exactly what the item gets when it is processed alone — and its columns beyond that are written as 0.
+__global__ __launch_bounds__(256) void channel_norm_gelu_len_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const int* __restrict__ lens,
+                                                                    float* __restrict__ y, int C, int T, float eps, int apply_gelu) {
+  __shared__ double sh[2][256];
+  const long long row = blockIdx.x;
+  const int c = (int)(row % C), b = (int)(row / C);
+  const int Tv = min(max(lens[b], 1), T);
+  const float* xr = x + row * T;
+  float* yr = y + row * T;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < Tv; t += 256) {
+    const double v = xr[t];
+    s1 += v;
+    s2 += v * v;
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const double mean = sh[0][0] / Tv;
+  const double var = fmax(sh[1][0] / Tv - mean * mean, 0.0);
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean, g = gamma[c], bt = beta[c];
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = (xr[t] - mu) * rstd * g + bt;
+    yr[t] = t < Tv ? (apply_gelu ? svc_gelu(v) : v) : 0.f;
+  }
+}
+
 // ---- SinusoidalPosEmb (diffusion/wavenet.py:16-28) ---------------------------------------------------------------
 __global__ void sinusoidal_emb_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,6 +403,15 @@ extern "C" int svc_channel_norm_gelu_f32(const float* x, const float* gamma, con
   hipLaunchKernelGGL(channel_norm_gelu_kernel, dim3((unsigned)((long long)B * C)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                      beta, y, C, T, eps, apply_gelu);
   return svc::check_launch("channel_norm_gelu");
+}
+
+extern "C" int svc_channel_norm_gelu_len_f32(const float* x, const float* gamma, const float* beta, const int* lens, float* y, int B,
+                                             int C, int T, float eps, int apply_gelu, void* stream) {
+  SVC_REQUIRE(x && gamma && beta && lens && y && B > 0 && C > 0 && T > 0, "channel_norm_gelu_len: bad args");
+  svc::ProfScope ps((hipStream_t)stream, "channel_norm_gelu", 0.0, 12.0 * B * C * (double)T);
+  hipLaunchKernelGGL(channel_norm_gelu_len_kernel, dim3((unsigned)((long long)B * C)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, lens, y, C, T, eps, apply_gelu);
+  return svc::check_launch("channel_norm_gelu_len");
 }
 
 extern "C" int svc_sinusoidal_emb_f32(const float* t, float* out, int B, int dim, void* stream) {

@@ -140,6 +140,7 @@ def lib():
         L.svc_sinusoidal_emb_f32.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_void_p]
         L.svc_nsf_source_exact_f32.argtypes = [_f32p] * 7 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]
         L.svc_channel_norm_gelu_f32.argtypes = [_f32p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
+        L.svc_channel_norm_gelu_len_f32.argtypes = [_f32p] * 3 + [C.c_void_p, _f32p] + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p]
         L.svc_resample_sinc_f32.argtypes = [_f32p] * 3 + [C.c_longlong] * 2 + [C.c_int] * 7 + [C.c_void_p]
         L.svc_snake_alias_bwd_f32.argtypes = [_f32p] * 4 + [C.POINTER(C.c_float)] + [_f32p] * 3 + [C.c_longlong] * 6 + \
             [C.c_int] * 3 + [C.c_void_p]
@@ -159,7 +160,7 @@ EXPORTS = [
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
-    "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
+    "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
 
@@ -703,12 +704,19 @@ def snake_alias(x, alpha, beta, taps, out=None):
     return out
 
 
-def channel_norm_gelu(x, gamma, beta, eps=1e-5, gelu=True):
-    """GroupNorm(C, C) over time + GELU (vencoder/hubert/hubert_model.py:76,87)."""
+def channel_norm_gelu(x, gamma, beta, eps=1e-5, gelu=True, lengths=None):
+    """GroupNorm(C, C) over time + GELU (vencoder/hubert/hubert_model.py:76,87).  `lengths` (int32 [B] on the device): items of
+    different lengths zero-padded to T — statistics over each item's own length, zeros beyond it."""
     require_gpu(x, gamma, beta)
     x = x.contiguous()
     B, Cc, T = x.shape
     y = torch.empty_like(x)
+    if lengths is not None:
+        if lengths.dtype != torch.int32 or not lengths.is_cuda or lengths.numel() != B:
+            raise SvcError("channel_norm_gelu: lengths must be an int32 [B] device tensor")
+        check(lib().svc_channel_norm_gelu_len_f32(ptr(x), ptr(gamma), ptr(beta), C.c_void_p(lengths.data_ptr()), ptr(y), B, Cc, T, eps,
+                                                  1 if gelu else 0, stream_ptr()), "channel_norm_gelu_len")
+        return y
     check(lib().svc_channel_norm_gelu_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), B, Cc, T, eps, 1 if gelu else 0, stream_ptr()),
           "channel_norm_gelu")
     return y

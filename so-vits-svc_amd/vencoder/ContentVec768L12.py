@@ -5,7 +5,7 @@ output_layer=12)` (:28-36); here the same checkpoint file is mapped onto vencode
 (`load_fairseq_hubert`) and `Hubert.encode(wav, layer=12)` runs the stack in libsvc_hip.so."""
 import torch
 
-from vencoder.encoder import SpeechEncoder, batch_equal_lengths
+from vencoder.encoder import SpeechEncoder, batch_padded
 from vencoder.hubert import hubert_model
 
 
@@ -40,8 +40,8 @@ class ContentVec768L12(SpeechEncoder):
         return x
 
     def encoder_batch(self, wavs):
-        def run(x):
-            y, _ = self.model.encode(x.to(self.dev), layer=self.OUTPUT_LAYER)
-            return self.model.project(y) if self.USE_FINAL_PROJ else y
+        def run(x, lengths):
+            y, _ = self.model.encode(x.to(self.dev), layer=self.OUTPUT_LAYER, lengths=lengths)
+            return (self.model.project(y) if self.USE_FINAL_PROJ else y), self.model.last_frames
         with torch.no_grad():
-            return batch_equal_lengths(wavs, run)
+            return batch_padded(wavs, run)

@@ -1,7 +1,7 @@
 """Mirror of vencoder/HubertSoft.py: the `hubertsoft` speech encoder (256-d soft units) on the MI355X engine."""
 import torch
 
-from vencoder.encoder import SpeechEncoder, batch_equal_lengths
+from vencoder.encoder import SpeechEncoder, batch_padded
 from vencoder.hubert import hubert_model
 
 
@@ -31,5 +31,8 @@ class HubertSoft(SpeechEncoder):
             return units.transpose(1, 2)
 
     def encoder_batch(self, wavs):
+        def run(x, lengths):
+            u = self.model.units(x.to(self.dev), lengths=lengths).transpose(1, 2)
+            return u, self.model.last_frames
         with torch.no_grad():
-            return batch_equal_lengths(wavs, lambda x: self.model.units(x.to(self.dev)).transpose(1, 2))
+            return batch_padded(wavs, run)

@@ -59,18 +59,42 @@ class Hubert(nn.Module):
             self._cache[name] = (key, fn())
         return self._cache[name][1]
 
-    def encode(self, x: torch.Tensor, layer: Optional[int] = None):
-        """x: [B, 1, n] 16 kHz waveform -> ([B, 768, T] features in the engine's channel-major layout, None)."""
+    def encode(self, x: torch.Tensor, layer: Optional[int] = None, lengths=None):
+        """x: [B, 1, n] 16 kHz waveform -> ([B, 768, T] features in the engine's channel-major layout, None).
+
+        `lengths` (engine extension; list of B sample counts): the batch holds waves of DIFFERENT lengths, zero-padded to n
+        (Svc.slice_inference's chunks, inference/infer_tool.py:446-495, which the reference encodes one by one).  Every item then
+        comes out exactly as if it had been encoded alone, on its frames [:, :, :frames(lengths[b])]: the only ops of the stack
+        that look along time are (1) GroupNorm(512, 512) — per-item statistics over the item's own conv0 output length
+        (svc_channel_norm_gelu_len_f32), (2) the positional conv, whose padding must be zeros — the projected features are
+        masked to zero beyond each item's frames first — and (3) attention, which gets the padding mask (keys beyond an item's
+        frames weigh exp(-1e4 - max) == 0 in fp32).  The strided convs are local: a valid output never reads beyond its item's
+        valid input.  Returns (features, None) and leaves the per-item frame counts in `self.last_frames`."""
         if self.training and self._mask:
             raise NotImplementedError("masked training of the unit encoder is out of scope (inference only)")
         if not x.is_cuda:
             raise S.SvcError("Hubert.encode needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
         with torch.no_grad():
-            x = self.feature_extractor(x.float().contiguous(), self)
-            x = self.feature_projection(x, self)
+            if lengths is None:
+                x = self.feature_extractor(x.float().contiguous(), self)
+                x = self.feature_projection(x, self)
+                x = self.positional_embedding(x, self)
+                x = S.add_layernorm(x, None, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+                x = self.encoder(x, self, output_layer=layer)
+                self.last_frames = [x.shape[2]] * x.shape[0]
+                return x, None
+            lengths = [int(v) for v in lengths]
+            if len(lengths) != x.shape[0] or max(lengths) > x.shape[2] or min(lengths) < 400:
+                raise S.SvcError(f"Hubert.encode: lengths {lengths} do not fit a batch of shape {tuple(x.shape)} (>= 400 samples each)")
+            x, frames = self.feature_extractor(x.float().contiguous(), self, lengths=lengths)
+            T = x.shape[2]
+            fl = torch.tensor(frames, device=x.device, dtype=torch.int64)
+            mask = (torch.arange(T, device=x.device).view(1, 1, T) < fl.view(-1, 1, 1)).to(torch.float32)      # [B, 1, T]
+            x = self.feature_projection(x, self, mask=mask)
             x = self.positional_embedding(x, self)
             x = S.add_layernorm(x, None, self.norm.weight, self.norm.bias, eps=self.norm.eps)
-            x = self.encoder(x, self, output_layer=layer)
+            x = self.encoder(x, self, output_layer=layer, src_key_padding_mask=mask)
+            self.last_frames = frames
         return x, None
 
     def project(self, x):
@@ -90,15 +114,16 @@ class HubertSoft(Hubert):
         super().__init__()
 
     @torch.no_grad()
-    def units(self, wav: torch.Tensor) -> torch.Tensor:
-        """wav [B, 1, n] -> soft units [B, T, 256] (reference :63-68: zero-pad 40 samples each side, encode, proj)."""
-        x, _ = self._encode_padded(wav)
+    def units(self, wav: torch.Tensor, lengths=None) -> torch.Tensor:
+        """wav [B, 1, n] -> soft units [B, T, 256] (reference :63-68: zero-pad 40 samples each side, encode, proj).  `lengths`:
+        see Hubert.encode (item b's units are rows [:self.last_frames[b]])."""
+        x, _ = self._encode_padded(wav, lengths)
         return self.project(x).transpose(1, 2)
 
-    def _encode_padded(self, wav):
+    def _encode_padded(self, wav, lengths=None):
         self.feature_extractor.pad = (400 - 320) // 2
         try:
-            return self.encode(wav)
+            return self.encode(wav, lengths=lengths)
         finally:
             self.feature_extractor.pad = 0
 
@@ -126,12 +151,19 @@ class FeatureExtractor(nn.Module):
         wd = wpad.view(Cout, Cin, KSd, s).permute(0, 3, 1, 2).reshape(Cout, s * Cin, KSd).contiguous()
         return _pack(wd), KSd
 
-    def forward(self, x, owner):
+    def forward(self, x, owner, lengths=None):
+        """lengths (list of sample counts, batch of unequal waves): returns (h, frames per item) — see Hubert.encode."""
         B, _, n = x.shape
         w0 = owner._packed("conv0", lambda: _pack(self.conv0.weight))
         T = (n + 2 * self.pad - 10) // 5 + 1
         h = S.conv1d_direct(x, w0, 512, 10, stride=5, pad_left=self.pad, Tout=T)
-        h = S.channel_norm_gelu(h, self.norm0.weight, self.norm0.bias, eps=self.norm0.eps)
+        lens = None
+        if lengths is not None:
+            lens = [(m + 2 * self.pad - 10) // 5 + 1 for m in lengths]
+            h = S.channel_norm_gelu(h, self.norm0.weight, self.norm0.bias, eps=self.norm0.eps,
+                                    lengths=torch.tensor(lens, device=x.device, dtype=torch.int32))
+        else:
+            h = S.channel_norm_gelu(h, self.norm0.weight, self.norm0.bias, eps=self.norm0.eps)
         for i in range(1, 7):
             conv = getattr(self, f"conv{i}")
             KS = conv.kernel_size[0]
@@ -140,7 +172,9 @@ class FeatureExtractor(nn.Module):
             Tout = (Tin - KS) // 2 + 1
             hd = S.decimate(h, 2, 0, (Tin + 1) // 2)                                  # [B, 1024, Q]
             h = S.conv1d(hd, wp, 512, KSd, pad_left=0, Tout=Tout, post_act=S.ACT_GELU)
-        return h
+            if lens is not None:
+                lens = [(m - KS) // 2 + 1 for m in lens]
+        return h if lengths is None else (h, lens)
 
 
 class FeatureProjection(nn.Module):
@@ -150,10 +184,10 @@ class FeatureProjection(nn.Module):
         self.projection = nn.Linear(512, 768)
         self.dropout = nn.Dropout(0.1)
 
-    def forward(self, x, owner):
+    def forward(self, x, owner, mask=None):
         x = S.add_layernorm(x, None, self.norm.weight, self.norm.bias, eps=self.norm.eps)
         wp = owner._packed("projection", lambda: _pack(self.projection.weight.unsqueeze(-1)))
-        return S.conv1d(x, wp, 768, 1, bias=self.projection.bias)
+        return S.conv1d(x, wp, 768, 1, bias=self.projection.bias, mask=mask)
 
 
 class PositionalConvEmbedding(nn.Module):
@@ -181,8 +215,11 @@ class TransformerEncoder(nn.Module):
         self.num_layers = num_layers
 
     def forward(self, src, owner, mask=None, src_key_padding_mask=None, output_layer: Optional[int] = None):
-        if mask is not None or src_key_padding_mask is not None:
+        if mask is not None:
             raise NotImplementedError("attention masks are not used by the so-vits-svc unit encoders")
+        # src_key_padding_mask here: the engine's [B, 1, T] float mask of VALID frames (1 = frame of the item, 0 = padding) of a
+        # batch of unequal items (Hubert.encode(lengths=...)) — the opposite polarity of torch's boolean argument of that name
+        pm = src_key_padding_mask
         x = src
         for li, layer in enumerate(self.layers[:output_layer]):
             sa = layer.self_attn
@@ -192,7 +229,7 @@ class TransformerEncoder(nn.Module):
             w1 = owner._packed(f"l{li}.w1", lambda layer=layer: _pack(layer.linear1.weight.unsqueeze(-1)))
             w2 = owner._packed(f"l{li}.w2", lambda layer=layer: _pack(layer.linear2.weight.unsqueeze(-1)))
             qkv = S.conv1d(x, wqkv, 3 * E, 1, bias=sa.in_proj_bias)
-            att = S.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], H)
+            att = S.attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], H, mask=pm, mask_mode=1 if pm is not None else 0)
             y = S.conv1d(att, wo, E, 1, bias=sa.out_proj.bias)
             x = S.add_layernorm(x, y, layer.norm1.weight, layer.norm1.bias, eps=layer.norm1.eps)
             h = S.conv1d(x, w1, layer.linear1.out_features, 1, bias=layer.linear1.bias, post_act=S.ACT_GELU)

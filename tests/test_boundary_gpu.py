@@ -317,7 +317,7 @@ def test_slice_inference_batches_the_unit_encoder_over_equal_length_chunks(dev, 
     svc = Svc(ck, cj, "cuda:0", "")
     sizes = []
     orig = enc.model.encode
-    enc.model.encode = lambda x, layer=None: (sizes.append(x.shape[0]), orig(x, layer=layer))[1]
+    enc.model.encode = lambda x, layer=None, lengths=None: (sizes.append(x.shape[0]), orig(x, layer=layer, lengths=lengths))[1]
     kw = dict(pad_seconds=0.3, clip_seconds=0.7, lg_num=0.1, lgr_num=0.75)
     serial = svc.slice_inference("song.wav", "alice", 0, -40, 0, False, 0.4, **kw)
     assert len(sizes) >= 4 and set(sizes) == {1}

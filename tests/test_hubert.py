@@ -68,6 +68,44 @@ def test_hubert_units_match_oracle(dev, B, n):
 
 
 @pytest.mark.gpu
+def test_unit_encoder_batches_unequal_lengths_exactly(dev):
+    """Svc.slice_inference's chunks (reference inference/infer_tool.py:446-495 + :220-224: one encoder call per chunk) as padded
+    batches with per-item lengths: masked GroupNorm statistics (svc_channel_norm_gelu_len_f32), zero-masked positional-conv input,
+    padding-mask attention.  Every item must equal its own serial encoding (<= 2e-5) — for the soft-unit wrapper (40-sample
+    padding, proj) and for the ContentVec-style path (layer-12 features), including groups split by the padding-waste rule."""
+    from vencoder.HubertSoft import HubertSoft
+    net = _mirror(7, dev)
+    enc = HubertSoft(device=dev, model=net)
+    g = torch.Generator().manual_seed(3)
+    lens = [16000, 13337, 16000, 9001, 12000, 401, 15999]
+    wavs = [(0.3 * torch.randn(n, generator=g)).to(dev) for n in lens]
+    serial = [enc.encoder(w) for w in wavs]
+    calls = []
+    orig = net.encode
+    net.encode = lambda x, layer=None, lengths=None: (calls.append((x.shape[0], lengths)), orig(x, layer=layer, lengths=lengths))[1]
+    batched = enc.encoder_batch(wavs)
+    net.encode = orig
+    assert len(calls) < len(lens) and max(b for b, _ in calls) >= 3, calls          # really batched, unequal lengths together
+    assert any(l is not None and len(set(l)) > 1 for _, l in calls)
+    for n, a, b in zip(lens, serial, batched):
+        assert a.shape == b.shape, (n, a.shape, b.shape)
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, a.abs().max().item()), (n, err)
+    # the raw stack at an inner layer (what ContentVec768L12 / 256L9 read), unequal items in ONE call
+    x = torch.zeros(3, 1, 24000, device=dev)
+    ns = [24000, 17003, 20480]
+    for b, n in enumerate(ns):
+        x[b, 0, :n] = 0.3 * torch.randn(n, generator=g).to(dev)
+    y, _ = net.encode(x, layer=9, lengths=ns)
+    frames = list(net.last_frames)
+    for b, n in enumerate(ns):
+        yb, _ = net.encode(x[b:b + 1, :, :n].contiguous(), layer=9)
+        assert yb.shape[2] == frames[b]
+        err = (y[b:b + 1, :, :frames[b]] - yb).abs().max().item()
+        assert err <= 2e-5 * max(1.0, yb.abs().max().item()), (n, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,T", [(1, 500), (2, 77), (1, 31), (1, 130)])
 def test_positional_conv_matches_torch(dev, B, T):
     """csrc/posconv.hip (grouped k = 128 conv on the matrix pipe + GELU + residual in one launch) against torch's
