@@ -92,7 +92,16 @@ def cpu_baseline(cfg, W, inputs, max_seconds=45.0, runs=5):
     ref = os.path.join(ROOT, "profiles", "cpu_reference_build_container.json")
     if os.path.exists(ref):
         try:
-            out["reference"] = json.load(open(ref))
+            rj = json.load(open(ref))
+            out["reference"] = rj
+            # the label the port's number needs: how the port compares with the UNMODIFIED reference where both could be timed
+            # (same machine, same cores, same clip) — and what this box's figure becomes under that ratio
+            ratio = rj["port_on_same_cores"]["value"] / rj["value"]
+            out["port_vs_reference"] = dict(
+                ratio=round(ratio, 3), reference_estimate_on_this_box=out["value"] / ratio,
+                note=f"port throughput / reference throughput = {ratio:.3f}, both measured in the build container on {rj['cores']} cores "
+                     "(scripts/time_reference_cpu.py -> profiles/cpu_reference_build_container.json); the estimate divides this box's port "
+                     "figure by it — the reference itself cannot run here (no /root/reference on the GPU box)")
         except Exception:      # noqa: BLE001
             pass
     return out
@@ -315,6 +324,48 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                 roofline=roof if fams is not None else None, families=fams, allreduce=red, cpu_baseline=cpu)
 
 
+def collect_pmc_traffic(timeout_s=200):
+    """roofline.traffic, collected IN this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — the TCC block
+    cannot hold both, MI355X_MICROARCH.md counter table) around a short eager infer of this same script (one stream, launches back to
+    back), summarised per kernel family by scripts/pmc_summary.py: read = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-byte
+    requests at 64 B), write = WRITE_SIZE KiB x 1024 (uncalibrated), Infinity-Cache hits included -> an upper bound on HBM bytes.
+    Returns (bytes per launch of the conv1d_mfma family, bytes per clip, note) or None when rocprofv3 is absent / a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pmc_summary as PS
+    steps, warm = 3, 1
+    env = dict(os.environ, SVC_MRF_STREAMS="0", TMPDIR="/tmp")
+    per = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(td, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
+                   "--mode", "infer", "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-graph", "--no-roofline",
+                   "--no-extras", "--no-host-io", "--no-steady", "--no-pmc"]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
+            except Exception:      # noqa: BLE001 — a hung / missing profiler must not take the bench line down
+                return None
+            if r.returncode != 0:
+                return None
+            per[counter], _ = PS.load(d, counter)
+    rd = sum(v for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024 * 2
+    wr = sum(v for k, (v, n) in per["WRITE_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024
+    n = sum(n for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma")
+    if n == 0:
+        return None
+    total = sum(v for v, _ in per["FETCH_SIZE"].values()) * 1024 * 2 + sum(v for v, _ in per["WRITE_SIZE"].values()) * 1024
+    return (rd + wr) / n, total / (steps + warm), (
+        f"collected in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE x1024 x2 for gfx950's 128-byte requests, WRITE_SIZE "
+        f"x1024 uncalibrated; Infinity-Cache hits included) over a {steps + warm}-clip eager infer of this script, {n} conv launches; "
+        f"{total / (steps + warm) / 1e9:.2f} GB per clip over all kernels")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +382,7 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run a short infer under rocprofv3 --pmc for roofline.traffic (the stamped profiles/pmc_conv1d_mfma.json is quoted when it matches the kernel sources)")
     ap.add_argument("--no-steady", action="store_true", help="skip the 200-replay steady_state look (profiling runs: keeps the step count exact)")
     args = ap.parse_args()
 
@@ -475,12 +527,19 @@ def main():
         fam = max(rep.items(), key=lambda kv: kv[1]["ms"])
         name, r = fam
         achieved = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-        # HBM traffic needs rocprofv3 --pmc passes around the process (MI355X_MICROARCH.md): it cannot be measured from
-        # inside this run.  The figure below is read from the committed PMC summary of an EARLIER builder-side run of this
-        # same command and is labelled as such; null when that file is missing.
+        # HBM traffic needs rocprofv3 --pmc passes AROUND a process (MI355X_MICROARCH.md): when rocprofv3 is on the box this run
+        # re-executes a short eager infer of this script under it, twice (collect_pmc_traffic), and quotes what it measured;
+        # otherwise the committed PMC summary of an earlier builder-side run is quoted — only if it was taken on these kernel
+        # sources, and labelled as such; null when neither exists.
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv1d_mfma.json")
-        if os.path.exists(pmc):
+        live = None
+        if not args.no_pmc and world == 1 and os.environ.get("SVC_BENCH_PMC", "1") != "0":
+            torch.cuda.synchronize()
+            live = collect_pmc_traffic()
+        if live is not None:
+            traffic, _, traffic_source = live
+        elif os.path.exists(pmc):
             try:
                 import importlib.util
                 spec = importlib.util.spec_from_file_location("svc_build", os.path.join(ROOT, "so-vits-svc_amd", "csrc", "build.py"))
