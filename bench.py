@@ -275,6 +275,23 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                                     note="the same FLOP over ms_per_step (hipGraph replay): element-wise / copy launches and gaps included"),
                     traffic=None, note="per-launch hipEvent durations from one eager iteration after the timed region; launches_per_step "
                                        "counts the library's kernels only (torch element-wise / copy launches are in the rocprof summary)")
+        # frames padded to T count as work in flop_per_step: say how much of it the items' own frames are.  The frame-proportional
+        # part of the iteration (pre + prior encoder + F0 decoder + posterior encoder + flow: SURVEY §8a, 402 GFLOP forward at
+        # B 16 x T 400 = 62.8 MFLOP per item-frame, x3 with the two backward products) shrinks with the masked frames; the
+        # generator's 8192-sample segments and the discriminators do not depend on T.
+        lens = items_cpu[5].float()
+        frac = float(lens.mean()) / T
+        fp = 3 * 62.8e6 * TRAIN_B * T
+        roof["padding"] = dict(padded_frames=T, mean_item_frames=round(float(lens.mean()), 1), item_frame_fraction=round(frac, 4),
+                               frame_proportional_flop=fp, flop_per_step_item_frames_only=mflop - fp * (1 - frac),
+                               frac_item_frames_only=round((mflop - fp * (1 - frac)) / (mms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if mms else 0.0,
+                               note="flop_per_step counts frames padded to T as work; the *_item_frames_only figures remove the padded share of "
+                                    "the frame-proportional networks (estimate from SURVEY §8a's per-network FLOP)")
+        if not args.no_pmc and world == 1 and not bf16 and os.environ.get("SVC_BENCH_PMC", "1") != "0":
+            torch.cuda.synchronize()
+            live = collect_pmc_traffic(timeout_s=300, mode="train")
+            if live is not None:
+                roof["traffic"], roof["traffic_all_kernels"], roof["traffic_source"] = live
     red = None
     if getattr(net_g, "reducer", None) is not None:
         rg, rd = net_g.reducer, net_d.reducer
@@ -324,7 +341,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                 roofline=roof if fams is not None else None, families=fams, allreduce=red, cpu_baseline=cpu)
 
 
-def collect_pmc_traffic(timeout_s=200):
+def collect_pmc_traffic(timeout_s=200, mode="infer"):
     """roofline.traffic, collected IN this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — the TCC block
     cannot hold both, MI355X_MICROARCH.md counter table) around a short eager infer of this same script (one stream, launches back to
     back), summarised per kernel family by scripts/pmc_summary.py: read = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-byte
@@ -338,14 +355,14 @@ def collect_pmc_traffic(timeout_s=200):
         return None
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import pmc_summary as PS
-    steps, warm = 3, 1
+    steps, warm = (3, 1) if mode == "infer" else (1, 1)
     env = dict(os.environ, SVC_MRF_STREAMS="0", TMPDIR="/tmp")
     per = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(td, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
-                   "--mode", "infer", "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-graph", "--no-roofline",
+                   "--mode", mode, "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-graph", "--no-roofline",
                    "--no-extras", "--no-host-io", "--no-steady", "--no-pmc"]
             try:
                 r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
@@ -354,6 +371,20 @@ def collect_pmc_traffic(timeout_s=200):
             if r.returncode != 0:
                 return None
             per[counter], _ = PS.load(d, counter)
+    if mode == "train":
+        # one iteration = every launch of it: MFMA families (dense convs forward + dgrad, weight gradients, attention GEMMs) and all
+        mf = lambda k: PS.family(k) in ("conv1d_mfma", "conv1d_wgrad", "conv1d_wgrad_small") or PS.family(k).startswith("gemm_f32")
+        it = steps + warm
+        rdm = sum(v for k, (v, n) in per["FETCH_SIZE"].items() if mf(k)) * 1024 * 2
+        wrm = sum(v for k, (v, n) in per["WRITE_SIZE"].items() if mf(k)) * 1024
+        total = sum(v for v, _ in per["FETCH_SIZE"].values()) * 1024 * 2 + sum(v for v, _ in per["WRITE_SIZE"].values()) * 1024
+        nl = sum(n for k, (v, n) in per["FETCH_SIZE"].items() if mf(k))
+        if nl == 0:
+            return None
+        return (rdm + wrm) / it, total / it, (
+            f"collected in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE x1024 x2 for gfx950's 128-byte requests, WRITE_SIZE "
+            f"x1024 uncalibrated; Infinity-Cache hits included) over {it} eager iterations of this script; traffic = bytes per iteration of "
+            f"the MFMA families ({nl // it} launches), {total / it / 1e9:.1f} GB per iteration over all kernels")
     rd = sum(v for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024 * 2
     wr = sum(v for k, (v, n) in per["WRITE_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024
     n = sum(n for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma")
