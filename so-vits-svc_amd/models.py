@@ -142,7 +142,8 @@ class Encoder(nn.Module):
             if noise is None:
                 noise = torch.randn(x.shape[0], self.out_channels, x.shape[2], device=x.device)      # models.py:123
             z = A.reparam(stats, noise, m, 1.0)
-            return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
+            m_, logs_ = A.chunk_channels(stats, 2, views=True)      # (one gradient buffer in the backward, no zero-filled slices)
+            return z, m_, logs_, x_mask
         h = self.pre.run(x, mask=m)
         h = self.enc(h, x_mask, g=g)
         stats = self.proj.run(h, mask=m)
@@ -176,7 +177,8 @@ class TextEncoder(nn.Module):
             if noise is None:
                 noise = torch.randn(stats.shape[0], self.out_channels, stats.shape[2], device=stats.device)   # :160
             z = A.reparam(stats, noise, m, float(noice_scale))
-            return z, stats[:, :self.out_channels], stats[:, self.out_channels:], x_mask
+            m_, logs_ = A.chunk_channels(stats, 2, views=True)      # (one gradient buffer in the backward, no zero-filled slices)
+            return z, m_, logs_, x_mask
         if not x_is_embedded:
             emb = self.f0_emb.weight[f0].transpose(1, 2).contiguous()      # index gather (no arithmetic)
             x = _add_bc(x, emb)

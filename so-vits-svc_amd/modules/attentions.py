@@ -310,8 +310,8 @@ class FFT(nn.Module):
         pre = None
         if g is not None:
             H = self.hidden_channels
-            gc = self.cond_layer.forward_train(g)                                   # [B, 2H*L, 1]
-            pre = lambda i, x: A.gate(A.add_bcast(self.cond_pre.forward_train(x), gc[:, i * 2 * H:(i + 1) * 2 * H]))
+            gcs = A.chunk_channels(self.cond_layer.forward_train(g), self.n_layers, views=True)  # L x [B, 2H, 1]: one backward buffer
+            pre = lambda i, x: A.gate(A.add_bcast(self.cond_pre.forward_train(x), gcs[i]))
         return _encoder_forward_train(self, x, x_mask, self.self_attn_layers, self.norm_layers_0, self.norm_layers_1,
                                       MASK_CAUSAL, dropout_u, pre_layer=pre)
 

@@ -84,6 +84,9 @@ class WN(nn.Module):
         """Reference modules/modules.py:110-138, one autograd op per reference op."""
         H = self.hidden_channels
         gc = self.cond_layer.forward_train(g) if g is not None else None          # [B, 2H*L, 1|T]
+        # the per-layer conditioning rows as ONE op: its backward writes the L gradients into one buffer (a Python slice per
+        # layer costs a zero-fill + copy + accumulate launch each in torch's slice backward: 36 WN layers per iteration)
+        gcs = A.chunk_channels(gc, self.n_layers, views=True) if gc is not None else None
         output = None
         # fused form (default; SVC_WN_FUSED=0 = one autograd op per reference op): the conditioning add in in_layer's epilogue,
         # res / skip / mask in res_skip_layer's (the inference path's epilogues, with their adjoints in svc_autograd)
@@ -92,13 +95,13 @@ class WN(nn.Module):
         for i in range(self.n_layers):
             last = i == self.n_layers - 1
             if fused:
-                cond = gc[:, i * 2 * H:(i + 1) * 2 * H] if gc is not None else None
+                cond = gcs[i] if gcs is not None else None
                 acts = A.gate(self.in_layers[i].forward_train(x, cond=cond))
                 x, output = self.res_skip_layers[i].forward_train_res_skip(acts, x, output, x_mask, last)
                 continue
             x_in = self.in_layers[i].forward_train(x)
-            if gc is not None:
-                x_in = A.add_bcast(x_in, gc[:, i * 2 * H:(i + 1) * 2 * H])
+            if gcs is not None:
+                x_in = A.add_bcast(x_in, gcs[i])
             acts = A.gate(x_in)
             rs = self.res_skip_layers[i].forward_train(acts)
             if not last:
@@ -197,7 +200,7 @@ class ResidualCouplingLayer(nn.Module):
         """Reference modules/modules.py:288-307 with mean_only=True (logs == 0).  `dropout_u`: injected dropout draws for
         a transformer coupling network (WN has no dropout on this path)."""
         half = self.half_channels
-        x0, x1 = x[:, :half], x[:, half:]
+        x0, x1 = A.chunk_channels(x, 2, views=True)         # (one gradient buffer in the backward instead of two zero-filled slices + an add)
         h = A.mul_bcast(self.pre.forward_train(x0), x_mask)
         if dropout_u is not None:
             h = self.enc.forward_train(h, x_mask, g=g, dropout_u=dropout_u)

@@ -405,10 +405,12 @@ class _ChunkC(Function):
     slice backward would zero-fill and add a full-size tensor per chunk)."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, views):
         B, Ct, T = x.shape
         C = Ct // n
         ctx.cfg = (n, C)
+        if views:       # channel-slice VIEWS (what a Python slice gives; consumers take strided [B, C, T] operands): no launch
+            return tuple(x.narrow(1, i * C, C) for i in range(n))
         outs = tuple(S.copy_bct(x[:, i * C:(i + 1) * C]) for i in range(n))
         return outs
 
@@ -417,17 +419,21 @@ class _ChunkC(Function):
         n, C = ctx.cfg
         g0 = next(g for g in gs if g is not None)
         B, _, T = g0.shape
+        if all(g is not None and g.is_contiguous() for g in gs) and (n > 2 or g0.numel() < (1 << 16)):
+            return torch.cat(gs, 1), None, None       # many small pieces (per-layer conditioning rows): ONE launch
         dx = torch.empty((B, n * C, T), device=g0.device, dtype=torch.float32)
         for i, g in enumerate(gs):
             if g is None:
                 dx[:, i * C:(i + 1) * C].zero_()
             else:
                 S.copy_bct(g, out=dx[:, i * C:(i + 1) * C])
-        return dx, None
+        return dx, None, None
 
 
-def chunk_channels(x, n):
-    return _ChunkC.apply(x, n)
+def chunk_channels(x, n, views=False):
+    """x [B, n*C, T] -> n [B, C, T] chunks whose gradients meet in ONE buffer in the backward (torch's own slice backward zero-fills
+    and accumulates a full-size tensor per chunk).  views=True: the chunks are channel-slice views of x (no forward launch)."""
+    return _ChunkC.apply(x, n, views)
 
 
 # ---- packed batches: [B, C, T] items laid end to end in ONE row of length Lp, `gap` zero columns after each item ----------
