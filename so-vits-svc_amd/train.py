@@ -327,7 +327,7 @@ class TrainStep:
         self._since_check = 0
         bad, last, n = self._guard.tolist()
         if bad:
-            self._guard.zero_()
+            self._guard[:2].zero_()          # (the launch counter keeps running)
             raise FloatingPointError(f"training diverged: {bad} non-finite loss value(s), last in iteration {last} of {n} "
                                      f"(counted on the device by svc_nonfinite_guard_f32; SVC_TRAIN_FINITE_EVERY={self.finite_every})")
 
