@@ -541,6 +541,16 @@ int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int 
                              const float* drop_u, float p_drop, float* Pd, void* stream);
 int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop,
                              const float* mask, int mask_mode, void* stream);
+/* The same with the keep decisions made from a counter-based uniform draw u(seed[0], site, element) instead of a tensor of draws
+ * (production path: no [B,H,T,T] torch.rand tensor per attention layer; the forward and the backward of a site pass the same seed
+ * pointer and site number).  seed: int64[1] in device memory — a replayed hipGraph sees the value its own iteration left there.
+ * svc_dropout_rng_f32: y = x * (u >= p ? 1/(1-p) : 0): nn.Dropout(p) on the activation sites (modules/attentions.py:51,100,344),
+ * forward on x and backward on dy. */
+int svc_attn_softmax_fwd_rng_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
+                                 const long long* seed, int site, float p_drop, float* Pd, void* stream);
+int svc_attn_softmax_bwd_rng_f32(const float* P, float* dP, int B, int H, int T, const long long* seed, int site, float p_drop,
+                                 const float* mask, int mask_mode, void* stream);
+int svc_dropout_rng_f32(const float* x, float* y, long long n, const long long* seed, int site, float p, void* stream);
 /* Leaky ReLU over rows with a padded tail (DiscriminatorP's feature maps, models.py:190-193: F.leaky_relu(l(x), 0.1) on the
  * [B,C,H,p] maps, kept here as [rows, P] with P % 4 == 0 and the first L columns meaningful): y = lrelu(x) for t < L, 0 for
  * L <= t < P; bwd: dx = dy * (y > 0 ? 1 : slope) for t < L, 0 on the tail.  slope = 1: tail mask only. */

@@ -112,6 +112,27 @@ __global__ void ln_bwd_param_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// ---- counter-based uniform draw for the dropout sites (nn.Dropout: modules/attentions.py:232,51,100,344): u in [0, 1) as a
+// function of (seed, site, element) — splitmix64's finaliser over seed + site * golden + element — so the forward and the
+// backward kernel of a site make the SAME keep decision without a [B,H,T,T] tensor of draws between them (900 MB written and
+// twice read per training iteration as torch.rand tensors).  `seed` lives in device memory: a replayed hipGraph sees the value
+// the iteration's own increment left there.
+__device__ __forceinline__ float svc_hash_uniform(unsigned long long seed, unsigned site, unsigned long long idx) {
+  unsigned long long z = seed + (unsigned long long)(site + 1u) * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);      // top 24 bits -> [0, 1)
+}
+
+__global__ __launch_bounds__(256) void dropout_rng_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                          const long long* __restrict__ seed, unsigned site, float p) {
+  const unsigned long long sd = (unsigned long long)seed[0];
+  const float ks = 1.f / (1.f - p);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = svc_hash_uniform(sd, site, (unsigned long long)i) >= p ? x[i] * ks : 0.f;
+}
+
 // ---- attention score post-processing: S[bh,i,:] += band(rel[bh,i,:]); mask; softmax over j --------------------------
 // mask_mode 1: key/query padding mask m[b,i]*m[b,j] == 0 -> -1e4 (attentions.Encoder :96); 2: causal j > i -> -1e4
 // (attentions.FFT :52 via commons.subsequent_mask).  One wave per row.
@@ -122,7 +143,8 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
                                                                const float* __restrict__ mask, int H, int T, int window,
                                                                int mask_mode, long long n_rows,
                                                                const float* __restrict__ drop_u, float p_drop,
-                                                               float* __restrict__ Pd) {
+                                                               float* __restrict__ Pd, const long long* __restrict__ seed,
+                                                               unsigned site) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -162,6 +184,15 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
       sp[j] = pv;
       dp[j] = up[j] >= p_drop ? pv * ks : 0.f;
     }
+  } else if (seed) {
+    float* dp = Pd + row * T;
+    const float ks = 1.f / (1.f - p_drop);
+    const unsigned long long sd = (unsigned long long)seed[0], base = (unsigned long long)row * T;
+    for (int j = lane; j < T; j += 64) {
+      const float pv = sp[j] * inv;
+      sp[j] = pv;
+      dp[j] = svc_hash_uniform(sd, site, base + j) >= p_drop ? pv * ks : 0.f;
+    }
   } else {
     for (int j = lane; j < T; j += 64) sp[j] *= inv;
   }
@@ -173,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int T,
                                                                long long n_rows, const float* __restrict__ drop_u,
                                                                float p_drop, const float* __restrict__ mask, int H,
-                                                               int mask_mode) {
+                                                               int mask_mode, const long long* __restrict__ seed, unsigned site) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -188,6 +219,14 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     const float ks = 1.f / (1.f - p_drop);
     for (int j = lane; j < T; j += 64) {
       const float g = up[j] >= p_drop ? dp[j] * ks : 0.f;
+      dp[j] = g;
+      dot += pp[j] * g;
+    }
+  } else if (seed) {
+    const float ks = 1.f / (1.f - p_drop);
+    const unsigned long long sd = (unsigned long long)seed[0], base = (unsigned long long)row * T;
+    for (int j = lane; j < T; j += 64) {
+      const float g = svc_hash_uniform(sd, site, base + j) >= p_drop ? dp[j] * ks : 0.f;
       dp[j] = g;
       dot += pp[j] * g;
     }
@@ -327,8 +366,18 @@ int svc_attn_softmax_fwd_f32(float* S, const float* rel, const float* mask, int 
   SVC_REQUIRE(drop_u == nullptr || (Pd != nullptr && p_drop >= 0.f && p_drop < 1.f), "attn_softmax_fwd: dropout needs Pd and 0 <= p < 1");
   const long long rows = (long long)B * H * T;
   hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rel, mask,
-                     H, T, window, mask_mode, rows, drop_u, p_drop, Pd);
+                     H, T, window, mask_mode, rows, drop_u, p_drop, Pd, (const long long*)nullptr, 0u);
   return svc::check_launch("attn_softmax_fwd");
+}
+
+int svc_attn_softmax_fwd_rng_f32(float* S, const float* rel, const float* mask, int B, int H, int T, int window, int mask_mode,
+                                 const long long* seed, int site, float p_drop, float* Pd, void* stream) {
+  SVC_REQUIRE(S && seed && Pd && B > 0 && H > 0 && T > 0 && window >= 0 && site >= 0, "attn_softmax_fwd_rng: bad args");
+  SVC_REQUIRE(p_drop > 0.f && p_drop < 1.f, "attn_softmax_fwd_rng: 0 < p < 1");
+  const long long rows = (long long)B * H * T;
+  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rel, mask,
+                     H, T, window, mask_mode, rows, (const float*)nullptr, p_drop, Pd, seed, (unsigned)site);
+  return svc::check_launch("attn_softmax_fwd_rng");
 }
 
 int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, const float* drop_u, float p_drop,
@@ -336,8 +385,26 @@ int svc_attn_softmax_bwd_f32(const float* P, float* dP, int B, int H, int T, con
   SVC_REQUIRE(P && dP && B > 0 && H > 0 && T > 0, "attn_softmax_bwd: bad args");
   const long long rows = (long long)B * H * T;
   hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows,
-                     drop_u, p_drop, mask, H, mask_mode);
+                     drop_u, p_drop, mask, H, mask_mode, (const long long*)nullptr, 0u);
   return svc::check_launch("attn_softmax_bwd");
+}
+
+int svc_attn_softmax_bwd_rng_f32(const float* P, float* dP, int B, int H, int T, const long long* seed, int site, float p_drop,
+                                 const float* mask, int mask_mode, void* stream) {
+  SVC_REQUIRE(P && dP && seed && B > 0 && H > 0 && T > 0 && site >= 0 && p_drop > 0.f && p_drop < 1.f, "attn_softmax_bwd_rng: bad args");
+  const long long rows = (long long)B * H * T;
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, T, rows,
+                     (const float*)nullptr, p_drop, mask, H, mask_mode, seed, (unsigned)site);
+  return svc::check_launch("attn_softmax_bwd_rng");
+}
+
+/* y = x * (u >= p ? 1 / (1 - p) : 0) with u = the counter-based draw of (seed, site, element): nn.Dropout(p) forward on x, and its
+ * backward on dy (same seed and site). */
+int svc_dropout_rng_f32(const float* x, float* y, long long n, const long long* seed, int site, float p, void* stream) {
+  SVC_REQUIRE(x && y && seed && n > 0 && site >= 0 && p > 0.f && p < 1.f, "dropout_rng: bad args");
+  hipLaunchKernelGGL(dropout_rng_kernel, dim3((unsigned)std::min<long long>((n + 1023) / 1024, 65535)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, n, seed, (unsigned)site, p);
+  return svc::check_launch("dropout_rng");
 }
 
 int svc_band_gather_f32(const float* M, float* band, long long n_rows, int T, int window, void* stream) {

@@ -226,9 +226,13 @@ class DropoutDraws:
     activation sites): the only torch call is the draw itself (torch.rand on the device, like every other random tensor
     on the path).  `injected`: a list of draws consumed from the front in the reference's call order (parity tests)."""
 
+    _SEED = {}          # device -> int64[1] running counter (advanced once per DropoutDraws that draws from it)
+    HASHED = __import__("os").environ.get("SVC_DROPOUT_HASH", "1") != "0"     # 0: torch.rand tensors (round-4 form, A/B switch)
+
     def __init__(self, p, training, injected=None):
         self.p = float(p) if training else 0.0
         self.injected = injected
+        self.seed, self.site = None, 0
 
     @property
     def active(self):
@@ -240,7 +244,21 @@ class DropoutDraws:
             if tuple(t.shape) != tuple(shape):
                 raise S.SvcError(f"injected dropout draw {tuple(t.shape)} does not match the site's shape {tuple(shape)}")
             return t.to(device=device, dtype=torch.float32).contiguous()
-        return torch.rand(shape, device=device)
+        if not self.HASHED:
+            return torch.rand(shape, device=device)
+        # production: no tensor of draws — the consuming kernels evaluate u(seed, site, element) themselves (900 MB of torch.rand
+        # output per iteration otherwise, 48 launches).  This stack's seed = a snapshot of the device counter, advanced by this
+        # stack only: it stays put between the sites' forward and backward kernels, and a replayed hipGraph re-executes the
+        # advance + snapshot, so every replay drops different elements.  (torch.manual_seed does not reach it: seeded runs that
+        # must reproduce torch's draws inject them or set SVC_DROPOUT_HASH=0.)
+        if self.seed is None:
+            ctr = DropoutDraws._SEED.get(device)
+            if ctr is None:
+                ctr = DropoutDraws._SEED[device] = torch.randint(1 << 40, (1,), dtype=torch.int64).to(device)
+            ctr.add_(0x632BE59BD9B4E019 % (1 << 62))
+            self.seed = ctr.clone()
+        self.site += 1
+        return S.HashDraw(self.seed, self.site)
 
     def __call__(self, x):
         if not self.active:

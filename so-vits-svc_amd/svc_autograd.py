@@ -789,7 +789,8 @@ class _Attention(Function):
             ek = _c(emb_k.view(-1, dk))
             ev = _c(emb_v.view(-1, dk))
             rel = S.gemm(q, ek, qs, (0, 1, dk), BH, T, 2 * window + 1, dk, alpha=sc)
-        if drop_u is not None:
+        hashed = isinstance(drop_u, S.HashDraw)      # keep decisions made inside the kernels from (seed, site, element)
+        if drop_u is not None and not hashed:
             drop_u = _c(drop_u)
             if drop_u.numel() != P.numel():
                 raise S.SvcError(f"attention dropout draws {tuple(drop_u.shape)} do not match [B,H,T,T] = {(B, H, T, T)}")
@@ -801,14 +802,17 @@ class _Attention(Function):
             pband = S.band_gather(Pd, BH * T, T, window)
             S.gemm(ev, pband, (0, 1, dk), (T * (2 * window + 1), 1, 2 * window + 1), BH, dk, T, 2 * window + 1, out=out,
                    c_strides=(dk * T, T, 1), beta=1.0)
-        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v, drop_u, Pd if drop_u is not None else None, mask)
+        ctx.save_for_backward(q, k, v, P, pband, emb_k, emb_v, None if hashed else drop_u, Pd if drop_u is not None else None, mask)
         ctx.cfg = (B, H, dk, T, window, p_drop, mask_mode)
+        ctx.hash_draw = drop_u if hashed else None
         return out
 
     @staticmethod
     def backward(ctx, dO):
         q, k, v, P, pband, emb_k, emb_v, drop_u, Pd, mask = ctx.saved_tensors
         B, H, dk, T, window, p_drop, mask_mode = ctx.cfg
+        if ctx.hash_draw is not None:
+            drop_u = ctx.hash_draw
         if Pd is None:
             Pd = P
         BH = B * H
@@ -860,7 +864,22 @@ class _Dropout(Function):
         return S.ew(S.EW_DROPOUT, dy, u, alpha=ctx.p), None, None
 
 
+class _DropoutRng(Function):
+    """nn.Dropout(p) with the keep decisions of a svc_hip.HashDraw: one svc_dropout_rng_f32 launch each way, no tensor of draws."""
+
+    @staticmethod
+    def forward(ctx, x, draw, p):
+        ctx.draw, ctx.p = draw, p
+        return S.dropout_rng(x, draw, p)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return S.dropout_rng(_c(dy), ctx.draw, ctx.p), None, None
+
+
 def dropout(x, u, p):
+    if isinstance(u, S.HashDraw):
+        return _DropoutRng.apply(x, u, float(p))
     return _Dropout.apply(x, _c(u), float(p))
 
 

@@ -1406,7 +1406,7 @@ def rfft_mag_bwd(z, mag, dmag, n):
 
 TRAIN_EXPORTS2 = [
     "svc_layernorm_fwd_f32", "svc_layernorm_bwd_f32", "svc_attn_softmax_fwd_f32", "svc_attn_softmax_bwd_f32",
-    "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",
+    "svc_attn_softmax_fwd_rng_f32", "svc_attn_softmax_bwd_rng_f32", "svc_dropout_rng_f32", "svc_band_gather_f32", "svc_band_scatter_add_f32", "svc_embed_fwd_f32", "svc_embed_bwd_f32", "svc_reparam_bwd_f32",
     "svc_nsf_source_train_f32", "svc_nsf_linear_fwd_f32", "svc_nsf_linear_bwd_f32", "svc_kl_fwd_f64", "svc_kl_bwd_f32",
     "svc_stft_frame_f32", "svc_stft_frame_bwd_f32", "svc_dft_basis_f32", "svc_cmag_f32", "svc_cmag_bwd_f32",
     "svc_lrelu_tail_fwd_f32", "svc_lrelu_tail_bwd_f32", "svc_spectral_norm_fwd_f32", "svc_spectral_norm_bwd_f32",
@@ -1424,6 +1424,9 @@ def t2lib():
         L.svc_layernorm_bwd_f32.argtypes = [_f32p] * 8 + [i, i, i, vp]
         L.svc_attn_softmax_fwd_f32.argtypes = [_f32p] * 3 + [i] * 5 + [_f32p, C.c_float, _f32p, vp]
         L.svc_attn_softmax_bwd_f32.argtypes = [_f32p] * 2 + [i] * 3 + [_f32p, C.c_float, _f32p, i, vp]
+        L.svc_attn_softmax_fwd_rng_f32.argtypes = [_f32p] * 3 + [i] * 5 + [vp, i, C.c_float, _f32p, vp]
+        L.svc_attn_softmax_bwd_rng_f32.argtypes = [_f32p] * 2 + [i] * 3 + [vp, i, C.c_float, _f32p, i, vp]
+        L.svc_dropout_rng_f32.argtypes = [_f32p, _f32p, ll, vp, i, C.c_float, vp]
         L.svc_band_gather_f32.argtypes = [_f32p, _f32p, ll, i, i, vp]
         L.svc_lrelu_tail_fwd_f32.argtypes = [_f32p, _f32p, ll, i, i, f, vp]
         L.svc_spectral_norm_fwd_f32.argtypes = [_f32p] * 6 + [i, i, i, f, vp]
@@ -1470,9 +1473,38 @@ def layernorm_bwd(x, gamma, dy, mean, rstd):
     return dx, dg, db
 
 
+class HashDraw:
+    """The uniform draws of one dropout site as a counter-based function u(seed, site, element) evaluated INSIDE the consuming
+    kernels (svc_attn_softmax_{fwd,bwd}_rng_f32, svc_dropout_rng_f32) instead of a torch.rand tensor: `seed` is an int64[1] device
+    tensor that stays untouched between the site's forward and backward, `site` numbers the site within its encoder call."""
+
+    def __init__(self, seed, site):
+        if seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:
+            raise SvcError("HashDraw: seed must be an int64[1] device tensor")
+        self.seed, self.site = seed, int(site)
+
+    def ptr(self):
+        return C.c_void_p(self.seed.data_ptr())
+
+
+def dropout_rng(x, draw, p, out=None):
+    """y = x * keep / (1 - p) with the keep decisions of `draw` (HashDraw): forward on x, backward on dy."""
+    require_gpu(x, out)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(t2lib().svc_dropout_rng_f32(ptr(x), ptr(out), x.numel(), draw.ptr(), draw.site, float(p), stream_ptr()), "dropout_rng")
+    return out
+
+
 def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode, drop_u=None, p_drop=0.0):
-    """In place scores -> probabilities; with drop_u (uniform draws, same shape) also returns the dropped
+    """In place scores -> probabilities; with drop_u (uniform draws, same shape, or a HashDraw) also returns the dropped
     probabilities P * (u >= p ? 1/(1-p) : 0) (modules/attentions.py:232), else returns S_ itself."""
+    if isinstance(drop_u, HashDraw):
+        Pd = torch.empty_like(S_)
+        check(t2lib().svc_attn_softmax_fwd_rng_f32(ptr(S_), ptr(rel), ptr(mask), B, H, T, window, mask_mode, drop_u.ptr(), drop_u.site,
+                                                   float(p_drop), ptr(Pd), stream_ptr()), "attn_softmax_fwd_rng")
+        return Pd
     require_gpu(drop_u)
     Pd = torch.empty_like(S_) if drop_u is not None else None
     check(t2lib().svc_attn_softmax_fwd_f32(ptr(S_), ptr(rel), ptr(mask), B, H, T, window, mask_mode, ptr(drop_u),
@@ -1481,6 +1513,10 @@ def attn_softmax_fwd(S_, rel, mask, B, H, T, window, mask_mode, drop_u=None, p_d
 
 
 def attn_softmax_bwd(P, dP, B, H, T, drop_u=None, p_drop=0.0, mask=None, mask_mode=0):
+    if isinstance(drop_u, HashDraw):
+        check(t2lib().svc_attn_softmax_bwd_rng_f32(ptr(P), ptr(dP), B, H, T, drop_u.ptr(), drop_u.site, float(p_drop), ptr(mask),
+                                                   mask_mode, stream_ptr()), "attn_softmax_bwd_rng")
+        return dP
     check(t2lib().svc_attn_softmax_bwd_f32(ptr(P), ptr(dP), B, H, T, ptr(drop_u), float(p_drop), ptr(mask), mask_mode,
                                            stream_ptr()), "attn_softmax_bwd")
     return dP

@@ -597,3 +597,57 @@ def test_gemm_attention_forms(dev, T, dk, BH):
     out.copy_(acc)
     S.gemm(qd, dSd, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1), alpha=0.25, beta=1.0)
     close(out, 0.25 * q @ dS + acc, "dK = q dS (+ accumulate)")
+
+
+def test_hashed_dropout_draws(dev):
+    """Production dropout (modules/attentions.py:232,51,100,344 = nn.Dropout): keep decisions from the counter-based draw
+    u(seed, site, element) inside the kernels (svc_dropout_rng_f32, svc_attn_softmax_{fwd,bwd}_rng_f32) instead of torch.rand
+    tensors.  Statistics of the draw, independence of sites / seeds, and — the property training needs — the attention's forward
+    and backward make the SAME decisions: the hashed path must equal the explicit-draw path fed with the mask the hash produces."""
+    import svc_autograd as A
+    import svc_hip as S
+    seed = torch.tensor([123456789], dtype=torch.int64, device=dev)
+    ones = torch.ones(1 << 22, device=dev)
+    p = 0.1
+    y1 = S.dropout_rng(ones, S.HashDraw(seed, 1), p)
+    keep = (y1 != 0).float()
+    assert abs(keep.mean().item() - (1 - p)) < 2e-3                                  # Bernoulli(0.9) over 4 M elements: sigma 1.5e-4
+    assert torch.allclose(y1[y1 != 0], torch.tensor(1 / (1 - p), device=dev))
+    assert torch.equal(y1, S.dropout_rng(ones, S.HashDraw(seed, 1), p))               # a function of (seed, site, element)
+    y2 = S.dropout_rng(ones, S.HashDraw(seed, 2), p)
+    agree = ((y1 != 0) == (y2 != 0)).float().mean().item()
+    assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 3e-3                               # another site: independent decisions
+    y3 = S.dropout_rng(ones, S.HashDraw(seed + 1, 1), p)
+    assert abs(((y1 != 0) == (y3 != 0)).float().mean().item() - 0.82) < 3e-3         # another seed likewise
+    # no structure along rows: every 768-element row keeps ~90 %
+    rows = keep[:768 * 4096].view(4096, 768).mean(1)
+    assert rows.min().item() > 0.84 and rows.max().item() < 0.96
+
+    # attention: hashed draw == explicit draws with the same keep mask, forward and every gradient
+    g = torch.Generator().manual_seed(3)
+    B, H, dk, T, w, pd = 2, 2, 32, 96, 4, 0.3
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    q0, k0, v0 = mk(B, H * dk, T), mk(B, H * dk, T), mk(B, H * dk, T)
+    ek0, ev0 = mk(1, 2 * w + 1, dk) * 0.2, mk(1, 2 * w + 1, dk) * 0.2
+    mask = (torch.arange(T, device=dev)[None, :] < torch.tensor([T, T - 17], device=dev)[:, None]).float()
+    draw = S.HashDraw(seed, 7)
+    kept = S.dropout_rng(torch.ones(B * H * T * T, device=dev), draw, pd) != 0
+    u_equiv = torch.where(kept, torch.ones((), device=dev), torch.zeros((), device=dev)).view(B, H, T, T)   # 1 >= p keeps, 0 < p drops
+    dO = mk(B, H * dk, T)
+
+    def run(drop_u):
+        leaves = [t.clone().requires_grad_(True) for t in (q0, k0, v0, ek0, ev0)]
+        out = A.attention(leaves[0], leaves[1], leaves[2], H, leaves[3], leaves[4], w, mask, 1, drop_u=drop_u, p_drop=pd)
+        out.backward(dO)
+        return out.detach(), [t.grad for t in leaves]
+    o_h, g_h = run(draw)
+    o_e, g_e = run(u_equiv)
+    assert torch.equal(o_h, o_e)
+    for a, b, name in zip(g_h, g_e, ("dq", "dk", "dv", "dEk", "dEv")):
+        tol = 0.0 if name in ("dq", "dk", "dv") else 1e-5 * max(1.0, b.abs().max().item())     # (the embeddings' thin-M products sum with atomics)
+        assert (a - b).abs().max().item() <= tol, name
+    # and the activation-site op, both directions
+    x = mk(3, 40, 50).requires_grad_(True)
+    yd = A.dropout(x, S.HashDraw(seed, 9), 0.25)
+    yd.backward(torch.ones_like(yd))
+    assert torch.equal(yd.detach() != 0, x.grad != 0) and torch.allclose(x.grad[x.grad != 0], torch.tensor(1 / 0.75, device=dev))
