@@ -336,6 +336,12 @@ typedef struct svc_conv1d_h_args {
 } svc_conv1d_h_args;
 int svc_pack_conv1d_h(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
 int svc_conv1d_h(const svc_conv1d_h_args* a, void* stream);
+/* One ResBlock1 pair of the 16-bit pipeline in ONE launch (vdecoder/hifigan/models.py:60-67):
+ * y = (beta*y_old + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x) / out_div, conv1 with dilation dil1, conv2 with dilation 1, both
+ * KS taps (3 | 7 | 11) and "same" padding; x / y blocked fp16 [B][C/8][T][8], w1 / w2 from svc_pack_conv1d_h (RP rows), C a multiple
+ * of 16 in 16..128.  The intermediate lives in LDS (fp16); x and y may not alias. */
+int svc_resblock_pair_h(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
+                        int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
 int svc_debug_set_conv_h(int cfg); /* tuning aid: 0 automatic tile choice, 1 no 64 x 128 tile, 2 four column tiles per wave where they fit */
 int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                  int B, int C, int T, void* stream);

@@ -47,6 +47,29 @@ for (C, L) in ((256, T0 * 8), (128, T0 * 64), (64, T0 * 128), (32, T0 * 256), (1
                     tot[c] += us * (3 if mode == "c2" else 1)
                     line += f"  cfg{c} {us:7.1f} us {fl / us / 1e6:6.1f} TF {by / us / 1e3:6.0f} GB/s"
                 print(line)
+# fused pair (svc_resblock_pair_h) against its two launches
+pair = {"two": 0.0, "one": 0.0}
+for (C, L) in ((128, T0 * 64), (64, T0 * 128), (32, T0 * 256), (16, T0 * 512)):
+    x = S.to_h(torch.randn(1, C, L, device=dev))
+    xt, y = torch.empty_like(x), torch.empty_like(x)
+    for k in (3, 7, 11):
+        for d in (1, 3, 5):
+            w1 = S.pack_conv1d_h(torch.randn(C, C, k, device=dev) / (C * k) ** 0.5)
+            w2 = S.pack_conv1d_h(torch.randn(C, C, k, device=dev) / (C * k) ** 0.5)
+            b = torch.randn(C, device=dev)
+            p1, p2 = (k * d - d) // 2, (k - 1) // 2
+
+            def two():
+                S.conv1d_h(x, w1, C, bias=b, dil=d, pad_left=p1, pre_slope=0.1, post_slope=0.1, out=xt)
+                S.conv1d_h(xt, w2, C, bias=b, pad_left=p2, res=x, out=y)
+            t2 = timeit(two)
+            t1 = timeit(lambda: S.resblock_pair_h(x, w1, b, w2, b, d, out=y))
+            pair["two"] += t2
+            pair["one"] += t1
+            fl = 4.0 * C * C * k * L
+            print(f"pair C={C:3d} L={L:6d} k={k:2d} d={d}: two launches {t2:7.1f} us   fused {t1:7.1f} us  {fl / t1 / 1e6:6.1f} TF  "
+                  f"{2.0 * C * L * 3 / t1 / 1e3:6.0f} GB/s")
+print("sum over one clip's pairs of the <= 128-channel stages (us):", {k: round(v, 1) for k, v in pair.items()})
 for (Cin, L, K, u) in ((256, T0 * 8, 16, 8), (128, T0 * 64, 4, 2), (64, T0 * 128, 4, 2), (32, T0 * 256, 4, 2)):
     x = S.to_h(torch.randn(1, Cin, L, device=dev))
     w = S.pack_conv1d_h(torch.randn(Cin, Cin // 2, K, device=dev) * 0.05, u=u)

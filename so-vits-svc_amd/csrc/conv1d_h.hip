@@ -238,6 +238,224 @@ int launch_h_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
   return launch_h<KS, 1, 2, 1, 4>(a, R, s);                                                           //  32 rows x 256 columns
 }
 
+// ---- fused ResBlock1 pair (vdecoder/hifigan/models.py:60-67): y = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x in ONE launch ----------
+// From 64 channels down the single convolutions above move their algorithmic bytes at 2-3.6 TB/s: the pair's intermediate
+// (written, then read back with its halo) is half of those bytes and half of the launches.  In fp16 both tiles fit LDS: a
+// workgroup owns all C rows of N2 = N1P - (KS - 1) output columns; it stages lrelu(x) for N1P + (KS - 1) d1 columns, runs conv1
+// over N1P intermediate columns (N1P = 128 or 256: whole MFMA column tiles; the KS - 1 extra ones are the second conv's halo,
+// 4-8 % recompute), writes lrelu(. + b1) as fp16 into the second LDS tile in the blocked layout (zero outside the sequence:
+// conv2's zero padding), runs conv2 from that tile, and finishes with the residual (raw x from global memory — its lines were
+// read by this workgroup microseconds ago), the MRF accumulate / divide and one 8-byte store per 4 channels.  Same MFMA loop,
+// weight ring and operand layouts as conv1d_h_kernel.  Built for C <= 128 (at 256 channels the 6 896-column stage would be 59
+// workgroups).
+struct PP {
+  const void* x;
+  const void* w1;
+  const void* w2;
+  const float* b1;
+  const float* b2;
+  void* y;
+  int B, C, T, d1, RP;
+  float slope, beta, out_div;
+};
+
+template <int KS, int MT, int NT, int CH>
+__device__ __forceinline__ void mma_steps_h(f32x16 (&acc)[MT][NT], const h8* __restrict__ wp, long long sstride, int S,
+                                            const h8* __restrict__ xw, int XW, int dil) {
+  // wp: this lane's first A fragment (+ step * sstride + mt * 64); xw: this lane's B base (+ 2 g XW + tap dil + nt * 32)
+  auto wload = [&](h8 (&af)[CH][MT], int s0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[j][mt] = wp[min(s0 + j, S - 1) * sstride + mt * 64];
+  };
+  auto chunk = [&](const h8 (&af)[CH][MT], int s0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int sidx = s0 + j;
+      if (sidx < S) {
+        const int g = sidx / KS, tap = sidx - g * KS;
+        const h8* xr = xw + 2 * g * XW + tap * dil;
+        h8 bq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[nt] = xr[nt * 32];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt], bq[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+  h8 a0[CH][MT], a1[CH][MT];
+  wload(a0, 0);
+  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
+    if (s0 + CH < S) wload(a1, s0 + CH);
+    chunk(a0, s0);
+    if (s0 + CH < S) {
+      if (s0 + 2 * CH < S) wload(a0, s0 + 2 * CH);
+      chunk(a1, s0 + CH);
+    }
+  }
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void respair_h_kernel(PP p) {
+  constexpr int N1P = 32 * NT * WN;            // intermediate columns computed per workgroup
+  constexpr int N2 = N1P - (KS - 1);           // output columns per workgroup
+  constexpr int H2 = (KS - 1) / 2;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int CB = p.C >> 3, G = p.C >> 4;
+  const int h1 = H2 * p.d1;
+  const int XW1 = N1P + 2 * h1, XW2 = N1P + (KS - 1);
+  h8* xs = reinterpret_cast<h8*>(smem_h);      // [CB][XW1]  lrelu(x), tile column tl <-> global t0 - H2 - h1 + tl
+  h8* ts = xs + CB * XW1;                      // [CB][XW2]  lrelu(c1 + b1), tile column j <-> global t0 - H2 + j
+  const int t0 = blockIdx.x * N2, b = blockIdx.y;
+  const h8* xg = reinterpret_cast<const h8*>(p.x) + (long long)b * CB * p.T;
+
+  // ---- stage lrelu(x); zero the halo tail of the intermediate tile
+  {
+    const _Float16 ps = (_Float16)p.slope;
+    const int total = CB * XW1;
+    constexpr int LD = 8;
+    for (int base = tid; base < total; base += 256 * LD) {
+      h8 v[LD];
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const int idx = base + j * 256;
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[j] = z;
+        if (idx < total) {
+          const int cb = idx / XW1, tl = idx - cb * XW1;
+          const int tin = t0 - H2 - h1 + tl;
+          if (tin >= 0 && tin < p.T) v[j] = xg[(long long)cb * p.T + tin];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const int idx = base + j * 256;
+        if (idx < total) xs[idx] = lrelu8(v[j], ps);
+      }
+    }
+    for (int idx = tid; idx < CB * (KS - 1); idx += 256) {
+      const int cb = idx / (KS - 1), e = idx - cb * (KS - 1);
+      h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      ts[cb * XW2 + N1P + e] = z;
+    }
+  }
+  __syncthreads();
+
+  const long long rowoff = ((long long)(wm * MT * 32 + li)) * 2 + kh;
+  const long long sstride = (long long)p.RP * 2;
+  const int col = wn * NT * 32 + li;
+  // ---- conv1 over the N1P intermediate columns -> ts (fp16, blocked), zero outside [0, T)
+  {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    mma_steps_h<KS, MT, NT, 4>(acc, reinterpret_cast<const h8*>(p.w1) + rowoff, sstride, G * KS, xs + kh * XW1 + col, XW1, p.d1);
+    _Float16* th = reinterpret_cast<_Float16*>(ts);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = col + nt * 32;
+        const int tg = t0 - H2 + j;
+        const bool inside = tg >= 0 && tg < p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row8 = (wm * MT + mt) * 32 + 8 * i;
+          if (row8 >= p.C) continue;
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = svc_lrelu(acc[mt][nt][4 * i + e] + p.b1[row8 + 4 * kh + e], p.slope);
+            o[e] = (_Float16)(inside ? v : 0.f);
+          }
+          *reinterpret_cast<h4*>(th + ((long long)((row8 >> 3) * XW2 + j)) * 8 + 4 * kh) = o;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- conv2 from the intermediate tile, residual, accumulate, store
+  {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    mma_steps_h<KS, MT, NT, 4>(acc, reinterpret_cast<const h8*>(p.w2) + rowoff, sstride, G * KS, ts + kh * XW2 + col, XW2, 1);
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y) + (long long)b * p.C * p.T;
+    const _Float16* xb = reinterpret_cast<const _Float16*>(p.x) + (long long)b * p.C * p.T;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = col + nt * 32;
+        const int t = t0 + j;
+        if (j >= N2 || t >= p.T) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row8 = (wm * MT + mt) * 32 + 8 * i;
+          if (row8 >= p.C) continue;
+          const long long off = ((long long)(row8 >> 3) * p.T + t) * 8 + 4 * kh;
+          const h4 rv = *reinterpret_cast<const h4*>(xb + off);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * i + e] + p.b2[row8 + 4 * kh + e] + (float)rv[e];
+          if (p.beta != 0.f) {
+            const h4 ov = *reinterpret_cast<const h4*>(yb + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(p.beta, (float)ov[e], v[e]);
+          }
+          if (p.out_div != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] /= p.out_div;
+          }
+          h4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+          *reinterpret_cast<h4*>(yb + off) = o;
+        }
+      }
+  }
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+int launch_respair(const PP& p, hipStream_t s) {
+  constexpr int N1P = 32 * NT * WN, N2 = N1P - (KS - 1);
+  const int h1 = (KS - 1) / 2 * p.d1;
+  const size_t lds = (size_t)(p.C / 8) * ((N1P + 2 * h1) + (N1P + KS - 1)) * 16;
+  SVC_REQUIRE(lds <= 160 * 1024, "resblock_pair_h: tiles of %zu bytes do not fit LDS", lds);
+  auto kern = respair_h_kernel<KS, MT, NT, WM, WN>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(svc::cdiv(p.T, N2), p.B), dim3(256), lds, s, p);
+  return svc::check_launch("resblock_pair_h");
+}
+
+template <int KS>
+int launch_respair_ks(const PP& p, hipStream_t s) {
+  if (p.C > 64) return launch_respair<KS, 2, 2, 2, 2>(p, s);    // 128 rows, 128 intermediate columns
+  if (p.C > 32) return launch_respair<KS, 2, 1, 1, 4>(p, s);    //  64 rows, 128
+  return launch_respair<KS, 1, 2, 1, 4>(p, s);                  //  32 rows, 256
+}
+
 // ---- weight pack: dense fp32 (weight norm already folded) -> [Cin/16][tap][RP][16] fp16.
 // conv (u == 1): w [Cout][Cin][KS], row = co, tap = k.   transposed (u > 1): w [Cin][Cout][K], row = ph * Cout + co, tap mr of
 // M = ceil(K / u): k = ph + (M - 1 - mr) * u (taps time-reversed: each phase is a plain correlation, as pack_convt1d_kernel).
@@ -362,6 +580,32 @@ extern "C" int svc_conv1d_h(const svc_conv1d_h_args* ap, void* stream) {
     case 7: return launch_h_ks<7>(a, R, s);
     case 11: return launch_h_ks<11>(a, R, s);
     default: SVC_REQUIRE(false, "conv1d_h: tap count %d not built (1, 2, 3, 7, 11)", a.KS);
+  }
+  return SVC_OK;
+}
+
+extern "C" int svc_resblock_pair_h(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B,
+                                  int C, int T, int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream) {
+  SVC_REQUIRE(x && w1 && w2 && b1 && b2 && y, "resblock_pair_h: null tensor");
+  SVC_REQUIRE(B > 0 && T > 0 && C >= 16 && C <= 128 && (C % 16) == 0, "resblock_pair_h: C must be a multiple of 16 in 16..128 (got %d)", C);
+  SVC_REQUIRE(dil1 >= 1 && (RP % 128) == 0 && RP >= C, "resblock_pair_h: bad dil1 / RP");
+  SVC_REQUIRE(slope > 0.f && slope <= 1.f, "resblock_pair_h: leaky-ReLU slope in (0, 1]");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
+                reinterpret_cast<uintptr_t>(y)) & 15) == 0, "resblock_pair_h: tensors must be 16-byte aligned");
+  PP p;
+  p.x = x; p.w1 = w1; p.w2 = w2; p.b1 = b1; p.b2 = b2; p.y = y;
+  p.B = B; p.C = C; p.T = T; p.d1 = dil1; p.RP = RP;
+  p.slope = slope; p.beta = beta; p.out_div = out_div;
+  hipStream_t s = (hipStream_t)stream;
+  char pname[96];
+  if (svc::prof_on() && svc::prof_shapes()) snprintf(pname, sizeof(pname), "resblock_pair_h[B%d,C%d,K%d,d%d,T%d]", B, C, KS, dil1, T);
+  else snprintf(pname, sizeof(pname), "resblock_pair_h");
+  svc::ProfScope prof(s, pname, 4.0 * B * (double)C * C * KS * T, 2.0 * B * (double)C * T * 3);
+  switch (KS) {
+    case 3: return launch_respair_ks<3>(p, s);
+    case 7: return launch_respair_ks<7>(p, s);
+    case 11: return launch_respair_ks<11>(p, s);
+    default: SVC_REQUIRE(false, "resblock_pair_h: tap count %d not built (3, 7, 11)", KS);
   }
   return SVC_OK;
 }

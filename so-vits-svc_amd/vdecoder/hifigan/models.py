@@ -31,6 +31,7 @@ FUSED_TRAIN = __import__("os").environ.get("SVC_FUSED_TRAIN", "1") != "0"
 _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/B switch of the fused second leaky_relu
 _MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
+_FUSE_PAIR_H = __import__("os").environ.get("SVC_HALF_FUSE_PAIR", "1") != "0"  # A/B switch of svc_resblock_pair_h (16-bit pipeline)
 # the chains' same-step convs in one launch (svc_conv1d_multi_f32): 0 never (default), 1 every stage, 2 only stages whose single
 # launches cannot fill the chip (fewer workgroups than CUs: the 256-channel stage, 216).  Measured on one box, 10 s clip
 # (profiles/r05b_infer_merge{0,1}.json, r05d_infer_merge_modes_realtime.txt): launches back to back on ONE stream the merged form
@@ -109,6 +110,17 @@ class ResBlock1(nn.Module):
         n = len(self.convs1)
         cur = xh
         xt, ping, pong = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(3)]
+        if _FUSE_PAIR_H and xh.shape[1] * 8 <= S.RESBLOCK_PAIR_H_MAX_C and self.convs1[0].kernel_size in (3, 7, 11):
+            # up to 128 channels: one launch per pair, the intermediate (and its halo) never leaves LDS (svc_resblock_pair_h)
+            for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+                lastp = j == n - 1
+                dst = (out if out is not None else (ping if cur is not ping else pong)) if lastp else (ping if cur is not ping else pong)
+                if lastp and before_last is not None:
+                    before_last()
+                S.resblock_pair_h(cur, c1.packed_h(), c1.bias, c2.packed_h(), c2.bias, c1.dilation, slope=LRELU_SLOPE, out=dst,
+                                  beta=beta if lastp else 0.0, out_div=out_div if lastp else 1.0)
+                cur = dst
+            return cur
         for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             # the second leaky_relu (:64) once, in the epilogue of the conv that produces xt (no other reader)
             c1.run_h(cur, pre_slope=LRELU_SLOPE, post_slope=LRELU_SLOPE, out=xt)

@@ -81,6 +81,40 @@ def test_conv1d_h_vs_torch(dev, B, Cin, Cout, T, KS, dil):
         assert _rel(S.from_h(out).cpu(), ref3) < 1e-3, "residual + accumulate"
 
 
+@pytest.mark.parametrize("B,C,T,KS,d1", [(1, 128, 1000, 11, 5), (2, 64, 515, 7, 3), (1, 32, 2100, 3, 1), (1, 16, 4099, 11, 3),
+                                         (1, 128, 55168, 7, 1), (1, 16, 37, 7, 5), (2, 96, 300, 3, 5), (1, 48, 129, 11, 1)])
+def test_resblock_pair_h_vs_two_launches_and_torch(dev, B, C, T, KS, d1):
+    """svc_resblock_pair_h (one launch, intermediate in LDS) against the two svc_conv1d_h launches it replaces — the same fp16
+    roundings in the same places (the intermediate is rounded to fp16 either way), so the two agree to accumulation order — and
+    against torch's fp32 pair on the fp16-rounded operands; with the MRF accumulate / divide epilogue; tile borders, sequence
+    ends shorter than a halo, and channel counts that leave row tiles partly empty."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(C + T + KS)
+    x = _h(torch.randn(B, C, T, generator=g))
+    w1 = _h(torch.randn(C, C, KS, generator=g) / (C * KS) ** 0.5)
+    w2 = _h(torch.randn(C, C, KS, generator=g) / (C * KS) ** 0.5)
+    b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    old = _h(torch.randn(B, C, T, generator=g))
+    xh = S.to_h(x.to(dev))
+    w1p, w2p = S.pack_conv1d_h(w1.to(dev)), S.pack_conv1d_h(w2.to(dev))
+    p1, p2 = (KS - 1) * d1 // 2, (KS - 1) // 2
+    # two launches
+    xt = S.conv1d_h(xh, w1p, C, bias=b1.to(dev), dil=d1, pad_left=p1, pre_slope=0.1, post_slope=0.1)
+    two = S.to_h(old.to(dev))
+    S.conv1d_h(xt, w2p, C, bias=b2.to(dev), pad_left=p2, res=xh, out=two, beta=1.0, out_div=3.0)
+    # one launch
+    one = S.to_h(old.to(dev))
+    S.resblock_pair_h(xh, w1p, b1.to(dev), w2p, b2.to(dev), d1, out=one, beta=1.0, out_div=3.0)
+    a, b_ = S.from_h(one).cpu(), S.from_h(two).cpu()
+    assert _rel(a, b_) < 1.5e-3, "fused vs two launches"          # (an fp16 ulp of the intermediate may round the other way)
+    xa = _h(torch.where(x > 0, x, _h(x * _h(torch.tensor(0.1)))))
+    mid = _h(F.leaky_relu(F.conv1d(xa, w1, b1, dilation=d1, padding=p1), 0.1))
+    ref = (old + F.conv1d(mid, w2, b2, padding=p2) + x) / 3
+    assert _rel(a, ref) < 2e-3, "fused vs torch"
+    plain = S.from_h(S.resblock_pair_h(xh, w1p, b1.to(dev), w2p, b2.to(dev), d1)).cpu()
+    assert _rel(plain, F.conv1d(mid, w2, b2, padding=p2) + x) < 2e-3
+
+
 @pytest.mark.parametrize("B,Cin,L,K,u", [(1, 256, 300, 16, 8), (2, 128, 515, 4, 2), (1, 64, 1000, 4, 2), (1, 32, 2077, 4, 2),
                                          (1, 256, 6896, 16, 8), (1, 32, 97, 8, 4)])
 def test_conv_transpose1d_h_vs_torch(dev, B, Cin, L, K, u):
