@@ -515,6 +515,34 @@ def main():
         dt = (time.perf_counter() - t1) / ns
         steady = dict(steps=ns, ms_per_step=round(1e3 * dt, 4), samples_per_s=samples_per_step / dt)
 
+    # ---- N clips in flight (beside `value`, never as it): N independent B = 1 clips as parallel branches of ONE hipGraph
+    # (SynthesizerTrn.infer_many) — the throughput a chunk stream / request queue sees; a clip's latency is the headline's ----
+    inflight = None
+    if rank == 0 and world == 1 and not args.no_steady and not args.no_graph:
+        inflight = dict(note="N independent B = 1 clips (own inputs / noise / outputs) replayed as parallel branches of one hipGraph "
+                             "(SynthesizerTrn.infer_many): throughput of a chunk stream or a request queue — one clip alone leaves most "
+                             "CUs idle through its encoder + flow section; every clip bit-identical to its single replay; per-clip "
+                             "LATENCY is the headline's ms_per_step")
+        try:
+            one, _ = step()
+            for nfl in [int(v) for v in os.environ.get("SVC_BENCH_IN_FLIGHT", "2,4").split(",")]:
+                many = lambda: net.infer_many([(c, f0, uv, sid)] * nfl, noice_scale=0.4)
+                outs = many()
+                same = all(torch.equal(o, one) for o, _ in outs)
+                for _ in range(3):
+                    many()
+                nrep = max(max(args.steps, 24) // nfl, 4)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nrep):
+                    many()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / (nfl * nrep)
+                inflight[str(nfl)] = dict(clips=nfl * nrep, ms_per_clip=round(1e3 * dt, 4), samples_per_s=samples_per_step / dt,
+                                          outputs_equal_single_clip=bool(same))
+        except Exception as e:      # noqa: BLE001 — an extra must not take the headline down
+            inflight["error"] = f"{type(e).__name__}: {e}"
+
     # ---- PCIe-inclusive rate (reported beside `value`, never as it): units / f0 / uv start in pinned host memory and the
     # waveform ends in pinned host memory, one clip at a time, synchronised per clip (what a caller holding host buffers sees) --
     host_io = None
@@ -653,7 +681,7 @@ def main():
                                batch=B, frames=T_FRAMES, samples_per_step=samples_per_step,
                                launch="hipGraph replay" if not args.no_graph else "eager",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU"),
-                   steady_state=steady, roofline=roof, cpu_baseline=cpu, host_io=host_io, train=train_res, **extras)
+                   steady_state=steady, clips_in_flight=inflight, roofline=roof, cpu_baseline=cpu, host_io=host_io, train=train_res, **extras)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -468,6 +468,96 @@ class SynthesizerTrn(nn.Module):
         return self._infer_body(c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths)
 
     # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def infer_many(self, items, noice_scale=0.35, seed=52468, predict_f0=False):
+        """Engine extension: several INDEPENDENT infer() calls — `items` = [(c, f0, uv, g[, vol]), ...], each what one infer() call
+        takes (the chunks of Svc.slice_inference, requests of a serving queue) — replayed as PARALLEL BRANCHES of one hipGraph.
+        One clip alone leaves most CUs idle through its encoder + flow section (~100 latency-bound launches on T columns, a
+        quarter of a 10 s clip's time for 6 % of its FLOPs) and replays of different graphs do not overlap on this runtime; as
+        branches of one graph the clips' kernels interleave (two 10 s clips: 13.0 ms against 2 x 7.4, profiles/r08h_*).  Every
+        item is computed exactly as its own infer() call computes it — same seed, same draws (the reference re-seeds per call,
+        models.py:498-501), same kernels — and the outputs are bit-identical to it.  Needs enable_graph(True); returns
+        [(audio, f0), ...] in the order of `items`."""
+        if not self.use_graph:
+            return [self.infer(*it[:3], g=it[3], noice_scale=noice_scale, seed=seed, predict_f0=predict_f0,
+                               vol=it[4] if len(it) > 4 else None) for it in items]
+        prepared = []
+        for it in items:
+            c, f0, uv, g = it[:4]
+            vol = it[4] if len(it) > 4 else None
+            if not c.is_cuda:
+                raise S.SvcError("SynthesizerTrn.infer needs CUDA/ROCm tensors: the MI355X engine has no CPU fallback")
+            c, f0, uv = c.float().contiguous(), f0.float().contiguous(), uv.float().contiguous()
+            torch.manual_seed(seed)
+            g = self._speaker(g, c)
+            B, _, T = c.shape
+            noise = dict(enc_p=torch.randn(B, self.inter_channels, T, device=c.device), rand_ini=torch.rand(B, 9, device=c.device),
+                         sine=torch.randn(B, T * self.dec.upp, 9, device=c.device))
+            ins = dict(c=c, f0=f0, uv=uv, g=g, enc_p=noise["enc_p"], rand_ini=noise["rand_ini"], sine=noise["sine"])
+            if vol is not None:
+                ins["vol"] = vol.float().contiguous()
+            prepared.append(ins)
+        key = ("many", tuple((tuple(p["c"].shape), tuple(p["g"].shape), "vol" in p) for p in prepared), float(noice_scale),
+               bool(predict_f0), str(prepared[0]["c"].device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            import vdecoder.hifigan.models as _gen
+            static = [{k: v.clone() for k, v in p.items()} for p in prepared]
+
+            def run(i):
+                st = static[i]
+                return self._infer_body(st["c"], st["f0"], st["uv"], st["g"], dict(enc_p=st["enc_p"], rand_ini=st["rand_ini"], sine=st["sine"]),
+                                        noice_scale, predict_f0, st.get("vol"))
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for i in range(len(static)):
+                    run(i)
+            torch.cuda.current_stream().wait_stream(warm)
+            sides = [torch.cuda.Stream() for _ in static[1:]]
+            graph = torch.cuda.CUDAGraph()
+            outs = [None] * len(static)
+            with S.graph_capture(graph):
+                main = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                dones = []
+                # the branches on side streams run their launches on ONE stream each: a fork inside a forked branch (the three MRF
+                # chains, the early harmonic source) crashes hipStreamEndCapture on ROCm 7.2 (segmentation fault in capture_end,
+                # reproduced by scripts/bench_pipeline_onegraph.py); the clip on the capturing stream keeps its inner streams
+                was = _gen._MRF_STREAMS
+                try:
+                    _gen._MRF_STREAMS = False
+                    for i, st in enumerate(sides, start=1):
+                        with torch.cuda.stream(st):
+                            st.wait_event(fork)
+                            outs[i] = run(i)
+                            ev = torch.cuda.Event()
+                            ev.record(st)
+                            dones.append(ev)
+                    if os.environ.get("SVC_MANY_MAIN_STREAMS", "0") != "1":      # A/B: inner streams for the capturing stream's clip
+                        outs[0] = run(0)
+                finally:
+                    _gen._MRF_STREAMS = was
+                if outs[0] is None:
+                    outs[0] = run(0)
+                for ev in dones:
+                    main.wait_event(ev)
+            ent = (graph, static, outs)
+            self._graphs[key] = ent
+        graph, static, outs = ent
+        dst, src = [], []
+        for st, p in zip(static, prepared):
+            for k, v in p.items():
+                if v.dtype == torch.float32 and v.shape == st[k].shape:
+                    dst.append(st[k])
+                    src.append(v)
+                else:
+                    st[k].copy_(v, non_blocking=True)
+        torch._foreach_copy_(dst, src)
+        graph.replay()
+        return [(o[0].clone(), o[1].clone()) for o in outs]
+
     def _infer_graph(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths=None):
         key = (tuple(c.shape), tuple(g.shape), float(noice_scale), bool(predict_f0), vol is not None, lengths is not None,
                str(c.device))

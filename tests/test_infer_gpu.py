@@ -79,6 +79,34 @@ def test_infer_matches_oracle_at_the_benchmarked_shape(dev):
     _check(o3, ref)
 
 
+def test_infer_many_runs_clips_as_graph_branches_bit_identical(dev):
+    """SynthesizerTrn.infer_many: independent clips as parallel branches of ONE hipGraph (the side branches on one stream each, the
+    capturing stream's clip with its inner MRF / source streams).  Different inputs, lengths and speakers per item; every output
+    must equal the item's own infer() call bit for bit, replay after replay, in fp32 and in half mode."""
+    import bench
+    cfg = W.full_config()
+    net, sd = _build(cfg, 1234, dev)
+    items = []
+    for T, seed in ((bench.T_FRAMES, 1234), (431, 7), (bench.T_FRAMES, 9)):
+        c, f0, uv, sid = W.make_inputs(cfg, 1, T, seed=seed)
+        items.append((c.to(dev), f0.to(dev), uv.to(dev), sid.to(dev)))
+    for half in (False, True):
+        if half:
+            net.half()
+        net.enable_graph(False)
+        single = [net.infer(*it[:3], g=it[3], noice_scale=0.4)[0] for it in items]
+        net.enable_graph(True)
+        for _ in range(2):
+            outs = net.infer_many(items, noice_scale=0.4)
+            assert len(outs) == len(items)
+            for (o, _), ref in zip(outs, single):
+                assert torch.equal(o, ref)
+        # a pair of the SAME clip (what bench.py times)
+        outs = net.infer_many([items[0], items[0]], noice_scale=0.4)
+        assert torch.equal(outs[0][0], single[0]) and torch.equal(outs[1][0], single[0])
+        net.enable_graph(False)
+
+
 def test_snake_long_form_matches_oracle_on_full_clips(dev):
     """BASELINE configs[3] at its real length: nsf-snake-hifigan, T = 2584 frames (30.0 s, 1,323,008 samples), B = 2 full
     clips against the CPU oracle (the B = 8 run of the same config is covered by the batch-consistency test below)."""
