@@ -397,6 +397,34 @@ def collect_pmc_traffic(timeout_s=200, mode="infer"):
         f"{total / (steps + warm) / 1e9:.2f} GB per clip over all kernels")
 
 
+def run_inflight(args, dev):
+    """`--mode inflight` (child of the default run): N independent B = 1 clips per hipGraph replay, fp32 (N = 2, 4) and the
+    half-precision mode (N = 4); prints one JSON object."""
+    import bench_extra as X
+    net, cfg, W = build_model(dev)
+    c, f0, uv, sid = [t.to(dev) for t in W.make_inputs(cfg, 1, T_FRAMES, seed=1234)]
+    samples = T_FRAMES * HOP
+    out = dict(note="N independent B = 1 clips (own inputs / noise / outputs) replayed as parallel branches of one hipGraph "
+                    "(SynthesizerTrn.infer_many): throughput of a chunk stream or a request queue — one clip alone leaves most CUs "
+                    "idle through its encoder + flow section; every clip bit-identical to its single replay; per-clip LATENCY is the "
+                    "headline's ms_per_step")
+
+    def leg(tag, counts):
+        net.enable_graph(True)
+        one, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4)
+        for nfl in counts:
+            many = lambda: net.infer_many([(c, f0, uv, sid)] * nfl, noice_scale=0.4)
+            same = all(torch.equal(o, one) for o, _ in many())
+            dt = X._timeit(many, max(args.steps // nfl, 4), warm=3) / nfl
+            out[f"{tag}{nfl}"] = dict(clips_in_flight=nfl, ms_per_clip=round(1e3 * dt, 4), samples_per_s=samples / dt,
+                                      outputs_equal_single_clip=bool(same))
+        net.enable_graph(False)
+    leg("f32_", [int(v) for v in os.environ.get("SVC_BENCH_IN_FLIGHT", "2,4").split(",")])
+    net.half()
+    leg("half_", [4])
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,7 +433,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--mode", choices=["infer", "train", "both"], default="both")
+    ap.add_argument("--mode", choices=["infer", "train", "both", "inflight"], default="both")
     ap.add_argument("--train-steps", type=int, default=None)
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
@@ -459,6 +487,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.mode == "inflight":
+        run_inflight(args, dev)
+        return
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps
         args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
@@ -516,32 +547,19 @@ def main():
         steady = dict(steps=ns, ms_per_step=round(1e3 * dt, 4), samples_per_s=samples_per_step / dt)
 
     # ---- N clips in flight (beside `value`, never as it): N independent B = 1 clips as parallel branches of ONE hipGraph
-    # (SynthesizerTrn.infer_many) — the throughput a chunk stream / request queue sees; a clip's latency is the headline's ----
+    # (SynthesizerTrn.infer_many).  Measured in a CHILD process (`--mode inflight`): a graph with forked branches is the one
+    # construct that has crashed this runtime at capture time during development (nested forks, hipStreamEndCapture) — an extra
+    # must not be able to take the headline line down with it ----
     inflight = None
     if rank == 0 and world == 1 and not args.no_steady and not args.no_graph:
-        inflight = dict(note="N independent B = 1 clips (own inputs / noise / outputs) replayed as parallel branches of one hipGraph "
-                             "(SynthesizerTrn.infer_many): throughput of a chunk stream or a request queue — one clip alone leaves most "
-                             "CUs idle through its encoder + flow section; every clip bit-identical to its single replay; per-clip "
-                             "LATENCY is the headline's ms_per_step")
+        import subprocess
         try:
-            one, _ = step()
-            for nfl in [int(v) for v in os.environ.get("SVC_BENCH_IN_FLIGHT", "2,4").split(",")]:
-                many = lambda: net.infer_many([(c, f0, uv, sid)] * nfl, noice_scale=0.4)
-                outs = many()
-                same = all(torch.equal(o, one) for o, _ in outs)
-                for _ in range(3):
-                    many()
-                nrep = max(max(args.steps, 24) // nfl, 4)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(nrep):
-                    many()
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / (nfl * nrep)
-                inflight[str(nfl)] = dict(clips=nfl * nrep, ms_per_clip=round(1e3 * dt, 4), samples_per_s=samples_per_step / dt,
-                                          outputs_equal_single_clip=bool(same))
-        except Exception as e:      # noqa: BLE001 — an extra must not take the headline down
-            inflight["error"] = f"{type(e).__name__}: {e}"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "inflight", "--steps", str(max(args.steps, 24))],
+                               capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            inflight = json.loads(line[-1]) if r.returncode == 0 and line else dict(error=f"child exited {r.returncode}: {r.stderr[-300:]}")
+        except Exception as e:      # noqa: BLE001
+            inflight = dict(error=f"{type(e).__name__}: {e}")
 
     # ---- PCIe-inclusive rate (reported beside `value`, never as it): units / f0 / uv start in pinned host memory and the
     # waveform ends in pinned host memory, one clip at a time, synchronised per clip (what a caller holding host buffers sees) --

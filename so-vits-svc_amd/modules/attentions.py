@@ -89,14 +89,26 @@ class MultiHeadAttention(nn.Module):
         """Reference modules/attentions.py:198-239: separate q/k/v projections, attention as GEMMs + masked softmax, and
         `p_attn = self.drop(p_attn)` (:232) fused into the softmax kernel (`draws`: the DropoutDraws of this pass;
         without one the module draws for itself when it is in training mode with p_dropout > 0)."""
-        q = self.conv_q.forward_train(x)
-        k = self.conv_k.forward_train(x)
-        v = self.conv_v.forward_train(x)
         win = self.window_size or 0
         if draws is None:
             draws = DropoutDraws(self.p_dropout, self.training)
-        B, _, T = x.shape
+        B, C, T = x.shape
         u = draws.u((B, self.n_heads, T, T), x.device) if draws.active else None
+        if QKV_FUSED_TRAIN and self.conv_q.kernel_size == 1 and not self.conv_q.is_weight_norm and self.conv_q.bias is not None:
+            # the three 1 x 1 projections as ONE 3C-row convolution whose rows are ordered (head, {q, k, v}, d): x has one consumer
+            # (no accumulation of three input gradients), one input-gradient and one weight-gradient launch instead of three each,
+            # and the attention op reads / writes q, k, v and their gradients in place of that tensor (svc_autograd._AttentionQKV).
+            # The stack is an index copy of the three parameters; its backward hands each its rows of the fused gradient.
+            H, dk = self.n_heads, C // self.n_heads
+            w = torch.stack([m.weight.view(H, dk, C) for m in (self.conv_q, self.conv_k, self.conv_v)], 1).reshape(3 * C, C, 1)
+            b = torch.stack([m.bias.view(H, dk) for m in (self.conv_q, self.conv_k, self.conv_v)], 1).reshape(3 * C)
+            qkv = A.conv1d(x, w, b)
+            att = A.attention_qkv(qkv, self.n_heads, self.emb_rel_k if win else None, self.emb_rel_v if win else None, win,
+                                  mask_vec, mask_mode, drop_u=u, p_drop=draws.p)
+            return self.conv_o.forward_train(att)
+        q = self.conv_q.forward_train(x)
+        k = self.conv_k.forward_train(x)
+        v = self.conv_v.forward_train(x)
         att = A.attention(q, k, v, self.n_heads, self.emb_rel_k if win else None, self.emb_rel_v if win else None, win,
                           mask_vec, mask_mode, drop_u=u, p_drop=draws.p)
         return self.conv_o.forward_train(att)
@@ -218,6 +230,10 @@ class Encoder(nn.Module):
             y = self.ffn_layers[i](x, x_mask, x_is_masked=True)
             x = self.norm_layers_2[i](x, residual=y, x_mask=x_mask)
         return x
+
+
+# training: q / k / v projections as one convolution (SVC_QKV_FUSED_TRAIN=0: three, one autograd op per reference op — A/B switch)
+QKV_FUSED_TRAIN = __import__("os").environ.get("SVC_QKV_FUSED_TRAIN", "1") != "0"
 
 
 class DropoutDraws:

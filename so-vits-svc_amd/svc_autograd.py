@@ -849,6 +849,92 @@ def attention(q, k, v, n_heads, emb_rel_k=None, emb_rel_v=None, window=0, mask=N
     return _Attention.apply(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window or 0, mask_mode, drop_u, float(p_drop))
 
 
+class _AttentionQKV(Function):
+    """_Attention on ONE fused projection output qkv [B, 3*H*dk, T] whose rows are ordered (head, {q, k, v}, d): head h of item b has
+    its q / k / v blocks at ((b*H + h)*3 + {0, 1, 2}) * dk * T — one batch stride for the GEMMs, and the backward writes dQ, dK, dV
+    straight into ONE [B, 3C, T] gradient buffer, which is the fused conv's dy.  With the q / k / v projections as one 3C-row conv
+    (modules/attentions.MultiHeadAttention.forward_train) a layer saves two forward convs, two input-gradient convs, two
+    weight-gradient launches and the two accumulation adds of x's three consumers."""
+
+    @staticmethod
+    def forward(ctx, qkv, emb_k, emb_v, mask, n_heads, window, mask_mode, drop_u, p_drop):
+        qkv = _c(qkv)
+        B, C3, T = qkv.shape
+        H = n_heads
+        dk = C3 // (3 * H)
+        BH, BS = B * H, 3 * dk * T
+        sc = dk ** -0.5
+        v5 = qkv.view(BH, 3, dk, T)
+        q, k, v = v5[:, 0], v5[:, 1], v5[:, 2]
+        qs = (BS, 1, T)          # A[m=i, k=d] = q[bh, d, i]
+        P = S.gemm(q, k, qs, (BS, T, 1), BH, T, T, dk, alpha=sc)
+        rel = None
+        if window:
+            ek = _c(emb_k.view(-1, dk))
+            ev = _c(emb_v.view(-1, dk))
+            rel = S.gemm(q, ek, qs, (0, 1, dk), BH, T, 2 * window + 1, dk, alpha=sc)
+        hashed = isinstance(drop_u, S.HashDraw)
+        if drop_u is not None and not hashed:
+            drop_u = _c(drop_u)
+            if drop_u.numel() != P.numel():
+                raise S.SvcError(f"attention dropout draws {tuple(drop_u.shape)} do not match [B,H,T,T] = {(B, H, T, T)}")
+        Pd = S.attn_softmax_fwd(P, rel, mask, B, H, T, window, mask_mode, drop_u, p_drop)
+        out = torch.empty((B, H * dk, T), device=qkv.device, dtype=torch.float32)
+        S.gemm(v, Pd, (BS, T, 1), (T * T, 1, T), BH, dk, T, T, out=out, c_strides=(dk * T, T, 1))
+        pband = None
+        if window:
+            pband = S.band_gather(Pd, BH * T, T, window)
+            S.gemm(ev, pband, (0, 1, dk), (T * (2 * window + 1), 1, 2 * window + 1), BH, dk, T, 2 * window + 1, out=out,
+                   c_strides=(dk * T, T, 1), beta=1.0)
+        ctx.save_for_backward(qkv, P, pband, emb_k, emb_v, None if hashed else drop_u, Pd if drop_u is not None else None, mask)
+        ctx.cfg = (B, H, dk, T, window, p_drop, mask_mode)
+        ctx.hash_draw = drop_u if hashed else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P, pband, emb_k, emb_v, drop_u, Pd, mask = ctx.saved_tensors
+        B, H, dk, T, window, p_drop, mask_mode = ctx.cfg
+        if ctx.hash_draw is not None:
+            drop_u = ctx.hash_draw
+        if Pd is None:
+            Pd = P
+        BH, BS = B * H, 3 * dk * T
+        sc = dk ** -0.5
+        nrel = 2 * window + 1
+        dO = _c(dO)
+        v5 = qkv.view(BH, 3, dk, T)
+        q, k, v = v5[:, 0], v5[:, 1], v5[:, 2]
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(BH, 3, dk, T)
+        dQ, dK, dV = d5[:, 0], d5[:, 1], d5[:, 2]
+        S.gemm(dO, Pd, (dk * T, T, 1), (T * T, T, 1), BH, dk, T, T, out=dV, c_strides=(BS, T, 1))
+        dP = S.gemm(dO, v, (dk * T, 1, T), (BS, T, 1), BH, T, T, dk)
+        dEk = dEv = None
+        if window:
+            ek = _c(emb_k.view(-1, dk))
+            ev = _c(emb_v.view(-1, dk))
+            dpband = S.gemm(dO, ev, (dk * T, 1, T), (0, 1, dk), BH, T, nrel, dk)
+            S.band_scatter_add(dP, dpband, BH * T, T, window)
+            dEv_b = S.gemm(pband, dO, (T * nrel, 1, nrel), (dk * T, 1, T), BH, nrel, dk, T, split_k_atomic=True)      # [BH, nrel, dk]
+            dEv = S.reduce_bct(dEv_b.view(BH, nrel * dk, 1), 0).view(emb_v.shape)
+        S.attn_softmax_bwd(P, dP, B, H, T, drop_u, p_drop, mask, mask_mode)          # dP(d) -> dS in place
+        dS = dP
+        S.gemm(k, dS, (BS, T, 1), (T * T, 1, T), BH, dk, T, T, out=dQ, c_strides=(BS, T, 1), alpha=sc)
+        S.gemm(q, dS, (BS, T, 1), (T * T, T, 1), BH, dk, T, T, out=dK, c_strides=(BS, T, 1), alpha=sc)
+        if window:
+            drel = S.band_gather(dS, BH * T, T, window)
+            S.gemm(ek, drel, (0, 1, dk), (T * nrel, 1, nrel), BH, dk, T, nrel, out=dQ, c_strides=(BS, T, 1), alpha=sc, beta=1.0)
+            dEk_b = S.gemm(drel, q, (T * nrel, 1, nrel), (BS, 1, T), BH, nrel, dk, T, alpha=sc, split_k_atomic=True)
+            dEk = S.reduce_bct(dEk_b.view(BH, nrel * dk, 1), 0).view(emb_k.shape)
+        return dqkv, dEk, dEv, None, None, None, None, None, None
+
+
+def attention_qkv(qkv, n_heads, emb_rel_k=None, emb_rel_v=None, window=0, mask=None, mask_mode=0, drop_u=None, p_drop=0.0):
+    """attention() on a fused [B, 3C, T] projection whose rows are ordered (head, {q, k, v}, d) — see _AttentionQKV."""
+    return _AttentionQKV.apply(qkv, emb_rel_k, emb_rel_v, mask, n_heads, window or 0, mask_mode, drop_u, float(p_drop))
+
+
 class _Dropout(Function):
     """nn.Dropout(p) with the uniform draws `u` explicit: y = x * (u >= p ? 1/(1-p) : 0), one svc_ew_f32 launch each way."""
 

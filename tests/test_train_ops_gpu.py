@@ -651,3 +651,45 @@ def test_hashed_dropout_draws(dev):
     yd = A.dropout(x, S.HashDraw(seed, 9), 0.25)
     yd.backward(torch.ones_like(yd))
     assert torch.equal(yd.detach() != 0, x.grad != 0) and torch.allclose(x.grad[x.grad != 0], torch.tensor(1 / 0.75, device=dev))
+
+
+@pytest.mark.parametrize("window,mode", [(4, 1), (0, 2)])
+def test_fused_qkv_projection_matches_the_three_conv_form(dev, window, mode):
+    """MultiHeadAttention.forward_train with q / k / v as ONE 3C-row convolution (rows ordered head, {q,k,v}, d; attention reading and
+    writing that tensor in place: svc_autograd._AttentionQKV) against the three-conv form (one autograd op per reference op,
+    modules/attentions.py:198-205): output, input gradient and every parameter gradient, with hashed dropout on (same seed / site
+    on both sides) and a padding or causal mask."""
+    import modules.attentions as AT
+    import svc_hip as S
+    torch.manual_seed(5)
+    B, C, T, H = 3, 192, 130, 2
+    att = AT.MultiHeadAttention(C, C, H, p_dropout=0.2, window_size=window or None).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(B, C, T, generator=g).to(dev)
+    dO = torch.randn(B, C, T, generator=g).to(dev)
+    mask = (torch.arange(T, device=dev)[None, :] < torch.tensor([T, T - 30, T - 7], device=dev)[:, None]).float() if mode == 1 else None
+    seed = torch.tensor([77], dtype=torch.int64, device=dev)
+
+    class Draws(AT.DropoutDraws):          # the same (seed, site) on both runs
+        def u(self, shape, device):
+            return S.HashDraw(seed, 3)
+
+    def run(fused):
+        AT.QKV_FUSED_TRAIN = fused
+        att.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = att.forward_train(x, mode, mask, draws=Draws(0.2, True))
+        y.backward(dO)
+        return y.detach(), x.grad, {k: p.grad.clone() for k, p in att.named_parameters() if p.grad is not None}
+    try:
+        y1, dx1, g1 = run(True)
+        y0, dx0, g0 = run(False)
+    finally:
+        AT.QKV_FUSED_TRAIN = True
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    assert rel(y1, y0) < 2e-6 and rel(dx1, dx0) < 5e-6
+    assert set(g1) == set(g0)
+    for k in g0:
+        if k.endswith("conv_k.bias"):        # d/d(k bias) == 0 analytically (softmax is shift-invariant): both sides hold round-off
+            continue
+        assert rel(g1[k], g0[k]) < 2e-5, k
