@@ -189,11 +189,28 @@ def bench_snake_b8(dev, steps=3):
         return net.infer(c, f0, uv, g=sid, noice_scale=0.4)
     dt = _timeit(step, steps, warm=2)
     n = B * T * HOP
+    # the same batch in the reference's half-precision mode (SynthesizerTrn.half(): generator + SnakeAlias sites on blocked fp16)
+    half = None
+    try:
+        noise = dict(enc_p=torch.randn(B, net.inter_channels, T, device=dev), rand_ini=torch.rand(B, 9, device=dev),
+                     sine=torch.randn(B, T * net.dec.upp, 9, device=dev))
+        net.enable_graph(False)
+        o32, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+        net.half()
+        oh, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+        mse = (oh - o32).pow(2).mean().item()
+        del o32, oh, noise
+        net.enable_graph(True)
+        dth = _timeit(step, steps, warm=2)
+        half = dict(ms_per_step=round(1e3 * dth, 3), samples_per_s=n / dth, speedup_vs_f32=round(dt / dth, 3), waveform_mse_vs_f32_path=mse,
+                    note="SynthesizerTrn.half(): fp16 activations + weights in the generator (conv1d_h, snake_alias_h), f32 accumulate")
+    except Exception as e:      # noqa: BLE001
+        half = dict(error=f"{type(e).__name__}: {e}")
     del net
     torch.cuda.empty_cache()
     return dict(workload="BASELINE configs[3]: nsf-snake-hifigan (SnakeAlias activations), batch 8 x 30.0 s clips "
                          f"(T={T} frames, {T * HOP} samples each), fp32, hipGraph replay",
-                ms_per_step=round(1e3 * dt, 3), samples_per_s=n / dt, rtf=dt / (n / 44100.0), steps=steps)
+                ms_per_step=round(1e3 * dt, 3), samples_per_s=n / dt, rtf=dt / (n / 44100.0), steps=steps, half=half)
 
 
 def bench_diffusion(dev):

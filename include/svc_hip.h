@@ -342,6 +342,10 @@ int svc_conv1d_h(const svc_conv1d_h_args* a, void* stream);
  * of 16 in 16..128.  The intermediate lives in LDS (fp16); x and y may not alias. */
 int svc_resblock_pair_h(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
                         int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
+/* SnakeAlias (vdecoder/hifiganwithsnake/alias/act.py:125-130) on blocked fp16 tensors: y = DownSample1d(SnakeBeta(UpSample1d(x))), the
+ * 2x intermediate in LDS, fp32 arithmetic; alpha / beta [C] fp32 (log scale), taps12 = the 12 kaiser-sinc taps (HOST array).
+ * x and y may alias only if identical. */
+int svc_snake_alias_h(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T, void* stream);
 int svc_debug_set_conv_h(int cfg); /* tuning aid: 0 automatic tile choice, 1 no 64 x 128 tile, 2 four column tiles per wave where they fit */
 int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                  int B, int C, int T, void* stream);

@@ -456,6 +456,66 @@ int launch_respair_ks(const PP& p, hipStream_t s) {
   return launch_respair<KS, 1, 2, 1, 4>(p, s);                  //  32 rows, 256
 }
 
+// ---- SnakeAlias on the blocked fp16 layout (vdecoder/hifiganwithsnake/alias/act.py:125-130; the fp32 form and its derivation:
+// snake_alias.hip): UpSample1d x2 (replicate pad 5, 12-tap polyphase) -> SnakeBeta (log-scale alpha / beta) -> DownSample1d x2
+// (replicate pad (5, 6), 12 taps), the 2x intermediate in LDS, fp32 arithmetic between the fp16 load and the fp16 store.  A
+// workgroup owns SH_TILE time steps of ONE channel block (8 channels): a 16-byte word per time step in, one out.
+constexpr int SH_TILE = 256;
+struct TapsH {
+  float f[12];
+};
+__global__ __launch_bounds__(256) void snake_alias_h_kernel(const h8* __restrict__ x, h8* __restrict__ y, const float* __restrict__ alpha,
+                                                            const float* __restrict__ beta, TapsH taps, int CB, int T) {
+  __shared__ float xs[(SH_TILE + 10) * 8];
+  __shared__ float ua[(2 * SH_TILE + 12) * 8];
+  const int t0 = blockIdx.x * SH_TILE, cb = blockIdx.y, b = blockIdx.z;
+  const h8* xr = x + ((long long)b * CB + cb) * T;
+  h8* yr = y + ((long long)b * CB + cb) * T;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SH_TILE + 10; i += 256) {
+    int t = t0 - 5 + i;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const h8 v = xr[t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[i * 8 + j] = (float)v[j];
+  }
+  __syncthreads();
+  const int n_lo = 2 * t0 - 5;
+  // (position m, channel j) pairs: j fastest, so a wave's 64 lanes touch 8 consecutive positions x 8 channels (LDS rows of 32 B)
+  for (int e = tid; e < (2 * SH_TILE + 10) * 8; e += 256) {
+    const int m = e >> 3, j = e & 7;
+    int n = n_lo + m;
+    n = n < 0 ? 0 : (n > 2 * T - 1 ? 2 * T - 1 : n);
+    const int par = (n + 1) & 1;
+    const int j0 = (n + 15 - par) >> 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      int xi = j0 - q - 5;
+      xi = xi < 0 ? 0 : (xi > T - 1 ? T - 1 : xi);
+      acc = fmaf(par ? taps.f[2 * q + 1] : taps.f[2 * q], xs[(xi - (t0 - 5)) * 8 + j], acc);
+    }
+    const float u = 2.f * acc;
+    const int c = cb * 8 + j;
+    const float sn = sinf(u * __expf(alpha[c]));
+    ua[m * 8 + j] = u + (sn * sn) / (__expf(beta[c]) + 1e-9f);
+  }
+  __syncthreads();
+  for (int i = tid; i < SH_TILE; i += 256) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc = fmaf(taps.f[k], ua[(2 * i + k) * 8 + j], acc);
+      o[j] = (_Float16)acc;
+    }
+    yr[t] = o;
+  }
+}
+
 // ---- weight pack: dense fp32 (weight norm already folded) -> [Cin/16][tap][RP][16] fp16.
 // conv (u == 1): w [Cout][Cin][KS], row = co, tap = k.   transposed (u > 1): w [Cin][Cout][K], row = ph * Cout + co, tap mr of
 // M = ceil(K / u): k = ph + (M - 1 - mr) * u (taps time-reversed: each phase is a plain correlation, as pack_convt1d_kernel).
@@ -608,6 +668,17 @@ extern "C" int svc_resblock_pair_h(const void* x, const void* w1, const float* b
     default: SVC_REQUIRE(false, "resblock_pair_h: tap count %d not built (3, 7, 11)", KS);
   }
   return SVC_OK;
+}
+
+extern "C" int svc_snake_alias_h(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T,
+                                 void* stream) {
+  SVC_REQUIRE(x && y && alpha && beta && taps12 && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "snake_alias_h: bad args");
+  TapsH tp;
+  for (int i = 0; i < 12; ++i) tp.f[i] = taps12[i];
+  svc::ProfScope prof((hipStream_t)stream, "snake_alias_h", 0.0, 4.0 * B * (double)C * T);
+  hipLaunchKernelGGL(snake_alias_h_kernel, dim3(svc::cdiv(T, SH_TILE), C / 8, B), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), reinterpret_cast<h8*>(y), alpha, beta, tp, C / 8, T);
+  return svc::check_launch("snake_alias_h");
 }
 
 extern "C" int svc_debug_set_conv_h(int cfg) {

@@ -126,6 +126,7 @@ def lib():
         L.svc_attention_f32.argtypes = [C.POINTER(AttentionArgs), C.c_void_p]
         L.svc_pack_conv1d_h.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.svc_conv1d_h.argtypes = [C.POINTER(Conv1dHArgs), C.c_void_p]
+        L.svc_snake_alias_h.argtypes = [C.c_void_p, C.c_void_p, _f32p, _f32p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.svc_resblock_pair_h.argtypes = [C.c_void_p, C.c_void_p, _f32p, C.c_void_p, _f32p, C.c_void_p] + [C.c_int] * 6 + \
             [C.c_float] * 3 + [C.c_void_p]
         L.svc_cvt_to_h.argtypes = [_f32p, _f32p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int,
@@ -161,7 +162,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -490,6 +491,20 @@ def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0,
         raise SvcError("resblock_pair_h: x and out may not alias (neighbouring workgroups read x's halo)")
     check(lib().svc_resblock_pair_h(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1, w1p.shape[2],
                                     slope, beta, out_div, stream_ptr()), "resblock_pair_h")
+    return out
+
+
+def snake_alias_h(xh, alpha, beta, taps, out=None):
+    """SnakeAlias on a blocked fp16 tensor (svc_snake_alias_h); out may not be xh (a tile reads its neighbours' halo)."""
+    _require_gpu_h(xh, alpha, beta, out)
+    _check_h(xh, "snake_alias_h")
+    B, CB, T, _ = xh.shape
+    if out is None:
+        out = torch.empty_like(xh)
+    if out.data_ptr() == xh.data_ptr():
+        raise SvcError("snake_alias_h: in-place use is not supported")
+    tp = (C.c_float * 12)(*[float(v) for v in taps])
+    check(lib().svc_snake_alias_h(_hptr(xh), _hptr(out), ptr(alpha), ptr(beta), tp, B, CB * 8, T, stream_ptr()), "snake_alias_h")
     return out
 
 

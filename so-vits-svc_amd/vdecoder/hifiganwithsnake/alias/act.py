@@ -46,6 +46,10 @@ class SnakeAlias(nn.Module):
         # of the state_dict), the taps are fixed at construction
         self._taps = [float(v) for v in self.upsample.filter.flatten().tolist()]
 
+    def run_h(self, xh, out=None):
+        """The activation on a blocked fp16 tensor of the 16-bit pipeline (svc_snake_alias_h)."""
+        return S.snake_alias_h(xh, self.act.alpha, self.act.beta, self._taps, out=out)
+
     def forward(self, x, C=None, out=None):
         if torch.is_grad_enabled() and (self.act.alpha.requires_grad or getattr(x, "requires_grad", False)):
             return A.snake_alias(x, self.act.alpha, self.act.beta, self._taps)      # training: HIP forward + backward

@@ -65,6 +65,27 @@ class ResBlock1(nn.Module):
             c2.run(act, res=cur, res_mode=1, out=dst)
             cur = dst
 
+    def forward_h(self, xh, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
+        """The same block on the 16-bit pipeline (blocked fp16 tensors): snake -> conv -> snake -> conv + x per dilation."""
+        n = len(self.convs1)
+        acts1, acts2 = self.activations[::2], self.activations[1::2]
+        bufs = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(4)]
+        xt, ping, pong, act = bufs
+        cur = xh
+        for j, (c1, c2, a1, a2) in enumerate(zip(self.convs1, self.convs2, acts1, acts2)):
+            a1.run_h(cur, out=act)
+            c1.run_h(act, out=xt)
+            a2.run_h(xt, out=act)
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
+                c2.run_h(act, res=cur, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c2.run_h(act, res=cur, out=dst)
+            cur = dst
+
     def remove_weight_norm(self):
         for l in list(self.convs1) + list(self.convs2):
             l.remove_weight_norm()
@@ -145,10 +166,36 @@ class Generator(base.Generator):
         x = self.conv_post.forward_train(x)
         return A.tanh(x)
 
+    def forward_h(self, x, f0, g=None, noise=None, source=None):
+        """forward() in the reference's half-precision mode (base.Generator.set_half): the MRF stages, snakes[1:], ups[1:],
+        snake_post and conv_post on blocked fp16 tensors (svc_conv1d_h, svc_snake_alias_h); conv_pre, snakes[0], ups[0] and the
+        harmonic source in fp32 as in the plain generator."""
+        _no_grad_guard()
+        if source is None:
+            har, _, _ = self.m_source(f0, self.upp, noise=noise)
+        gc = self.cond(g) if g is not None else None
+        x = self.conv_pre.run(x, cond=gc)
+        if source is not None:
+            torch.cuda.current_stream().wait_event(source[1])
+        xh = None
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            xs = source[0][i] if source is not None else self.noise_convs[i](har)
+            if i == 0:
+                xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs))
+            else:
+                xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs))
+            xh = base.mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), n_tmp=4, half=True)
+        cp = self.conv_post
+        return S.conv_post_h(self.snake_post.run_h(xh), cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias,
+                             cp.kernel_size, cp.padding, pre_slope=1.0, act=S.ACT_TANH)
+
     def forward(self, x, f0, g=None, noise=None, source=None):
         """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413); `source`: see base.Generator.forward."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.conv_post.parameters()):
             return self.forward_train(x, f0, g=g, noise=noise)
+        if getattr(self, "half_mode", False):
+            return self.forward_h(x, f0, g=g, noise=noise, source=source)
         _no_grad_guard()
         if source is None:
             har, _, _ = self.m_source(f0, self.upp, noise=noise)

@@ -214,6 +214,46 @@ def test_half_inference_at_the_benchmarked_shape(dev):
     assert torch.equal(o2, o) and torch.equal(o3, o)
 
 
+@pytest.mark.parametrize("B,C,T", [(1, 16, 1000), (2, 32, 257), (1, 128, 256), (1, 8, 7), (1, 64, 3001)])
+def test_snake_alias_h_vs_fp32_kernel(dev, B, C, T):
+    """svc_snake_alias_h (blocked fp16 in / out, fp32 arithmetic) against svc_snake_alias_f32 on the same fp16-rounded input: what
+    differs is the one rounding of the stored result (and libm-level differences of sin / exp at 1e-7)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(C + T)
+    x = _h(torch.randn(B, C, T, generator=g) * 2.0)
+    alpha, beta = 0.4 * torch.randn(C, generator=g), 0.4 * torch.randn(C, generator=g)
+    taps = W.snake_filter().tolist()
+    ref = S.snake_alias(x.to(dev), alpha.to(dev), beta.to(dev), taps).cpu()
+    y = S.from_h(S.snake_alias_h(S.to_h(x.to(dev)), alpha.to(dev), beta.to(dev), taps)).cpu()
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_snake_generator_half_inference(dev):
+    """BASELINE configs[3]'s generator (vocoder_name = nsf-snake-hifigan, full template widths) in half-precision mode: every
+    SnakeAlias site after the first stage on blocked fp16 tensors, against the fp32 CPU oracle — north_star's waveform bar — and
+    hipGraph replay bit-equal to the eager launches."""
+    cfg = W.full_config()
+    cfg["vocoder_name"] = "nsf-snake-hifigan"
+    net, sd = _build(cfg, 77, dev)
+    B, T = 2, 60
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=21)
+    noise = W.make_noise(cfg, B, T, seed=22)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    net.half()
+    assert net.dec.half_mode
+    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    mse = (o.cpu() - ref).pow(2).mean().item()
+    print(f"snake generator, half mode, B={B} T={T}: MSE vs fp32 oracle {mse:.3e}, max|err| {(o.cpu() - ref).abs().max().item():.3e}, "
+          f"max|ref| {ref.abs().max().item():.3f}")
+    assert o.shape == ref.shape and mse < 1e-4, mse
+    net.enable_graph(True)
+    o2, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)
+    assert torch.equal(o2, o)
+
+
 def test_half_mode_refuses_generators_without_a_16_bit_form(dev):
     net, _ = _build(W.small_config(), 3, dev)          # stage widths 64 / 32 / 16 / 8 / 4
     with pytest.raises(NotImplementedError):
