@@ -215,7 +215,7 @@ class Svc(object):
         utils.load_checkpoint(self.net_g_path, self.net_g_ms, None)
         # A "half" checkpoint (compress_model.py:21-48) is up-cast at load (utils.load_checkpoint: the fp32 masters then hold the
         # fp16 values exactly) and, as in the reference (:196-198), switches the model to half-precision inference: the generator's
-        # 16-bit pipeline (SynthesizerTrn.half).  Generators without one (snake variant, the tiny template's odd widths) compute in fp32.
+        # 16-bit pipeline (SynthesizerTrn.half).  (plain and snake generators; the tiny template's odd stage widths have none and compute in fp32).
         self.dtype = torch.float32
         self.net_g_ms.float().eval().to(self.dev)
         self.half_mode = False

@@ -319,7 +319,8 @@ class SynthesizerTrn(nn.Module):
         FLOPs) to the 16-bit pipeline — fp16 activations and weights, fp32 accumulation (vdecoder.hifigan.models.Generator.set_half)
         — and leaves the fp32 master parameters, the encoder / flow kernels and the harmonic source as they are: nothing is
         LESS precise than the reference's half mode, and `list(net.parameters())[0].dtype` stays float32 (Svc casts its inputs to
-        that).  Generators without a 16-bit form (the snake variant, odd stage widths) raise NotImplementedError."""
+        that).  Both generators have a 16-bit form (plain: conv1d_h + fused ResBlock pairs; snake: conv1d_h + snake_alias_h); stage widths
+        that are not multiples of 16 (the tiny template's 200/100/50/25/12) raise NotImplementedError."""
         if not hasattr(self.dec, "set_half"):
             raise NotImplementedError(f"half-precision inference is not built for the {type(self.dec).__module__} generator")
         self.dec.set_half(True)
