@@ -463,6 +463,9 @@ enum {
                             backward with a = dy (modules/attentions.py:51,55,100,104,344) */
 };
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream);
+/* y = leaky_relu'(x; slope) * dy + r over n contiguous floats: the leaky-ReLU backward and the accumulation of the residual branch's
+ * gradient in one launch (svc_autograd._LReluRes: the input of a ResBlock pair feeds lrelu -> conv AND the residual add). */
+int svc_lrelu_bwd_add_f32(const float* dy, const float* x, const float* r, float* y, long long n, float slope, void* stream);
 /* y[b,c,t] = op(x[b,c,t], side[b*s_bs + c*s_cs + t*s_ts]) — masks ([B,1,T]: s_cs = 0), speaker conditions ([B,C,1]:
  * s_ts = 0), channel-flipped operands (negative strides). */
 int svc_ew_bct_f32(int op, const float* x, const float* side, float* y, long long x_bs, long long x_cs, long long s_bs,

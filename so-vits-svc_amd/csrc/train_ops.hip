@@ -296,6 +296,12 @@ __device__ __forceinline__ float ew_apply(int op, float a, float b, float alpha,
   }
 }
 
+__global__ void lrelu_bwd_add_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ r,
+                                     float* __restrict__ y, long long n, float slope) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = (x[i] > 0.f ? dy[i] : dy[i] * slope) + r[i];
+}
+
 __global__ void ew_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                           long long n, float alpha, float beta) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -756,6 +762,15 @@ int svc_reduce_c_f32(const float* x, const float* w, float* out, int B, int C, i
   SVC_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "reduce_c: bad args");
   hipLaunchKernelGGL(reduce_c_kernel, dim3(svc::cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, x, w, out, C, T);
   return svc::check_launch("reduce_c");
+}
+
+/* y = leaky_relu'(x) * dy + r : the backward of `xt = c1(lrelu(x)); x = c2(xt) + x` (a ResBlock pair's input, vdecoder/hifigan/
+ * models.py:60-67) at the point where x's two consumers meet — one launch instead of the leaky-ReLU backward plus the autograd
+ * engine's accumulation add. */
+int svc_lrelu_bwd_add_f32(const float* dy, const float* x, const float* r, float* y, long long n, float slope, void* stream) {
+  SVC_REQUIRE(dy && x && r && y && n > 0, "lrelu_bwd_add: bad args");
+  hipLaunchKernelGGL(lrelu_bwd_add_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, x, r, y, n, slope);
+  return svc::check_launch("lrelu_bwd_add");
 }
 
 int svc_ew_f32(int op, const float* a, const float* b, float* y, long long n, float alpha, float beta, void* stream) {

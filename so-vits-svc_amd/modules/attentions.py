@@ -99,9 +99,8 @@ class MultiHeadAttention(nn.Module):
             # (no accumulation of three input gradients), one input-gradient and one weight-gradient launch instead of three each,
             # and the attention op reads / writes q, k, v and their gradients in place of that tensor (svc_autograd._AttentionQKV).
             # The stack is an index copy of the three parameters; its backward hands each its rows of the fused gradient.
-            H, dk = self.n_heads, C // self.n_heads
-            w = torch.stack([m.weight.view(H, dk, C) for m in (self.conv_q, self.conv_k, self.conv_v)], 1).reshape(3 * C, C, 1)
-            b = torch.stack([m.bias.view(H, dk) for m in (self.conv_q, self.conv_k, self.conv_v)], 1).reshape(3 * C)
+            w = A.stack_qkv(self.conv_q.weight, self.conv_k.weight, self.conv_v.weight, self.n_heads)       # [3C, C, 1]
+            b = A.stack_qkv(self.conv_q.bias, self.conv_k.bias, self.conv_v.bias, self.n_heads)             # [3C]
             qkv = A.conv1d(x, w, b)
             att = A.attention_qkv(qkv, self.n_heads, self.emb_rel_k if win else None, self.emb_rel_v if win else None, win,
                                   mask_vec, mask_mode, drop_u=u, p_drop=draws.p)

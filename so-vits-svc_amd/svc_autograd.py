@@ -430,6 +430,55 @@ class _ChunkC(Function):
         return dx, None, None
 
 
+class _SplitBatch(Function):
+    """(x[:n], x[n:]) along dim 0 as views; the backward joins the two gradients with ONE cat (torch's slice backward: a zero-fill,
+    a copy and an accumulate per half) — the real / generated halves of the discriminators' batched pass (models.py:246-250)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        n, shape = ctx.n, ctx.shape
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = torch.zeros((n,) + tuple(shape[1:]), device=ref.device, dtype=ref.dtype)
+        if g1 is None:
+            g1 = torch.zeros((shape[0] - n,) + tuple(shape[1:]), device=ref.device, dtype=ref.dtype)
+        return torch.cat([g0, g1], 0), None
+
+
+def split_batch(x, n):
+    return _SplitBatch.apply(x, n)
+
+
+class _StackQKV(Function):
+    """The fused q / k / v projection weight (or bias) of a training attention layer: three [H*dk, ...] parameters -> one tensor whose
+    rows are ordered (head, {q, k, v}, d).  Backward: ONE permuting copy of the fused gradient to [3, H, dk, ...], whose three slices
+    are contiguous — unbound views of torch.stack's own backward are strided, and AccumulateGrad clones every strided gradient
+    (six clone launches per layer)."""
+
+    @staticmethod
+    def forward(ctx, wq, wk, wv, H):
+        ctx.H, ctx.shape = H, wq.shape
+        dk = wq.shape[0] // H
+        rest = tuple(wq.shape[1:])
+        return torch.stack([w.reshape((H, dk) + rest) for w in (wq, wk, wv)], 1).reshape((3 * wq.shape[0],) + rest)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, shape = ctx.H, ctx.shape
+        dk = shape[0] // H
+        g3 = g.reshape((H, 3, dk) + tuple(shape[1:])).transpose(0, 1).contiguous()       # [3, H, dk, ...]: one launch
+        return g3[0].reshape(shape), g3[1].reshape(shape), g3[2].reshape(shape), None
+
+
+def stack_qkv(wq, wk, wv, n_heads):
+    return _StackQKV.apply(wq, wk, wv, n_heads)
+
+
 def chunk_channels(x, n, views=False):
     """x [B, n*C, T] -> n [B, C, T] chunks whose gradients meet in ONE buffer in the backward (torch's own slice backward zero-fills
     and accumulates a full-size tensor per chunk).  views=True: the chunks are channel-slice views of x (no forward launch)."""
@@ -543,6 +592,32 @@ def weight_norm(v, g):
 
 def leaky_relu(x, slope):
     return _EwUnary.apply(x, S.EW_LRELU, S.EW_LRELU_BWD, float(slope), False)
+
+
+class _LReluRes(Function):
+    """(leaky_relu(x), x) for an x that feeds `lrelu -> conv` AND a residual add (a ResBlock pair's input, vdecoder/hifigan/
+    models.py:60-67): as ONE node with two outputs, so that the two gradients meet in ONE launch — leaky_relu'(x) * g_act + g_res
+    (svc_lrelu_bwd_add_f32) — instead of the leaky-ReLU backward plus the autograd engine's own accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return S.ew(S.EW_LRELU, x, alpha=slope), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gr):
+        (x,) = ctx.saved_tensors
+        if ga is None:
+            return gr, None
+        if gr is None:
+            return S.ew(S.EW_LRELU_BWD, _c(ga), x, alpha=ctx.slope), None
+        return S.lrelu_bwd_add(ga, x, gr, ctx.slope), None
+
+
+def leaky_relu_res(x, slope):
+    return _LReluRes.apply(x, float(slope))
 
 
 class _LReluTail(Function):

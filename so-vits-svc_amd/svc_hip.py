@@ -896,6 +896,7 @@ TRAIN_EXPORTS = [
     "svc_gate_bwd_f32", "svc_decimate_f32", "svc_decimate_bwd_f32", "svc_gconv1d_fwd_f32", "svc_gconv1d_dgrad_f32",
     "svc_gconv1d_wgrad_f32", "svc_reduce_scalar_f64", "svc_f64_to_f32", "svc_adamw_f32", "svc_adamw_advance", "svc_debug_set_conv_cfg",
     "svc_debug_set_wgrad_target", "svc_debug_set_conv_strip", "svc_debug_set_gconv_version", "svc_nonfinite_guard_f32",
+    "svc_lrelu_bwd_add_f32",
 ]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
@@ -920,6 +921,7 @@ def tlib():
         L.svc_reduce_bct_f32.argtypes = [_f32p, _f32p, ll, ll, i, i, i, i, f, vp]
         L.svc_reduce_c_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
         L.svc_ew_f32.argtypes = [i, _f32p, _f32p, _f32p, ll, f, f, vp]
+        L.svc_lrelu_bwd_add_f32.argtypes = [_f32p, _f32p, _f32p, _f32p, ll, f, vp]
         L.svc_ew_bct_f32.argtypes = [i, _f32p, _f32p, _f32p] + [ll] * 7 + [i, i, i, f, f, vp]
         L.svc_gate_fwd_f32.argtypes = [_f32p, _f32p, i, i, i, vp]
         L.svc_gate_bwd_f32.argtypes = [_f32p, _f32p, _f32p, i, i, i, vp]
@@ -956,6 +958,15 @@ def ew(op, a, b=None, alpha=1.0, beta=0.0, out=None):
         out = torch.empty_like(a)
     if a.numel():
         check(tlib().svc_ew_f32(op, ptr(a), ptr(b), ptr(out), a.numel(), alpha, beta, stream_ptr()), "ew")
+    return out
+
+
+def lrelu_bwd_add(dy, x, r, slope):
+    """leaky_relu'(x) * dy + r in one launch (all three contiguous, same shape)."""
+    require_gpu(dy, x, r)
+    dy, x, r = dy.contiguous(), x.contiguous(), r.contiguous()
+    out = torch.empty_like(x)
+    check(tlib().svc_lrelu_bwd_add_f32(ptr(dy), ptr(x), ptr(r), ptr(out), x.numel(), float(slope), stream_ptr()), "lrelu_bwd_add")
     return out
 
 

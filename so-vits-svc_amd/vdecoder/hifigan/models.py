@@ -57,8 +57,10 @@ class ResBlock1(nn.Module):
         for c1, c2 in zip(self.convs1, self.convs2):
             if FUSED_TRAIN and c1.fused_train_ok() and c2.fused_train_ok():
                 # the leaky ReLU in front of c2 in c1's epilogue (c1's raw output has no other reader), `xt + x` in c2's
-                xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE), post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE)
-                x = c2.forward_train(xt, res=x)
+                # x feeds lrelu -> c1 and the residual: one autograd node with two outputs, so the gradients meet in one launch
+                xa, xr = A.leaky_relu_res(x, LRELU_SLOPE)
+                xt = c1.forward_train(xa, post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE)
+                x = c2.forward_train(xt, res=xr)
             else:
                 xt = c1.forward_train(A.leaky_relu(x, LRELU_SLOPE))
                 xt = c2.forward_train(A.leaky_relu(xt, LRELU_SLOPE))
@@ -151,7 +153,8 @@ class ResBlock2(nn.Module):
         """Reference vdecoder/hifigan/models.py:88-93."""
         for c in self.convs:
             if FUSED_TRAIN and c.fused_train_ok():
-                x = c.forward_train(A.leaky_relu(x, LRELU_SLOPE), res=x)
+                xa, xr = A.leaky_relu_res(x, LRELU_SLOPE)
+                x = c.forward_train(xa, res=xr)
             else:
                 x = A.add(c.forward_train(A.leaky_relu(x, LRELU_SLOPE)), x)
         return x
