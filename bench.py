@@ -659,6 +659,10 @@ def main():
         if isinstance(ih, dict) and "ms_per_step" in ih:
             ih["speedup_vs_f32"] = round(1e3 * elapsed / args.steps / ih["ms_per_step"], 3)
         extras["infer_half"] = ih
+        isp = X.guarded(X.bench_infer_split, dev, net, (c, f0, uv, sid), T_FRAMES)
+        if isinstance(isp, dict) and "ms_per_step" in isp:
+            isp["speedup_vs_f32_mfma"] = round(1e3 * elapsed / args.steps / isp["ms_per_step"], 3)
+        extras["infer_split"] = isp
 
     train_res = None
     if args.mode == "both":

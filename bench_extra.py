@@ -172,6 +172,49 @@ def bench_infer_half(dev, net, inputs, frames, steps=20):
                 families=fams)
 
 
+def bench_infer_split(dev, net, inputs, frames, steps=20, oracle_err=None):
+    """The headline clip with the generator on the SPLIT pipeline (SynthesizerTrn.split_f16(); csrc/conv1d_hl.hip): fp32 inference
+    whose generator convolutions run on the fp16 matrix instruction at fp32-level precision — every value a hi and a lo fp16 plane
+    (22 mantissa bits), every product three fp16 instructions with fp32 accumulation, where the fp32 instruction needs sixteen.
+    Own key, never the headline (the headline is the fp32-MFMA path).  The waveform's distance to the fp32-MFMA path on the same noise
+    is measured here; the FLOPs counted are the convolutions' (one multiply-add per product, not three), against the fp32 MFMA peak —
+    a fraction above 1 is what the split buys."""
+    c, f0, uv, sid = inputs
+    noise = dict(enc_p=torch.randn(1, net.inter_channels, frames, device=dev), rand_ini=torch.rand(1, 9, device=dev),
+                 sine=torch.randn(1, frames * net.dec.upp, 9, device=dev))
+    was_graph = net.use_graph
+    net.enable_graph(False)
+    o32, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+    net.split_f16()
+    try:
+        oh, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+        mse = (oh - o32).pow(2).mean().item()
+        mx = (oh - o32).abs().max().item()
+        fams = _families(lambda: net.infer(c, f0, uv, g=sid, noice_scale=0.4), n=3)
+        net.enable_graph(True)
+        step = lambda: net.infer(c, f0, uv, g=sid, noice_scale=0.4)
+        dt = _timeit(step, steps, warm=3)
+    finally:
+        net.float()
+        net.enable_graph(was_graph)
+    samples = frames * HOP
+    h = {k: v for k, v in fams.items() if k.endswith("_hl")}
+    hms = sum(v["ms_per_step"] for v in h.values())
+    hflop = sum(v["tflops"] * v["ms_per_step"] * 1e9 for v in h.values())
+    ach = hflop / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
+    return dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.split_f16().infer)", value=samples / dt, unit="samples/s",
+                ms_per_step=round(1e3 * dt, 4), steps=steps,
+                dtype="f32 values as hi + lo fp16 planes in the generator (22 mantissa bits), 3 fp16 MFMA per product, f32 accumulate; "
+                      "encoder / flow / harmonic source f32", launch="hipGraph replay",
+                waveform_vs_f32_mfma_path=dict(mse=mse, max_abs=mx, max_abs_waveform=o32.abs().max().item()),
+                roofline=dict(bound="mfma", kernel="+".join(sorted(h)), achieved=round(ach, 1), peak=157.3, peak_f16_issued=2500.0,
+                              unit="TFLOP/s", frac=round(ach / 157.3, 4), frac_of_f16_peak_issued=round(3 * ach / 2500.0, 4),
+                              kernel_ms_per_step=round(hms, 4), traffic=None,
+                              note="split conv launches of the generator (serialised eager pass, hipEvents per launch): delivered "
+                                   "convolution FLOPs against the fp32 MFMA peak; the instructions issued are 3x that, against the f16 peak"),
+                families=fams)
+
+
 def bench_snake_b8(dev, steps=3):
     import models
     import synthetic_data as W

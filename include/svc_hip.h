@@ -353,6 +353,20 @@ int svc_cvt_from_h(const void* x, float* y, int B, int C, int T, void* stream);
 int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
                     float pre_slope, int act, void* stream);
 
+/* ---- split pipeline (csrc/conv1d_hl.hip): the same decoder convolutions (vdecoder/hifigan/models.py:41-67,340-342,378,390-392) at
+ * fp32-level precision on the fp16 matrix instruction.  A fp32 value v is two fp16 values, hi = rn16(v) and lo = rn16(v - hi)
+ * (hi + lo = v to 22 mantissa bits); a product is a_hi b_hi + a_hi b_lo + a_lo b_hi, three fp16 instructions with fp32
+ * accumulation in place of sixteen fp32 ones.  Every tensor of the 16-bit pipeline gains a second plane behind the first:
+ * activations fp16 [2][B][C/8][T][8], weight packs fp16 [2][Cin/16][taps][RP][16] (plane 0 = hi, 1 = lo; contiguous).  Entry points
+ * mirror the 16-bit ones one for one and take the same argument struct (x / res / y / w point at plane 0). */
+int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
+int svc_conv1d_hl(const svc_conv1d_h_args* a, void* stream);
+int svc_cvt_to_hl(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
+                  int B, int C, int T, void* stream);
+int svc_cvt_from_hl(const void* x, float* y, int B, int C, int T, void* stream);
+int svc_conv_post_hl(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
+                     float pre_slope, int act, void* stream);
+
 
 /* ================================================================================================
  * TRAINING path.  Backward of the convolutions above plus the small ops of the

@@ -1,0 +1,442 @@
+// conv1d_hl.hip — the decoder's convolutions at fp32-level precision on the fp16 matrix pipe ("split" pipeline).
+//
+// gfx950 multiplies fp16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_f16: 2.5 PFLOP/s; v_mfma_f32_32x32x2_f32: 157 TFLOP/s),
+// both accumulating in fp32.  A fp32 number v is carried as TWO fp16 numbers, hi = rn16(v), lo = rn16(v - hi): hi + lo reproduces v
+// to 22 mantissa bits (|v - hi - lo| <= 2^-22 |v| while lo is a normal or subnormal fp16, i.e. down to 2^-24 absolute), and a product
+// of two such pairs is  a_hi b_hi + a_hi b_lo + a_lo b_hi  (+ a_lo b_lo, 2^-22 relative, dropped): THREE fp16 instructions — each
+// fp16 x fp16 product is exact in the fp32 accumulator — replace SIXTEEN fp32 ones, and the sums round in fp32 exactly as the fp32
+// instruction's do.  The pipeline is the 16-bit one of conv1d_h.hip (blocked [B][C/8][T][8] activations, [Cin/16][tap][rows][16] weight
+// packs, B operand = one ds_read_b128, A operand from L2 through a ring of chunks, phases-as-rows ConvTranspose1d) with a second PLANE
+// behind every tensor: activations [2][B][C/8][T][8], weights [2][Cin/16][tap][RP][16] (plane 0 = hi, plane 1 = lo) — the same bytes
+// as the fp32 tensors.  What the reference computes here: ResBlock1 convs vdecoder/hifigan/models.py:41-67, ups :340-342,378,
+// conv_post :390-392 — in fp32 (`net_g_ms` without .half()); measured against that the split pipeline is as close as the fp32 MFMA
+// path is (tests/test_split_gpu.py), which is why it is offered as a precision mode of fp32 inference and not of the half mode.
+//
+// Differences from conv1d_h_kernel: two planes double the LDS tile, so the input channels are staged in chunks of GC groups (one
+// barrier pair per chunk; the accumulators live across chunks); the pre-activation is applied to hi + lo in fp32 and re-split;
+// the ring holds 2 steps x 2 planes per chunk (a step is 3 MT NT instructions: the same matrix time per chunk as four 16-bit steps).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct HLP {
+  svc_conv1d_h_args a;
+  int XW;   // columns of the staged tile: BN + (KS - 1) * dil
+  int G;    // Cin / 16
+  int GC;   // channel groups staged per chunk
+  int R;    // valid rows
+  long long xplane, yplane, wplane;   // elements (halves) between the hi and the lo plane
+};
+
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+template <int KS, int MT, int NT, int CH>
+__device__ __forceinline__ void mma_steps_hl(f32x16 (&acc)[MT][NT], const h8* __restrict__ wp, long long wplane8, long long sstride,
+                                             int S, const h8* __restrict__ xw, int lplane8, int XW, int dil) {
+  // wp: this lane's first hi A fragment (+ step * sstride + mt * 64; lo at + wplane8); xw: this lane's hi B base (lo at + lplane8)
+  auto wload = [&](h8 (&af)[CH][MT][2], int s0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const h8* q = wp + min(s0 + j, S - 1) * sstride + mt * 64;
+        af[j][mt][0] = q[0];
+        af[j][mt][1] = q[wplane8];
+      }
+  };
+  auto chunk = [&](const h8 (&af)[CH][MT][2], int s0) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int sidx = s0 + j;
+      if (sidx < S) {
+        const int g = sidx / KS, tap = sidx - g * KS;
+        const h8* xr = xw + 2 * g * XW + tap * dil;
+        h8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bh[nt] = xr[nt * 32];
+          bl[nt] = xr[lplane8 + nt * 32];
+        }
+        // term-major: MT NT independent accumulators between two instructions on the same one
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][1], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+  h8 a0[CH][MT][2], a1[CH][MT][2];
+  wload(a0, 0);
+  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
+    if (s0 + CH < S) wload(a1, s0 + CH);
+    chunk(a0, s0);
+    if (s0 + CH < S) {
+      if (s0 + 2 * CH < S) wload(a0, s0 + 2 * CH);
+      chunk(a1, s0 + CH);
+    }
+  }
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  const svc_conv1d_h_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_hl[];
+  const int XW = p.XW, GC = p.GC;
+  const int lplane8 = 2 * GC * XW;              // h8 words per LDS plane
+  h8* xs = reinterpret_cast<h8*>(smem_hl);      // [2][2 GC][XW]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int t0 = blockIdx.x * BN, r0 = blockIdx.y * BM, b = blockIdx.z;
+  const int CB = a.Cin >> 3;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const h8* xg = reinterpret_cast<const h8*>(a.x) + (long long)b * CB * a.Tin;
+  const long long xplane8 = p.xplane >> 3, wplane8 = p.wplane >> 3;
+  const h8* wp = reinterpret_cast<const h8*>(a.w) + ((long long)(r0 + wm * MT * 32 + li)) * 2 + kh;
+  const long long sstride = (long long)a.RP * 2;
+  const float ps = a.pre_slope;
+  const bool act = a.pre_slope != 1.f;
+
+  for (int g0 = 0; g0 < p.G; g0 += GC) {
+    const int gc = min(GC, p.G - g0);
+    if (g0) __syncthreads();                    // every wave is done with the previous chunk's tile
+    // ---- stage channel blocks [2 g0, 2 (g0 + gc)) of both planes; the pre-activation acts on hi + lo and is split again
+    {
+      const int total = 2 * gc * XW;
+      constexpr int LD = 4;
+      for (int base = tid; base < total; base += 256 * LD) {
+        h8 vh[LD], vl[LD];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+          const int idx = base + j * 256;
+          h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          vh[j] = z;
+          vl[j] = z;
+          if (idx < total) {
+            const int cbl = idx / XW, tl = idx - cbl * XW;
+            const int tin = t0 - a.pad_left + tl;
+            if (tin >= 0 && tin < a.Tin) {
+              const h8* q = xg + (long long)(2 * g0 + cbl) * a.Tin + tin;
+              vh[j] = q[0];
+              vl[j] = q[xplane8];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+          const int idx = base + j * 256;
+          if (idx < total) {
+            if (act) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float v = svc_lrelu((float)vh[j][e] + (float)vl[j][e], ps);
+                _Float16 hi, lo;
+                split1(v, hi, lo);
+                vh[j][e] = hi;
+                vl[j][e] = lo;
+              }
+            }
+            xs[idx] = vh[j];
+            xs[lplane8 + idx] = vl[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    mma_steps_hl<KS, MT, NT, 2>(acc, wp + (long long)g0 * KS * sstride, wplane8, sstride, gc * KS, xs + kh * XW + wn * NT * 32 + li,
+                                lplane8, XW, a.dil);
+  }
+
+  // ---- epilogue: bias, activation, residual, accumulate / divide in fp32, split, 8-byte stores into both planes
+  _Float16* yb = reinterpret_cast<_Float16*>(a.y) + (long long)b * a.Cout * a.Ty;
+  const _Float16* rb = a.res ? reinterpret_cast<const _Float16*>(a.res) + (long long)b * a.Cout * a.Ty : nullptr;
+  const bool lre = a.post_act == SVC_ACT_LRELU;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int q = t0 + wn * NT * 32 + nt * 32 + li;
+      if (q >= a.Tq) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row8 = r0 + (wm * MT + mt) * 32 + 8 * i;      // this lane holds rows row8 + 4 kh + (0..3) of column q
+        if (row8 >= p.R) continue;
+        int ph = 0, co8 = row8;
+        if (a.u > 1) {
+          ph = row8 / a.Cout;
+          co8 = row8 - ph * a.Cout;
+        }
+        const int t = a.u > 1 ? q * a.u + ph + a.y_t0 : q;
+        if (t < 0 || t >= a.Ty) continue;
+        const long long off = ((long long)(co8 >> 3) * a.Ty + t) * 8 + 4 * kh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mt][nt][4 * i + e] + (a.bias ? a.bias[co8 + 4 * kh + e] : 0.f);
+          if (lre) v[e] = svc_lrelu(v[e], a.post_slope);
+        }
+        if (rb) {
+          const h4 rh = *reinterpret_cast<const h4*>(rb + off);
+          const h4 rl = *reinterpret_cast<const h4*>(rb + p.yplane + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+        }
+        if (a.beta != 0.f) {
+          const h4 oh = *reinterpret_cast<const h4*>(yb + off);
+          const h4 ol = *reinterpret_cast<const h4*>(yb + p.yplane + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(a.beta, (float)oh[e] + (float)ol[e], v[e]);
+        }
+        if (a.out_div != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] /= a.out_div;
+        }
+        h4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hi, lo;
+          split1(v[e], hi, lo);
+          oh[e] = hi;
+          ol[e] = lo;
+        }
+        *reinterpret_cast<h4*>(yb + off) = oh;
+        *reinterpret_cast<h4*>(yb + p.yplane + off) = ol;
+      }
+    }
+  }
+}
+
+constexpr size_t HL_LDS_TARGET = 72 * 1024;   // two workgroups per CU
+
+template <int KS, int MT, int NT, int WM, int WN>
+int launch_hl(const svc_conv1d_h_args& a, int R, hipStream_t s) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  HLP p;
+  p.a = a;
+  p.XW = BN + (a.KS - 1) * a.dil;
+  p.G = a.Cin / 16;
+  p.R = R;
+  const size_t per_group = (size_t)64 * p.XW;                 // 2 planes x 2 channel blocks x XW x 16 bytes
+  const int gmax = (int)std::max<size_t>(1, HL_LDS_TARGET / per_group);
+  const int nch = svc::cdiv(p.G, gmax);
+  p.GC = svc::cdiv(p.G, nch);
+  p.xplane = (long long)a.B * a.Cin * a.Tin;
+  p.yplane = (long long)a.B * a.Cout * a.Ty;
+  p.wplane = (long long)p.G * a.KS * a.RP * 16;
+  const size_t lds = per_group * p.GC;
+  SVC_REQUIRE(lds <= 160 * 1024, "conv1d_hl: tile of %zu bytes does not fit LDS (KS %d, dil %d)", lds, a.KS, a.dil);
+  auto kern = conv1d_hl_kernel<KS, MT, NT, WM, WN>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  dim3 grid(svc::cdiv(a.Tq, BN), svc::cdiv(R, BM), a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  return svc::check_launch("conv1d_hl");
+}
+
+template <int KS>
+int launch_hl_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
+  // tile choice as launch_h_ks (conv1d_h.hip): narrow wave tiles; 64 x 128 where 128 x 128 would leave CUs without a workgroup
+  if (R >= 128) {
+    const long long wgs128 = (long long)svc::cdiv(R, 128) * svc::cdiv(a.Tq, 128) * a.B;
+    if (wgs128 < 200) return launch_hl<KS, 2, 1, 1, 4>(a, R, s);      //  64 rows x 128 columns
+    return launch_hl<KS, 2, 2, 2, 2>(a, R, s);                        // 128 rows x 128 columns
+  }
+  if (R > 32) return launch_hl<KS, 2, 2, 1, 4>(a, R, s);              //  64 rows x 256 columns
+  return launch_hl<KS, 1, 2, 1, 4>(a, R, s);                          //  32 rows x 256 columns
+}
+
+// ---- weight pack: dense fp32 -> [2][Cin/16][tap][RP][16] fp16 (hi plane, lo plane); index rules of pack_h_kernel (conv1d_h.hip)
+__global__ void pack_hl_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int K, int taps, int RP,
+                               int u, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int j = (int)(idx & 15);
+  long long r = idx >> 4;
+  const int row = (int)(r % RP);
+  r /= RP;
+  const int tap = (int)(r % taps), g = (int)(r / taps);
+  const int ci = g * 16 + j;
+  float v = 0.f;
+  if (u <= 1) {
+    if (row < Cout) v = w[((long long)row * Cin + ci) * K + tap];
+  } else if (row < u * Cout) {
+    const int ph = row / Cout, co = row - ph * Cout;
+    const int k = ph + (taps - 1 - tap) * u;
+    if (k < K) v = w[((long long)ci * Cout + co) * K + k];
+  }
+  _Float16 hi, lo;
+  split1(v, hi, lo);
+  dst[idx] = hi;
+  dst[n + idx] = lo;
+}
+
+// ---- fp32 [B,C,T] (strided) (+ a second fp32 tensor) -> split blocked planes, and back
+__global__ void cvt_to_hl_kernel(const float* __restrict__ x, const float* __restrict__ add, h8* __restrict__ y, long long x_bs,
+                                 long long x_cs, long long a_bs, long long a_cs, int B, int C, int T) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = C >> 3;
+  const long long n = (long long)B * CB * T;
+  if (idx >= n) return;
+  const int t = (int)(idx % T);
+  const long long r = idx / T;
+  const int cb = (int)(r % CB), b = (int)(r / CB);
+  h8 oh, ol;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = x[(long long)b * x_bs + (long long)(cb * 8 + j) * x_cs + t];
+    if (add) v += add[(long long)b * a_bs + (long long)(cb * 8 + j) * a_cs + t];
+    _Float16 hi, lo;
+    split1(v, hi, lo);
+    oh[j] = hi;
+    ol[j] = lo;
+  }
+  y[idx] = oh;
+  y[n + idx] = ol;
+}
+
+__global__ void cvt_from_hl_kernel(const h8* __restrict__ x, float* __restrict__ y, int B, int C, int T) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = C >> 3;
+  const long long n = (long long)B * CB * T;
+  if (idx >= n) return;
+  const int t = (int)(idx % T);
+  const long long r = idx / T;
+  const int cb = (int)(r % CB), b = (int)(r / CB);
+  const h8 vh = x[idx], vl = x[n + idx];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[((long long)b * C + cb * 8 + j) * T + t] = (float)vh[j] + (float)vl[j];
+}
+
+// ---- conv_post (vdecoder/hifigan/models.py:390-392) from the split planes: leaky_relu(0.01) -> Conv1d(C, 1, KS) -> tanh, fp32 out
+__global__ __launch_bounds__(256) void conv_post_hl_kernel(const h8* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int C, int T,
+                                                           int KS, int pad, float pre_slope, int act) {
+  extern __shared__ float wsh_hl[];       // [C][KS]
+  for (int i = threadIdx.x; i < C * KS; i += blockDim.x) wsh_hl[i] = w[i];
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * T) return;
+  const int t = (int)(idx % T), b = (int)(idx / T);
+  const int CB = C >> 3;
+  const long long plane = (long long)B * CB * T;
+  float acc = bias ? bias[0] : 0.f;
+  for (int cb = 0; cb < CB; ++cb) {
+    const h8* xr = x + ((long long)b * CB + cb) * T;
+    for (int k = 0; k < KS; ++k) {
+      const int tin = t - pad + k;
+      if (tin < 0 || tin >= T) continue;
+      const h8 vh = xr[tin], vl = xr[plane + tin];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(svc_lrelu((float)vh[j] + (float)vl[j], pre_slope), wsh_hl[(cb * 8 + j) * KS + k], acc);
+    }
+  }
+  y[idx] = act == SVC_ACT_TANH ? tanhf(acc) : acc;
+}
+
+}  // namespace
+
+extern "C" int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream) {
+  SVC_REQUIRE(w && dst, "pack_conv1d_hl: null tensor");
+  SVC_REQUIRE(Cout > 0 && Cin > 0 && (Cin % 16) == 0 && K >= 1 && u >= 1, "pack_conv1d_hl: bad shape (Cin must be a multiple of 16)");
+  const int taps = u > 1 ? (K + u - 1) / u : K;
+  const int R = u > 1 ? u * Cout : Cout;
+  SVC_REQUIRE(RP >= R && (RP % 128) == 0, "pack_conv1d_hl: RP must be a multiple of 128 >= the row count %d", R);
+  const long long n = (long long)taps * (Cin / 16) * RP * 16;
+  hipLaunchKernelGGL(pack_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<_Float16*>(dst), Cout, Cin, K, taps, RP, u, n);
+  return svc::check_launch("pack_conv1d_hl");
+}
+
+extern "C" int svc_conv1d_hl(const svc_conv1d_h_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "conv1d_hl: null args");
+  const svc_conv1d_h_args& a = *ap;
+  SVC_REQUIRE(a.x && a.w && a.y, "conv1d_hl: null tensor");
+  SVC_REQUIRE(a.B > 0 && a.Cin > 0 && a.Cout > 0 && a.Tin > 0 && a.Tq > 0 && a.Ty > 0, "conv1d_hl: empty shape");
+  SVC_REQUIRE((a.Cin % 16) == 0 && (a.Cout % 8) == 0, "conv1d_hl: Cin must be a multiple of 16 and Cout of 8 (got %d, %d)", a.Cin, a.Cout);
+  SVC_REQUIRE(a.dil >= 1 && a.u >= 1 && (a.RP % 128) == 0, "conv1d_hl: bad dil / u / RP");
+  SVC_REQUIRE(a.post_act == SVC_ACT_NONE || a.post_act == SVC_ACT_LRELU, "conv1d_hl: post_act must be none or leaky_relu");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.y) |
+                reinterpret_cast<uintptr_t>(a.res)) & 15) == 0, "conv1d_hl: tensors must be 16-byte aligned");
+  SVC_REQUIRE((((long long)a.B * a.Cin * a.Tin) & 7) == 0 && (((long long)a.B * a.Cout * a.Ty) & 7) == 0, "conv1d_hl: plane size");
+  const int R = a.u > 1 ? a.u * a.Cout : a.Cout;
+  SVC_REQUIRE(a.RP >= R, "conv1d_hl: RP %d below the row count %d", a.RP, R);
+  hipStream_t s = (hipStream_t)stream;
+  // profile rows carry the fp32 convolution's FLOPs (what the launch delivers), not the three instructions issued per product
+  const double flop = 2.0 * a.B * (double)R * a.Cin * a.KS * a.Tq;
+  const double bytes = 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Ty * (a.res ? 2 : 1));
+  char pname[96];
+  if (svc::prof_on() && svc::prof_shapes())
+    snprintf(pname, sizeof(pname), "%s[B%d,Ci%d,Co%d,K%d,d%d,T%d]", a.u > 1 ? "convt1d_hl" : "conv1d_hl", a.B, a.Cin, a.Cout, a.KS, a.dil, a.Tq);
+  else
+    snprintf(pname, sizeof(pname), "%s", a.u > 1 ? "convt1d_hl" : "conv1d_hl");
+  svc::ProfScope prof(s, pname, flop, bytes);
+  switch (a.KS) {
+    case 1: return launch_hl_ks<1>(a, R, s);
+    case 2: return launch_hl_ks<2>(a, R, s);
+    case 3: return launch_hl_ks<3>(a, R, s);
+    case 7: return launch_hl_ks<7>(a, R, s);
+    case 11: return launch_hl_ks<11>(a, R, s);
+    default: SVC_REQUIRE(false, "conv1d_hl: tap count %d not built (1, 2, 3, 7, 11)", a.KS);
+  }
+  return SVC_OK;
+}
+
+extern "C" int svc_cvt_to_hl(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs,
+                             long long add_cs, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "cvt_to_hl: bad args (C must be a multiple of 8)");
+  const long long n = (long long)B * (C / 8) * T;
+  hipLaunchKernelGGL(cvt_to_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, x, add,
+                     reinterpret_cast<h8*>(y), x_bs, x_cs, add_bs, add_cs, B, C, T);
+  return svc::check_launch("cvt_to_hl");
+}
+
+extern "C" int svc_cvt_from_hl(const void* x, float* y, int B, int C, int T, void* stream) {
+  SVC_REQUIRE(x && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "cvt_from_hl: bad args");
+  const long long n = (long long)B * (C / 8) * T;
+  hipLaunchKernelGGL(cvt_from_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), y, B, C, T);
+  return svc::check_launch("cvt_from_hl");
+}
+
+extern "C" int svc_conv_post_hl(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
+                                float pre_slope, int act, void* stream) {
+  SVC_REQUIRE(x && w && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0 && KS >= 1, "conv_post_hl: bad args");
+  SVC_REQUIRE((size_t)C * KS * 4 <= 48 * 1024, "conv_post_hl: weight does not fit LDS");
+  const long long n = (long long)B * T;
+  svc::ProfScope prof((hipStream_t)stream, "conv_post_hl", 2.0 * n * C * KS, 4.0 * n * C + 4.0 * n);
+  hipLaunchKernelGGL(conv_post_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), (size_t)C * KS * 4, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), w, bias, y, B, C, T, KS, pad, pre_slope, act);
+  return svc::check_launch("conv_post_hl");
+}

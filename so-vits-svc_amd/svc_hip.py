@@ -134,6 +134,12 @@ def lib():
         L.svc_cvt_from_h.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.svc_conv_post_h.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                       C.c_void_p]
+        for sfx in ("hl",):     # the split pipeline's entry points mirror the 16-bit ones
+            getattr(L, "svc_pack_conv1d_" + sfx).argtypes = L.svc_pack_conv1d_h.argtypes
+            getattr(L, "svc_conv1d_" + sfx).argtypes = L.svc_conv1d_h.argtypes
+            getattr(L, "svc_cvt_to_" + sfx).argtypes = L.svc_cvt_to_h.argtypes
+            getattr(L, "svc_cvt_from_" + sfx).argtypes = L.svc_cvt_from_h.argtypes
+            getattr(L, "svc_conv_post_" + sfx).argtypes = L.svc_conv_post_h.argtypes
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
@@ -162,7 +168,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -424,14 +430,24 @@ def _require_gpu_h(*tensors):
             raise SvcError(f"svc_hip 16-bit ops take fp16 / fp32 tensors; got {t.dtype}")
 
 
-def _check_h(t, what):
-    if t.dtype != torch.float16 or t.dim() != 4 or t.shape[3] != 8 or not t.is_contiguous():
-        raise SvcError(f"{what}: expected a contiguous fp16 [B, C/8, T, 8] tensor, got {t.dtype} {tuple(t.shape)}")
+def _check_h(t, what, split=None):
+    """A blocked fp16 activation: [B, C/8, T, 8], or [2, B, C/8, T, 8] (hi plane, lo plane) on the split pipeline."""
+    ok = t.dtype == torch.float16 and t.is_contiguous() and t.shape[-1] == 8 and \
+        (t.dim() == 4 or (t.dim() == 5 and t.shape[0] == 2))
+    if ok and split is not None:
+        ok = (t.dim() == 5) == bool(split)
+    if not ok:
+        raise SvcError(f"{what}: expected a contiguous fp16 [B, C/8, T, 8] (or split [2, B, C/8, T, 8]) tensor, got {t.dtype} {tuple(t.shape)}")
 
 
-def pack_conv1d_h(w, u=1):
+def is_split(t):
+    """True for a tensor of the split (hi / lo plane) pipeline (csrc/conv1d_hl.hip)."""
+    return t.dim() == 5
+
+
+def pack_conv1d_h(w, u=1, split=False):
     """Dense fp32 weight (weight norm folded) -> the fp16 operand pack of svc_conv1d_h.  u == 1: Conv1d [Cout, Cin, K];
-    u > 1: ConvTranspose1d [Cin, Cout, K] with stride u (phases as rows)."""
+    u > 1: ConvTranspose1d [Cin, Cout, K] with stride u (phases as rows).  split: the [2, ...] hi / lo pack of svc_conv1d_hl."""
     _require_gpu_h(w)
     w = w.detach().float().contiguous()
     if u > 1:
@@ -441,34 +457,37 @@ def pack_conv1d_h(w, u=1):
         Cout, Cin, K = w.shape
         taps, R = K, Cout
     RP = round_up(R, 128)
-    dst = torch.empty((Cin // 16, taps, RP, 16), device=w.device, dtype=torch.float16)
-    check(lib().svc_pack_conv1d_h(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
+    dst = torch.empty(((2,) if split else ()) + (Cin // 16, taps, RP, 16), device=w.device, dtype=torch.float16)
+    fn = lib().svc_pack_conv1d_hl if split else lib().svc_pack_conv1d_h
+    check(fn(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
     return dst
 
 
 def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=1.0, post_slope=None, res=None, out=None, beta=0.0,
              out_div=1.0):
-    """Conv1d on the 16-bit pipeline: x / res / out are blocked fp16 [B, C/8, T, 8]; wp from pack_conv1d_h."""
+    """Conv1d on the 16-bit pipeline: x / res / out are blocked fp16 [B, C/8, T, 8]; wp from pack_conv1d_h.  With split tensors
+    ([2, B, C/8, T, 8] and a split pack) the same call runs the split pipeline (svc_conv1d_hl)."""
     _require_gpu_h(x, wp, bias, res, out)
     _check_h(x, "conv1d_h")
-    B, CB, Tin, _ = x.shape
-    KS = wp.shape[1]
-    if wp.shape[0] * 16 != CB * 8:
-        raise SvcError(f"conv1d_h: packed weight {tuple(wp.shape)} does not match Cin={CB * 8}")
+    sp = is_split(x)
+    B, CB, Tin, _ = x.shape[-4:]
+    KS = wp.shape[-3]
+    if wp.shape[-4] * 16 != CB * 8 or (wp.dim() == 5) != sp:
+        raise SvcError(f"conv1d_h: packed weight {tuple(wp.shape)} does not match the input {tuple(x.shape)}")
     if Tout is None:
         Tout = Tin
     if out is None:
-        out = torch.empty((B, Cout // 8, Tout, 8), device=x.device, dtype=torch.float16)
-    _check_h(out, "conv1d_h out")
+        out = torch.empty(((2,) if sp else ()) + (B, Cout // 8, Tout, 8), device=x.device, dtype=torch.float16)
+    _check_h(out, "conv1d_h out", sp)
     a = Conv1dHArgs()
     a.x, a.w, a.bias, a.res, a.y = _hptr(x), _hptr(wp), ptr(bias), _hptr(res), _hptr(out)
     if res is not None:
-        _check_h(res, "conv1d_h res")
+        _check_h(res, "conv1d_h res", sp)
     a.B, a.Cin, a.Cout, a.Tin, a.Tq, a.Ty = B, CB * 8, Cout, Tin, Tout, Tout
-    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = KS, dil, pad_left, 1, 0, wp.shape[2]
+    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = KS, dil, pad_left, 1, 0, wp.shape[-2]
     a.post_act = ACT_LRELU if post_slope is not None else ACT_NONE
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope or 0.0, beta, out_div
-    check(lib().svc_conv1d_h(C.byref(a), stream_ptr()), "conv1d_h")
+    check((lib().svc_conv1d_hl if sp else lib().svc_conv1d_h)(C.byref(a), stream_ptr()), "conv1d_h")
     return out
 
 
@@ -479,7 +498,7 @@ def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0,
     """out = (beta * out + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x) / out_div on blocked fp16 tensors, one launch
     (svc_resblock_pair_h); w1p / w2p from pack_conv1d_h, both with the same tap count."""
     _require_gpu_h(x, w1p, b1, w2p, b2, out)
-    _check_h(x, "resblock_pair_h")
+    _check_h(x, "resblock_pair_h", False)
     B, CB, T, _ = x.shape
     KS = w1p.shape[1]
     if tuple(w1p.shape) != tuple(w2p.shape) or w1p.shape[0] * 16 != CB * 8:
@@ -497,7 +516,7 @@ def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0,
 def snake_alias_h(xh, alpha, beta, taps, out=None):
     """SnakeAlias on a blocked fp16 tensor (svc_snake_alias_h); out may not be xh (a tile reads its neighbours' halo)."""
     _require_gpu_h(xh, alpha, beta, out)
-    _check_h(xh, "snake_alias_h")
+    _check_h(xh, "snake_alias_h", False)
     B, CB, T, _ = xh.shape
     if out is None:
         out = torch.empty_like(xh)
@@ -512,30 +531,39 @@ def conv_transpose1d_h(x, wp, Cout, K, stride, padding, *, bias=None, pre_slope=
     """ConvTranspose1d on the 16-bit pipeline (phases as rows); wp from pack_conv1d_h(w, u=stride)."""
     _require_gpu_h(x, wp, bias, res, out)
     _check_h(x, "conv_transpose1d_h")
-    B, CB, Tin, _ = x.shape
-    M = wp.shape[1]
+    sp = is_split(x)
+    B, CB, Tin, _ = x.shape[-4:]
+    M = wp.shape[-3]
+    if (wp.dim() == 5) != sp:
+        raise SvcError("conv_transpose1d_h: split input needs a split pack (and the other way round)")
     Lout = (Tin - 1) * stride - 2 * padding + K
     if out is None:
-        out = torch.empty((B, Cout // 8, Lout, 8), device=x.device, dtype=torch.float16)
+        out = torch.empty(((2,) if sp else ()) + (B, Cout // 8, Lout, 8), device=x.device, dtype=torch.float16)
+    _check_h(out, "conv_transpose1d_h out", sp)
+    if res is not None:
+        _check_h(res, "conv_transpose1d_h res", sp)
     a = Conv1dHArgs()
     a.x, a.w, a.bias, a.res, a.y = _hptr(x), _hptr(wp), ptr(bias), _hptr(res), _hptr(out)
     a.B, a.Cin, a.Cout, a.Tin, a.Ty = B, CB * 8, Cout, Tin, Lout
     a.Tq = (Lout - 1 + padding) // stride + 1
-    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = M, 1, M - 1, stride, -padding, wp.shape[2]
+    a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = M, 1, M - 1, stride, -padding, wp.shape[-2]
     a.post_act, a.pre_slope, a.post_slope, a.beta, a.out_div = ACT_NONE, pre_slope, 0.0, 0.0, 1.0
-    check(lib().svc_conv1d_h(C.byref(a), stream_ptr()), "conv_transpose1d_h")
+    check((lib().svc_conv1d_hl if sp else lib().svc_conv1d_h)(C.byref(a), stream_ptr()), "conv_transpose1d_h")
     return out
 
 
-def to_h(x, add=None, out=None):
-    """fp32 [B, C, T] (time-contiguous view) (+ add) -> blocked fp16 [B, C/8, T, 8]."""
+def to_h(x, add=None, out=None, split=False):
+    """fp32 [B, C, T] (time-contiguous view) (+ add) -> blocked fp16 [B, C/8, T, 8]; split: -> [2, B, C/8, T, 8], hi and lo planes
+    with hi + lo = the fp32 value to 22 bits."""
     _require_gpu_h(x, add, out)
     B, Cc, T = x.shape
     if out is None:
-        out = torch.empty((B, Cc // 8, T, 8), device=x.device, dtype=torch.float16)
+        out = torch.empty(((2,) if split else ()) + (B, Cc // 8, T, 8), device=x.device, dtype=torch.float16)
+    _check_h(out, "to_h out", split)
     xb, xc = _bct_strides(x)
     ab, ac = _bct_strides(add) if add is not None else (0, 0)
-    check(lib().svc_cvt_to_h(ptr(x), ptr(add), _hptr(out), xb, xc, ab, ac, B, Cc, T, stream_ptr()), "cvt_to_h")
+    fn = lib().svc_cvt_to_hl if split else lib().svc_cvt_to_h
+    check(fn(ptr(x), ptr(add), _hptr(out), xb, xc, ab, ac, B, Cc, T, stream_ptr()), "cvt_to_h")
     return out
 
 
@@ -543,9 +571,10 @@ def from_h(xh):
     """Blocked fp16 [B, C/8, T, 8] -> fp32 [B, C, T]."""
     _require_gpu_h(xh)
     _check_h(xh, "from_h")
-    B, CB, T, _ = xh.shape
+    B, CB, T, _ = xh.shape[-4:]
     out = torch.empty((B, CB * 8, T), device=xh.device, dtype=torch.float32)
-    check(lib().svc_cvt_from_h(_hptr(xh), ptr(out), B, CB * 8, T, stream_ptr()), "cvt_from_h")
+    fn = lib().svc_cvt_from_hl if is_split(xh) else lib().svc_cvt_from_h
+    check(fn(_hptr(xh), ptr(out), B, CB * 8, T, stream_ptr()), "cvt_from_h")
     return out
 
 
@@ -553,11 +582,12 @@ def conv_post_h(xh, w, bias, KS, pad, pre_slope=0.01, act=None):
     """leaky_relu -> Conv1d(C -> 1) -> act on a blocked fp16 input; fp32 arithmetic and output [B, 1, T]."""
     _require_gpu_h(xh, w, bias)
     _check_h(xh, "conv_post_h")
-    B, CB, T, _ = xh.shape
+    B, CB, T, _ = xh.shape[-4:]
     out = torch.empty((B, 1, T), device=xh.device, dtype=torch.float32)
     w = w.detach().float().contiguous()
-    check(lib().svc_conv_post_h(_hptr(xh), ptr(w), ptr(bias), ptr(out), B, CB * 8, T, KS, pad, pre_slope,
-                                ACT_TANH if act is None else act, stream_ptr()), "conv_post_h")
+    fn = lib().svc_conv_post_hl if is_split(xh) else lib().svc_conv_post_h
+    check(fn(_hptr(xh), ptr(w), ptr(bias), ptr(out), B, CB * 8, T, KS, pad, pre_slope,
+             ACT_TANH if act is None else act, stream_ptr()), "conv_post_h")
     return out
 
 

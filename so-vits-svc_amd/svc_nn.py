@@ -104,13 +104,14 @@ class Conv1d(nn.Module, _PackedMixin):
                 return S.weight_norm_fwd(self.weight_v.detach(), self.weight_g.detach().reshape(-1))[0]
             return self.weight.detach()
 
-    def packed_h(self):
-        return self._get_packed(("h",), lambda: S.pack_conv1d_h(self.dense_weight()))
+    def packed_h(self, split=False):
+        return self._get_packed(("h", bool(split)), lambda: S.pack_conv1d_h(self.dense_weight(), split=split))
 
     def run_h(self, xh, **kw):
         """Stride-1 dense conv on blocked fp16 activations; keyword arguments are the epilogue options of svc_hip.conv1d_h."""
         _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
-        return S.conv1d_h(xh, self.packed_h(), self.out_channels, bias=self.bias, dil=self.dilation, pad_left=self.padding, **kw)
+        return S.conv1d_h(xh, self.packed_h(S.is_split(xh)), self.out_channels, bias=self.bias, dil=self.dilation,
+                          pad_left=self.padding, **kw)
 
     # -- compute ------------------------------------------------------------------------------------------
     def _is_direct(self):
@@ -309,7 +310,7 @@ class ConvTranspose1d(nn.Module, _PackedMixin):
     def effective_weight(self):
         return A.weight_norm(self.weight_v, self.weight_g) if self.is_weight_norm else self.weight
 
-    def packed_h(self):
+    def packed_h(self, split=False):
         """fp16 operand pack (phases as rows) of the weight-norm-folded weight for svc_conv1d_h's transposed form."""
         def fn():
             with torch.no_grad():
@@ -317,12 +318,12 @@ class ConvTranspose1d(nn.Module, _PackedMixin):
                     w = S.weight_norm_fwd(self.weight_v.detach(), self.weight_g.detach().reshape(-1))[0]
                 else:
                     w = self.weight.detach()
-                return S.pack_conv1d_h(w, u=self.stride)
-        return self._get_packed(("cth",), fn)
+                return S.pack_conv1d_h(w, u=self.stride, split=split)
+        return self._get_packed(("cth", bool(split)), fn)
 
     def run_h(self, xh, **kw):
         _no_grad_guard(getattr(self, "weight", None), getattr(self, "weight_v", None), self.bias)
-        return S.conv_transpose1d_h(xh, self.packed_h(), self.out_channels, self.kernel_size, self.stride, self.padding,
+        return S.conv_transpose1d_h(xh, self.packed_h(S.is_split(xh)), self.out_channels, self.kernel_size, self.stride, self.padding,
                                     bias=self.bias, **kw)
 
     def forward_train(self, x):

@@ -112,7 +112,8 @@ class ResBlock1(nn.Module):
         n = len(self.convs1)
         cur = xh
         xt, ping, pong = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(3)]
-        if _FUSE_PAIR_H and xh.shape[1] * 8 <= S.RESBLOCK_PAIR_H_MAX_C and self.convs1[0].kernel_size in (3, 7, 11):
+        if _FUSE_PAIR_H and not S.is_split(xh) and xh.shape[1] * 8 <= S.RESBLOCK_PAIR_H_MAX_C and \
+                self.convs1[0].kernel_size in (3, 7, 11):
             # up to 128 channels: one launch per pair, the intermediate (and its halo) never leaves LDS (svc_resblock_pair_h)
             for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
                 lastp = j == n - 1
@@ -415,18 +416,24 @@ class Generator(nn.Module):
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
 
     # -- half-precision inference: the reference's `net_g_ms.half()` (inference/infer_tool.py:196-198) -----------------------
-    def set_half(self, on=True):
+    def set_half(self, on=True, split=False):
         """Run the generator's convolution stack as the 16-bit pipeline of csrc/conv1d_h.hip: fp16 activations (HBM and LDS) and
         fp16 weights from the first MRF stage on, fp32 accumulation.  What stays fp32, and why: the harmonic source (its phase
         integration needs > 16 bits — the reference's own half mode loses it there), conv_pre and ups[0] on the 862-frame input
-        (latency-bound launches, 1.5 % of the FLOPs) and the waveform that conv_post + tanh emit."""
+        (latency-bound launches, 1.5 % of the FLOPs) and the waveform that conv_post + tanh emit.
+
+        split=True: the SPLIT pipeline of csrc/conv1d_hl.hip instead — every tensor as a hi and a lo fp16 plane (22 mantissa bits),
+        every product as three fp16 matrix instructions: fp32-level results from the fp16 matrix pipe (a precision mode of fp32
+        inference, not of the reference's half mode)."""
         if on and not (self.h["resblock"] == '1' and all(c % 16 == 0 for c in self._stage_channels()[1:]) and
                        all(k in (3, 7, 11) for k in self.h["resblock_kernel_sizes"]) and
                        all(-(-k // u) in (1, 2, 3) for u, k in zip(self.h["upsample_rates"], self.h["upsample_kernel_sizes"]))):
             raise NotImplementedError("half-precision generator: needs ResBlock1 with kernel sizes in {3, 7, 11}, stage widths that are "
                                       "multiples of 16 and upsample kernels of at most 3 taps per phase (both templates' decoders except "
                                       "the tiny template's 200/100/50/25/12 widths)")
-        self.half_mode = bool(on)
+        if on and split and not getattr(self, "SPLIT_OK", True):
+            raise NotImplementedError("the split (hi / lo fp16 plane) pipeline is built for the plain NSF-HiFiGAN generator")
+        self.half_mode = ("split" if split else True) if on else False
         return self
 
     def _stage_channels(self):
@@ -445,13 +452,14 @@ class Generator(nn.Module):
             torch.cuda.current_stream().wait_event(source[1])
         xh = None
         nk = self.num_kernels
+        sp = self.half_mode == "split"
         for i in range(self.num_upsamples):
             xs = source[0][i] if source is not None else self.noise_convs[i](har)     # fp32 [B, C_i, L_i] (:379)
             if i == 0:
                 x = self.ups[0].run(x, pre_slope=LRELU_SLOPE, res=xs)                 # fp32: lrelu + ConvT + add (:377-381)
-                xh = S.to_h(x)
+                xh = S.to_h(x, split=sp)
             else:
-                xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs))
+                xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs, split=sp))
             xh = mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), half=True)
         cp = self.conv_post
         return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,

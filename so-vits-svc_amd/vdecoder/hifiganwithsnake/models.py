@@ -166,6 +166,8 @@ class Generator(base.Generator):
         x = self.conv_post.forward_train(x)
         return A.tanh(x)
 
+    SPLIT_OK = False      # svc_snake_alias_h has no split form
+
     def forward_h(self, x, f0, g=None, noise=None, source=None):
         """forward() in the reference's half-precision mode (base.Generator.set_half): the MRF stages, snakes[1:], ups[1:],
         snake_post and conv_post on blocked fp16 tensors (svc_conv1d_h, svc_snake_alias_h); conv_pre, snakes[0], ups[0] and the
