@@ -346,7 +346,7 @@ int svc_resblock_pair_h(const void* x, const void* w1, const float* b1, const vo
  * 2x intermediate in LDS, fp32 arithmetic; alpha / beta [C] fp32 (log scale), taps12 = the 12 kaiser-sinc taps (HOST array).
  * x and y may alias only if identical. */
 int svc_snake_alias_h(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T, void* stream);
-int svc_debug_set_conv_h(int cfg); /* tuning aid: 0 automatic tile choice, 1 no 64 x 128 tile, 2 four column tiles per wave where they fit */
+int svc_debug_set_conv_h(int cfg); /* tuning aid: 0 automatic tile choice, 1 128 x 128 tiles only, 2 four column tiles per wave where they fit, 3 64 x 128 (not 64 x 64) tiles for under-filled launches */
 int svc_cvt_to_h(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                  int B, int C, int T, void* stream);
 int svc_cvt_from_h(const void* x, float* y, int B, int C, int T, void* stream);
@@ -361,6 +361,10 @@ int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, 
  * mirror the 16-bit ones one for one and take the same argument struct (x / res / y / w point at plane 0). */
 int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
 int svc_conv1d_hl(const svc_conv1d_h_args* a, void* stream);
+/* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..64. */
+int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
+                         int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
+int svc_debug_set_conv_hl(int cfg); /* tuning aid: bit 0 = 64 x 128 (not 64 x 64) tiles for under-filled launches */
 int svc_cvt_to_hl(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                   int B, int C, int T, void* stream);
 int svc_cvt_from_hl(const void* x, float* y, int B, int C, int T, void* stream);

@@ -54,3 +54,27 @@ for (C, L) in ((256, T0 * 8), (128, T0 * 64), (64, T0 * 128), (32, T0 * 256), (1
                 print(f"C={C:3d} L={L:6d} k={k:2d} d={d} {mode}:  f32 {t32:7.1f} us {fl / t32 / 1e6:6.1f} TF   split {tsp:7.1f} us {fl / tsp / 1e6:6.1f} TF"
                       f"   16-bit {th:7.1f} us {fl / th / 1e6:6.1f} TF")
 print("sum over one clip's MRF convolutions, single launches (us):", {k: round(v, 1) for k, v in tot.items()})
+
+# fused pair (svc_resblock_pair_hl) against its two launches
+pair = {"two": 0.0, "one": 0.0}
+for (C, L) in ((64, T0 * 128), (32, T0 * 256), (16, T0 * 512)):
+    x = S.to_h(torch.randn(1, C, L, device=dev), split=True)
+    xt, y = torch.empty_like(x), torch.empty_like(x)
+    for k in (3, 7, 11):
+        for d in (1, 3, 5):
+            w1 = S.pack_conv1d_h(torch.randn(C, C, k, device=dev) / (C * k) ** 0.5, split=True)
+            w2 = S.pack_conv1d_h(torch.randn(C, C, k, device=dev) / (C * k) ** 0.5, split=True)
+            b = torch.randn(C, device=dev)
+            p1, p2 = (k * d - d) // 2, (k - 1) // 2
+
+            def two():
+                S.conv1d_h(x, w1, C, bias=b, dil=d, pad_left=p1, pre_slope=0.1, post_slope=0.1, out=xt)
+                S.conv1d_h(xt, w2, C, bias=b, pad_left=p2, res=x, out=y)
+            t2 = timeit(two)
+            t1 = timeit(lambda: S.resblock_pair_h(x, w1, b, w2, b, d, out=y))
+            pair["two"] += t2
+            pair["one"] += t1
+            fl = 4.0 * C * C * k * L
+            print(f"pair C={C:3d} L={L:6d} k={k:2d} d={d}: two launches {t2:7.1f} us   fused {t1:7.1f} us  {fl / t1 / 1e6:6.1f} TF  "
+                  f"{4.0 * C * L * 3 / t1 / 1e3:6.0f} GB/s")
+print("sum over one clip's split pairs of the <= 64-channel stages (us):", {k: round(v, 1) for k, v in pair.items()})

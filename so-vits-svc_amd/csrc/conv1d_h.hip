@@ -212,7 +212,7 @@ int launch_h(const svc_conv1d_h_args& a, int R, hipStream_t s) {
   return svc::check_launch("conv1d_h");
 }
 
-int g_h_cfg = 0;   // svc_debug_set_conv_h(cfg): 0 automatic; 1 never the 64 x 128 tile; 2 the wide wave tiles (NT = 4) where they fit
+int g_h_cfg = 0;   // svc_debug_set_conv_h(cfg): 0 automatic; 1 128 x 128 only; 2 the wide wave tiles (NT = 4) where they fit; 3 64 x 128 (not 64 x 64) for under-filled launches
 
 template <int KS>
 int launch_h_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
@@ -227,7 +227,10 @@ int launch_h_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
     const long long wgs128 = (long long)svc::cdiv(R, 128) * svc::cdiv(a.Tq, 128) * a.B;
     const size_t lds_wide = (size_t)(a.Cin / 8) * (256 + (a.KS - 1) * a.dil) * 16;
     if (wide && wgs128 >= 320 && lds_wide <= 160 * 1024) return launch_h<KS, 2, 4, 2, 2>(a, R, s);   // 128 rows x 256 columns
-    if (g_h_cfg != 1 && wgs128 < 200) return launch_h<KS, 2, 1, 1, 4>(a, R, s);                       //  64 rows x 128 columns
+    if (g_h_cfg == 3 && wgs128 < 200) return launch_h<KS, 2, 1, 1, 4>(a, R, s);                       //  64 rows x 128 columns
+    // 64 x 64 (two workgroups per CU on the 256-channel stage) against 64 x 128: 11.3 / 17.3 / 22.5 against 13.5 / 18.9 / 23.9 us for
+    // 3 / 7 / 11 taps, 23.4 against 30.1 at dilation 5 (profiles/r09d_conv_h_cfg.txt)
+    if (g_h_cfg != 1 && wgs128 < 200) return launch_h<KS, 1, 1, 2, 2>(a, R, s);                       //  64 rows x  64 columns
     return launch_h<KS, 2, 2, 2, 2>(a, R, s);                                                         // 128 rows x 128 columns
   }
   if (R > 32) {

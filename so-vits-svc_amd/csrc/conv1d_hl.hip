@@ -51,6 +51,8 @@ __device__ __forceinline__ void mma_steps_hl(f32x16 (&acc)[MT][NT], const h8* __
         af[j][mt][1] = q[wplane8];
       }
   };
+  // (Reading the B fragments of step s + 1 in front of the instructions of step s — two register sets — was measured: nothing at
+  // 64..256 channels, 10-15 % slower at 16 / 32; profiles/r09d_conv_hl_cfg.txt.  The second wave of the SIMD covers the LDS round trip.)
   auto chunk = [&](const h8 (&af)[CH][MT][2], int s0) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
 }
 
 constexpr size_t HL_LDS_TARGET = 72 * 1024;   // two workgroups per CU
+int g_hl_cfg = 0;   // svc_debug_set_conv_hl: bit 0 = 64 x 128 instead of 64 x 64 tiles for under-filled launches
 
 template <int KS, int MT, int NT, int WM, int WN>
 int launch_hl(const svc_conv1d_h_args& a, int R, hipStream_t s) {
@@ -268,13 +271,236 @@ int launch_hl(const svc_conv1d_h_args& a, int R, hipStream_t s) {
 template <int KS>
 int launch_hl_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
   // tile choice as launch_h_ks (conv1d_h.hip): narrow wave tiles; 64 x 128 where 128 x 128 would leave CUs without a workgroup
+  // Tried and dropped (profiles/r09c_conv_hl_cfg.txt): s_setprio around the matrix bursts (-1 %), three workgroups per CU
+  // (168 registers: spills, no gain).
   if (R >= 128) {
     const long long wgs128 = (long long)svc::cdiv(R, 128) * svc::cdiv(a.Tq, 128) * a.B;
-    if (wgs128 < 200) return launch_hl<KS, 2, 1, 1, 4>(a, R, s);      //  64 rows x 128 columns
+    if (wgs128 < 200) {
+      if (g_hl_cfg & 1) return launch_hl<KS, 2, 1, 1, 4>(a, R, s);    //  64 rows x 128 columns
+      // the 256-channel stage of one clip (6 896 columns): 216 workgroups of 64 x 128 are one per CU (30 / 46 / 62 us for 3 / 7 / 11
+      // taps), 432 of 64 x 64 two (20 / 36 / 52 us; profiles/r09c_conv_hl_cfg.txt)
+      return launch_hl<KS, 1, 1, 2, 2>(a, R, s);                      //  64 rows x  64 columns
+    }
     return launch_hl<KS, 2, 2, 2, 2>(a, R, s);                        // 128 rows x 128 columns
   }
   if (R > 32) return launch_hl<KS, 2, 2, 1, 4>(a, R, s);              //  64 rows x 256 columns
   return launch_hl<KS, 1, 2, 1, 4>(a, R, s);                          //  32 rows x 256 columns
+}
+
+// ---- fused ResBlock1 pair on the split planes (vdecoder/hifigan/models.py:60-67): y = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x, ONE launch.
+// respair_h_kernel (conv1d_h.hip) with a lo plane behind every tile: the intermediate tile ts (all channels, both planes) stays in
+// LDS for the whole launch, the input tile xs is staged in channel chunks while conv1 accumulates (the two planes of both tiles at
+// once would not leave room for two workgroups per CU).  From 64 channels down the single launches move their algorithmic bytes at
+// 2.5-4 TB/s (profiles/r09a_conv_hl_shapes.txt): the intermediate's round trip is a third of the pair's traffic.  Built for C <= 64.
+struct PPL {
+  const void* x;
+  const void* w1;
+  const void* w2;
+  const float* b1;
+  const float* b2;
+  void* y;
+  int B, C, T, d1, RP, GC;
+  float slope, beta, out_div;
+};
+
+template <int KS, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void respair_hl_kernel(PPL p) {
+  constexpr int N1P = 32 * NT * WN;            // intermediate columns computed per workgroup
+  constexpr int N2 = N1P - (KS - 1);           // output columns per workgroup
+  constexpr int H2 = (KS - 1) / 2;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_hl[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int CB = p.C >> 3, G = p.C >> 4, GC = p.GC;
+  const int h1 = H2 * p.d1;
+  const int XW1 = N1P + 2 * h1, XW2 = N1P + (KS - 1);
+  const int tplane8 = CB * XW2, xplane8l = 2 * GC * XW1;
+  h8* ts = reinterpret_cast<h8*>(smem_hl);     // [2][CB][XW2]    lrelu(c1 + b1), tile column j <-> global t0 - H2 + j
+  h8* xs = ts + 2 * tplane8;                   // [2][2 GC][XW1]  lrelu(x) of one channel chunk, column tl <-> global t0 - H2 - h1 + tl
+  const int t0 = blockIdx.x * N2, b = blockIdx.y;
+  const long long gplane8 = (long long)p.B * CB * p.T;        // h8 words between the planes of x / y
+  const h8* xg = reinterpret_cast<const h8*>(p.x) + (long long)b * CB * p.T;
+  const long long wplane8 = (long long)G * KS * p.RP * 2;
+  const long long rowoff = ((long long)(wm * MT * 32 + li)) * 2 + kh;
+  const long long sstride = (long long)p.RP * 2;
+  const int col = wn * NT * 32 + li;
+
+  for (int idx = tid; idx < 2 * CB * (KS - 1); idx += 256) {   // the halo tail of the intermediate tile (never computed)
+    const int pl = idx / (CB * (KS - 1)), r = idx - pl * CB * (KS - 1);
+    const int cb = r / (KS - 1), e = r - cb * (KS - 1);
+    h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    ts[pl * tplane8 + cb * XW2 + N1P + e] = z;
+  }
+
+  // ---- conv1 over the N1P intermediate columns, the input staged chunk by chunk
+  {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    for (int g0 = 0; g0 < G; g0 += GC) {
+      const int gc = min(GC, G - g0);
+      if (g0) __syncthreads();
+      const int total = 2 * gc * XW1;
+      constexpr int LD = 4;
+      for (int base = tid; base < total; base += 256 * LD) {
+        h8 vh[LD], vl[LD];
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+          const int idx = base + j * 256;
+          h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          vh[j] = z;
+          vl[j] = z;
+          if (idx < total) {
+            const int cbl = idx / XW1, tl = idx - cbl * XW1;
+            const int tin = t0 - H2 - h1 + tl;
+            if (tin >= 0 && tin < p.T) {
+              const h8* q = xg + (long long)(2 * g0 + cbl) * p.T + tin;
+              vh[j] = q[0];
+              vl[j] = q[gplane8];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+          const int idx = base + j * 256;
+          if (idx < total) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = svc_lrelu((float)vh[j][e] + (float)vl[j][e], p.slope);
+              _Float16 hi, lo;
+              split1(v, hi, lo);
+              vh[j][e] = hi;
+              vl[j][e] = lo;
+            }
+            xs[idx] = vh[j];
+            xs[xplane8l + idx] = vl[j];
+          }
+        }
+      }
+      __syncthreads();
+      mma_steps_hl<KS, MT, NT, 2>(acc, reinterpret_cast<const h8*>(p.w1) + rowoff + (long long)g0 * KS * sstride, wplane8, sstride,
+                                  gc * KS, xs + kh * XW1 + col, xplane8l, XW1, p.d1);
+    }
+    _Float16* th = reinterpret_cast<_Float16*>(ts);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = col + nt * 32;
+        const int tg = t0 - H2 + j;
+        const bool inside = tg >= 0 && tg < p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row8 = (wm * MT + mt) * 32 + 8 * i;
+          if (row8 >= p.C) continue;
+          h4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = inside ? svc_lrelu(acc[mt][nt][4 * i + e] + p.b1[row8 + 4 * kh + e], p.slope) : 0.f;
+            _Float16 hi, lo;
+            split1(v, hi, lo);
+            oh[e] = hi;
+            ol[e] = lo;
+          }
+          const long long o = ((long long)((row8 >> 3) * XW2 + j)) * 8 + 4 * kh;
+          *reinterpret_cast<h4*>(th + o) = oh;
+          *reinterpret_cast<h4*>(th + (long long)tplane8 * 8 + o) = ol;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- conv2 from the intermediate tile, residual, accumulate, split, store
+  {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    mma_steps_hl<KS, MT, NT, 2>(acc, reinterpret_cast<const h8*>(p.w2) + rowoff, wplane8, sstride, G * KS, ts + kh * XW2 + col, tplane8,
+                                XW2, 1);
+    const long long gplane = gplane8 * 8;
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y) + (long long)b * p.C * p.T;
+    const _Float16* xb = reinterpret_cast<const _Float16*>(p.x) + (long long)b * p.C * p.T;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = col + nt * 32;
+        const int t = t0 + j;
+        if (j >= N2 || t >= p.T) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row8 = (wm * MT + mt) * 32 + 8 * i;
+          if (row8 >= p.C) continue;
+          const long long off = ((long long)(row8 >> 3) * p.T + t) * 8 + 4 * kh;
+          const h4 rh = *reinterpret_cast<const h4*>(xb + off);
+          const h4 rl = *reinterpret_cast<const h4*>(xb + gplane + off);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * i + e] + p.b2[row8 + 4 * kh + e] + ((float)rh[e] + (float)rl[e]);
+          if (p.beta != 0.f) {
+            const h4 oh = *reinterpret_cast<const h4*>(yb + off);
+            const h4 ol = *reinterpret_cast<const h4*>(yb + gplane + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(p.beta, (float)oh[e] + (float)ol[e], v[e]);
+          }
+          if (p.out_div != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] /= p.out_div;
+          }
+          h4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            _Float16 hi, lo;
+            split1(v[e], hi, lo);
+            oh[e] = hi;
+            ol[e] = lo;
+          }
+          *reinterpret_cast<h4*>(yb + off) = oh;
+          *reinterpret_cast<h4*>(yb + gplane + off) = ol;
+        }
+      }
+  }
+}
+
+template <int KS, int MT, int NT, int WM, int WN>
+int launch_respair_hl(PPL p, hipStream_t s) {
+  constexpr int N1P = 32 * NT * WN, N2 = N1P - (KS - 1);
+  const int h1 = (KS - 1) / 2 * p.d1;
+  const int XW1 = N1P + 2 * h1, XW2 = N1P + KS - 1;
+  const int G = p.C / 16;
+  const size_t ts_bytes = (size_t)2 * (p.C / 8) * XW2 * 16;
+  const size_t per_group = (size_t)64 * XW1;
+  const size_t budget = 78 * 1024;            // two workgroups per CU
+  const int gmax = ts_bytes + per_group <= budget ? (int)((budget - ts_bytes) / per_group) : 1;
+  const int nch = svc::cdiv(G, gmax);
+  p.GC = svc::cdiv(G, nch);
+  const size_t lds = ts_bytes + per_group * p.GC;
+  SVC_REQUIRE(lds <= 160 * 1024, "resblock_pair_hl: tiles of %zu bytes do not fit LDS", lds);
+  auto kern = respair_hl_kernel<KS, MT, NT, WM, WN>;
+  if (lds > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(svc::cdiv(p.T, N2), p.B), dim3(256), lds, s, p);
+  return svc::check_launch("resblock_pair_hl");
+}
+
+template <int KS>
+int launch_respair_hl_ks(const PPL& p, hipStream_t s) {
+  if (p.C > 32) return launch_respair_hl<KS, 2, 1, 1, 4>(p, s);    // 64 rows, 128 intermediate columns
+  return launch_respair_hl<KS, 1, 2, 1, 4>(p, s);                  // 32 rows, 256
 }
 
 // ---- weight pack: dense fp32 -> [2][Cin/16][tap][RP][16] fp16 (hi plane, lo plane); index rules of pack_h_kernel (conv1d_h.hip)
@@ -439,4 +665,35 @@ extern "C" int svc_conv_post_hl(const void* x, const float* w, const float* bias
   hipLaunchKernelGGL(conv_post_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), (size_t)C * KS * 4, (hipStream_t)stream,
                      reinterpret_cast<const h8*>(x), w, bias, y, B, C, T, KS, pad, pre_slope, act);
   return svc::check_launch("conv_post_hl");
+}
+
+extern "C" int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B,
+                                   int C, int T, int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream) {
+  SVC_REQUIRE(x && w1 && w2 && b1 && b2 && y, "resblock_pair_hl: null tensor");
+  SVC_REQUIRE(B > 0 && T > 0 && C >= 16 && C <= 64 && (C % 16) == 0, "resblock_pair_hl: C must be a multiple of 16 in 16..64 (got %d)", C);
+  SVC_REQUIRE(dil1 >= 1 && (RP % 128) == 0 && RP >= C, "resblock_pair_hl: bad dil1 / RP");
+  SVC_REQUIRE(slope > 0.f && slope <= 1.f, "resblock_pair_hl: leaky-ReLU slope in (0, 1]");
+  SVC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
+                reinterpret_cast<uintptr_t>(y)) & 15) == 0, "resblock_pair_hl: tensors must be 16-byte aligned");
+  PPL p;
+  p.x = x; p.w1 = w1; p.w2 = w2; p.b1 = b1; p.b2 = b2; p.y = y;
+  p.B = B; p.C = C; p.T = T; p.d1 = dil1; p.RP = RP; p.GC = 1;
+  p.slope = slope; p.beta = beta; p.out_div = out_div;
+  hipStream_t s = (hipStream_t)stream;
+  char pname[96];
+  if (svc::prof_on() && svc::prof_shapes()) snprintf(pname, sizeof(pname), "resblock_pair_hl[B%d,C%d,K%d,d%d,T%d]", B, C, KS, dil1, T);
+  else snprintf(pname, sizeof(pname), "resblock_pair_hl");
+  svc::ProfScope prof(s, pname, 4.0 * B * (double)C * C * KS * T, 4.0 * B * (double)C * T * 3);
+  switch (KS) {
+    case 3: return launch_respair_hl_ks<3>(p, s);
+    case 7: return launch_respair_hl_ks<7>(p, s);
+    case 11: return launch_respair_hl_ks<11>(p, s);
+    default: SVC_REQUIRE(false, "resblock_pair_hl: tap count %d not built (3, 7, 11)", KS);
+  }
+  return SVC_OK;
+}
+
+extern "C" int svc_debug_set_conv_hl(int cfg) {
+  g_hl_cfg = cfg;
+  return SVC_OK;
 }

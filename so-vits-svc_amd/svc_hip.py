@@ -140,6 +140,7 @@ def lib():
             getattr(L, "svc_cvt_to_" + sfx).argtypes = L.svc_cvt_to_h.argtypes
             getattr(L, "svc_cvt_from_" + sfx).argtypes = L.svc_cvt_from_h.argtypes
             getattr(L, "svc_conv_post_" + sfx).argtypes = L.svc_conv_post_h.argtypes
+            getattr(L, "svc_resblock_pair_" + sfx).argtypes = L.svc_resblock_pair_h.argtypes
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
@@ -168,7 +169,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -492,24 +493,29 @@ def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=
 
 
 RESBLOCK_PAIR_H_MAX_C = 128
+RESBLOCK_PAIR_HL_MAX_C = 64      # split planes: both tiles of 128 channels would leave one workgroup per CU
 
 
 def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0, out_div=1.0):
     """out = (beta * out + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x) / out_div on blocked fp16 tensors, one launch
     (svc_resblock_pair_h); w1p / w2p from pack_conv1d_h, both with the same tap count."""
     _require_gpu_h(x, w1p, b1, w2p, b2, out)
-    _check_h(x, "resblock_pair_h", False)
-    B, CB, T, _ = x.shape
-    KS = w1p.shape[1]
-    if tuple(w1p.shape) != tuple(w2p.shape) or w1p.shape[0] * 16 != CB * 8:
-        raise SvcError(f"resblock_pair_h: packed weights {tuple(w1p.shape)} / {tuple(w2p.shape)} do not match C={CB * 8}")
+    _check_h(x, "resblock_pair_h")
+    sp = is_split(x)
+    B, CB, T, _ = x.shape[-4:]
+    KS = w1p.shape[-3]
+    if tuple(w1p.shape) != tuple(w2p.shape) or w1p.shape[-4] * 16 != CB * 8 or (w1p.dim() == 5) != sp:
+        raise SvcError(f"resblock_pair_h: packed weights {tuple(w1p.shape)} / {tuple(w2p.shape)} do not match the input {tuple(x.shape)}")
+    if sp and CB * 8 > RESBLOCK_PAIR_HL_MAX_C:
+        raise SvcError(f"resblock_pair_h: the split form is built for up to {RESBLOCK_PAIR_HL_MAX_C} channels")
     if out is None:
         out = torch.empty_like(x)
-    _check_h(out, "resblock_pair_h out")
+    _check_h(out, "resblock_pair_h out", sp)
     if out.data_ptr() == x.data_ptr():
         raise SvcError("resblock_pair_h: x and out may not alias (neighbouring workgroups read x's halo)")
-    check(lib().svc_resblock_pair_h(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1, w1p.shape[2],
-                                    slope, beta, out_div, stream_ptr()), "resblock_pair_h")
+    fn = lib().svc_resblock_pair_hl if sp else lib().svc_resblock_pair_h
+    check(fn(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1, w1p.shape[-2],
+             slope, beta, out_div, stream_ptr()), "resblock_pair_h")
     return out
 
 

@@ -112,7 +112,8 @@ class ResBlock1(nn.Module):
         n = len(self.convs1)
         cur = xh
         xt, ping, pong = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(3)]
-        if _FUSE_PAIR_H and not S.is_split(xh) and xh.shape[1] * 8 <= S.RESBLOCK_PAIR_H_MAX_C and \
+        sp = S.is_split(xh)
+        if _FUSE_PAIR_H and xh.shape[-3] * 8 <= (S.RESBLOCK_PAIR_HL_MAX_C if sp else S.RESBLOCK_PAIR_H_MAX_C) and \
                 self.convs1[0].kernel_size in (3, 7, 11):
             # up to 128 channels: one launch per pair, the intermediate (and its halo) never leaves LDS (svc_resblock_pair_h)
             for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
@@ -120,7 +121,7 @@ class ResBlock1(nn.Module):
                 dst = (out if out is not None else (ping if cur is not ping else pong)) if lastp else (ping if cur is not ping else pong)
                 if lastp and before_last is not None:
                     before_last()
-                S.resblock_pair_h(cur, c1.packed_h(), c1.bias, c2.packed_h(), c2.bias, c1.dilation, slope=LRELU_SLOPE, out=dst,
+                S.resblock_pair_h(cur, c1.packed_h(sp), c1.bias, c2.packed_h(sp), c2.bias, c1.dilation, slope=LRELU_SLOPE, out=dst,
                                   beta=beta if lastp else 0.0, out_div=out_div if lastp else 1.0)
                 cur = dst
             return cur

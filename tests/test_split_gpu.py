@@ -80,6 +80,37 @@ def test_conv1d_split_is_as_exact_as_the_fp32_kernel(dev, B, Cin, Cout, T, KS, d
         assert _err(S.from_h(out).cpu(), (old.double() + exact + x.double()) / 3) < SCALE_BOUND
 
 
+@pytest.mark.parametrize("B,C,T,KS,d1", [(2, 64, 515, 7, 3), (1, 64, 3000, 11, 5), (1, 32, 2100, 3, 1), (1, 16, 4099, 11, 3), (1, 16, 37, 7, 5),
+                                         (1, 48, 129, 11, 1), (1, 32, 30000, 7, 5), (1, 64, 260, 3, 5)])
+def test_resblock_pair_split_vs_float64_and_two_launches(dev, B, C, T, KS, d1):
+    """svc_resblock_pair_hl (one launch, the intermediate's two planes in LDS, the input staged in channel chunks) against the pair in
+    float64 and against the two svc_conv1d_hl launches it replaces; with the MRF accumulate / divide epilogue; tile borders, sequence
+    ends shorter than a halo, channel counts that leave row tiles partly empty."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(C + T + KS)
+    x = torch.randn(B, C, T, generator=g)
+    w1 = torch.randn(C, C, KS, generator=g) / (C * KS) ** 0.5
+    w2 = torch.randn(C, C, KS, generator=g) / (C * KS) ** 0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    old = torch.randn(B, C, T, generator=g)
+    p1, p2 = (KS - 1) * d1 // 2, (KS - 1) // 2
+    mid = F.leaky_relu(F.conv1d(F.leaky_relu(x.double(), 0.1), w1.double(), b1.double(), dilation=d1, padding=p1), 0.1)
+    exact = F.conv1d(mid, w2.double(), b2.double(), padding=p2) + x.double()
+    xh = S.to_h(x.to(dev), split=True)
+    w1p, w2p = S.pack_conv1d_h(w1.to(dev), split=True), S.pack_conv1d_h(w2.to(dev), split=True)
+    xt = S.conv1d_h(xh, w1p, C, bias=b1.to(dev), dil=d1, pad_left=p1, pre_slope=0.1, post_slope=0.1)
+    two = S.to_h(old.to(dev), split=True)
+    S.conv1d_h(xt, w2p, C, bias=b2.to(dev), pad_left=p2, res=xh, out=two, beta=1.0, out_div=3.0)
+    one = S.to_h(old.to(dev), split=True)
+    S.resblock_pair_h(xh, w1p, b1.to(dev), w2p, b2.to(dev), d1, out=one, beta=1.0, out_div=3.0)
+    a, b_ = S.from_h(one).cpu(), S.from_h(two).cpu()
+    ref = (old.double() + exact) / 3
+    print(f"pair C={C} k{KS} d{d1} T{T}: fused {_err(a, ref):.2e}, two launches {_err(b_, ref):.2e}")
+    assert _err(a, ref) < SCALE_BOUND and _err(b_, ref) < SCALE_BOUND
+    plain = S.from_h(S.resblock_pair_h(xh, w1p, b1.to(dev), w2p, b2.to(dev), d1)).cpu()
+    assert _err(plain, exact) < SCALE_BOUND
+
+
 @pytest.mark.parametrize("B,Cin,L,K,u", [(1, 256, 300, 16, 8), (2, 128, 515, 4, 2), (1, 64, 1000, 4, 2), (1, 32, 2077, 4, 2),
                                          (1, 256, 6896, 16, 8), (1, 32, 97, 8, 4)])
 def test_conv_transpose1d_split(dev, B, Cin, L, K, u):
@@ -124,6 +155,9 @@ def test_split_and_plain_tensors_do_not_mix(dev):
     with pytest.raises(S.SvcError):
         S.resblock_pair_h(S.to_h(x, split=True), S.pack_conv1d_h(w), torch.zeros(16, device=dev), S.pack_conv1d_h(w),
                           torch.zeros(16, device=dev), 1)
+    x128, w128 = torch.randn(1, 128, 64).to(dev), S.pack_conv1d_h(torch.randn(128, 128, 3).to(dev), split=True)
+    with pytest.raises(S.SvcError):                        # the fused split pair is built for up to 64 channels
+        S.resblock_pair_h(S.to_h(x128, split=True), w128, torch.zeros(128, device=dev), w128, torch.zeros(128, device=dev), 1)
 
 
 def _build(cfg, seed, dev):
