@@ -399,7 +399,7 @@ def collect_pmc_traffic(timeout_s=200, mode="infer"):
 
 def run_inflight(args, dev):
     """`--mode inflight` (child of the default run): N independent B = 1 clips per hipGraph replay, fp32 (N = 2, 4) and the
-    half-precision mode (N = 4); prints one JSON object."""
+    half-precision and split modes (N = 4); prints one JSON object."""
     import bench_extra as X
     net, cfg, W = build_model(dev)
     c, f0, uv, sid = [t.to(dev) for t in W.make_inputs(cfg, 1, T_FRAMES, seed=1234)]
@@ -422,6 +422,9 @@ def run_inflight(args, dev):
     leg("f32_", [int(v) for v in os.environ.get("SVC_BENCH_IN_FLIGHT", "2,4").split(",")])
     net.half()
     leg("half_", [4])
+    net.float()
+    net.split_f16()
+    leg("split_", [4])
     print(json.dumps(out))
 
 

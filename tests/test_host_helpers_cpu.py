@@ -61,3 +61,38 @@ def test_chunk_stack_and_split_ops_match_plain_torch_autograd():
     assert torch.equal(y.grad, yr.grad)
     a2, _ = A.split_batch(y.detach().clone().requires_grad_(True), 4)          # one half unused: its gradient is zero
     a2.sum().backward()
+
+
+def test_precision_mode_switches_are_host_logic():
+    """SynthesizerTrn.half() / split_f16() / float() only choose the generator's pipeline (no GPU needed to flip them): which
+    generators accept which mode, and that a mode switch drops captured graphs."""
+    import pytest
+    import models
+    from oracle import weights as W
+
+    def build(cfg):
+        kw = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+        return models.SynthesizerTrn(cfg["spec_channels"], cfg["segment_size"], **kw).eval()
+
+    net = build(W.full_config())
+    net._graphs["x"] = object()
+    assert net.split_f16() is net and net.dec.half_mode == "split" and not net._graphs
+    assert next(net.parameters()).dtype == torch.float32
+    net.half()
+    assert net.dec.half_mode is True
+    net.split_f16(False)
+    assert net.dec.half_mode is False
+    net.split_f16()
+    net.float()
+    assert net.dec.half_mode is False
+    snake = W.full_config()
+    snake["vocoder_name"] = "nsf-snake-hifigan"
+    net = build(snake)
+    net.half()                                        # the snake generator has a 16-bit form ...
+    assert net.dec.half_mode is True
+    with pytest.raises(NotImplementedError):          # ... but no split one
+        net.split_f16()
+    net = build(W.small_config())                     # stage widths 64 / 32 / 16 / 8 / 4: neither
+    for switch in (net.half, net.split_f16):
+        with pytest.raises(NotImplementedError):
+            switch()
