@@ -112,13 +112,17 @@ TRAIN_SEG = 8192
 
 
 def train_hps(cfg, bf16=False):
-    """bf16: False (fp32), True / "bf16" (fp16_run + half_type bf16) or "fp16" (fp16_run + half_type fp16)."""
+    """bf16: False (fp32), True / "bf16" (fp16_run + half_type bf16), "fp16" (fp16_run + half_type fp16) or "x6" (fp32 training with
+    `train.mma: bf16x6`: fp32-level products from three exact bf16 pieces per operand — the engine's own precision mode)."""
     model = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
+    x6 = bf16 == "x6"
+    amp = bool(bf16) and not x6
+    tr = dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
+              fp16_run=amp, half_type=("fp16" if bf16 == "fp16" else "bf16") if amp else "fp16", batch_size=TRAIN_B)
+    if x6:
+        tr["mma"] = "bf16x6"
     return dict(data=dict(filter_length=2048, hop_length=HOP, win_length=2048, n_mel_channels=80, sampling_rate=44100,
-                          mel_fmin=0.0, mel_fmax=22050),
-                train=dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
-                           fp16_run=bool(bf16), half_type=("fp16" if bf16 == "fp16" else "bf16") if bf16 else "fp16", batch_size=TRAIN_B),
-                model=model)
+                          mel_fmin=0.0, mel_fmax=22050), train=tr, model=model)
 
 
 def make_train_items(cfg, B, seed):
@@ -315,7 +319,11 @@ def run_train(args, dev, rank, world, dist, bf16=False):
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not bf16:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)
-    if bf16 and roof is not None:
+    if bf16 == "x6" and roof is not None:
+        # delivered convolution FLOPs (one multiply-add per product, whatever the instruction count) against the fp32 MFMA peak
+        roof["note"] += "; train.mma = bf16x6: six v_mfma_f32_32x32x16_bf16 per product group where the fp32 path issues eight v_mfma_f32_32x32x2_f32"
+        roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
+    elif bf16 and roof is not None:
         # the step mixes bf16-operand launches (the LDS-DMA tilings of the batched convolutions, the 128 x 64 weight-gradient
         # kernel) with fp32 ones (unaligned / narrow shapes, attention products): the fraction is quoted against the bf16 peak
         roof["peak"] = PEAK_BF16_MFMA_TFLOPS
@@ -323,14 +331,21 @@ def run_train(args, dev, rank, world, dist, bf16=False):
         roof["whole_step"]["frac"] = round(roof["whole_step"]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
         roof["note"] += "; bf16-operand and fp32 launches share these family rows, peak = dense bf16 MFMA"
         roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
-    return dict(metric="train steps/sec (train.py D+G iteration)" + (f", fp16_run + half_type {'fp16' if bf16 == 'fp16' else 'bf16'}" if bf16 else ""),
+    if bf16 == "x6":
+        tag, dt, cfgtag = ", fp32 with train.mma = bf16x6", "f32 operands as three exact bf16 pieces, six bf16 MFMA per product group, f32 accumulate / storage", "fp32, train.mma=bf16x6"
+    elif bf16:
+        h = "fp16" if bf16 == "fp16" else "bf16"
+        tag, dt, cfgtag = f", fp16_run + half_type {h}", f"{h} matrix operands, f32 accumulate / storage", "fp16_run half_type=" + h
+    else:
+        tag, dt, cfgtag = "", "f32", "fp32"
+    return dict(metric="train steps/sec (train.py D+G iteration)" + tag,
                 value=steps / elapsed, unit="steps/s",
                 ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warm, n_gpus=world, scaling="weak",
-                dtype=f"{'fp16' if bf16 == 'fp16' else 'bf16'} matrix operands, f32 accumulate / storage" if bf16 else "f32",
+                dtype=dt,
                 items_per_s=world * TRAIN_B * steps / elapsed,
                 config=dict(workload="BASELINE configs[2]: config_template.json model + MultiPeriodDiscriminator, "
                                      f"batch_size={TRAIN_B} per GPU, segment_size={TRAIN_SEG}, T padded to {T} frames, "
-                                     f"4 speakers, {('fp16_run half_type=' + ('fp16' if bf16 == 'fp16' else 'bf16')) if bf16 else 'fp32'}, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
+                                     f"4 speakers, {cfgtag}, FusedAdamW(lr 1e-4, betas (0.8,0.99), eps 1e-9)",
                             global_batch=TRAIN_B * world, frames=T,
                             launch="eager (fp16: the GradScaler rule decides every optimizer step on the host)" if bf16 == "fp16" else
                             (("hipGraph replay of the whole iteration" if world == 1 else
@@ -441,6 +456,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
+    ap.add_argument("--x6", action="store_true", help="--mode train only: fp32 training with train.mma = bf16x6 (fp32-level products on the bf16 instruction)")
     ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
@@ -496,7 +512,7 @@ def main():
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps
         args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
-        res = run_train(args, dev, rank, world, dist, bf16="fp16" if args.fp16 else args.bf16)
+        res = run_train(args, dev, rank, world, dist, bf16="x6" if args.x6 else ("fp16" if args.fp16 else args.bf16))
         if rank == 0:
             res.update(higher_is_better=True, vs_baseline=None, data="synthetic")
             print(json.dumps(res))
@@ -686,6 +702,8 @@ def main():
             if isinstance(tb, dict) and "ms_per_step" in tb:
                 tb["speedup_vs_f32"] = round(train_res["ms_per_step"] / tb["ms_per_step"], 3)
             train_res["train_bf16"] = tb
+            # (`--mode train --x6`: fp32 training with train.mma = bf16x6 — measured equal to the fp32 step, 86.9 against 87.4 ms,
+            #  profiles/r09f_train*.json: not part of the default line)
             torch.cuda.empty_cache()
             # the same iteration driven through the entry point's loader loop (files on disk -> DataLoader -> bucketed collate)
             tl = X.guarded(X.bench_train_loader, dev, train_hps(cfg))

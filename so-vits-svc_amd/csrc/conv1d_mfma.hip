@@ -79,6 +79,36 @@ template <> struct Op16<SVC_MMA_F16> {
   static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, f16x8); }
   static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
+// SVC_MMA_BF16X6 (include/svc_hip.h): v = p0 + p1 + p2 exactly in three bf16 pieces (bf16 -> fp32 is a shift: the remainders are
+// exact), a product = the six piece products of weight >= 2^-16, smallest first.
+struct frag_x6 {
+  bf16x8 p0, p1, p2;
+};
+template <> struct Op16<SVC_MMA_BF16X6> {
+  typedef frag_x6 frag;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) {
+    frag f;
+    f.p0 = __builtin_convertvector(t, bf16x8);
+    f32x8v r = t - __builtin_convertvector(f.p0, f32x8v);
+    f.p1 = __builtin_convertvector(r, bf16x8);
+    r = r - __builtin_convertvector(f.p1, f32x8v);
+    f.p2 = __builtin_convertvector(r, bf16x8);
+    return f;
+  }
+  template <int T>
+  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) {
+    if constexpr (T == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, c, 0, 0, 0);
+    else if constexpr (T == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, c, 0, 0, 0);
+    else if constexpr (T == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, c, 0, 0, 0);
+    else if constexpr (T == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, c, 0, 0, 0);
+    else if constexpr (T == 4) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, f32x16 c) {
+    c = term<0>(a, b, c); c = term<1>(a, b, c); c = term<2>(a, b, c); c = term<3>(a, b, c); c = term<4>(a, b, c);
+    return term<5>(a, b, c);
+  }
+};
 
 // One LDS-DMA piece: every lane's 16 B at `g` land at LDS byte address lds_byte + lane*16 (wave-uniform base in M0).
 // Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (svc_vmcnt0 before the barrier).
@@ -693,11 +723,20 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
               for (int j = 0; j < 8; ++j) t[j] = xa[j * XW + k * dil + jn * TS];
               bq[jn] = OP::cvt(t);
             }
+            if constexpr (MMA == SVC_MMA_BF16X6) {
+              // term-major: MT NT independent accumulators between two instructions on the same one
+#define SVC_X6_TERM(T)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int jn = 0; jn < NT; ++jn)      \
+      acc32[i][jn] = OP::template term<T>(af[i], bq[jn], acc32[i][jn]);
+              SVC_X6_TERM(0) SVC_X6_TERM(1) SVC_X6_TERM(2) SVC_X6_TERM(3) SVC_X6_TERM(4) SVC_X6_TERM(5)
+#undef SVC_X6_TERM
+            } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+              for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int jn = 0; jn < NT; ++jn)
-                acc32[i][jn] = OP::mfma(af[i], bq[jn], acc32[i][jn]);
+                for (int jn = 0; jn < NT; ++jn)
+                  acc32[i][jn] = OP::mfma(af[i], bq[jn], acc32[i][jn]);
+            }
           }
         }
       } else if constexpr (KSC > 0) {
@@ -1088,7 +1127,8 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     constexpr bool BF16_TILING = EPI == SVC_EPI_PLAIN && ((MT == 2 && NT == 2 && WM == 2 && WN == 2) || (MT == 2 && NT == 1 && WM == 1 && WN == 4) ||
                                                           (MT == 1 && NT == 3 && WM == 2 && WN == 2) || (MT == 1 && NT == 5 && WM == 4 && WN == 1) ||
                                                           (MT == 2 && NT == 2 && WM == 1 && WN == 4));
-    const bool want_bf16 = BF16_TILING && (a.mma == SVC_MMA_BF16 || a.mma == SVC_MMA_F16) && (a.Cin % 16) == 0 && g_bf16_enabled;
+    const bool want_bf16 = BF16_TILING && (a.mma == SVC_MMA_BF16 || a.mma == SVC_MMA_F16 || a.mma == SVC_MMA_BF16X6) && (a.Cin % 16) == 0 &&
+                           g_bf16_enabled;
     // a bf16 chunk is at least 16 channels (one instruction's reduction): 5..11 taps of them do not fit the 64 KiB the fp32
     // chunks are sized for — they take up to 144 KiB (one workgroup per CU; the instruction stream is 16x shorter per chunk)
     if (want_bf16) budget = std::max(budget, (size_t)144 * 1024);
@@ -1129,14 +1169,17 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
         if (want_bf16) {
           auto kb = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, SVC_MMA_BF16>;
           auto kh = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, SVC_MMA_F16>;
+          auto kx = conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, 0, true, true, SVC_MMA_BF16X6>;
           static bool doneb = false;
           if (!doneb) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void*>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             doneb = true;
           }
           ++g_bf16_launches;
           if (a.mma == SVC_MMA_F16) hipLaunchKernelGGL(kh, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
+          else if (a.mma == SVC_MMA_BF16X6) hipLaunchKernelGGL(kx, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
           else hipLaunchKernelGGL(kb, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
           return svc::check_launch("conv1d_mfma_16bit");
         }

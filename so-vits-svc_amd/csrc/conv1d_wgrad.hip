@@ -55,13 +55,44 @@ typedef float f32x8v __attribute__((ext_vector_type(8)));
 template <int MMA> struct WOp16;
 template <> struct WOp16<SVC_MMA_BF16> {
   typedef bf16x8 frag;
+  static constexpr int TERMS = 1;
   static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, bf16x8); }
-  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  template <int T>
+  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct WOp16<SVC_MMA_F16> {
   typedef f16x8 frag;
+  static constexpr int TERMS = 1;
   static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, f16x8); }
-  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  template <int T>
+  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// SVC_MMA_BF16X6 (include/svc_hip.h): both operands in three exact bf16 pieces, the six piece products of weight >= 2^-16, smallest
+// first — fp32-level weight gradients from the bf16 instruction, with fp32's exponent range (no loss scaling).
+struct wfrag_x6 {
+  bf16x8 p0, p1, p2;
+};
+template <> struct WOp16<SVC_MMA_BF16X6> {
+  typedef wfrag_x6 frag;
+  static constexpr int TERMS = 6;
+  static __device__ __forceinline__ frag cvt(const f32x8v& t) {
+    frag f;
+    f.p0 = __builtin_convertvector(t, bf16x8);
+    f32x8v r = t - __builtin_convertvector(f.p0, f32x8v);
+    f.p1 = __builtin_convertvector(r, bf16x8);
+    r = r - __builtin_convertvector(f.p1, f32x8v);
+    f.p2 = __builtin_convertvector(r, bf16x8);
+    return f;
+  }
+  template <int T>
+  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) {
+    if constexpr (T == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, c, 0, 0, 0);
+    else if constexpr (T == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, c, 0, 0, 0);
+    else if constexpr (T == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, c, 0, 0, 0);
+    else if constexpr (T == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, c, 0, 0, 0);
+    else if constexpr (T == 4) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, c, 0, 0, 0);
+  }
 };
 
 // ---- LDS-DMA staging (DMA = true) -------------------------------------------------------------------------------------
@@ -277,7 +308,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
         static_assert(NP % G == 0, "wgrad dma: pieces per macro-step");
         const float* ap8 = apb + 7 * lk;
         const float* bp8 = bpb + 7 * lk;
-        typename OP::frag fa[2][MT], fb[2][NK];
+        constexpr int SL = OP::TERMS > 1 ? 1 : 2;     // several instructions per operand pair: the LDS round trip is small beside them, one operand set
+        typename OP::frag fa[SL][MT], fb[SL][NK];
         auto load16 = [&](int slot, int s) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
@@ -294,19 +326,25 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
             fb[slot][q] = OP::cvt(tb);
           }
         };
-        load16(0, 0);
+        if constexpr (SL == 2) load16(0, 0);
         static_for<0, G>([&](auto gc) {
           constexpr int g = decltype(gc)::value;
-          if constexpr (g + 1 < G) load16((g + 1) & 1, 16 * (g + 1));
+          if constexpr (SL == 1) load16(0, 16 * g);
+          else if constexpr (g + 1 < G) load16((g + 1) & 1, 16 * (g + 1));
           __builtin_amdgcn_sched_barrier(0);
-          static_for<0, NK * MT>([&](auto ec) {
-            constexpr int e = decltype(ec)::value, q = e / MT, i = e % MT;
-            acc[q][i] = OP::mfma(fa[g & 1][i], fb[g & 1][q], acc[q][i]);
-            static_for<0, PPM>([&](auto xc) {
-              constexpr int d = e * PPM + decltype(xc)::value;
-              if constexpr (d < PPG && g * PPG + d < NP) dma_piece(g * PPG + d);
+          static_for<0, OP::TERMS>([&](auto tc) {       // term-major: NK MT independent accumulators between two on the same one
+            constexpr int T = decltype(tc)::value;
+            static_for<0, NK * MT>([&](auto ec) {
+              constexpr int e = decltype(ec)::value, q = e / MT, i = e % MT;
+              acc[q][i] = OP::template term<T>(fa[g & (SL - 1)][i], fb[g & (SL - 1)][q], acc[q][i]);
+              if constexpr (T == 0) {
+                static_for<0, PPM>([&](auto xc) {
+                  constexpr int d = e * PPM + decltype(xc)::value;
+                  if constexpr (d < PPG && g * PPG + d < NP) dma_piece(g * PPG + d);
+                });
+              }
+              __builtin_amdgcn_sched_barrier(0);
             });
-            __builtin_amdgcn_sched_barrier(0);
           });
         });
       } else {
@@ -378,8 +416,11 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgP p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) tb[j] = bp8[s + q * dil + j];
           const typename OP::frag bq = OP::cvt(tb);
-          acc[q][0] = OP::mfma(a0, bq, acc[q][0]);
-          acc[q][1] = OP::mfma(a1, bq, acc[q][1]);
+          static_for<0, OP::TERMS>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            acc[q][0] = OP::template term<T>(a0, bq, acc[q][0]);
+            acc[q][1] = OP::template term<T>(a1, bq, acc[q][1]);
+          });
         }
       }
     } else {
@@ -639,12 +680,13 @@ template <int NK, bool DMA, int MT>
 void launch_fmt(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma) {
   if (mma == SVC_MMA_BF16) launch_one<NK, SVC_MMA_BF16, DMA, MT>(p, grid, lds, s);
   else if (mma == SVC_MMA_F16) launch_one<NK, SVC_MMA_F16, DMA, MT>(p, grid, lds, s);
+  else if (mma == SVC_MMA_BF16X6) launch_one<NK, SVC_MMA_BF16X6, DMA, MT>(p, grid, lds, s);
   else launch_one<NK, SVC_MMA_F32, DMA, MT>(p, grid, lds, s);
 }
 
 template <int NK>
 void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma, bool dma, int mt) {
-  if (mma == SVC_MMA_BF16 || mma == SVC_MMA_F16) ++g_wgrad_bf16_launches;
+  if (mma == SVC_MMA_BF16 || mma == SVC_MMA_F16 || mma == SVC_MMA_BF16X6) ++g_wgrad_bf16_launches;
   if (dma && mt == 1) launch_fmt<NK, true, 1>(p, grid, lds, s, mma);
   else if (dma) launch_fmt<NK, true, 2>(p, grid, lds, s, mma);
   else launch_fmt<NK, false, 2>(p, grid, lds, s, mma);

@@ -293,7 +293,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
 _GROUP = None
 
 # ---- matrix-pipe operand format of the convolutions (svc_conv1d_args.mma): the engine's form of the reference's autocast region
-MMA_F32, MMA_BF16, MMA_F16 = 0, 1, 2
+MMA_F32, MMA_BF16, MMA_F16, MMA_BF16X6 = 0, 1, 2, 3     # BF16X6: three exact bf16 pieces per operand, six products (fp32-level)
 _MMA = MMA_F32
 
 

@@ -88,6 +88,13 @@ class TrainStep:
                 # as an fp16 operand.  The scaler's skip-on-overflow is a host decision per optimizer step (as in the reference:
                 # GradScaler reads found_inf back), so this mode launches eagerly — no whole-iteration hipGraph.
                 self.mma, self.scaler = S.MMA_F16, LossScaler()
+        elif (t.get("mma") if isinstance(t, dict) else getattr(t, "mma", None)) == "bf16x6" or os.environ.get("SVC_TRAIN_MMA") == "bf16x6":
+            # A precision mode of FP32 training with no counterpart in the reference (train.mma: "bf16x6" / SVC_TRAIN_MMA=bf16x6): the
+            # convolutions and their gradients take every fp32 operand apart into three bf16 pieces (exactly: 8 + 8 + 8 mantissa bits,
+            # fp32's exponent range — no loss scaling) and multiply the six piece products of weight >= 2^-16 on
+            # v_mfma_f32_32x32x16_bf16: fp32-level products (what is dropped is <= 2^-24 relative) at 3/8 of the fp32 instruction's
+            # matrix time.  Tensors, master weights, accumulation and everything outside the convolutions as in fp32 mode.
+            self.mma = S.MMA_BF16X6
 
         self.use_graph = False
         import collections
