@@ -138,6 +138,7 @@ int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
  * issued as ONE launch (heaviest workgroups first), the others one by one. */
 int svc_conv1d_multi_f32(const svc_conv1d_args* a, int n, void* stream);
 int svc_debug_conv_multi_merged(void);   /* merged launches of the tiled kernel so far (tests) */
+int svc_debug_set_sp(int min_taps, int min_wgs); /* SVC_MMA_BF16X6: fewest taps / workgroups the split-structure kernel takes (defaults 2, 224; tests: 1, 0) */
 int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */
 int svc_debug_wgrad_bf16_launches(void);
 
