@@ -456,6 +456,8 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=None)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
+    ap.add_argument("--split", action="store_true", help="--mode infer only: time SynthesizerTrn.split_f16() (the generator on the split pipeline: hi + lo "
+                    "fp16 planes, three fp16 MFMA per product, fp32-level output) instead of the fp32-MFMA path; labelled as such — profiling aid, not the headline")
     ap.add_argument("--x6", action="store_true", help="--mode train only: fp32 training with train.mma = bf16x6 (fp32-level products on the bf16 instruction)")
     ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
@@ -524,6 +526,10 @@ def main():
 
     import svc_hip as S
     net, cfg, W = build_model(dev)
+    if args.split:
+        net.split_f16()
+        args.no_extras = True
+
     B = args.batch
     cpu_in = W.make_inputs(cfg, B, T_FRAMES, seed=1234 + rank)
     c, f0, uv, sid = [t.to(dev) for t in cpu_in]
@@ -714,10 +720,12 @@ def main():
             train_res["train_loader"] = tl
 
     if rank == 0:
-        out = dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.infer)", value=value,
+        out = dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.split_f16().infer)" if args.split else
+                   "44.1kHz audio samples/sec (inference, SynthesizerTrn.infer)", value=value,
                    unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="f32", data="synthetic",
+                   dtype="f32 values as hi + lo fp16 planes in the generator, 3 fp16 MFMA per product, f32 accumulate (NOT the headline mode)" if args.split else "f32",
+                   data="synthetic",
                    rtf=(elapsed / args.steps) / (samples_per_step / 44100.0),
                    config=dict(workload="BASELINE configs[1]: config_template.json, 1 speaker id, ContentVec768 units, "
                                         "NSF-HiFiGAN, one 10.01 s clip per step (T=862 frames, 441344 samples)",

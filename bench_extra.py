@@ -242,11 +242,28 @@ def bench_snake_b8(dev, steps=3):
         net.half()
         oh, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
         mse = (oh - o32).pow(2).mean().item()
-        del o32, oh, noise
+        del oh
         net.enable_graph(True)
         dth = _timeit(step, steps, warm=2)
         half = dict(ms_per_step=round(1e3 * dth, 3), samples_per_s=n / dth, speedup_vs_f32=round(dt / dth, 3), waveform_mse_vs_f32_path=mse,
                     note="SynthesizerTrn.half(): fp16 activations + weights in the generator (conv1d_h, snake_alias_h), f32 accumulate")
+        # ... and on the split pipeline (SynthesizerTrn.split_f16(): hi + lo fp16 planes, three fp16 MFMA per product, fp32-level output)
+        try:
+            net.float()
+            net.split_f16()
+            net.enable_graph(False)
+            osp, _ = net.infer(c, f0, uv, g=sid, noice_scale=0.4, noise=noise)
+            mxs = (osp - o32).abs().max().item()
+            del osp
+            net.enable_graph(True)
+            dts = _timeit(step, steps, warm=2)
+            split = dict(ms_per_step=round(1e3 * dts, 3), samples_per_s=n / dts, speedup_vs_f32_mfma=round(dt / dts, 3),
+                         waveform_max_abs_vs_f32_mfma_path=mxs,
+                         note="SynthesizerTrn.split_f16(): conv1d_hl / snake_alias_hl (resblock pairs unfused: a SnakeAlias sits between the convs)")
+        except Exception as e:      # noqa: BLE001
+            split = dict(error=f"{type(e).__name__}: {e}")
+        half["split"] = split
+        del o32, noise
     except Exception as e:      # noqa: BLE001
         half = dict(error=f"{type(e).__name__}: {e}")
     del net

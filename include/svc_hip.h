@@ -372,6 +372,8 @@ int svc_conv1d_hl(const svc_conv1d_h_args* a, void* stream);
 /* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..64. */
 int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
                          int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
+/* svc_snake_alias_h on the split planes (x and y [2][B][C/8][T][8]; may not alias). */
+int svc_snake_alias_hl(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T, void* stream);
 int svc_debug_set_conv_hl(int cfg); /* tuning aid: bit 0 = 64 x 128 (not 64 x 64) tiles for under-filled launches */
 int svc_cvt_to_hl(const float* x, const float* add, void* y, long long x_bs, long long x_cs, long long add_bs, long long add_cs,
                   int B, int C, int T, void* stream);

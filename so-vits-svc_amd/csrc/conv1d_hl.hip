@@ -591,6 +591,68 @@ __global__ __launch_bounds__(256) void conv_post_hl_kernel(const h8* __restrict_
   y[idx] = act == SVC_ACT_TANH ? tanhf(acc) : acc;
 }
 
+// ---- SnakeAlias on the split planes (vdecoder/hifiganwithsnake/alias/act.py:125-130; snake_alias_h_kernel of conv1d_h.hip with a lo
+// plane behind the input and the output): UpSample1d x2 -> SnakeBeta -> DownSample1d x2, the 2x intermediate in LDS, fp32 arithmetic
+// between reading hi + lo and storing the split result.
+constexpr int SHL_TILE = 256;
+struct TapsHL {
+  float f[12];
+};
+__global__ __launch_bounds__(256) void snake_alias_hl_kernel(const h8* __restrict__ x, h8* __restrict__ y, const float* __restrict__ alpha,
+                                                             const float* __restrict__ beta, TapsHL taps, int CB, int T, long long plane8) {
+  __shared__ float xs[(SHL_TILE + 10) * 8];
+  __shared__ float ua[(2 * SHL_TILE + 12) * 8];
+  const int t0 = blockIdx.x * SHL_TILE, cb = blockIdx.y, b = blockIdx.z;
+  const h8* xr = x + ((long long)b * CB + cb) * T;
+  h8* yr = y + ((long long)b * CB + cb) * T;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SHL_TILE + 10; i += 256) {
+    int t = t0 - 5 + i;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const h8 vh = xr[t], vl = xr[plane8 + t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[i * 8 + j] = (float)vh[j] + (float)vl[j];
+  }
+  __syncthreads();
+  const int n_lo = 2 * t0 - 5;
+  for (int e = tid; e < (2 * SHL_TILE + 10) * 8; e += 256) {
+    const int m = e >> 3, j = e & 7;
+    int n = n_lo + m;
+    n = n < 0 ? 0 : (n > 2 * T - 1 ? 2 * T - 1 : n);
+    const int par = (n + 1) & 1;
+    const int j0 = (n + 15 - par) >> 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      int xi = j0 - q - 5;
+      xi = xi < 0 ? 0 : (xi > T - 1 ? T - 1 : xi);
+      acc = fmaf(par ? taps.f[2 * q + 1] : taps.f[2 * q], xs[(xi - (t0 - 5)) * 8 + j], acc);
+    }
+    const float u = 2.f * acc;
+    const int c = cb * 8 + j;
+    const float sn = sinf(u * __expf(alpha[c]));
+    ua[m * 8 + j] = u + (sn * sn) / (__expf(beta[c]) + 1e-9f);
+  }
+  __syncthreads();
+  for (int i = tid; i < SHL_TILE; i += 256) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    h8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc = fmaf(taps.f[k], ua[(2 * i + k) * 8 + j], acc);
+      _Float16 hi, lo;
+      split1(acc, hi, lo);
+      oh[j] = hi;
+      ol[j] = lo;
+    }
+    yr[t] = oh;
+    yr[plane8 + t] = ol;
+  }
+}
+
 }  // namespace
 
 extern "C" int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream) {
@@ -696,4 +758,15 @@ extern "C" int svc_resblock_pair_hl(const void* x, const void* w1, const float* 
 extern "C" int svc_debug_set_conv_hl(int cfg) {
   g_hl_cfg = cfg;
   return SVC_OK;
+}
+
+extern "C" int svc_snake_alias_hl(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T,
+                                  void* stream) {
+  SVC_REQUIRE(x && y && alpha && beta && taps12 && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "snake_alias_hl: bad args");
+  TapsHL tp;
+  for (int i = 0; i < 12; ++i) tp.f[i] = taps12[i];
+  svc::ProfScope prof((hipStream_t)stream, "snake_alias_hl", 0.0, 8.0 * B * (double)C * T);
+  hipLaunchKernelGGL(snake_alias_hl_kernel, dim3(svc::cdiv(T, SHL_TILE), C / 8, B), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const h8*>(x), reinterpret_cast<h8*>(y), alpha, beta, tp, C / 8, T, (long long)B * (C / 8) * T);
+  return svc::check_launch("snake_alias_hl");
 }

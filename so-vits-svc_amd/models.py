@@ -336,7 +336,7 @@ class SynthesizerTrn(nn.Module):
     def split_f16(self, on=True):
         """fp32 inference with the generator's convolutions on the fp16 matrix pipe at fp32-level precision: every activation and
         weight of the generator as a hi and a lo fp16 plane (22 mantissa bits), every product as three fp16 matrix instructions with
-        fp32 accumulation (csrc/conv1d_hl.hip; Generator.set_half(split=True)) — gfx950 multiplies fp16 sixteen times faster than
+        fp32 accumulation (csrc/conv1d_hl.hip; Generator.set_half(split=True); both generators) — gfx950 multiplies fp16 sixteen times faster than
         fp32.  Same inputs, outputs and parameters as the fp32 mode; `split_f16(False)` / `float()` switch back."""
         if not hasattr(self.dec, "set_half"):
             raise NotImplementedError(f"the split pipeline is not built for the {type(self.dec).__module__} generator")

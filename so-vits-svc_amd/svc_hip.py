@@ -141,6 +141,7 @@ def lib():
             getattr(L, "svc_cvt_from_" + sfx).argtypes = L.svc_cvt_from_h.argtypes
             getattr(L, "svc_conv_post_" + sfx).argtypes = L.svc_conv_post_h.argtypes
             getattr(L, "svc_resblock_pair_" + sfx).argtypes = L.svc_resblock_pair_h.argtypes
+            getattr(L, "svc_snake_alias_" + sfx).argtypes = L.svc_snake_alias_h.argtypes
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
@@ -169,7 +170,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_set_sp", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -522,14 +523,17 @@ def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0,
 def snake_alias_h(xh, alpha, beta, taps, out=None):
     """SnakeAlias on a blocked fp16 tensor (svc_snake_alias_h); out may not be xh (a tile reads its neighbours' halo)."""
     _require_gpu_h(xh, alpha, beta, out)
-    _check_h(xh, "snake_alias_h", False)
-    B, CB, T, _ = xh.shape
+    _check_h(xh, "snake_alias_h")
+    sp = is_split(xh)
+    B, CB, T, _ = xh.shape[-4:]
     if out is None:
         out = torch.empty_like(xh)
+    _check_h(out, "snake_alias_h out", sp)
     if out.data_ptr() == xh.data_ptr():
         raise SvcError("snake_alias_h: in-place use is not supported")
     tp = (C.c_float * 12)(*[float(v) for v in taps])
-    check(lib().svc_snake_alias_h(_hptr(xh), _hptr(out), ptr(alpha), ptr(beta), tp, B, CB * 8, T, stream_ptr()), "snake_alias_h")
+    fn = lib().svc_snake_alias_hl if sp else lib().svc_snake_alias_h
+    check(fn(_hptr(xh), _hptr(out), ptr(alpha), ptr(beta), tp, B, CB * 8, T, stream_ptr()), "snake_alias_h")
     return out
 
 

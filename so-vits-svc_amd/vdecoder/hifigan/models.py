@@ -432,8 +432,6 @@ class Generator(nn.Module):
             raise NotImplementedError("half-precision generator: needs ResBlock1 with kernel sizes in {3, 7, 11}, stage widths that are "
                                       "multiples of 16 and upsample kernels of at most 3 taps per phase (both templates' decoders except "
                                       "the tiny template's 200/100/50/25/12 widths)")
-        if on and split and not getattr(self, "SPLIT_OK", True):
-            raise NotImplementedError("the split (hi / lo fp16 plane) pipeline is built for the plain NSF-HiFiGAN generator")
         self.half_mode = ("split" if split else True) if on else False
         return self
 

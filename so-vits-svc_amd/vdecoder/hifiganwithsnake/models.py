@@ -166,8 +166,6 @@ class Generator(base.Generator):
         x = self.conv_post.forward_train(x)
         return A.tanh(x)
 
-    SPLIT_OK = False      # svc_snake_alias_h has no split form
-
     def forward_h(self, x, f0, g=None, noise=None, source=None):
         """forward() in the reference's half-precision mode (base.Generator.set_half): the MRF stages, snakes[1:], ups[1:],
         snake_post and conv_post on blocked fp16 tensors (svc_conv1d_h, svc_snake_alias_h); conv_pre, snakes[0], ups[0] and the
@@ -181,12 +179,13 @@ class Generator(base.Generator):
             torch.cuda.current_stream().wait_event(source[1])
         xh = None
         nk = self.num_kernels
+        sp = self.half_mode == "split"      # the split pipeline (hi + lo fp16 planes: svc_conv1d_hl, svc_snake_alias_hl)
         for i in range(self.num_upsamples):
             xs = source[0][i] if source is not None else self.noise_convs[i](har)
             if i == 0:
-                xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs))
+                xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs), split=sp)
             else:
-                xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs))
+                xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs, split=sp))
             xh = base.mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), n_tmp=4, half=True)
         cp = self.conv_post
         return S.conv_post_h(self.snake_post.run_h(xh), cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias,

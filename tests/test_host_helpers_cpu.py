@@ -90,8 +90,8 @@ def test_precision_mode_switches_are_host_logic():
     net = build(snake)
     net.half()                                        # the snake generator has a 16-bit form ...
     assert net.dec.half_mode is True
-    with pytest.raises(NotImplementedError):          # ... but no split one
-        net.split_f16()
+    net.split_f16()                                   # ... and a split one
+    assert net.dec.half_mode == "split"
     net = build(W.small_config())                     # stage widths 64 / 32 / 16 / 8 / 4: neither
     for switch in (net.half, net.split_f16):
         with pytest.raises(NotImplementedError):

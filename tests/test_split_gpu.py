@@ -221,9 +221,41 @@ def test_split_inference_at_the_benchmarked_shape(dev):
     assert torch.equal(o2, o) and torch.equal(o3, o)
 
 
-def test_split_mode_refuses_the_snake_generator(dev):
+@pytest.mark.parametrize("B,C,T", [(1, 16, 1000), (2, 32, 257), (1, 128, 256), (1, 8, 7), (1, 64, 3001)])
+def test_snake_alias_split_vs_fp32_kernel(dev, B, C, T):
+    """svc_snake_alias_hl (split planes in / out, fp32 arithmetic) against svc_snake_alias_f32 on the same input: what differs is the
+    22-bit carriage of input and output (and libm-level differences of sin / exp)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, C, T, generator=g) * 2.0
+    alpha, beta = 0.4 * torch.randn(C, generator=g), 0.4 * torch.randn(C, generator=g)
+    taps = W.snake_filter().tolist()
+    ref = S.snake_alias(x.to(dev), alpha.to(dev), beta.to(dev), taps).cpu()
+    y = S.from_h(S.snake_alias_h(S.to_h(x.to(dev), split=True), alpha.to(dev), beta.to(dev), taps)).cpu()
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_snake_generator_split_inference(dev):
+    """BASELINE configs[3]'s generator (nsf-snake-hifigan, full template widths) on the split pipeline against the fp32 CPU oracle and
+    the engine's fp32 kernels; hipGraph replay bit-equal to the eager launches."""
     cfg = W.full_config()
     cfg["vocoder_name"] = "nsf-snake-hifigan"
-    net, _ = _build(cfg, 3, dev)
-    with pytest.raises(NotImplementedError):
-        net.split_f16()
+    net, sd = _build(cfg, 77, dev)
+    B, T = 2, 60
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=21)
+    noise = W.make_noise(cfg, B, T, seed=22)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    run = lambda: net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)[0]
+    o32 = run()
+    net.split_f16()
+    assert net.dec.half_mode == "split"
+    o = run()
+    mx32, mx = (o32.cpu() - ref).abs().max().item(), (o.cpu() - ref).abs().max().item()
+    print(f"snake generator, B={B} T={T} vs fp32 oracle: fp32 kernels max {mx32:.3e}, split pipeline max {mx:.3e}, "
+          f"split vs fp32 kernels {(o - o32).abs().max().item():.3e}; max|ref| {ref.abs().max().item():.3f}")
+    assert o.shape == ref.shape and mx <= 4 * mx32 + 5e-6, (mx, mx32)
+    net.enable_graph(True)
+    assert torch.equal(run(), o)
