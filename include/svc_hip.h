@@ -369,7 +369,7 @@ int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, 
  * mirror the 16-bit ones one for one and take the same argument struct (x / res / y / w point at plane 0). */
 int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
 int svc_conv1d_hl(const svc_conv1d_h_args* a, void* stream);
-/* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..64. */
+/* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..128. */
 int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
                          int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
 /* svc_snake_alias_h on the split planes (x and y [2][B][C/8][T][8]; may not alias). */

@@ -57,7 +57,7 @@ print("sum over one clip's MRF convolutions, single launches (us):", {k: round(v
 
 # fused pair (svc_resblock_pair_hl) against its two launches
 pair = {"two": 0.0, "one": 0.0}
-for (C, L) in ((64, T0 * 128), (32, T0 * 256), (16, T0 * 512)):
+for (C, L) in ((128, T0 * 64), (64, T0 * 128), (32, T0 * 256), (16, T0 * 512)):
     x = S.to_h(torch.randn(1, C, L, device=dev), split=True)
     xt, y = torch.empty_like(x), torch.empty_like(x)
     for k in (3, 7, 11):
@@ -77,4 +77,4 @@ for (C, L) in ((64, T0 * 128), (32, T0 * 256), (16, T0 * 512)):
             fl = 4.0 * C * C * k * L
             print(f"pair C={C:3d} L={L:6d} k={k:2d} d={d}: two launches {t2:7.1f} us   fused {t1:7.1f} us  {fl / t1 / 1e6:6.1f} TF  "
                   f"{4.0 * C * L * 3 / t1 / 1e3:6.0f} GB/s")
-print("sum over one clip's split pairs of the <= 64-channel stages (us):", {k: round(v, 1) for k, v in pair.items()})
+print("sum over one clip's split pairs of the <= 128-channel stages (us):", {k: round(v, 1) for k, v in pair.items()})

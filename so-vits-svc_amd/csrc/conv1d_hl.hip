@@ -304,11 +304,12 @@ struct PPL {
 };
 
 template <int KS, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void respair_hl_kernel(PPL p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
+  constexpr int NTHR = 64 * WM * WN;          // four waves (two workgroups per CU) or eight (one: the 128-channel form)
   constexpr int N1P = 32 * NT * WN;            // intermediate columns computed per workgroup
   constexpr int N2 = N1P - (KS - 1);           // output columns per workgroup
   constexpr int H2 = (KS - 1) / 2;
-  static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_hl[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = w / WN, wn = w - wm * WN;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void respair_hl_kernel(PPL p) {
   const long long sstride = (long long)p.RP * 2;
   const int col = wn * NT * 32 + li;
 
-  for (int idx = tid; idx < 2 * CB * (KS - 1); idx += 256) {   // the halo tail of the intermediate tile (never computed)
+  for (int idx = tid; idx < 2 * CB * (KS - 1); idx += NTHR) {   // the halo tail of the intermediate tile (never computed)
     const int pl = idx / (CB * (KS - 1)), r = idx - pl * CB * (KS - 1);
     const int cb = r / (KS - 1), e = r - cb * (KS - 1);
     h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -347,11 +348,11 @@ __global__ __launch_bounds__(256, 2) void respair_hl_kernel(PPL p) {
       if (g0) __syncthreads();
       const int total = 2 * gc * XW1;
       constexpr int LD = 4;
-      for (int base = tid; base < total; base += 256 * LD) {
+      for (int base = tid; base < total; base += NTHR * LD) {
         h8 vh[LD], vl[LD];
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-          const int idx = base + j * 256;
+          const int idx = base + j * NTHR;
           h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
           vh[j] = z;
           vl[j] = z;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void respair_hl_kernel(PPL p) {
         }
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-          const int idx = base + j * 256;
+          const int idx = base + j * NTHR;
           if (idx < total) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -479,7 +480,7 @@ int launch_respair_hl(PPL p, hipStream_t s) {
   const int G = p.C / 16;
   const size_t ts_bytes = (size_t)2 * (p.C / 8) * XW2 * 16;
   const size_t per_group = (size_t)64 * XW1;
-  const size_t budget = 78 * 1024;            // two workgroups per CU
+  const size_t budget = (WM * WN == 8 ? 150 : 78) * 1024;   // two four-wave workgroups per CU, or one of eight waves
   const int gmax = ts_bytes + per_group <= budget ? (int)((budget - ts_bytes) / per_group) : 1;
   const int nch = svc::cdiv(G, gmax);
   p.GC = svc::cdiv(G, nch);
@@ -493,12 +494,15 @@ int launch_respair_hl(PPL p, hipStream_t s) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(svc::cdiv(p.T, N2), p.B), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(svc::cdiv(p.T, N2), p.B), dim3(64 * WM * WN), lds, s, p);
   return svc::check_launch("resblock_pair_hl");
 }
 
 template <int KS>
 int launch_respair_hl_ks(const PPL& p, hipStream_t s) {
+  // 128 channels: both tiles' two planes are 116-139 KB — ONE workgroup per CU, so it has eight waves (two per SIMD, as two
+  // four-wave workgroups would), 32 x 64 wave tiles: the weight bytes per instruction of the 128 x 128 single launches
+  if (p.C > 64) return launch_respair_hl<KS, 1, 2, 4, 2>(p, s);    // 128 rows, 128 intermediate columns, 512 threads
   if (p.C > 32) return launch_respair_hl<KS, 2, 1, 1, 4>(p, s);    // 64 rows, 128 intermediate columns
   return launch_respair_hl<KS, 1, 2, 1, 4>(p, s);                  // 32 rows, 256
 }
@@ -732,7 +736,7 @@ extern "C" int svc_conv_post_hl(const void* x, const float* w, const float* bias
 extern "C" int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B,
                                    int C, int T, int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream) {
   SVC_REQUIRE(x && w1 && w2 && b1 && b2 && y, "resblock_pair_hl: null tensor");
-  SVC_REQUIRE(B > 0 && T > 0 && C >= 16 && C <= 64 && (C % 16) == 0, "resblock_pair_hl: C must be a multiple of 16 in 16..64 (got %d)", C);
+  SVC_REQUIRE(B > 0 && T > 0 && C >= 16 && C <= 128 && (C % 16) == 0, "resblock_pair_hl: C must be a multiple of 16 in 16..128 (got %d)", C);
   SVC_REQUIRE(dil1 >= 1 && (RP % 128) == 0 && RP >= C, "resblock_pair_hl: bad dil1 / RP");
   SVC_REQUIRE(slope > 0.f && slope <= 1.f, "resblock_pair_hl: leaky-ReLU slope in (0, 1]");
   SVC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |

@@ -494,7 +494,7 @@ def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=
 
 
 RESBLOCK_PAIR_H_MAX_C = 128
-RESBLOCK_PAIR_HL_MAX_C = 64      # split planes: both tiles of 128 channels would leave one workgroup per CU
+RESBLOCK_PAIR_HL_MAX_C = int(os.environ.get("SVC_PAIR_HL_MAX_C", "128"))   # split planes (the 128-channel form: one eight-wave workgroup per CU)
 
 
 def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0, out_div=1.0):

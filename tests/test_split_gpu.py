@@ -81,7 +81,8 @@ def test_conv1d_split_is_as_exact_as_the_fp32_kernel(dev, B, Cin, Cout, T, KS, d
 
 
 @pytest.mark.parametrize("B,C,T,KS,d1", [(2, 64, 515, 7, 3), (1, 64, 3000, 11, 5), (1, 32, 2100, 3, 1), (1, 16, 4099, 11, 3), (1, 16, 37, 7, 5),
-                                         (1, 48, 129, 11, 1), (1, 32, 30000, 7, 5), (1, 64, 260, 3, 5)])
+                                         (1, 48, 129, 11, 1), (1, 32, 30000, 7, 5), (1, 64, 260, 3, 5), (1, 128, 1000, 11, 5), (2, 128, 300, 3, 1),
+                                         (1, 96, 515, 7, 3), (1, 128, 20000, 7, 1)])
 def test_resblock_pair_split_vs_float64_and_two_launches(dev, B, C, T, KS, d1):
     """svc_resblock_pair_hl (one launch, the intermediate's two planes in LDS, the input staged in channel chunks) against the pair in
     float64 and against the two svc_conv1d_hl launches it replaces; with the MRF accumulate / divide epilogue; tile borders, sequence
@@ -155,9 +156,9 @@ def test_split_and_plain_tensors_do_not_mix(dev):
     with pytest.raises(S.SvcError):
         S.resblock_pair_h(S.to_h(x, split=True), S.pack_conv1d_h(w), torch.zeros(16, device=dev), S.pack_conv1d_h(w),
                           torch.zeros(16, device=dev), 1)
-    x128, w128 = torch.randn(1, 128, 64).to(dev), S.pack_conv1d_h(torch.randn(128, 128, 3).to(dev), split=True)
-    with pytest.raises(S.SvcError):                        # the fused split pair is built for up to 64 channels
-        S.resblock_pair_h(S.to_h(x128, split=True), w128, torch.zeros(128, device=dev), w128, torch.zeros(128, device=dev), 1)
+    x256, w256 = torch.randn(1, 256, 64).to(dev), S.pack_conv1d_h(torch.randn(256, 256, 3).to(dev), split=True)
+    with pytest.raises(S.SvcError):                        # the fused split pair is built for up to 128 channels
+        S.resblock_pair_h(S.to_h(x256, split=True), w256, torch.zeros(256, device=dev), w256, torch.zeros(256, device=dev), 1)
 
 
 def _build(cfg, seed, dev):
