@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ / GRBM counters + durations of the launches of ONE kernel (name substring) in a command; separate rocprofv3 --pmc passes with
-# --kernel-trace only.  usage: pmc_kernel.sh TAG KERNEL_SUBSTRING "command ..."   -> gpurun_out/TAG_pmc_KERNEL.txt
+# --kernel-trace only.  (Eight counters per pass at most: a ninth in the first set — SQ_INSTS_VALU_MFMA_MOPS_F16, round 5 — made both
+# passes of that set sit until their 300 s timeout and cost ten GPU-minutes for nothing.)  usage: pmc_kernel.sh TAG KERNEL_SUBSTRING "command ..."   -> gpurun_out/TAG_pmc_KERNEL.txt
 set -x
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=$1; KNAME=$2; CMD=$3
@@ -8,7 +9,7 @@ D=gpurun_out/pmc_k; mkdir -p $D; rm -rf $D/p_*
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAVE32_INSTS"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $D/p_$i -o run -- $CMD > $D/p_$i.log 2>&1; echo "rc=$?"; tail -1 $D/p_$i.log
+  timeout 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $D/p_$i -o run -- $CMD > $D/p_$i.log 2>&1; echo "rc=$?"; tail -1 $D/p_$i.log
 done
 OUT=gpurun_out/${TAG}_pmc_${KNAME}.txt
 echo "=== kernel *$KNAME* in: $CMD" >> $OUT
