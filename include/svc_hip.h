@@ -123,7 +123,7 @@ typedef struct svc_conv1d_args {
 #define SVC_MMA_F16 2  /* `half_type: fp16`: the same with fp16 operands (v_mfma_f32_32x32x16_f16); the caller scales the loss (GradScaler) */
 /* SVC_MMA_BF16X6 (3): fp32-LEVEL products on the bf16 matrix instruction (no counterpart in the reference; a precision mode of fp32
  * training).  Every fp32 operand is taken apart into three bf16 pieces as it is fetched, v = p0 + p1 + p2 EXACTLY (8 + 8 + 8 mantissa
- * bits; bf16 has fp32's exponent range, so gradients of any magnitude survive), and a product is the six piece products of weight
+ * bits, while the third piece is a normal number: |v| >= 2^-110; bf16 has fp32's exponent range, so gradients of any magnitude survive), and a product is the six piece products of weight
  * >= 2^-16: p0q0 + p0q1 + p1q0 + p0q2 + p1q1 + p2q0 — each exact in the fp32 accumulator; the three dropped ones are <= 2^-24 relative,
  * fp32's own rounding.  Six v_mfma_f32_32x32x16_bf16 (32 clocks each) replace eight v_mfma_f32_32x32x2_f32 (64 clocks each).  Same
  * tensors, same kernels and shapes as SVC_MMA_BF16. */
