@@ -103,8 +103,9 @@ def test_autograd_conv_in_x6_mode_matches_fp32_gradients(dev):
     instruction (launch counters) and agree with the fp32 kernels' to fp32 rounding."""
     import svc_autograd as A
     import svc_hip as S
-    x = torch.randn(16, 192, 768, device=dev, requires_grad=True)
-    w = (torch.randn(384, 192, 5, device=dev) * 0.03).requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(16, 192, 768, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(384, 192, 5, generator=g) * 0.03).to(dev).requires_grad_(True)
     b = torch.zeros(384, device=dev, requires_grad=True)
     with S.mma_mode(S.MMA_BF16X6):
         y = A.conv1d(x, w, b, padding=2)
@@ -117,7 +118,7 @@ def test_autograd_conv_in_x6_mode_matches_fp32_gradients(dev):
     y.square().sum().backward()
     for name, a_, b_ in (("y", y6, y.detach()), ("dx", gx, x.grad), ("dw", gw, w.grad)):
         rel = (a_ - b_).abs().max().item() / b_.abs().max().item()
-        assert rel < 6e-6, (name, rel)            # (two fp32-level results of a 960-term reduction: each is ~1e-6 from exact)
+        assert rel < 1e-5, (name, rel)            # (two fp32-level results of a 960- / 12 288-term reduction, each ~1e-6 from exact; bf16 operands: 1e-2)
 
 
 def test_training_step_in_x6_mode_meets_the_fp32_bounds_against_the_reference(dev):
