@@ -291,7 +291,8 @@ int launch_hl_ks(const svc_conv1d_h_args& a, int R, hipStream_t s) {
 // respair_h_kernel (conv1d_h.hip) with a lo plane behind every tile: the intermediate tile ts (all channels, both planes) stays in
 // LDS for the whole launch, the input tile xs is staged in channel chunks while conv1 accumulates (the two planes of both tiles at
 // once would not leave room for two workgroups per CU).  From 64 channels down the single launches move their algorithmic bytes at
-// 2.5-4 TB/s (profiles/r09a_conv_hl_shapes.txt): the intermediate's round trip is a third of the pair's traffic.  Built for C <= 64.
+// 2.5-4 TB/s (profiles/r09a_conv_hl_shapes.txt): the intermediate's round trip is a third of the pair's traffic.  Built for C <= 128
+// (four waves and two workgroups per CU up to 64 channels; eight waves and one workgroup at 65..128: launch_respair_hl_ks).
 struct PPL {
   const void* x;
   const void* w1;
