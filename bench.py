@@ -112,15 +112,11 @@ TRAIN_SEG = 8192
 
 
 def train_hps(cfg, bf16=False):
-    """bf16: False (fp32), True / "bf16" (fp16_run + half_type bf16), "fp16" (fp16_run + half_type fp16) or "x6" (fp32 training with
-    `train.mma: bf16x6`: fp32-level products from three exact bf16 pieces per operand — the engine's own precision mode)."""
+    """bf16: False (fp32), True / "bf16" (fp16_run + half_type bf16) or "fp16" (fp16_run + half_type fp16)."""
     model = {k: v for k, v in cfg.items() if k not in ("spec_channels", "segment_size")}
-    x6 = bf16 == "x6"
-    amp = bool(bf16) and not x6
+    amp = bool(bf16)
     tr = dict(segment_size=TRAIN_SEG, learning_rate=1e-4, betas=[0.8, 0.99], eps=1e-9, c_mel=45, c_kl=1.0,
               fp16_run=amp, half_type=("fp16" if bf16 == "fp16" else "bf16") if amp else "fp16", batch_size=TRAIN_B)
-    if x6:
-        tr["mma"] = "bf16x6"
     return dict(data=dict(filter_length=2048, hop_length=HOP, win_length=2048, n_mel_channels=80, sampling_rate=44100,
                           mel_fmin=0.0, mel_fmax=22050), train=tr, model=model)
 
@@ -201,6 +197,9 @@ def run_train(args, dev, rank, world, dist, bf16=False):
     # SVC_TRAIN_GRAPH=0 selects the eager, hook-driven bucket-overlapped path instead.
     use_graph = (not args.no_graph) and os.environ.get("SVC_TRAIN_GRAPH", "1") != "0"
     step_fn.enable_graph(use_graph)
+    for net in (net_g, net_d):                     # exposed-communication timing is opt-in (two hipEvents per wait)
+        if getattr(net, "reducer", None) is not None:
+            net.reducer.time_exposed = True
     items_cpu, T = make_train_items(cfg, TRAIN_B, 4321 + rank)
     items = tuple(t.to(dev) if t is not None else None for t in items_cpu)
     torch.manual_seed(99 + rank)
@@ -221,6 +220,9 @@ def run_train(args, dev, rank, world, dist, bf16=False):
             use_graph = False
             step_fn.enable_graph(False)
             step_fn.dp_ordered = True              # keep issuing the bucket-ordered collectives the other ranks' replays issue
+            # a capture issues no collective before its first replay, so the failed call left this rank one iteration behind its
+            # peers (who are in, or past, D's buckets 0..n-1 then G's): run that iteration now in the same collective order
+            last = step_fn(items)
     trace = [] if os.environ.get("SVC_BENCH_TRACE") else None      # determinism experiments: per-iteration losses
     for _ in range(warm):
         last = step_fn(items)
@@ -237,10 +239,13 @@ def run_train(args, dev, rank, world, dist, bf16=False):
     if trace is not None and rank == 0:
         print("TRACE " + " ".join(f"{float(l['loss_disc']):.4f}/{float(l['loss_kl']):.3f}/{float(l['loss_mel']):.3f}" for l in trace),
               file=sys.stderr)
+    per_rank_ms = None
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)                 # every rank's own clock over the same K iterations (value uses the MAX)
+        per_rank_ms = [round(p.item() * 1e3 / steps, 3) for p in parts]
+        elapsed = max(p.item() for p in parts)
     if rank != 0:
         return None
     fams = roof = None
@@ -319,11 +324,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not bf16:
         cpu = cpu_baseline_train(cfg, hps, items_cpu)
-    if bf16 == "x6" and roof is not None:
-        # delivered convolution FLOPs (one multiply-add per product, whatever the instruction count) against the fp32 MFMA peak
-        roof["note"] += "; train.mma = bf16x6: six v_mfma_f32_32x32x16_bf16 per product group where the fp32 path issues eight v_mfma_f32_32x32x2_f32"
-        roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
-    elif bf16 and roof is not None:
+    if bf16 and roof is not None:
         # the step mixes bf16-operand launches (the LDS-DMA tilings of the batched convolutions, the 128 x 64 weight-gradient
         # kernel) with fp32 ones (unaligned / narrow shapes, attention products): the fraction is quoted against the bf16 peak
         roof["peak"] = PEAK_BF16_MFMA_TFLOPS
@@ -331,9 +332,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
         roof["whole_step"]["frac"] = round(roof["whole_step"]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
         roof["note"] += "; bf16-operand and fp32 launches share these family rows, peak = dense bf16 MFMA"
         roof["bf16_launches"] = dict(conv=S.lib().svc_debug_bf16(-1), wgrad=S.tlib().svc_debug_wgrad_bf16_launches())
-    if bf16 == "x6":
-        tag, dt, cfgtag = ", fp32 with train.mma = bf16x6", "f32 operands as three exact bf16 pieces, six bf16 MFMA per product group, f32 accumulate / storage", "fp32, train.mma=bf16x6"
-    elif bf16:
+    if bf16:
         h = "fp16" if bf16 == "fp16" else "bf16"
         tag, dt, cfgtag = f", fp16_run + half_type {h}", f"{h} matrix operands, f32 accumulate / storage", "fp16_run half_type=" + h
     else:
@@ -353,7 +352,8 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                             parallelism=f"dp{world} (sharded minibatch, bucketed RCCL all-reduce)" if world > 1 else "single GPU",
                             p_dropout=cfg["p_dropout"]),
                 losses={k: round(float(v), 4) for k, v in last.items()},
-                roofline=roof if fams is not None else None, families=fams, allreduce=red, cpu_baseline=cpu)
+                roofline=roof if fams is not None else None, families=fams, allreduce=red, per_rank_ms_per_step=per_rank_ms,
+                cpu_baseline=cpu)
 
 
 def collect_pmc_traffic(timeout_s=200, mode="infer"):
@@ -458,7 +458,6 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
     ap.add_argument("--split", action="store_true", help="--mode infer only: time SynthesizerTrn.split_f16() (the generator on the split pipeline: hi + lo "
                     "fp16 planes, three fp16 MFMA per product, fp32-level output) instead of the fp32-MFMA path; labelled as such — profiling aid, not the headline")
-    ap.add_argument("--x6", action="store_true", help="--mode train only: fp32 training with train.mma = bf16x6 (fp32-level products on the bf16 instruction)")
     ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
@@ -514,7 +513,7 @@ def main():
     if args.mode == "train":
         args.train_steps = args.train_steps or args.steps
         args.train_warmup = args.warmup if args.train_warmup is None else args.train_warmup
-        res = run_train(args, dev, rank, world, dist, bf16="x6" if args.x6 else ("fp16" if args.fp16 else args.bf16))
+        res = run_train(args, dev, rank, world, dist, bf16="fp16" if args.fp16 else args.bf16)
         if rank == 0:
             res.update(higher_is_better=True, vs_baseline=None, data="synthetic")
             print(json.dumps(res))
@@ -708,8 +707,6 @@ def main():
             if isinstance(tb, dict) and "ms_per_step" in tb:
                 tb["speedup_vs_f32"] = round(train_res["ms_per_step"] / tb["ms_per_step"], 3)
             train_res["train_bf16"] = tb
-            # (`--mode train --x6`: fp32 training with train.mma = bf16x6 — measured equal to the fp32 step, 86.9 against 87.4 ms,
-            #  profiles/r09f_train*.json: not part of the default line)
             torch.cuda.empty_cache()
             # the same iteration driven through the entry point's loader loop (files on disk -> DataLoader -> bucketed collate)
             tl = X.guarded(X.bench_train_loader, dev, train_hps(cfg))
@@ -733,6 +730,24 @@ def main():
                                launch="hipGraph replay" if not args.no_graph else "eager",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU"),
                    steady_state=steady, clips_in_flight=inflight, roofline=roof, cpu_baseline=cpu, host_io=host_io, train=train_res, **extras)
+
+        # LAST key of the line: the leg results again, compact — a log tail that cuts the long line still holds every figure
+        def _ms(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return round(d, 3) if isinstance(d, (int, float)) else None
+        out["summary"] = dict(
+            infer_f32_ms=round(out["ms_per_step"], 3), infer_f32_roofline_frac=_ms(roof, "frac"),
+            infer_split_ms=_ms(extras, "infer_split", "ms_per_step"), infer_half_ms=_ms(extras, "infer_half", "ms_per_step"),
+            e2e_ms=_ms(extras, "e2e", "ms_per_step"),
+            train_f32_ms=_ms(train_res, "ms_per_step"), train_f32_whole_step_frac=_ms(train_res, "roofline", "whole_step", "frac"),
+            train_bf16_ms=_ms(train_res, "train_bf16", "ms_per_step"),
+            train_loader_ms=_ms(train_res, "train_loader", "bucketed_graph", "ms_per_step_without_epoch_start"),
+            train_per_rank_ms=train_res.get("per_rank_ms_per_step") if isinstance(train_res, dict) else None,
+            train_allreduce=({k: train_res["allreduce"].get(k) for k in ("mode", "exposed_ms", "bytes", "launches")}
+                             if isinstance(train_res, dict) and isinstance(train_res.get("allreduce"), dict) else None),
+            snake_b8_ms=_ms(extras, "snake_b8", "ms_per_step"), diffusion_train_ms=_ms(extras, "diffusion_train", "ms_per_step"),
+            cpu_baseline_samples_per_s=_ms(cpu, "value"), n_gpus=world)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

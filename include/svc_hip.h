@@ -33,7 +33,14 @@ typedef enum svc_status {
 } svc_status;
 
 const char* svc_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature OR argument-struct layout change (the structs are passed by pointer and
+ * read in full: a caller built against an older header hands over a shorter struct).  A caller checks
+ * svc_abi_version() == SVC_ABI_VERSION once after loading the library (svc_hip.py does) and refuses to run otherwise.
+ *   3: svc_conv1d_args.mma / svc_wgrad_args.mma, svc_conv1d_multi_f32
+ *   4: svc_attention_args grew {ws, ws_bytes} (key-split workspace), svc_gemm_args grew {split_k_atomic}; the 16-bit / split
+ *      generator entry points (svc_conv1d_h*, svc_conv1d_hl*, svc_resblock_pair_h / _hl)
+ *   5: SVC_MMA_BF16X6 removed (svc_conv1d_args.mma / svc_wgrad_args.mma accept fp32, bf16, fp16 only) */
+#define SVC_ABI_VERSION 5
 int svc_abi_version(void);
 /* Fills name[0..len) with the gcnArchName of the current device, returns number of CUs (or <0). */
 int svc_device_info(char* name, int len);
@@ -121,13 +128,6 @@ typedef struct svc_conv1d_args {
 #define SVC_MMA_F32 0
 #define SVC_MMA_BF16 1
 #define SVC_MMA_F16 2  /* `half_type: fp16`: the same with fp16 operands (v_mfma_f32_32x32x16_f16); the caller scales the loss (GradScaler) */
-/* SVC_MMA_BF16X6 (3): fp32-LEVEL products on the bf16 matrix instruction (no counterpart in the reference; a precision mode of fp32
- * training).  Every fp32 operand is taken apart into three bf16 pieces as it is fetched, v = p0 + p1 + p2 EXACTLY (8 + 8 + 8 mantissa
- * bits, while the third piece is a normal number: |v| >= 2^-110; bf16 has fp32's exponent range, so gradients of any magnitude survive), and a product is the six piece products of weight
- * >= 2^-16: p0q0 + p0q1 + p1q0 + p0q2 + p1q1 + p2q0 — each exact in the fp32 accumulator; the three dropped ones are <= 2^-24 relative,
- * fp32's own rounding.  Six v_mfma_f32_32x32x16_bf16 (32 clocks each) replace eight v_mfma_f32_32x32x2_f32 (64 clocks each).  Same
- * tensors, same kernels and shapes as SVC_MMA_BF16. */
-#define SVC_MMA_BF16X6 3
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
 
@@ -138,7 +138,6 @@ int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
  * issued as ONE launch (heaviest workgroups first), the others one by one. */
 int svc_conv1d_multi_f32(const svc_conv1d_args* a, int n, void* stream);
 int svc_debug_conv_multi_merged(void);   /* merged launches of the tiled kernel so far (tests) */
-int svc_debug_set_sp(int min_taps, int min_wgs); /* SVC_MMA_BF16X6: fewest taps / workgroups the split-structure kernel takes (defaults 2, 224; tests: 1, 0) */
 int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */
 int svc_debug_wgrad_bf16_launches(void);
 

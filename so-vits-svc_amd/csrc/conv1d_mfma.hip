@@ -58,7 +58,6 @@ struct ConvP {
   int fast_epi;   // DB kernels: 1 = plain epilogue with all residual / accumulate loads issued up front (conv_epilogue<BATCH>)
   int direct_epi; // DB kernels: 1 = epilogue straight from the accumulators (conv_epilogue_direct): no LDS transpose, no barrier
   const float* zero;  // DB kernels: 16 B of zeros in global memory (source of padding / out-of-tile pieces)
-  int sp_gc, sp_xw;   // conv1d_sp_kernel: 16-channel groups staged per chunk, columns of the staged tile
 };
 
 __device__ float4 g_zero_block[2];
@@ -80,37 +79,6 @@ template <> struct Op16<SVC_MMA_F16> {
   static __device__ __forceinline__ frag cvt(const f32x8v& t) { return __builtin_convertvector(t, f16x8); }
   static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
-// SVC_MMA_BF16X6 (include/svc_hip.h): v = p0 + p1 + p2 exactly in three bf16 pieces (bf16 -> fp32 is a shift: the remainders are
-// exact), a product = the six piece products of weight >= 2^-16, smallest first.
-struct frag_x6 {
-  bf16x8 p0, p1, p2;
-};
-template <> struct Op16<SVC_MMA_BF16X6> {
-  typedef frag_x6 frag;
-  static __device__ __forceinline__ frag cvt(const f32x8v& t) {
-    frag f;
-    f.p0 = __builtin_convertvector(t, bf16x8);
-    f32x8v r = t - __builtin_convertvector(f.p0, f32x8v);
-    f.p1 = __builtin_convertvector(r, bf16x8);
-    r = r - __builtin_convertvector(f.p1, f32x8v);
-    f.p2 = __builtin_convertvector(r, bf16x8);
-    return f;
-  }
-  template <int T>
-  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) {
-    if constexpr (T == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, c, 0, 0, 0);
-    else if constexpr (T == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, c, 0, 0, 0);
-    else if constexpr (T == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, c, 0, 0, 0);
-    else if constexpr (T == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, c, 0, 0, 0);
-    else if constexpr (T == 4) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ f32x16 mfma(const frag& a, const frag& b, f32x16 c) {
-    c = term<0>(a, b, c); c = term<1>(a, b, c); c = term<2>(a, b, c); c = term<3>(a, b, c); c = term<4>(a, b, c);
-    return term<5>(a, b, c);
-  }
-};
-
 // One LDS-DMA piece: every lane's 16 B at `g` land at LDS byte address lds_byte + lane*16 (wave-uniform base in M0).
 // Not tracked by hipcc's s_waitcnt bookkeeping: the kernel counts these itself (svc_vmcnt0 before the barrier).
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_byte) {
@@ -724,20 +692,11 @@ __device__ __forceinline__ void conv1d_mfma_body(const ConvP& p, int bid) {
               for (int j = 0; j < 8; ++j) t[j] = xa[j * XW + k * dil + jn * TS];
               bq[jn] = OP::cvt(t);
             }
-            if constexpr (MMA == SVC_MMA_BF16X6) {
-              // term-major: MT NT independent accumulators between two instructions on the same one
-#define SVC_X6_TERM(T)                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int jn = 0; jn < NT; ++jn)      \
-      acc32[i][jn] = OP::template term<T>(af[i], bq[jn], acc32[i][jn]);
-              SVC_X6_TERM(0) SVC_X6_TERM(1) SVC_X6_TERM(2) SVC_X6_TERM(3) SVC_X6_TERM(4) SVC_X6_TERM(5)
-#undef SVC_X6_TERM
-            } else {
 #pragma unroll
-              for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NT; ++jn)
-                  acc32[i][jn] = OP::mfma(af[i], bq[jn], acc32[i][jn]);
-            }
+              for (int jn = 0; jn < NT; ++jn)
+                acc32[i][jn] = OP::mfma(af[i], bq[jn], acc32[i][jn]);
           }
         }
       } else if constexpr (KSC > 0) {
@@ -1038,166 +997,7 @@ int g_bf16_enabled = 1;    // svc_debug_bf16(0) forces fp32 operands whatever th
 int g_bf16_launches = 0;   // launches that ran with bf16 operands (tests ask through svc_debug_bf16(-1))
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
 int g_no_ksc = 0;      // debug: 1 disables the compile-time-KS kernels
-// ---- SVC_MMA_BF16X6 on the structure of the split inference pipeline (conv1d_hl.hip) with fp32 tensors either side -----------
-// The first x6 form (the chunk loop above with three-piece fragments built from the fp32 LDS tiles) was as exact as it should be and
-// no faster than fp32 (training step 86.9 against 87.4 ms, profiles/r09f_*): those kernels spend ~2 300 clocks per 16-channel step on
-// filling and reading their fp32 tiles (every workgroup pulls its rows' weights through LDS, every fragment is eight ds_read_b32 and
-// is re-split by every wave and tap that uses it) against 128-768 clocks of matrix work.  Here: the activations are taken apart ONCE,
-// while the tile is staged (fp32 rows from global memory, time-contiguous -> three bf16 planes in LDS in the blocked [C/8][t][8]
-// layout: a B fragment is three ds_read_b128, a dilated tap an address offset); the weights go from L2 straight into registers
-// (packed fp32 [Cin][KS][CoutP]: eight coalesced dword loads per fragment, through a ring two steps ahead) and are split there; six
-// v_mfma_f32_32x32x16_bf16 per 16-channel step and tile pair, term-major.  Same C layout as the fp32 instruction: the epilogues of
-// this file are shared (direct, or through the LDS transpose).  Input channels are staged in chunks of sp_gc groups.
-template <int MT, int NT, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv1d_sp_kernel(ConvP p) {
-  constexpr int TS = 32, BM = WM * MT * TS, BN = WN * NT * TS, NTHR = 256, CH = 2;
-  static_assert(WM * WN == 4, "four waves per workgroup");
-  typedef Op16<SVC_MMA_BF16X6> OP;
-  const svc_conv1d_args& a = p.a;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  bf16x8* xs = reinterpret_cast<bf16x8*>(smem);           // [3][2 GC][XW]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, lk = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
-  const int ph = bid % a.n_phase;
-  bid /= a.n_phase;
-  const int tt = bid % p.n_t_tiles;
-  bid /= p.n_t_tiles;
-  const int mtile = bid % p.n_m_tiles;
-  const int b = bid / p.n_m_tiles;
-  const int t0 = tt * BN, co0 = mtile * BM;
-  const int KS = a.KS, dil = a.dil, XW = p.sp_xw, GC = p.sp_gc, G = a.Cin >> 4;
-  const int lplane = 2 * GC * XW;                         // 16-byte words per LDS plane
-  const float* xb = a.x + (long long)b * a.x_bs;
-  const float* wph = a.w + (long long)ph * a.w_phase_stride;
-  const float ps = a.pre_slope;
-  const bool act = a.pre_slope != 1.f;
-
-  f32x16 acc32[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-
-  // this lane's weight column per row tile (rows past CoutP are clamped: their accumulators are never stored)
-  int wcol[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) wcol[i] = min(co0 + (wm * MT + i) * TS + ln, a.CoutP - 1);
-  const long long wci = (long long)KS * a.CoutP;          // floats between consecutive input channels of one tap
-  // raw fp32 weights of step s (group-major: g = s / KS, tap = s % KS): channels g*16 + 8 lk + (0..7)
-  auto wload = [&](float (&raw)[CH][MT][8], int s0, int S, int gbase) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int s = min(s0 + j, S - 1);
-      const int g = s / KS, tap = s - g * KS;
-      const float* q = wph + ((long long)((gbase + g) * 16 + 8 * lk) * KS + tap) * a.CoutP;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) raw[j][i][e] = q[e * wci + wcol[i]];
-    }
-  };
-
-  for (int g0 = 0; g0 < G; g0 += GC) {
-    const int gc = min(GC, G - g0);
-    if (g0) __syncthreads();
-    // ---- stage 2 gc channel blocks: eight time-coalesced fp32 loads per (block, column), pre-activation, split, three 16-byte stores
-    {
-      const int total = 2 * gc * XW;
-      for (int idx = tid; idx < total; idx += NTHR) {
-        const int cbl = idx / XW, tl = idx - cbl * XW;
-        const int tin = t0 - a.pad_left + tl;
-        f32x8v v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (tin >= 0 && tin < a.Tin) {
-          const float* q = xb + (long long)((2 * g0 + cbl) * 8) * a.x_cs + tin;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = q[(long long)e * a.x_cs];
-          if (act) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * ps);
-          }
-        }
-        const OP::frag f = OP::cvt(v);
-        xs[idx] = f.p0;
-        xs[lplane + idx] = f.p1;
-        xs[2 * lplane + idx] = f.p2;
-      }
-    }
-    __syncthreads();
-    // ---- matrix loop over this chunk's (group, tap) steps; the weights of the next two steps are in flight meanwhile
-    const int S = gc * KS;
-    const bf16x8* xw = xs + lk * XW + wn * (NT * TS) + ln;
-    float r0[CH][MT][8], r1[CH][MT][8];
-    auto chunk = [&](const float (&raw)[CH][MT][8], int s0) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int s = s0 + j;
-        if (s < S) {
-          const int g = s / KS, tap = s - g * KS;
-          const bf16x8* xr = xw + 2 * g * XW + tap * dil;
-          OP::frag af[MT], bq[NT];
-#pragma unroll
-          for (int jn = 0; jn < NT; ++jn) {
-            bq[jn].p0 = xr[jn * TS];
-            bq[jn].p1 = xr[lplane + jn * TS];
-            bq[jn].p2 = xr[2 * lplane + jn * TS];
-          }
-#pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            f32x8v t;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = raw[j][i][e];
-            af[i] = OP::cvt(t);
-          }
-#define SVC_SP_TERM(T)                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int jn = 0; jn < NT; ++jn)      \
-      acc32[i][jn] = OP::template term<T>(af[i], bq[jn], acc32[i][jn]);
-          SVC_SP_TERM(0) SVC_SP_TERM(1) SVC_SP_TERM(2) SVC_SP_TERM(3) SVC_SP_TERM(4) SVC_SP_TERM(5)
-#undef SVC_SP_TERM
-        }
-      }
-    };
-    wload(r0, 0, S, g0);
-    for (int s0 = 0; s0 < S; s0 += 2 * CH) {
-      if (s0 + CH < S) wload(r1, s0 + CH, S, g0);
-      chunk(r0, s0);
-      if (s0 + CH < S) {
-        if (s0 + 2 * CH < S) wload(r0, s0 + 2 * CH, S, g0);
-        chunk(r1, s0 + CH);
-      }
-    }
-  }
-
-  // ---- epilogue: as the LDS-DMA kernels above
-  if (p.direct_epi) {
-    conv_epilogue_direct<MT, NT>(p, acc32, b, t0, co0 + wm * (MT * TS), wn * (NT * TS), lane);
-    return;
-  }
-  constexpr int CP = BN + 4;
-  __syncthreads();
-  {
-    float* cw = smem + (wm * (MT * TS)) * CP + wn * (NT * TS) + ln;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * TS + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          cw[row * CP + j * TS] = acc32[i][j][r];
-        }
-  }
-  __syncthreads();
-  conv_epilogue<BM, BN, NTHR, 1, EPI, NT != 7>(p, smem, tid, b, ph, t0, co0);
-}
-
 int g_dbg = 0;         // debug: ConvP.dbg
-int g_sp_min_taps = 2; // SVC_MMA_BF16X6: fewest taps the split-structure kernel takes (tuning: environment SVC_SP_MIN_TAPS at first use)
-int g_sp_min_wgs = 224; // ... and fewest workgroups (SVC_SP_MIN_WGS): wins at 240 (192 -> 384 x 5 taps on the 128 x 160 tile), loses at 192
 int g_db_budget_kb = 64;
 int g_db_mode = 1;     // 1: use the LDS-DMA double-buffered kernels where eligible (svc_debug_set_conv_cfg: +10000 disables)
 int g_no224 = 1;       // 1: the 128x224 one-workgroup-per-CU tile stays out of the selection (svc_debug_set_conv_cfg: +100000000
@@ -1287,7 +1087,7 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
     constexpr bool BF16_TILING = EPI == SVC_EPI_PLAIN && ((MT == 2 && NT == 2 && WM == 2 && WN == 2) || (MT == 2 && NT == 1 && WM == 1 && WN == 4) ||
                                                           (MT == 1 && NT == 3 && WM == 2 && WN == 2) || (MT == 1 && NT == 5 && WM == 4 && WN == 1) ||
                                                           (MT == 2 && NT == 2 && WM == 1 && WN == 4));
-    bool want_bf16 = BF16_TILING && (a.mma == SVC_MMA_BF16 || a.mma == SVC_MMA_F16 || a.mma == SVC_MMA_BF16X6) && (a.Cin % 16) == 0 &&
+    bool want_bf16 = BF16_TILING && (a.mma == SVC_MMA_BF16 || a.mma == SVC_MMA_F16) && (a.Cin % 16) == 0 &&
                      g_bf16_enabled;
     auto set_epi = [&]() {
       p.fast_epi = (g_fast_epi && p.row_phases == 1 && a.epi == SVC_EPI_PLAIN && a.mask == nullptr && (a.res_mode == 0 || a.res_mode == 1) &&
@@ -1297,36 +1097,6 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
                       (a.post_act == SVC_ACT_NONE || (a.post_act == SVC_ACT_LRELU && a.post_slope >= 0.f && a.post_slope <= 1.f)) &&
                       a.y_cs >= 0 && a.y_cs < (1ll << 24) && a.res_cs >= 0 && a.res_cs < (1ll << 24)) ? 1 : 0;
     };
-    // ---- SVC_MMA_BF16X6: the split-structure kernel (conv1d_sp_kernel) — no LDS-DMA piece limits, any tap count >= 2.  One-tap
-    // convolutions (and anything it does not take) run the fp32 kernels: 23 against 20 us on the 192 -> 192 layers of the training
-    // step (profiles/r09h_conv_mma_modes.txt) — a chunk's matrix work is then shorter than its staging round trip.
-    if constexpr (BF16_TILING) {
-      // ... and launches that leave many CUs without a workgroup (nothing overlaps a lone workgroup's staging round trips: 768 -> 192 x 3 taps at
-      // B x T = 16 x 768 is 192 workgroups, 3.63 against 3.14 ms per training step; 1024 -> 1024 at B = 16: 0.78 against 0.60 —
-      // profiles/r09j_train_shapes_f32_vs_x6.txt); from 240 workgroups up it wins 15-35 % (192 -> 384 x 5: 2.18 against 2.86 ms)
-      if (want_bf16 && a.mma == SVC_MMA_BF16X6 && a.KS >= g_sp_min_taps && a.premask == nullptr && a.pre_slope >= 0.f && a.pre_slope <= 1.f &&
-          nblk >= g_sp_min_wgs) {
-        set_epi();
-        p.dump_off = 0;
-        // three bf16 planes of the staged tile: 96 bytes per (16-channel group, column); chunks sized for two workgroups per CU
-        p.sp_xw = BN + (a.KS - 1) * a.dil;
-        const size_t per_group = (size_t)96 * p.sp_xw;
-        const int G = a.Cin / 16;
-        const int gmax = (int)std::max<size_t>(1, (size_t)(72 * 1024) / per_group);
-        p.sp_gc = svc::cdiv(G, svc::cdiv(G, gmax));
-        const size_t lds_sp = std::max(per_group * p.sp_gc, p.direct_epi ? (size_t)0 : epi_bytes);
-        auto ks = conv1d_sp_kernel<MT, NT, WM, WN, EPI>;
-        static bool dones = false;
-        if (!dones) {
-          hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          dones = true;
-        }
-        ++g_bf16_launches;
-        hipLaunchKernelGGL(ks, dim3((unsigned)nblk), dim3(256), lds_sp, s, p);
-        return svc::check_launch("conv1d_sp_bf16x6");
-      }
-    }
-    if (a.mma == SVC_MMA_BF16X6) want_bf16 = false;
     // a bf16 chunk is at least 16 channels (one instruction's reduction): 5..11 taps of them do not fit the 64 KiB the fp32
     // chunks are sized for — they take up to 144 KiB (one workgroup per CU; the instruction stream is 16x shorter per chunk)
     const size_t base_budget = budget;
@@ -1648,21 +1418,8 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     const char* e = getenv("SVC_CONV_NO192");
     g_no192 = (e && e[0] == '1') ? 1 : 0;
   }
-  {
-    static bool sp_env = false;
-    if (!sp_env) {
-      const char* e = getenv("SVC_SP_MIN_TAPS");
-      if (e && e[0] >= '1' && e[0] <= '9') g_sp_min_taps = atoi(e);
-      const char* w = getenv("SVC_SP_MIN_WGS");
-      if (w && w[0] >= '0' && w[0] <= '9') g_sp_min_wgs = atoi(w);
-      sp_env = true;
-    }
-  }
   // long sequences that one round of 224-column strips covers (the decoder's MRF convs): conv1d_strip.hip
-  // (SVC_MMA_BF16X6 on shapes the split-structure kernel takes: 130-160 TFLOP/s there against the strips' 105-117)
-  const bool sp_first = a.mma == SVC_MMA_BF16X6 && g_bf16_enabled && (a.Cin % 16) == 0 && a.Cout >= 64 && a.KS >= g_sp_min_taps &&
-                        a.epi == SVC_EPI_PLAIN && a.premask == nullptr;
-  if (g_force_cfg < 0 && t_row_phases == 1 && !sp_first) {      // (the strip kernel's epilogue knows nothing of phases-as-rows outputs)
+  if (g_force_cfg < 0 && t_row_phases == 1) {      // (the strip kernel's epilogue knows nothing of phases-as-rows outputs)
     const int rs = svc::conv1d_strip_try(a, s);
     if (rs <= 0) return rs;
   }
@@ -1876,12 +1633,6 @@ extern "C" int svc_conv1d_multi_f32(const svc_conv1d_args* ap, int n, void* stre
 }
 
 extern "C" int svc_debug_conv_multi_merged(void) { return g_tile_merged; }
-
-extern "C" int svc_debug_set_sp(int min_taps, int min_wgs) {
-  g_sp_min_taps = min_taps;
-  g_sp_min_wgs = min_wgs;
-  return SVC_OK;
-}
 
 extern "C" int svc_debug_bf16(int mode) {
   if (mode < 0) return g_bf16_launches;

@@ -67,34 +67,6 @@ template <> struct WOp16<SVC_MMA_F16> {
   template <int T>
   static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
-// SVC_MMA_BF16X6 (include/svc_hip.h): both operands in three exact bf16 pieces, the six piece products of weight >= 2^-16, smallest
-// first — fp32-level weight gradients from the bf16 instruction, with fp32's exponent range (no loss scaling).
-struct wfrag_x6 {
-  bf16x8 p0, p1, p2;
-};
-template <> struct WOp16<SVC_MMA_BF16X6> {
-  typedef wfrag_x6 frag;
-  static constexpr int TERMS = 6;
-  static __device__ __forceinline__ frag cvt(const f32x8v& t) {
-    frag f;
-    f.p0 = __builtin_convertvector(t, bf16x8);
-    f32x8v r = t - __builtin_convertvector(f.p0, f32x8v);
-    f.p1 = __builtin_convertvector(r, bf16x8);
-    r = r - __builtin_convertvector(f.p1, f32x8v);
-    f.p2 = __builtin_convertvector(r, bf16x8);
-    return f;
-  }
-  template <int T>
-  static __device__ __forceinline__ f32x16 term(const frag& a, const frag& b, const f32x16& c) {
-    if constexpr (T == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, c, 0, 0, 0);
-    else if constexpr (T == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, c, 0, 0, 0);
-    else if constexpr (T == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, c, 0, 0, 0);
-    else if constexpr (T == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, c, 0, 0, 0);
-    else if constexpr (T == 4) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, c, 0, 0, 0);
-  }
-};
-
 // ---- LDS-DMA staging (DMA = true) -------------------------------------------------------------------------------------
 // The register-staged tile hand-over above costs a launch more than its MFMAs when a tap group is short: per 64-step tile a
 // thread issues 64 global loads, waits for them behind the MFMA loop, writes 64 LDS words and passes two barriers — 4.3 us per
@@ -680,13 +652,12 @@ template <int NK, bool DMA, int MT>
 void launch_fmt(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma) {
   if (mma == SVC_MMA_BF16) launch_one<NK, SVC_MMA_BF16, DMA, MT>(p, grid, lds, s);
   else if (mma == SVC_MMA_F16) launch_one<NK, SVC_MMA_F16, DMA, MT>(p, grid, lds, s);
-  else if (mma == SVC_MMA_BF16X6) launch_one<NK, SVC_MMA_BF16X6, DMA, MT>(p, grid, lds, s);
   else launch_one<NK, SVC_MMA_F32, DMA, MT>(p, grid, lds, s);
 }
 
 template <int NK>
 void launch(const WgP& p, dim3 grid, size_t lds, hipStream_t s, int mma, bool dma, int mt) {
-  if (mma == SVC_MMA_BF16 || mma == SVC_MMA_F16 || mma == SVC_MMA_BF16X6) ++g_wgrad_bf16_launches;
+  if (mma == SVC_MMA_BF16 || mma == SVC_MMA_F16) ++g_wgrad_bf16_launches;
   if (dma && mt == 1) launch_fmt<NK, true, 1>(p, grid, lds, s, mma);
   else if (dma) launch_fmt<NK, true, 2>(p, grid, lds, s, mma);
   else launch_fmt<NK, false, 2>(p, grid, lds, s, mma);

@@ -92,7 +92,7 @@ extern "C" {
 
 const char* svc_last_error(void) { return svc::g_err; }
 
-int svc_abi_version(void) { return 3; }   // 3: svc_conv1d_args.mma / svc_wgrad_args.mma, svc_conv1d_multi_f32
+int svc_abi_version(void) { return SVC_ABI_VERSION; }   // history: include/svc_hip.h (SVC_ABI_VERSION)
 
 int svc_device_info(char* name, int len) {
   int dev = 0;

@@ -115,7 +115,11 @@ class GradReducer:
         self._works = []
         self._launched = None
         self.stats = dict(reduced_bytes=0, launches=0, backward_passes=0, reduce_all_calls=0, wait_all_calls=0)
-        self._exposed = []          # (start, end) event pairs around reduce_all on the compute stream
+        # exposed-communication timing is OPT-IN (bench.py / the GPU tests set `time_exposed`): a training run of hundreds of
+        # thousands of iterations must not collect two hipEvents per wait that nobody drains
+        self.time_exposed = os.environ.get("SVC_DP_TIME_EXPOSED", "0") == "1"
+        self._exposed = []          # (start, end) event pairs around the waits on the compute stream, while time_exposed
+        self._exposed_ms = 0.0      # pairs already folded into a running sum (the list is drained every _EXPOSED_KEEP pairs)
         self._seg_cb = None         # segmented(): callback(bucket) instead of a collective (hipGraph capture of a backward pass)
         self.seg_next = 0           # ... first bucket (index order) not yet handed to the callback
         arena.add_listener(self._on_grad)
@@ -201,6 +205,16 @@ class GradReducer:
             nb = self.seg_next
             self.seg_next += 1
             self._seg_cb(nb)
+        if self._pending[b] == 0 and b >= self.seg_next and not self.__dict__.get("_stall_logged"):
+            # bucket b is complete but an EARLIER bucket still waits for a gradient (a parameter without one in this pass): every
+            # bucket from seg_next on is then reduced after the last graph — correct, identical on all ranks, but without overlap
+            self.__dict__["_stall_logged"] = True
+            import logging
+            missing = [i2 for i2 in self.buckets[self.seg_next]["members"]]
+            logging.getLogger("train").warning(
+                "GradReducer: bucket %d completed before bucket %d (%d of its %d parameters still without a gradient): buckets are "
+                "released in index order, so all-reduces from bucket %d on lose their overlap with this backward pass",
+                b, self.seg_next, self._pending[self.seg_next], len(missing), self.seg_next)
 
     def launch_bucket(self, b):
         """Asynchronous all-reduce (mean) of bucket b, ordered after the work queued on the current stream so far (RCCL's
@@ -209,14 +223,32 @@ class GradReducer:
             return
         self._launch(b)
 
-    def wait_all(self, time_it=True):
+    _EXPOSED_KEEP = 64
+
+    def _timing(self, time_it):
+        on = self.time_exposed if time_it is None else time_it
+        return bool(on) and self.arena.grad.is_cuda
+
+    def _note_exposed(self, ev):
+        self._exposed.append(ev)
+        if len(self._exposed) > self._EXPOSED_KEEP and ev[0].query():
+            # bounded: fold the pairs that have completed into the running sum (no device synchronisation)
+            keep = []
+            for a, b in self._exposed:
+                if b.query():
+                    self._exposed_ms += a.elapsed_time(b)
+                else:
+                    keep.append((a, b))
+            self._exposed = keep
+
+    def wait_all(self, time_it=None):
         """The current stream waits for every all-reduce issued by launch_bucket since the last call.  The time the stream
         stalls here is the iteration's EXPOSED communication (`exposed_ms()`)."""
         if self.single:
             return
         self.stats["wait_all_calls"] += 1
         ev = None
-        if time_it and self.arena.grad.is_cuda:
+        if self._timing(time_it):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         for w, buf in self._works:
@@ -227,9 +259,9 @@ class GradReducer:
         self._launched = None
         if ev is not None:
             ev[1].record()
-            self._exposed.append(ev)
+            self._note_exposed(ev)
 
-    def reduce_all(self, time_it=True):
+    def reduce_all(self, time_it=None):
         """All-reduce (mean) of the whole flat gradient buffer, ordered after the work already queued on the current stream:
         the reduction used BETWEEN hipGraph replays (train.TrainStep with a process group) — the per-bucket path above is
         driven by Python autograd hooks, which do not run when a captured backward is replayed.  The same contiguous buckets
@@ -241,7 +273,7 @@ class GradReducer:
             return
         self.stats["reduce_all_calls"] += 1
         ev = None
-        if time_it and self.arena.grad.is_cuda:
+        if self._timing(time_it):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         works = []
@@ -257,15 +289,15 @@ class GradReducer:
                 buf.mul_(1.0 / self.world)
         if ev is not None:
             ev[1].record()
-            self._exposed.append(ev)
+            self._note_exposed(ev)
 
     def exposed_ms(self):
-        """Total time the compute stream spent inside reduce_all since the last call (synchronises the device)."""
-        if not self._exposed:
-            return 0.0
-        torch.cuda.synchronize()
-        total = sum(a.elapsed_time(b) for a, b in self._exposed)
-        self._exposed = []
+        """Total time the compute stream spent waiting for all-reduces since the last call (synchronises the device).  Only
+        measured while `time_exposed` is set (bench.py, tests; SVC_DP_TIME_EXPOSED=1): 0.0 otherwise."""
+        if self._exposed:
+            torch.cuda.synchronize()
+        total = self._exposed_ms + sum(a.elapsed_time(b) for a, b in self._exposed)
+        self._exposed, self._exposed_ms = [], 0.0
         return total
 
     @contextlib.contextmanager

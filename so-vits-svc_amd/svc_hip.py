@@ -103,6 +103,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.svc_last_error.restype = C.c_char_p
         L.svc_abi_version.restype = C.c_int
+        if L.svc_abi_version() != ABI_VERSION:      # argument structs are read in full: a stale library must not be driven
+            raise SvcError(f"{LIB_PATH} has ABI version {L.svc_abi_version()}, this binding was written against {ABI_VERSION} "
+                           "(include/svc_hip.h SVC_ABI_VERSION): rebuild with `python so-vits-svc_amd/csrc/build.py`")
         L.svc_device_info.argtypes = [C.c_char_p, C.c_int]
         L.svc_prof_enable.argtypes = [C.c_int]
         L.svc_prof_report.argtypes = [C.c_char_p, C.c_int]
@@ -164,10 +167,12 @@ def lib():
     return _lib
 
 
+ABI_VERSION = 5      # include/svc_hip.h SVC_ABI_VERSION (tests/test_abi_cpu.py keeps the two and the struct layouts in step)
+
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
-    "svc_debug_bf16", "svc_debug_set_sp", "svc_debug_wgrad_bf16_launches",
+    "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
@@ -294,7 +299,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
 _GROUP = None
 
 # ---- matrix-pipe operand format of the convolutions (svc_conv1d_args.mma): the engine's form of the reference's autocast region
-MMA_F32, MMA_BF16, MMA_F16, MMA_BF16X6 = 0, 1, 2, 3     # BF16X6: three exact bf16 pieces per operand, six products (fp32-level)
+MMA_F32, MMA_BF16, MMA_F16 = 0, 1, 2
 _MMA = MMA_F32
 
 

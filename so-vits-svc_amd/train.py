@@ -88,13 +88,6 @@ class TrainStep:
                 # as an fp16 operand.  The scaler's skip-on-overflow is a host decision per optimizer step (as in the reference:
                 # GradScaler reads found_inf back), so this mode launches eagerly — no whole-iteration hipGraph.
                 self.mma, self.scaler = S.MMA_F16, LossScaler()
-        elif (t.get("mma") if isinstance(t, dict) else getattr(t, "mma", None)) == "bf16x6" or os.environ.get("SVC_TRAIN_MMA") == "bf16x6":
-            # A precision mode of FP32 training with no counterpart in the reference (train.mma: "bf16x6" / SVC_TRAIN_MMA=bf16x6): the
-            # convolutions and their gradients take every fp32 operand apart into three bf16 pieces (exactly: 8 + 8 + 8 mantissa bits,
-            # fp32's exponent range — no loss scaling) and multiply the six piece products of weight >= 2^-16 on
-            # v_mfma_f32_32x32x16_bf16: fp32-level products (what is dropped is <= 2^-24 relative) at 3/8 of the fp32 instruction's
-            # matrix time.  Tensors, master weights, accumulation and everything outside the convolutions as in fp32 mode.
-            self.mma = S.MMA_BF16X6
 
         self.use_graph = False
         import collections
@@ -105,7 +98,14 @@ class TrainStep:
         self.finite_every = max(1, int(os.environ.get("SVC_TRAIN_FINITE_EVERY", "200")))
         # every captured shape keeps its own ~10 GB tape alive: bound the count (bucketed batches need 2-4; a data set of
         # odd batch sizes falls back to eager launches for the shapes beyond the cap instead of growing without limit)
-        self.max_graphs = int(os.environ.get("SVC_TRAIN_GRAPH_MAX", "8"))
+        # default: every frame bucket of the loader (data_utils.FRAME_BUCKETS) + a few for the short last batch of an epoch, so
+        # that a bucketed data set never cycles through evictions (a miss costs two warm-ups + a capture + the tape re-allocation)
+        try:
+            from data_utils import FRAME_BUCKETS
+            dflt = len(FRAME_BUCKETS) + 3
+        except Exception:      # noqa: BLE001 — TrainStep is usable without the loader module
+            dflt = 12
+        self.max_graphs = int(os.environ.get("SVC_TRAIN_GRAPH_MAX", str(dflt)))
         self.eager_fallbacks = 0
         self.plan_sets = S.PlanSets()     # one-launch weight preparation per forward pass (G, D, D again after its step)
 
@@ -499,11 +499,21 @@ class TrainStep:
             with red_g.no_sync(), red_d.no_sync():
                 ctx = self._seg_d(items, noise)
             red_d.reduce_all()
-            self.optim_d.step()
+            # fp16 operands (LossScaler): the reduced gradients are still scaled — unscale, skip on overflow, update, exactly as
+            # _step_body does (the mean of the ranks' scaled gradients is inf / nan on every rank alike, so all ranks skip together)
+            if self.scaler is None:
+                self.optim_d.step()
+            else:
+                self.scaler.step(self.optim_d)
             with red_g.no_sync(), red_d.no_sync():
                 out = self._seg_g(ctx)
             red_g.reduce_all()
-            self.optim_g.step()
+            if self.scaler is None:
+                self.optim_g.step()
+            else:
+                self.scaler.step(self.optim_g)
+                self.scaler.update()
+                out["loss_scale"] = self.scaler.scale
         finally:
             S.wgrad_slab.active = False
         return out
@@ -533,6 +543,11 @@ class TrainStep:
             return True
         self._graphs.popitem(last=False)
         self.graph_evictions += 1
+        if self.graph_evictions in (10, 100) or self.graph_evictions % 1000 == 0:
+            import logging
+            logging.getLogger("train").warning(
+                "TrainStep: %d graph evictions so far (each costs two warm-up iterations, a capture and the tape's re-allocation): "
+                "the data set cycles through more than SVC_TRAIN_GRAPH_MAX=%d padded shapes", self.graph_evictions, self.max_graphs)
         return False
 
     def _graph_put(self, key, ent):
@@ -701,6 +716,12 @@ def train_and_evaluate(rank, epoch, hps, step, loaders, logger, writers, device)
     t_epoch = time.time()
     for batch_idx, items in enumerate(train_loader):
         out = step(_to_device(items, device))
+        if global_step % hps.train.eval_interval == 0:
+            # every rank, same global_step, BEFORE rank 0 evaluates / writes G_<step>.pth: the periodic guard read counts calls
+            # since construction (not global_step), so after a resume a checkpoint could otherwise be written up to
+            # finite_every - 1 iterations into a divergence, and `keep_ckpts` rotation could delete the last good one; and all
+            # ranks raise on the same iteration instead of leaving peers blocked in a collective
+            step.check_finite(force=True)
         if rank == 0:
             if global_step % hps.train.log_interval == 0:
                 lr = optim_g.param_groups[0]["lr"]

@@ -31,9 +31,42 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.svc_abi_version.restype = ctypes.c_int
-    assert lib.svc_abi_version() >= 1
+    hdr_version = int(re.search(r"#define\s+SVC_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.svc_abi_version() == hdr_version == S.ABI_VERSION
     lib.svc_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.svc_last_error(), bytes)
+
+
+def test_argument_struct_layouts_match_the_header(tmp_path):
+    """The argument structs cross the boundary by pointer and are read in full, so the ctypes mirrors must have the C compiler's
+    layout of include/svc_hip.h: sizeof and the offset of every field, taken from a program gcc builds from the header itself.  (A
+    struct that grows without SVC_ABI_VERSION moving is what ADVICE r5 flagged: svc_attention_args.ws, svc_gemm_args.split_k_atomic.)"""
+    import shutil
+    import subprocess
+    import svc_hip as S
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler on this host")
+    pairs = {"svc_conv1d_args": S.Conv1dArgs, "svc_convt1d_args": S.ConvT1dArgs, "svc_conv1d_direct_args": S.Conv1dDirectArgs,
+             "svc_resblock_pair_args": S.ResblockPairArgs, "svc_attention_args": S.AttentionArgs, "svc_conv1d_h_args": S.Conv1dHArgs,
+             "svc_conv_weight_args": S.ConvWeightArgs, "svc_wgrad_args": S.WgradArgs, "svc_gemm_args": S.GemmArgs}
+    src = open(HEADER).read()
+    declared = set(re.findall(r"^}\s*(svc_[a-z0-9_]+_args)\s*;", src, flags=re.M))
+    assert declared == set(pairs), (declared ^ set(pairs))
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_binding_export_list_matches_header():

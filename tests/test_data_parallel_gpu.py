@@ -59,6 +59,7 @@ def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False, en
         net_g.train()
         net_d.train()
         step = T.TrainStep(hps, net_g, net_d, og, od).enable_graph(bool(graph))
+        net_g.reducer.time_exposed = net_d.reducer.time_exposed = True      # opt-in (bench.py does the same)
         c, f0, uv, spec, y, sid, lengths = [t.to(dev) for t in cs["batch"]]
         noise = {k: v.to(dev) for k, v in cs["noise"].items()}
         sl = slice(rank, rank + 1)                          # rank r trains on item r of the 2-item batch
@@ -84,16 +85,24 @@ def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False, en
         q.put((rank, traceback.format_exc(), None, None))
 
 
-def _run_two_ranks(graph, backend="gloo", capture=False, world=2, env=None):
+def _run_two_ranks(graph, backend="gloo", capture=False, world=2, env=None, timeout=600):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, graph, backend, capture, env)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    try:
+        res = [q.get(timeout=timeout) for _ in procs]
+    except Exception:      # noqa: BLE001 — queue.Empty: a rank hangs (e.g. a mis-captured collective): never leave it on the GPU
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
     for rank, msg, stats, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
     return res
@@ -243,6 +252,22 @@ def test_split_graph_iteration_over_rccl_world1():
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "dp_split_rccl_world1.txt"), "w") as f:
             f.write(repr(dict(split=split[0][2], mono=mono[0][2])) + "\n")
+
+
+def test_captured_collectives_over_rccl_world1():
+    """SVC_DP_CAPTURE_COLLECTIVES=1 on what ONE GPU can exercise of it: process group "nccl" at world size 1 with
+    SVC_DP_FORCE=1 — the autograd hooks fire DURING the two captures, so every bucket's ncclAllReduce is recorded on RCCL's stream
+    inside the hipGraphs and replayed with them; nothing is issued between the replays.  Three replayed iterations must equal the
+    split-graph mode's (same kernels, same gradients) to the weight gradients' atomics noise.  The worker is killed if it does not
+    answer (a mis-captured collective hangs instead of raising)."""
+    env = {"SVC_DP_FORCE": "1"}
+    cap = _run_two_ranks(True, backend="nccl", world=1, env=env, capture=True, timeout=300)
+    st = cap[0][2][0]
+    assert st["mode"].startswith("collectives captured"), st
+    split = _run_two_ranks(True, backend="nccl", world=1, env=env)
+    lr, steps = 2e-4, 3
+    d = (split[0][3] - cap[0][3]).abs()
+    assert d.max().item() <= 2.5 * lr * steps and d.mean().item() <= 0.02 * lr, (d.max().item(), d.mean().item())
 
 
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")

@@ -2,11 +2,13 @@
 even — what v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 do) and fp32 matmuls standing in for the matrix instruction's fp32 accumulation:
 
 * split pipeline (csrc/conv1d_hl.hip): v = hi + lo in two fp16 pieces, product = hi*hi' + hi*lo' + lo*hi';
-* SVC_MMA_BF16X6 (include/svc_hip.h): v = p0 + p1 + p2 in three bf16 pieces, product = the six piece products of weight >= 2^-16.
+* three bf16 pieces, six products (v = p0 + p1 + p2, the piece products of weight >= 2^-16): the round-5 training mode SVC_MMA_BF16X6.
+  It was as exact as fp32 and no faster, and was removed in round 6 (ABI 5); the arithmetic stays here as the comparison that
+  explains why the inference pipeline splits into fp16 pieces and what range that costs.
 
 What the kernels' headers claim is checked here without a GPU: the decompositions carry 22 bits / are exact, every piece product is
 exact in fp32, and a long dot product computed that way is as close to the float64 result as a plain fp32 dot product is.  The GPU
-tests (test_split_gpu.py, test_mma_x6_gpu.py) check that the kernels implement exactly this."""
+tests (test_split_gpu.py) check that the kernels implement exactly this."""
 import torch
 
 
