@@ -739,7 +739,7 @@ def main():
         out["summary"] = dict(
             infer_f32_ms=round(out["ms_per_step"], 3), infer_f32_roofline_frac=_ms(roof, "frac"),
             infer_split_ms=_ms(extras, "infer_split", "ms_per_step"), infer_half_ms=_ms(extras, "infer_half", "ms_per_step"),
-            e2e_ms=_ms(extras, "e2e", "ms_per_step"),
+            e2e_ms=_ms(extras, "e2e", "e2e_ms"),
             train_f32_ms=_ms(train_res, "ms_per_step"), train_f32_whole_step_frac=_ms(train_res, "roofline", "whole_step", "frac"),
             train_bf16_ms=_ms(train_res, "train_bf16", "ms_per_step"),
             train_loader_ms=_ms(train_res, "train_loader", "bucketed_graph", "ms_per_step_without_epoch_start"),

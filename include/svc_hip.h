@@ -39,7 +39,8 @@ const char* svc_last_error(void);
  *   3: svc_conv1d_args.mma / svc_wgrad_args.mma, svc_conv1d_multi_f32
  *   4: svc_attention_args grew {ws, ws_bytes} (key-split workspace), svc_gemm_args grew {split_k_atomic}; the 16-bit / split
  *      generator entry points (svc_conv1d_h*, svc_conv1d_hl*, svc_resblock_pair_h / _hl)
- *   5: SVC_MMA_BF16X6 removed (svc_conv1d_args.mma / svc_wgrad_args.mma accept fp32, bf16, fp16 only) */
+ *   5: SVC_MMA_BF16X6 removed (svc_conv1d_args.mma / svc_wgrad_args.mma accept fp32, bf16, fp16 only); split pipeline range guard:
+ *      svc_conv1d_h_args.acc_scale, svc_pack_conv1d_hl(scale), svc_resblock_pair_hl(acc_scale1, acc_scale2), svc_hl_range_flag; svc_coupling_fused_h */
 #define SVC_ABI_VERSION 5
 int svc_abi_version(void);
 /* Fills name[0..len) with the gcnArchName of the current device, returns number of CUs (or <0). */
@@ -340,6 +341,8 @@ typedef struct svc_conv1d_h_args {
   int u, y_t0, RP;
   int post_act;
   float pre_slope, post_slope, beta, out_div;
+  float acc_scale;   /* svc_conv1d_hl only: the accumulators are multiplied by this before the bias — 1 / the power-of-two scale the weight
+                      * pack was built with (svc_pack_conv1d_hl); 0 is read as 1.  svc_conv1d_h ignores it.  (ABI 5) */
 } svc_conv1d_h_args;
 int svc_pack_conv1d_h(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
 int svc_conv1d_h(const svc_conv1d_h_args* a, void* stream);
@@ -365,12 +368,26 @@ int svc_conv_post_h(const void* x, const float* w, const float* bias, float* y, 
  * (hi + lo = v to 22 mantissa bits); a product is a_hi b_hi + a_hi b_lo + a_lo b_hi, three fp16 instructions with fp32
  * accumulation in place of sixteen fp32 ones.  Every tensor of the 16-bit pipeline gains a second plane behind the first:
  * activations fp16 [2][B][C/8][T][8], weight packs fp16 [2][Cin/16][taps][RP][16] (plane 0 = hi, 1 = lo; contiguous).  Entry points
- * mirror the 16-bit ones one for one and take the same argument struct (x / res / y / w point at plane 0). */
-int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream);
+ * mirror the 16-bit ones one for one and take the same argument struct (x / res / y / w point at plane 0).
+ *
+ * RANGE (what fp32 has and two fp16 pieces do not, and how the boundary deals with it).  A stored value s is carried to
+ * max(2^-22 |s|, 2^-25): below |s| ~ 0.125 the lo piece is a subnormal fp16 and the error is absolute; above 65 504 hi overflows.
+ *   - Weights: svc_pack_conv1d_hl multiplies by `scale`, a power of two the caller derives from max |w| (svc_hip.pack_conv1d_h puts
+ *     max |w| at 2^14: every weight within 2^-17 of the largest keeps 22 bits, whatever the tensor's magnitude — weight-norm gains of
+ *     1e-6 or 1e5 alike); the convolution multiplies its accumulators by 1 / scale (acc_scale; both exact).
+ *   - Activations: the planes hold 32 v (exact; internal to the kernels — svc_cvt_to_hl / svc_cvt_from_hl are the only way in and out):
+ *     v ranges over +-2047 with an absolute floor of 2^-30 (9.3e-10), i.e. 22 bits down to |v| = 0.004.  Every value these kernels
+ *     PRODUCE is checked as it is encoded; |v| > 2047 (or nan) ORs 1 into the int the calling host thread registered with
+ *     svc_hl_range_flag (NULL = no reporting; the pointer is read at launch time, so it is part of a captured graph).  The flag is
+ *     sticky; the owner reads and clears it after the clip and re-runs the fp32 path if set (SynthesizerTrn.split_range_exceeded,
+ *     Svc.infer_units).  tests/test_split_gpu.py measures all three: weight magnitudes 1e-6..1e5, the flag, the small-value floor. */
+int svc_hl_range_flag(int* flag);
+int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, float scale, void* stream);
 int svc_conv1d_hl(const svc_conv1d_h_args* a, void* stream);
-/* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..128. */
+/* svc_resblock_pair_h on the split planes: C a multiple of 16 in 16..128; acc_scale1 / 2 = 1 / the scales of the two packs. */
 int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B, int C, int T,
-                         int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream);
+                         int KS, int dil1, int RP, float slope, float beta, float out_div, float acc_scale1, float acc_scale2,
+                         void* stream);
 /* svc_snake_alias_h on the split planes (x and y [2][B][C/8][T][8]; may not alias). */
 int svc_snake_alias_hl(const void* x, void* y, const float* alpha, const float* beta, const float* taps12, int B, int C, int T, void* stream);
 int svc_debug_set_conv_hl(int cfg); /* tuning aid: bit 0 = 64 x 128 (not 64 x 64) tiles for under-filled launches */
@@ -379,6 +396,38 @@ int svc_cvt_to_hl(const float* x, const float* add, void* y, long long x_bs, lon
 int svc_cvt_from_hl(const void* x, float* y, int B, int C, int T, void* stream);
 int svc_conv_post_hl(const void* x, const float* w, const float* bias, float* y, int B, int C, int T, int KS, int pad,
                      float pre_slope, int act, void* stream);
+
+/* ---- fused coupling layer of the flow for the 16-bit and the split inference modes (csrc/flow_fused.hip): ONE launch for
+ * modules/modules.py:288-307 ResidualCouplingLayer.forward with mean_only — pre 1x1 (:291), WN.forward :110-138 (per layer: k = 5 conv
+ * hidden -> 2 hidden, + g_l, tanh * sigmoid gate, 1x1 res/skip, x = (x + res) * mask, output += skip), post 1x1 (:297), x1 <- m + x1 * mask /
+ * (x1 - m) * mask (:300-306) — on the flow's fp32 working buffer IN PLACE, the pending channel Flip (:232-239, models.py:45-52) folded into
+ * x_cs < 0.  The fp32 path runs these as 10 launches per coupling.  planes = 1: fp16 arithmetic of the reference's `.half()` mode
+ * (fp16 operands, fp32 accumulation, h / activations stored as fp16 in LDS); planes = 2: the split pipeline's hi / lo planes (fp32-level,
+ * range-checked into the svc_hl_range_flag word).  Weights: packs of svc_pack_conv1d_h (planes 1) / svc_pack_conv1d_hl (planes 2) of the
+ * weight-norm-folded dense weights in their natural row order: w_pre [hidden, channels/2, 1], w_in[l] [2 hidden, hidden, 5],
+ * w_rs[l] [2 hidden (last layer: hidden), hidden, 1], w_post [channels/2, hidden, 1]; s_* = their acc scales (planes 2; 0 reads as 1).
+ * cond: cond_layer(g), [B][2 hidden n_layers][1 | T] through (cond_bs, cond_cs, cond_ts), or NULL.  Built for channels 192, hidden 192,
+ * kernel size 5, dilation rate 1, 1..6 layers (both templates' flows); anything else: SVC_ERR_BAD_ARG, callers keep the unfused launches. */
+#define SVC_COUPLING_MAX_LAYERS 8
+typedef struct svc_coupling_args {
+  float* x;                 /* channel 0 of the VIEW of the [B][channels][T] buffer; view channel c at x + c * x_cs */
+  long long x_bs, x_cs;
+  const float* mask;        /* [B][T] or NULL */
+  const float* cond;
+  long long cond_bs, cond_cs;
+  int cond_ts;
+  const void* w_pre;
+  const float* b_pre;
+  const void* w_in[SVC_COUPLING_MAX_LAYERS];
+  const float* b_in[SVC_COUPLING_MAX_LAYERS];
+  const void* w_rs[SVC_COUPLING_MAX_LAYERS];
+  const float* b_rs[SVC_COUPLING_MAX_LAYERS];
+  const void* w_post;
+  const float* b_post;
+  float s_pre, s_in[SVC_COUPLING_MAX_LAYERS], s_rs[SVC_COUPLING_MAX_LAYERS], s_post;
+  int B, T, channels, hidden, kernel_size, n_layers, reverse, planes;
+} svc_coupling_args;
+int svc_coupling_fused_h(const svc_coupling_args* a, void* stream);
 
 
 /* ================================================================================================

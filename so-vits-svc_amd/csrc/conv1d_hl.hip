@@ -17,6 +17,7 @@
 // the ring holds 2 steps x 2 planes per chunk (a step is 3 MT NT instructions: the same matrix time per chunk as four 16-bit steps).
 #include "common.h"
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -30,12 +31,37 @@ struct HLP {
   int GC;   // channel groups staged per chunk
   int R;    // valid rows
   long long xplane, yplane, wplane;   // elements (halves) between the hi and the lo plane
+  int* flag;                          // range flag word (may be null)
+  float acc_scale;                    // 1 / the weight pack's power-of-two scale
 };
 
 __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)(v - (float)hi);
 }
+// Range of the representation: hi is an fp16, so a stored value must stay below 65 520 (above it hi = inf and every later product is
+// inf / nan), and it is carried to max(2^-22 |s|, 2^-25): below |s| ~ 0.125 the lo piece is a subnormal fp16 and the error is ABSOLUTE.
+//   * Weights are packed times a per-tensor power of two that puts max |w| at 2^14 (exact; the accumulators are multiplied back by its
+//     inverse in the epilogue: svc_conv1d_h_args.acc_scale).
+//   * Activation planes hold ASC * v (ASC = 32, exact): the range of v is +-2047 and the absolute floor 2^-30 (9.3e-10) — 22 bits down
+//     to |v| = 0.004, where the unscaled planes of round 5 started losing bits at 0.125 (floor 3e-8).  Nothing else changes: the
+//     pre-activation is positively homogeneous (lrelu(32 v) = 32 lrelu(v)), the products carry the factor into the accumulators and the
+//     epilogue's acc_scale takes it out; decoding a plane pair is (hi + lo) / 32.
+//   * Every value a kernel of this file PRODUCES is range-checked as it is encoded: enc_act ORs "not (|32 v| <= 65504)" (overflow or
+//     nan) into `bad`, and a lane with bad set raises the caller's sticky flag word (svc_hl_range_flag) — the caller reads it after
+//     the clip and re-runs the fp32 path (SynthesizerTrn.split_range_exceeded / Svc do).
+constexpr float ASC = 32.f, IASC = 1.f / 32.f;
+__device__ __forceinline__ void enc_act(float v, _Float16& hi, _Float16& lo, bool& bad) {
+  const float s = v * ASC;
+  hi = (_Float16)s;
+  lo = (_Float16)(s - (float)hi);
+  bad |= !(fabsf(s) <= 65504.f);
+}
+__device__ __forceinline__ float dec_act(_Float16 hi, _Float16 lo) { return ((float)hi + (float)lo) * IASC; }
+__device__ __forceinline__ void raise_range(int* flag, bool bad) {
+  if (bad && flag) atomicOr(flag, 1);
+}
+thread_local int* t_hl_flag = nullptr;      // svc_hl_range_flag: the flag word the launches of this host thread report into
 
 template <int KS, int MT, int NT, int CH>
 __device__ __forceinline__ void mma_steps_hl(f32x16 (&acc)[MT][NT], const h8* __restrict__ wp, long long wplane8, long long sstride,
@@ -180,6 +206,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
   _Float16* yb = reinterpret_cast<_Float16*>(a.y) + (long long)b * a.Cout * a.Ty;
   const _Float16* rb = a.res ? reinterpret_cast<const _Float16*>(a.res) + (long long)b * a.Cout * a.Ty : nullptr;
   const bool lre = a.post_act == SVC_ACT_LRELU;
+  const float asc = p.acc_scale;
+  bool bad = false;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -201,20 +229,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[mt][nt][4 * i + e] + (a.bias ? a.bias[co8 + 4 * kh + e] : 0.f);
+          v[e] = acc[mt][nt][4 * i + e] * asc + (a.bias ? a.bias[co8 + 4 * kh + e] : 0.f);
           if (lre) v[e] = svc_lrelu(v[e], a.post_slope);
         }
         if (rb) {
           const h4 rh = *reinterpret_cast<const h4*>(rb + off);
           const h4 rl = *reinterpret_cast<const h4*>(rb + p.yplane + off);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+          for (int e = 0; e < 4; ++e) v[e] += dec_act(rh[e], rl[e]);
         }
         if (a.beta != 0.f) {
           const h4 oh = *reinterpret_cast<const h4*>(yb + off);
           const h4 ol = *reinterpret_cast<const h4*>(yb + p.yplane + off);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(a.beta, (float)oh[e] + (float)ol[e], v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(a.beta, dec_act(oh[e], ol[e]), v[e]);
         }
         if (a.out_div != 1.f) {
 #pragma unroll
@@ -224,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           _Float16 hi, lo;
-          split1(v[e], hi, lo);
+          enc_act(v[e], hi, lo, bad);
           oh[e] = hi;
           ol[e] = lo;
         }
@@ -233,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_hl_kernel(HLP p) {
       }
     }
   }
+  raise_range(p.flag, bad);
 }
 
 constexpr size_t HL_LDS_TARGET = 72 * 1024;   // two workgroups per CU
@@ -253,6 +282,8 @@ int launch_hl(const svc_conv1d_h_args& a, int R, hipStream_t s) {
   p.xplane = (long long)a.B * a.Cin * a.Tin;
   p.yplane = (long long)a.B * a.Cout * a.Ty;
   p.wplane = (long long)p.G * a.KS * a.RP * 16;
+  p.flag = t_hl_flag;
+  p.acc_scale = (a.acc_scale != 0.f ? a.acc_scale : 1.f) * IASC;      // the B operand planes hold ASC * x
   const size_t lds = per_group * p.GC;
   SVC_REQUIRE(lds <= 160 * 1024, "conv1d_hl: tile of %zu bytes does not fit LDS (KS %d, dil %d)", lds, a.KS, a.dil);
   auto kern = conv1d_hl_kernel<KS, MT, NT, WM, WN>;
@@ -302,6 +333,8 @@ struct PPL {
   void* y;
   int B, C, T, d1, RP, GC;
   float slope, beta, out_div;
+  float s1, s2;     // 1 / the power-of-two scales of the two weight packs
+  int* flag;
 };
 
 template <int KS, int MT, int NT, int WM, int WN>
@@ -335,6 +368,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
     ts[pl * tplane8 + cb * XW2 + N1P + e] = z;
   }
 
+  bool bad = false;
   // ---- conv1 over the N1P intermediate columns, the input staged chunk by chunk
   {
     f32x16 acc[MT][NT];
@@ -403,9 +437,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
           h4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float v = inside ? svc_lrelu(acc[mt][nt][4 * i + e] + p.b1[row8 + 4 * kh + e], p.slope) : 0.f;
+            const float v = inside ? svc_lrelu(acc[mt][nt][4 * i + e] * p.s1 + p.b1[row8 + 4 * kh + e], p.slope) : 0.f;
             _Float16 hi, lo;
-            split1(v, hi, lo);
+            enc_act(v, hi, lo, bad);
             oh[e] = hi;
             ol[e] = lo;
           }
@@ -447,12 +481,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
           const h4 rl = *reinterpret_cast<const h4*>(xb + gplane + off);
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * i + e] + p.b2[row8 + 4 * kh + e] + ((float)rh[e] + (float)rl[e]);
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * i + e] * p.s2 + p.b2[row8 + 4 * kh + e] + dec_act(rh[e], rl[e]);
           if (p.beta != 0.f) {
             const h4 oh = *reinterpret_cast<const h4*>(yb + off);
             const h4 ol = *reinterpret_cast<const h4*>(yb + gplane + off);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(p.beta, (float)oh[e] + (float)ol[e], v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(p.beta, dec_act(oh[e], ol[e]), v[e]);
           }
           if (p.out_div != 1.f) {
 #pragma unroll
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             _Float16 hi, lo;
-            split1(v[e], hi, lo);
+            enc_act(v[e], hi, lo, bad);
             oh[e] = hi;
             ol[e] = lo;
           }
@@ -471,6 +505,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void respair_hl_kernel(PPL p) {
         }
       }
   }
+  raise_range(p.flag, bad);
 }
 
 template <int KS, int MT, int NT, int WM, int WN>
@@ -510,7 +545,7 @@ int launch_respair_hl_ks(const PPL& p, hipStream_t s) {
 
 // ---- weight pack: dense fp32 -> [2][Cin/16][tap][RP][16] fp16 (hi plane, lo plane); index rules of pack_h_kernel (conv1d_h.hip)
 __global__ void pack_hl_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int Cout, int Cin, int K, int taps, int RP,
-                               int u, long long n) {
+                               int u, long long n, float scale) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int j = (int)(idx & 15);
@@ -528,14 +563,14 @@ __global__ void pack_hl_kernel(const float* __restrict__ w, _Float16* __restrict
     if (k < K) v = w[((long long)ci * Cout + co) * K + k];
   }
   _Float16 hi, lo;
-  split1(v, hi, lo);
+  split1(v * scale, hi, lo);      // scale: a power of two chosen by the caller from max |w| (exact; 1 / scale goes to acc_scale)
   dst[idx] = hi;
   dst[n + idx] = lo;
 }
 
 // ---- fp32 [B,C,T] (strided) (+ a second fp32 tensor) -> split blocked planes, and back
 __global__ void cvt_to_hl_kernel(const float* __restrict__ x, const float* __restrict__ add, h8* __restrict__ y, long long x_bs,
-                                 long long x_cs, long long a_bs, long long a_cs, int B, int C, int T) {
+                                 long long x_cs, long long a_bs, long long a_cs, int B, int C, int T, int* flag) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int CB = C >> 3;
   const long long n = (long long)B * CB * T;
@@ -544,17 +579,19 @@ __global__ void cvt_to_hl_kernel(const float* __restrict__ x, const float* __res
   const long long r = idx / T;
   const int cb = (int)(r % CB), b = (int)(r / CB);
   h8 oh, ol;
+  bool bad = false;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float v = x[(long long)b * x_bs + (long long)(cb * 8 + j) * x_cs + t];
     if (add) v += add[(long long)b * a_bs + (long long)(cb * 8 + j) * a_cs + t];
     _Float16 hi, lo;
-    split1(v, hi, lo);
+    enc_act(v, hi, lo, bad);
     oh[j] = hi;
     ol[j] = lo;
   }
   y[idx] = oh;
   y[n + idx] = ol;
+  raise_range(flag, bad);
 }
 
 __global__ void cvt_from_hl_kernel(const h8* __restrict__ x, float* __restrict__ y, int B, int C, int T) {
@@ -567,7 +604,7 @@ __global__ void cvt_from_hl_kernel(const h8* __restrict__ x, float* __restrict__
   const int cb = (int)(r % CB), b = (int)(r / CB);
   const h8 vh = x[idx], vl = x[n + idx];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) y[((long long)b * C + cb * 8 + j) * T + t] = (float)vh[j] + (float)vl[j];
+  for (int j = 0; j < 8; ++j) y[((long long)b * C + cb * 8 + j) * T + t] = dec_act(vh[j], vl[j]);
 }
 
 // ---- conv_post (vdecoder/hifigan/models.py:390-392) from the split planes: leaky_relu(0.01) -> Conv1d(C, 1, KS) -> tanh, fp32 out
@@ -590,7 +627,7 @@ __global__ __launch_bounds__(256) void conv_post_hl_kernel(const h8* __restrict_
       if (tin < 0 || tin >= T) continue;
       const h8 vh = xr[tin], vl = xr[plane + tin];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = fmaf(svc_lrelu((float)vh[j] + (float)vl[j], pre_slope), wsh_hl[(cb * 8 + j) * KS + k], acc);
+      for (int j = 0; j < 8; ++j) acc = fmaf(svc_lrelu(dec_act(vh[j], vl[j]), pre_slope), wsh_hl[(cb * 8 + j) * KS + k], acc);
     }
   }
   y[idx] = act == SVC_ACT_TANH ? tanhf(acc) : acc;
@@ -604,7 +641,8 @@ struct TapsHL {
   float f[12];
 };
 __global__ __launch_bounds__(256) void snake_alias_hl_kernel(const h8* __restrict__ x, h8* __restrict__ y, const float* __restrict__ alpha,
-                                                             const float* __restrict__ beta, TapsHL taps, int CB, int T, long long plane8) {
+                                                             const float* __restrict__ beta, TapsHL taps, int CB, int T, long long plane8,
+                                                             int* flag) {
   __shared__ float xs[(SHL_TILE + 10) * 8];
   __shared__ float ua[(2 * SHL_TILE + 12) * 8];
   const int t0 = blockIdx.x * SHL_TILE, cb = blockIdx.y, b = blockIdx.z;
@@ -616,7 +654,7 @@ __global__ __launch_bounds__(256) void snake_alias_hl_kernel(const h8* __restric
     t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
     const h8 vh = xr[t], vl = xr[plane8 + t];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xs[i * 8 + j] = (float)vh[j] + (float)vl[j];
+    for (int j = 0; j < 8; ++j) xs[i * 8 + j] = dec_act(vh[j], vl[j]);
   }
   __syncthreads();
   const int n_lo = 2 * t0 - 5;
@@ -639,6 +677,7 @@ __global__ __launch_bounds__(256) void snake_alias_hl_kernel(const h8* __restric
     ua[m * 8 + j] = u + (sn * sn) / (__expf(beta[c]) + 1e-9f);
   }
   __syncthreads();
+  bool bad = false;
   for (int i = tid; i < SHL_TILE; i += 256) {
     const int t = t0 + i;
     if (t >= T) break;
@@ -649,26 +688,40 @@ __global__ __launch_bounds__(256) void snake_alias_hl_kernel(const h8* __restric
 #pragma unroll
       for (int k = 0; k < 12; ++k) acc = fmaf(taps.f[k], ua[(2 * i + k) * 8 + j], acc);
       _Float16 hi, lo;
-      split1(acc, hi, lo);
+      enc_act(acc, hi, lo, bad);
       oh[j] = hi;
       ol[j] = lo;
     }
     yr[t] = oh;
     yr[plane8 + t] = ol;
   }
+  raise_range(flag, bad);
 }
 
 }  // namespace
 
-extern "C" int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, void* stream) {
+namespace svc {
+int* hl_range_flag_ptr() { return t_hl_flag; }      // for the other split kernels of the library (flow_fused.hip)
+}
+
+extern "C" int svc_hl_range_flag(int* flag) {
+  t_hl_flag = flag;
+  return SVC_OK;
+}
+
+extern "C" int svc_pack_conv1d_hl(const float* w, void* dst, int Cout, int Cin, int K, int u, int RP, float scale, void* stream) {
   SVC_REQUIRE(w && dst, "pack_conv1d_hl: null tensor");
+  {
+    int ex = 0;
+    SVC_REQUIRE(scale > 0.f && std::isfinite(scale) && std::frexp(scale, &ex) == 0.5f, "pack_conv1d_hl: scale %g is not a power of two", (double)scale);
+  }
   SVC_REQUIRE(Cout > 0 && Cin > 0 && (Cin % 16) == 0 && K >= 1 && u >= 1, "pack_conv1d_hl: bad shape (Cin must be a multiple of 16)");
   const int taps = u > 1 ? (K + u - 1) / u : K;
   const int R = u > 1 ? u * Cout : Cout;
   SVC_REQUIRE(RP >= R && (RP % 128) == 0, "pack_conv1d_hl: RP must be a multiple of 128 >= the row count %d", R);
   const long long n = (long long)taps * (Cin / 16) * RP * 16;
   hipLaunchKernelGGL(pack_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     reinterpret_cast<_Float16*>(dst), Cout, Cin, K, taps, RP, u, n);
+                     reinterpret_cast<_Float16*>(dst), Cout, Cin, K, taps, RP, u, n, scale);
   return svc::check_launch("pack_conv1d_hl");
 }
 
@@ -711,7 +764,7 @@ extern "C" int svc_cvt_to_hl(const float* x, const float* add, void* y, long lon
   SVC_REQUIRE(x && y && B > 0 && C > 0 && (C % 8) == 0 && T > 0, "cvt_to_hl: bad args (C must be a multiple of 8)");
   const long long n = (long long)B * (C / 8) * T;
   hipLaunchKernelGGL(cvt_to_hl_kernel, dim3((unsigned)svc::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, x, add,
-                     reinterpret_cast<h8*>(y), x_bs, x_cs, add_bs, add_cs, B, C, T);
+                     reinterpret_cast<h8*>(y), x_bs, x_cs, add_bs, add_cs, B, C, T, t_hl_flag);
   return svc::check_launch("cvt_to_hl");
 }
 
@@ -735,7 +788,8 @@ extern "C" int svc_conv_post_hl(const void* x, const float* w, const float* bias
 }
 
 extern "C" int svc_resblock_pair_hl(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int B,
-                                   int C, int T, int KS, int dil1, int RP, float slope, float beta, float out_div, void* stream) {
+                                   int C, int T, int KS, int dil1, int RP, float slope, float beta, float out_div, float acc_scale1,
+                                   float acc_scale2, void* stream) {
   SVC_REQUIRE(x && w1 && w2 && b1 && b2 && y, "resblock_pair_hl: null tensor");
   SVC_REQUIRE(B > 0 && T > 0 && C >= 16 && C <= 128 && (C % 16) == 0, "resblock_pair_hl: C must be a multiple of 16 in 16..128 (got %d)", C);
   SVC_REQUIRE(dil1 >= 1 && (RP % 128) == 0 && RP >= C, "resblock_pair_hl: bad dil1 / RP");
@@ -746,6 +800,9 @@ extern "C" int svc_resblock_pair_hl(const void* x, const void* w1, const float* 
   p.x = x; p.w1 = w1; p.w2 = w2; p.b1 = b1; p.b2 = b2; p.y = y;
   p.B = B; p.C = C; p.T = T; p.d1 = dil1; p.RP = RP; p.GC = 1;
   p.slope = slope; p.beta = beta; p.out_div = out_div;
+  p.s1 = (acc_scale1 != 0.f ? acc_scale1 : 1.f) * IASC;      // both convs read planes that hold ASC * value
+  p.s2 = (acc_scale2 != 0.f ? acc_scale2 : 1.f) * IASC;
+  p.flag = t_hl_flag;
   hipStream_t s = (hipStream_t)stream;
   char pname[96];
   if (svc::prof_on() && svc::prof_shapes()) snprintf(pname, sizeof(pname), "resblock_pair_hl[B%d,C%d,K%d,d%d,T%d]", B, C, KS, dil1, T);
@@ -772,6 +829,7 @@ extern "C" int svc_snake_alias_hl(const void* x, void* y, const float* alpha, co
   for (int i = 0; i < 12; ++i) tp.f[i] = taps12[i];
   svc::ProfScope prof((hipStream_t)stream, "snake_alias_hl", 0.0, 8.0 * B * (double)C * T);
   hipLaunchKernelGGL(snake_alias_hl_kernel, dim3(svc::cdiv(T, SHL_TILE), C / 8, B), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const h8*>(x), reinterpret_cast<h8*>(y), alpha, beta, tp, C / 8, T, (long long)B * (C / 8) * T);
+                     reinterpret_cast<const h8*>(x), reinterpret_cast<h8*>(y), alpha, beta, tp, C / 8, T, (long long)B * (C / 8) * T,
+                     t_hl_flag);
   return svc::check_launch("snake_alias_hl");
 }

@@ -22,6 +22,7 @@ import gc
 import hashlib
 import io
 import json
+import logging
 import os
 import pickle
 import time
@@ -327,9 +328,22 @@ class Svc(object):
     def infer_units(self, c, f0, uv, sid, auto_predict_f0=False, noice_scale=0.4, vol=None, seed=52468, noise=None, lengths=None):
         """(c [B,ssl,T], f0 [B,T], uv [B,T], sid) -> (audio [B,1,T*hop], f0): net_g_ms.infer (infer_tool.py:297)."""
         with torch.no_grad():
-            return self.net_g_ms.infer(c.to(self.dev), f0=f0.to(self.dev), g=sid.to(self.dev), uv=uv.to(self.dev),
-                                       predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol, seed=seed, noise=noise,
-                                       lengths=lengths)
+            call = lambda: self.net_g_ms.infer(c.to(self.dev), f0=f0.to(self.dev), g=sid.to(self.dev), uv=uv.to(self.dev),
+                                               predict_f0=auto_predict_f0, noice_scale=noice_scale, vol=vol, seed=seed, noise=noise,
+                                               lengths=lengths)
+            out = call()
+            if self.split_mode and self.net_g_ms.split_range_exceeded():
+                # the split pipeline's range guard (include/svc_hip.h, RANGE): an activation of the generator left what two fp16
+                # pieces can carry (|v| > 65504) — that result is not fp32-level.  Same call on the fp32 kernels (same seed, same
+                # draws), and the model stays there: a checkpoint that does this once will do it again.
+                self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+                logging.getLogger("infer_tool").warning(
+                    "SVC_INFER_SPLIT: an activation exceeded the fp16 range of the split pipeline; re-running on the fp32 kernels "
+                    "and leaving split mode")
+                self.net_g_ms.split_f16(False)
+                self.split_mode = False
+                out = call()
+            return out
 
     def _load_at_target_rate(self, raw_path):
         wav, sr = self._load(raw_path)

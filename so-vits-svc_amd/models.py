@@ -344,6 +344,13 @@ class SynthesizerTrn(nn.Module):
         self._graphs.clear()
         return self
 
+    def split_range_exceeded(self, clear=True):
+        """After infer() in split mode: True if a value of the generator left the range two fp16 pieces can carry (|v| > 65504, or a
+        nan) — the waveform is then NOT fp32-level; call split_f16(False) and infer again (inference.infer_tool.Svc.infer does).  Weights
+        of any magnitude are covered by the packs' power-of-two scales; this is about activations.  Reads one device word."""
+        fn = getattr(self.dec, "split_range_exceeded", None)
+        return bool(fn(clear)) if fn is not None else False
+
     def EnableCharacterMix(self, n_speakers_map, device):
         self.speaker_map = torch.zeros((n_speakers_map, 1, 1, self.gin_channels)).to(device)
         for i in range(n_speakers_map):

@@ -4,6 +4,7 @@ This is the only place Python touches the native library.  There is NO fallback:
 or a call fails, an exception is raised (the product path must fail loudly without the HIP extension).
 """
 import ctypes as C
+import math
 import os
 
 import torch
@@ -74,7 +75,24 @@ class Conv1dHArgs(C.Structure):
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tq", C.c_int), ("Ty", C.c_int),
                 ("KS", C.c_int), ("dil", C.c_int), ("pad_left", C.c_int),
                 ("u", C.c_int), ("y_t0", C.c_int), ("RP", C.c_int), ("post_act", C.c_int),
-                ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
+                ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float),
+                ("acc_scale", C.c_float)]
+
+
+COUPLING_MAX_LAYERS = 8
+
+
+class CouplingArgs(C.Structure):
+    _fields_ = [("x", _f32p), ("x_bs", C.c_longlong), ("x_cs", C.c_longlong), ("mask", _f32p),
+                ("cond", _f32p), ("cond_bs", C.c_longlong), ("cond_cs", C.c_longlong), ("cond_ts", C.c_int),
+                ("w_pre", C.c_void_p), ("b_pre", _f32p),
+                ("w_in", C.c_void_p * COUPLING_MAX_LAYERS), ("b_in", _f32p * COUPLING_MAX_LAYERS),
+                ("w_rs", C.c_void_p * COUPLING_MAX_LAYERS), ("b_rs", _f32p * COUPLING_MAX_LAYERS),
+                ("w_post", C.c_void_p), ("b_post", _f32p),
+                ("s_pre", C.c_float), ("s_in", C.c_float * COUPLING_MAX_LAYERS), ("s_rs", C.c_float * COUPLING_MAX_LAYERS),
+                ("s_post", C.c_float),
+                ("B", C.c_int), ("T", C.c_int), ("channels", C.c_int), ("hidden", C.c_int), ("kernel_size", C.c_int),
+                ("n_layers", C.c_int), ("reverse", C.c_int), ("planes", C.c_int)]
 
 
 class AttentionArgs(C.Structure):
@@ -138,13 +156,17 @@ def lib():
         L.svc_conv_post_h.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                       C.c_void_p]
         for sfx in ("hl",):     # the split pipeline's entry points mirror the 16-bit ones
-            getattr(L, "svc_pack_conv1d_" + sfx).argtypes = L.svc_pack_conv1d_h.argtypes
+            getattr(L, "svc_pack_conv1d_" + sfx).argtypes = [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                             C.c_void_p]
             getattr(L, "svc_conv1d_" + sfx).argtypes = L.svc_conv1d_h.argtypes
             getattr(L, "svc_cvt_to_" + sfx).argtypes = L.svc_cvt_to_h.argtypes
             getattr(L, "svc_cvt_from_" + sfx).argtypes = L.svc_cvt_from_h.argtypes
             getattr(L, "svc_conv_post_" + sfx).argtypes = L.svc_conv_post_h.argtypes
-            getattr(L, "svc_resblock_pair_" + sfx).argtypes = L.svc_resblock_pair_h.argtypes
+            getattr(L, "svc_resblock_pair_" + sfx).argtypes = [C.c_void_p, C.c_void_p, _f32p, C.c_void_p, _f32p, C.c_void_p] + \
+                [C.c_int] * 6 + [C.c_float] * 5 + [C.c_void_p]
             getattr(L, "svc_snake_alias_" + sfx).argtypes = L.svc_snake_alias_h.argtypes
+        L.svc_hl_range_flag.argtypes = [C.c_void_p]
+        L.svc_coupling_fused_h.argtypes = [C.POINTER(CouplingArgs), C.c_void_p]
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
         L.svc_f0_norm_lf0_f32.argtypes = [_f32p] * 6 + [C.c_int] * 3 + [C.c_void_p]
@@ -175,7 +197,7 @@ EXPORTS = [
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
-    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
+    "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_hl_range_flag", "svc_coupling_fused_h", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
 
@@ -465,9 +487,33 @@ def pack_conv1d_h(w, u=1, split=False):
         taps, R = K, Cout
     RP = round_up(R, 128)
     dst = torch.empty(((2,) if split else ()) + (Cin // 16, taps, RP, 16), device=w.device, dtype=torch.float16)
-    fn = lib().svc_pack_conv1d_hl if split else lib().svc_pack_conv1d_h
-    check(fn(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
+    if split:
+        # per-tensor power-of-two scale (exact): max |w| -> [2^13, 2^14), so every weight within 2^-17 of the largest keeps its 22 bits
+        # whatever the tensor's magnitude; the convolution multiplies its accumulators by 1 / scale (`acc_scale`, read off the pack).
+        # One host read per pack (packs are cached per parameter version, never built inside a capture).
+        amax = float(w.abs().max())
+        if not math.isfinite(amax):
+            raise SvcError("pack_conv1d_h(split=True): the weight holds inf / nan")
+        scale = 2.0 ** (14 - math.frexp(amax)[1]) if amax > 0.0 else 1.0
+        scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
+        check(lib().svc_pack_conv1d_hl(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, scale, stream_ptr()), "pack_conv1d_hl")
+        dst.acc_scale = 1.0 / scale
+        return dst
+    check(lib().svc_pack_conv1d_h(ptr(w), _hptr(dst), Cout, Cin, K, u, RP, stream_ptr()), "pack_conv1d_h")
     return dst
+
+
+def _acc_scale(wp):
+    return float(getattr(wp, "acc_scale", 1.0))
+
+
+def hl_range_flag(flag):
+    """Register (or, with None, withdraw) the int32 device word into which the split pipeline's launches of THIS host thread report a
+    value outside the fp16 range (include/svc_hip.h, RANGE).  The pointer is taken at launch time: launches captured into a hipGraph
+    keep reporting into the same tensor, which the caller must keep alive."""
+    if flag is not None and not (flag.is_cuda and flag.dtype == torch.int32 and flag.numel() >= 1 and flag.is_contiguous()):
+        raise SvcError("hl_range_flag: expected an int32 tensor on the GPU")
+    check(lib().svc_hl_range_flag(flag.data_ptr() if flag is not None else None), "hl_range_flag")
 
 
 def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=1.0, post_slope=None, res=None, out=None, beta=0.0,
@@ -494,6 +540,7 @@ def conv1d_h(x, wp, Cout, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slope=
     a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = KS, dil, pad_left, 1, 0, wp.shape[-2]
     a.post_act = ACT_LRELU if post_slope is not None else ACT_NONE
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope or 0.0, beta, out_div
+    a.acc_scale = _acc_scale(wp)
     check((lib().svc_conv1d_hl if sp else lib().svc_conv1d_h)(C.byref(a), stream_ptr()), "conv1d_h")
     return out
 
@@ -519,9 +566,13 @@ def resblock_pair_h(x, w1p, b1, w2p, b2, dil1, *, slope=0.1, out=None, beta=0.0,
     _check_h(out, "resblock_pair_h out", sp)
     if out.data_ptr() == x.data_ptr():
         raise SvcError("resblock_pair_h: x and out may not alias (neighbouring workgroups read x's halo)")
-    fn = lib().svc_resblock_pair_hl if sp else lib().svc_resblock_pair_h
-    check(fn(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1, w1p.shape[-2],
-             slope, beta, out_div, stream_ptr()), "resblock_pair_h")
+    if sp:
+        check(lib().svc_resblock_pair_hl(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1,
+                                         w1p.shape[-2], slope, beta, out_div, _acc_scale(w1p), _acc_scale(w2p), stream_ptr()),
+              "resblock_pair_hl")
+        return out
+    check(lib().svc_resblock_pair_h(_hptr(x), _hptr(w1p), ptr(b1), _hptr(w2p), ptr(b2), _hptr(out), B, CB * 8, T, KS, dil1, w1p.shape[-2],
+                                    slope, beta, out_div, stream_ptr()), "resblock_pair_h")
     return out
 
 
@@ -563,6 +614,7 @@ def conv_transpose1d_h(x, wp, Cout, K, stride, padding, *, bias=None, pre_slope=
     a.Tq = (Lout - 1 + padding) // stride + 1
     a.KS, a.dil, a.pad_left, a.u, a.y_t0, a.RP = M, 1, M - 1, stride, -padding, wp.shape[-2]
     a.post_act, a.pre_slope, a.post_slope, a.beta, a.out_div = ACT_NONE, pre_slope, 0.0, 0.0, 1.0
+    a.acc_scale = _acc_scale(wp)
     check((lib().svc_conv1d_hl if sp else lib().svc_conv1d_h)(C.byref(a), stream_ptr()), "conv_transpose1d_h")
     return out
 
@@ -604,6 +656,42 @@ def conv_post_h(xh, w, bias, KS, pad, pre_slope=0.01, act=None):
     check(fn(_hptr(xh), ptr(w), ptr(bias), ptr(out), B, CB * 8, T, KS, pad, pre_slope,
              ACT_TANH if act is None else act, stream_ptr()), "conv_post_h")
     return out
+
+
+def coupling_fused_h(view, mask, cond, pre, ins, rss, post, *, reverse, split):
+    """One ResidualCouplingLayer (mean_only) on the flow's fp32 working buffer, in place, ONE launch (svc_coupling_fused_h).
+    view: the [B, channels, T] buffer or a FlipView of it; mask [B, T] or None; cond = cond_layer(g) [B, 2 H L, 1 | T] or None;
+    pre / post: (pack, bias); ins / rss: per-layer lists of (pack, bias) — packs from pack_conv1d_h(dense weight, split=split)."""
+    B, Cc, T = view.shape
+    a = CouplingArgs()
+    a.x = view.data_ptr()
+    a.x_bs, a.x_cs = view.stride(0), view.stride(1)
+    if view.stride(2) != 1 and T > 1:
+        raise SvcError("coupling_fused_h: the buffer must be time-contiguous")
+    a.mask = ptr(mask)
+    if cond is not None:
+        require_gpu(cond)
+        a.cond = ptr(cond)
+        a.cond_bs, a.cond_cs = cond.stride(0), cond.stride(1)
+        a.cond_ts = 0 if cond.shape[2] == 1 else 1
+        if a.cond_ts and (cond.stride(2) != 1 or cond.shape[2] != T):
+            raise SvcError("coupling_fused_h: a per-frame conditioning tensor must be [B, C, T] with contiguous time")
+    L = len(ins)
+    if L != len(rss) or not 1 <= L <= COUPLING_MAX_LAYERS:
+        raise SvcError("coupling_fused_h: bad layer count")
+    want = 5 if split else 4
+    for wp, _ in [pre, post] + list(ins) + list(rss):
+        if wp.dim() != want or wp.dtype != torch.float16 or not wp.is_cuda:
+            raise SvcError("coupling_fused_h: weight packs must come from pack_conv1d_h(..., split=%s)" % bool(split))
+    a.w_pre, a.b_pre, a.s_pre = _hptr(pre[0]), ptr(pre[1]), _acc_scale(pre[0])
+    a.w_post, a.b_post, a.s_post = _hptr(post[0]), ptr(post[1]), _acc_scale(post[0])
+    for l in range(L):
+        require_gpu(ins[l][1], rss[l][1])
+        a.w_in[l], a.b_in[l], a.s_in[l] = ins[l][0].data_ptr(), ins[l][1].data_ptr(), _acc_scale(ins[l][0])
+        a.w_rs[l], a.b_rs[l], a.s_rs[l] = rss[l][0].data_ptr(), rss[l][1].data_ptr(), _acc_scale(rss[l][0])
+    a.B, a.T, a.channels, a.hidden = B, T, Cc, ins[0][0].shape[-4] * 16
+    a.kernel_size, a.n_layers, a.reverse, a.planes = ins[0][0].shape[-3], L, 1 if reverse else 0, 2 if split else 1
+    check(lib().svc_coupling_fused_h(C.byref(a), stream_ptr()), "coupling_fused_h")
 
 
 def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sampling_rate, sine_amp=0.1, noise_std=0.003, out=None,

@@ -15,6 +15,8 @@ Reference forward (vdecoder/hifigan/models.py:366-394) = ~165 aten launches per 
 import math
 
 import numpy as np
+import contextlib
+
 import torch
 from torch import nn
 
@@ -435,6 +437,36 @@ class Generator(nn.Module):
         self.half_mode = ("split" if split else True) if on else False
         return self
 
+    # -- split pipeline: range guard (include/svc_hip.h, RANGE) --------------------------------------------------------------------
+    def range_flag(self, device):
+        """The sticky int32 word this generator's split launches report an out-of-range value into (created on first use)."""
+        f = self.__dict__.get("_range_flag")
+        if f is None or f.device != device:
+            f = self.__dict__["_range_flag"] = torch.zeros(1, dtype=torch.int32, device=device)
+        return f
+
+    def split_range_exceeded(self, clear=True):
+        """True if a split launch since the last clear produced a value outside the fp16 range (|v| > 65504) or a nan — its
+        results are then not fp32-level and the caller re-runs the fp32 path.  One device read (synchronises)."""
+        f = self.__dict__.get("_range_flag")
+        if f is None:
+            return False
+        bad = bool(int(f.item()))
+        if bad and clear:
+            f.zero_()
+        return bad
+
+    @contextlib.contextmanager
+    def _range_guard(self, device):
+        if getattr(self, "half_mode", False) != "split":
+            yield
+            return
+        S.hl_range_flag(self.range_flag(device))
+        try:
+            yield
+        finally:
+            S.hl_range_flag(None)
+
     def _stage_channels(self):
         c0 = self.h["upsample_initial_channel"]
         return [c0] + [c0 // (2 ** (i + 1)) for i in range(self.num_upsamples)]
@@ -452,17 +484,18 @@ class Generator(nn.Module):
         xh = None
         nk = self.num_kernels
         sp = self.half_mode == "split"
-        for i in range(self.num_upsamples):
-            xs = source[0][i] if source is not None else self.noise_convs[i](har)     # fp32 [B, C_i, L_i] (:379)
-            if i == 0:
-                x = self.ups[0].run(x, pre_slope=LRELU_SLOPE, res=xs)                 # fp32: lrelu + ConvT + add (:377-381)
-                xh = S.to_h(x, split=sp)
-            else:
-                xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs, split=sp))
-            xh = mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), half=True)
-        cp = self.conv_post
-        return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,
-                             pre_slope=0.01, act=S.ACT_TANH)
+        with self._range_guard(x.device):
+            for i in range(self.num_upsamples):
+                xs = source[0][i] if source is not None else self.noise_convs[i](har)     # fp32 [B, C_i, L_i] (:379)
+                if i == 0:
+                    x = self.ups[0].run(x, pre_slope=LRELU_SLOPE, res=xs)                 # fp32: lrelu + ConvT + add (:377-381)
+                    xh = S.to_h(x, split=sp)
+                else:
+                    xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs, split=sp))
+                xh = mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), half=True)
+            cp = self.conv_post
+            return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,
+                                 pre_slope=0.01, act=S.ACT_TANH)
 
     def remove_weight_norm(self):
         for l in self.ups:

@@ -180,16 +180,17 @@ class Generator(base.Generator):
         xh = None
         nk = self.num_kernels
         sp = self.half_mode == "split"      # the split pipeline (hi + lo fp16 planes: svc_conv1d_hl, svc_snake_alias_hl)
-        for i in range(self.num_upsamples):
-            xs = source[0][i] if source is not None else self.noise_convs[i](har)
-            if i == 0:
-                xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs), split=sp)
-            else:
-                xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs, split=sp))
-            xh = base.mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), n_tmp=4, half=True)
-        cp = self.conv_post
-        return S.conv_post_h(self.snake_post.run_h(xh), cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias,
-                             cp.kernel_size, cp.padding, pre_slope=1.0, act=S.ACT_TANH)
+        with self._range_guard(x.device):
+            for i in range(self.num_upsamples):
+                xs = source[0][i] if source is not None else self.noise_convs[i](har)
+                if i == 0:
+                    xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs), split=sp)
+                else:
+                    xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs, split=sp))
+                xh = base.mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), n_tmp=4, half=True)
+            cp = self.conv_post
+            return S.conv_post_h(self.snake_post.run_h(xh), cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias,
+                                 cp.kernel_size, cp.padding, pre_slope=1.0, act=S.ACT_TANH)
 
     def forward(self, x, f0, g=None, noise=None, source=None):
         """x [B,inter,T], f0 [B,T], g [B,gin,1|T] -> [B,1,T*upp]  (reference :380-413); `source`: see base.Generator.forward."""

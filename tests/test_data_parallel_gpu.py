@@ -79,7 +79,8 @@ def _worker(rank, world, port, q, graph=False, backend="gloo", capture=False, en
         stats = (dict(net_g.reducer.stats, mode=getattr(step, "dp_mode", "eager"),
                       exposed_ms=net_g.reducer.exposed_ms() if graph else 0.0), dict(net_d.reducer.stats))
         dist.destroy_process_group()
-        q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats, flat if rank == 0 else None))
+        # (by value, as a numpy array: a torch tensor travels through the queue as a shared-memory handle that dies with this process)
+        q.put((rank, "ok" if (same and fin) else f"same={same} finite={fin}", stats, flat.numpy() if rank == 0 else None))
     except Exception:      # noqa: BLE001
         import traceback
         q.put((rank, traceback.format_exc(), None, None))
@@ -105,7 +106,7 @@ def _run_two_ranks(graph, backend="gloo", capture=False, world=2, env=None, time
             p.kill()
     for rank, msg, stats, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
-    return res
+    return [(r, m, st, torch.from_numpy(f) if f is not None and not torch.is_tensor(f) else f) for r, m, st, f in res]
 
 
 def test_two_rank_training_keeps_parameters_identical():
@@ -136,7 +137,7 @@ def test_two_rank_training_graph_segments():
         p.join(timeout=60)
     for rank, msg, _, _ in res:
         assert msg == "ok", f"rank {rank}: {msg}"
-    flat_e = next(f for r, _, _, f in res if f is not None)
+    flat_e = torch.as_tensor(next(f for r, _, _, f in res if f is not None))
     # Not bit-comparable: the weight-gradient kernels combine their time splits with fp32 atomics, and in its first steps
     # Adam moves every element by ~lr * sign(g) — an element whose gradient is ~0 can flip direction between two runs
     # (|difference| up to 2 * lr per step, isolated elements).  A skipped / doubled step would shift EVERY element by ~lr.

@@ -118,10 +118,29 @@ def test_snake_long_form_matches_oracle_on_full_clips(dev):
     noise = W.make_noise(cfg, B, T, seed=22)
     with torch.no_grad():
         ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
-    o, _ = net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4,
-                     noise={k: v.to(dev) for k, v in noise.items()})
+    run = lambda: net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4,
+                            noise={k: v.to(dev) for k, v in noise.items()})[0]
+    o = run()
     assert o.shape == ref.shape == (B, 1, T * 512)
     _check(o, ref)
+    # the same clips through the two 16-bit-instruction modes, against the SAME oracle output (these modes were
+    # oracle-pinned at T = 60 only and compared with the engine's own fp32 path at this length)
+    mx32 = (o.cpu() - ref).abs().max().item()
+    net.split_f16()
+    osp = run()
+    assert not net.split_range_exceeded()
+    mxs = (osp.cpu() - ref).abs().max().item()
+    _check(osp, ref)                                                       # the fp32 path's own bound
+    assert mxs <= 4 * mx32 + 5e-6, (mxs, mx32)
+    net.split_f16(False)
+    net.half()
+    oh = run()
+    mse_h = (oh.cpu() - ref).pow(2).mean().item()
+    print(f"snake B=2 x T=2584 vs the fp32 oracle: fp32 kernels max {mx32:.3e}, split max {mxs:.3e}, half MSE {mse_h:.3e} "
+          f"max {(oh.cpu() - ref).abs().max().item():.3e}")
+    assert oh.shape == ref.shape and mse_h < 1e-4                          # north_star's waveform bar for the reduced-precision mode
+    net.float()
+    assert torch.equal(run(), o)
 
 
 def test_tiny_template_at_its_true_widths_matches_oracle(dev):

@@ -7,6 +7,7 @@ multiple of the fp32 kernel's and below 2e-6 of the output scale (an fp16 pipeli
 through `SynthesizerTrn.split_f16()` against the real reference's fp32 output (tests/golden/infer_full_T24.npz) under the SAME
 bound the fp32 path is held to, and against the engine's own fp32 path at the benchmarked shape."""
 import json
+import math
 import os
 
 import numpy as np
@@ -34,13 +35,14 @@ def test_split_planes_carry_22_bits(dev):
     add = torch.randn(2, 24, 301, generator=g)
     xh = S.to_h(x.to(dev), split=True)
     assert xh.shape == (2, 2, 3, 301, 8) and xh.dtype == torch.float16
-    hi = x.view(2, 3, 8, 301).permute(0, 1, 3, 2).half()
-    assert torch.equal(xh[0].cpu(), hi)                                              # plane 0 = the value rounded to fp16
-    assert torch.equal(xh[1].cpu(), (x.view(2, 3, 8, 301).permute(0, 1, 3, 2) - hi.float()).half())
+    xs = 32.0 * x.view(2, 3, 8, 301).permute(0, 1, 3, 2)                             # activation planes hold 32 v (csrc/conv1d_hl.hip, ASC)
+    hi = xs.half()
+    assert torch.equal(xh[0].cpu(), hi)                                              # plane 0 = the stored value rounded to fp16
+    assert torch.equal(xh[1].cpu(), (xs - hi.float()).half())
     back = S.from_h(xh).cpu()
-    assert ((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -24).all()
+    assert ((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -29).all()
     back2 = S.from_h(S.to_h(x.to(dev), add=add.to(dev), split=True)).cpu()
-    assert ((back2 - (x + add)).abs() <= (x + add).abs() * 2.0 ** -21 + 2.0 ** -24).all()
+    assert ((back2 - (x + add)).abs() <= (x + add).abs() * 2.0 ** -21 + 2.0 ** -29).all()
 
 
 CONV_CASES = [
@@ -260,3 +262,119 @@ def test_snake_generator_split_inference(dev):
     assert o.shape == ref.shape and mx <= 4 * mx32 + 5e-6, (mx, mx32)
     net.enable_graph(True)
     assert torch.equal(run(), o)
+
+
+# ---- range of the representation (include/svc_hip.h, RANGE) ---------------------------------------------------------
+@pytest.mark.parametrize("wmag", [1e-6, 1e-3, 1.0, 1e2, 1e5])
+def test_weights_of_any_magnitude_keep_22_bits(dev, wmag):
+    """Weight tensors from 1e-6 to 1e5 (a nearly dead layer ... a weight-norm gain of trained magnitude): the pack's per-tensor power of
+    two puts max |w| at 2^14 whatever the magnitude, so the error against float64 — in units of the output scale — is the same at every
+    magnitude.  The INPUT is scaled the other way (clamped to the planes' range) so that the output stays O(1): what is measured is
+    the weights' carriage, not the output's.  (Round 5 packed unscaled: |w| > 65504 became inf, |w| ~ 1e-6 kept four bits.)"""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, T, KS = 1, 64, 64, 700, 7
+    xmag = min(max(1.0 / wmag, 1e-2), 300.0)
+    x = torch.randn(B, Cin, T, generator=g) * xmag
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5 * wmag
+    b = torch.randn(Cout, generator=g) * wmag * xmag
+    exact = F.conv1d(x.double(), w.double(), b.double(), padding=3)
+    wp = S.pack_conv1d_h(w.to(dev), split=True)
+    assert 2.0 ** 13 <= w.abs().max().item() / wp.acc_scale <= 2.0 ** 14 and torch.isfinite(wp.float()).all()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    S.hl_range_flag(flag)
+    try:
+        y = S.from_h(S.conv1d_h(S.to_h(x.to(dev), split=True), wp, Cout, bias=b.to(dev), pad_left=3)).cpu()
+    finally:
+        S.hl_range_flag(None)
+    y32 = S.conv1d(x.to(dev), S.pack_conv1d_weight(w.to(dev)), Cout, KS, bias=b.to(dev), pad_left=3).cpu()
+    e, e32 = _err(y, exact), _err(y32, exact)
+    print(f"weights x {wmag:g}, input x {xmag:g}: split {e:.2e}, fp32 kernel {e32:.2e} (of max |exact| = {exact.abs().max().item():.3g}), "
+          f"range flag {int(flag.item())}")
+    if exact.abs().max().item() <= 2000.0:
+        assert int(flag.item()) == 0
+        assert e < SCALE_BOUND and e < 4 * e32 + 2e-7, (wmag, e, e32)
+    else:                # wmag 1e5 with the input clamped at 1e-2: outputs of ~6e3 are beyond +-2047 — the flag's business, and it says so
+        assert int(flag.item()) == 1
+
+
+def test_rows_of_mixed_gain_inside_one_weight_tensor(dev):
+    """weight_norm gains differ per output row: rows at 1e2, 1, 1e-2 and 1e-4 in ONE tensor.  A weight is carried to
+    max(2^-22 |w|, 2^-39 max |w|); rows within 2^-17 of the largest keep their 22 bits, the 1e-6-of-the-largest rows keep ~19.  Measured per
+    row in units of that row's own output scale — which for the small rows is itself small, so the activation planes' absolute floor
+    (2^-30) shows in the last group's bound: stated, not hidden."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(12)
+    Cin, Cout, T, KS = 32, 64, 900, 3
+    gain = torch.tensor([1e2, 1.0, 1e-2, 1e-4]).repeat_interleave(16)
+    x = torch.randn(1, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5 * gain.view(-1, 1, 1)
+    exact = F.conv1d(x.double(), w.double(), padding=1)
+    y = S.from_h(S.conv1d_h(S.to_h(x.to(dev), split=True), S.pack_conv1d_h(w.to(dev), split=True), Cout, pad_left=1)).cpu()
+    per_row = (y.double() - exact).abs().amax(dim=(0, 2)) / exact.abs().amax(dim=(0, 2))
+    groups = per_row.view(4, 16).amax(dim=1).tolist()
+    print("per-row error (of the row's own scale) at gains 1e2 / 1 / 1e-2 / 1e-4:", " ".join(f"{v:.2e}" for v in groups))
+    assert groups[0] < SCALE_BOUND and groups[1] < SCALE_BOUND and groups[2] < SCALE_BOUND
+    assert groups[3] < 2e-5
+
+
+def test_activation_overflow_raises_the_range_flag(dev):
+    """|v| > 2047 cannot be carried by the activation planes (32 v as two fp16 pieces).  Every value the split kernels PRODUCE is checked
+    as it is encoded: the launches report into the int32 word registered with svc_hl_range_flag.  In range: flag stays 0 and the
+    result is fp32-level; out of range: flag set (by the conversion, by a convolution's epilogue, by the fused pair's intermediate)."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(13)
+    C_, T = 32, 600
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    w = (torch.randn(C_, C_, 3, generator=g) / (C_ * 3) ** 0.5).to(dev)
+    wp = S.pack_conv1d_h(w, split=True)
+    zb = torch.zeros(C_, device=dev)
+    S.hl_range_flag(flag)
+    try:
+        x_ok = (torch.randn(1, C_, T, generator=g) * 300.0).to(dev)                     # large but inside: max ~ 1.3e3
+        assert x_ok.abs().max().item() < 2000.0
+        xh = S.to_h(x_ok, split=True)
+        y = S.from_h(S.conv1d_h(xh, wp, C_, pad_left=1)).cpu()
+        assert int(flag.item()) == 0
+        assert _err(y, F.conv1d(x_ok.cpu().double(), w.cpu().double(), padding=1)) < SCALE_BOUND
+        x_bad = x_ok.clone()
+        x_bad[0, 3, 17] = 3.0e3
+        S.to_h(x_bad, split=True)                                                       # the conversion itself reports
+        assert int(flag.item()) == 1
+        flag.zero_()
+        big = S.pack_conv1d_h(w * 8.0, split=True)                                      # inputs in range, OUTPUT ~ 1e4 out of it
+        S.conv1d_h(xh, big, C_, pad_left=1)
+        assert int(flag.item()) == 1
+        flag.zero_()
+        S.resblock_pair_h(xh, big, zb, wp, zb, 1)                                       # the fused pair's intermediate
+        assert int(flag.item()) == 1
+        flag.zero_()
+        S.to_h(torch.full((1, 8, 5), float("nan"), device=dev), split=True)             # nan counts as out of range
+        assert int(flag.item()) == 1
+    finally:
+        S.hl_range_flag(None)
+    flag.zero_()
+    S.to_h(x_bad, split=True)                                                           # withdrawn: no reporting, no crash
+    assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("xmag", [1e-2, 1e-4, 1e-6])
+def test_small_activations_and_the_absolute_floor(dev, xmag):
+    """The activation planes hold 32 v: 22 bits down to |v| = 0.004 and an ABSOLUTE 2^-30 (9.3e-10) below (round 5, unscaled: 0.125 and
+    3e-8).  On a 1e-2-scale tensor the result is still fp32-level; at 1e-4 / 1e-6 (digital silence through the generator) the error is
+    bounded by the floor: 2^-30 per input element through sum |w|, plus 2^-30 on the output — inaudible, and stated as what it is."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(14)
+    C_, T, KS = 32, 800, 7
+    x = torch.randn(1, C_, T, generator=g) * xmag
+    w = torch.randn(C_, C_, KS, generator=g) / (C_ * KS) ** 0.5
+    exact = F.conv1d(x.double(), w.double(), padding=3)
+    y = S.from_h(S.conv1d_h(S.to_h(x.to(dev), split=True), S.pack_conv1d_h(w.to(dev), split=True), C_, pad_left=3)).cpu()
+    abs_err = (y.double() - exact).abs().max().item()
+    floor = 2.0 ** -30 * (w.abs().sum(dim=(1, 2)).max().item() + 1.0)
+    rel = abs_err / exact.abs().max().item()
+    print(f"{xmag:g}-scale input: max abs error {abs_err:.2e} = {rel:.2e} of the output scale {exact.abs().max().item():.2e} "
+          f"(floor bound {floor:.2e})")
+    assert abs_err <= floor + SCALE_BOUND * exact.abs().max().item()
+    if xmag >= 1e-2:
+        assert rel < SCALE_BOUND
