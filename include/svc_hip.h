@@ -428,6 +428,7 @@ typedef struct svc_coupling_args {
   int B, T, channels, hidden, kernel_size, n_layers, reverse, planes;
 } svc_coupling_args;
 int svc_coupling_fused_h(const svc_coupling_args* a, void* stream);
+int svc_debug_set_coupling_fused(int prefetch); /* A/B: 0 = without the L2 prefetch workgroups */
 
 
 /* ================================================================================================

@@ -50,6 +50,8 @@ struct CPL {
   float s_pre, s_in[MAXL], s_rs[MAXL], s_post;
   int B, T, L, reverse;
   int* flag;
+  int n_tiles;      // column tiles per batch item; blocks with blockIdx.x >= n_tiles (row blockIdx.y == 0 only) are L2 prefetchers
+  int* sink;        // never written (keeps the prefetchers' loads alive)
 };
 
 // ---- plane policies: P = 1 one fp16 plane of v; P = 2 hi / lo planes of 32 v, range-checked (include/svc_hip.h, RANGE)
@@ -71,18 +73,28 @@ __device__ __forceinline__ float dec(_Float16 hi, _Float16 lo) {
   else return ((float)hi + (float)lo) * IASC;
 }
 
+// Branch-free activations (the libm tanhf is two divergent branches and an IEEE division per element: 96 elements per lane and layer).
+// |error| <= ~1e-7 absolute: below the fp32 kernels' own distance from float64 on this block (tests/test_flow_fused_gpu.py).
+__device__ __forceinline__ float fast_tanh(float v) {
+  const float t = __expf(-2.f * fabsf(v));
+  const float r = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+  return copysignf(r, v);
+}
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
 // acc[mt][nt] += W[rows of tile mt] x X[:, columns of tile nt] over S = (channel group, tap) steps.
 //   wp: this lane's A fragment of its first row tile at step 0 (+ step * sstride + mt * 64; lo plane at + wplane8)
 //   xw: this lane's B fragment base (tile + kh * XW + li; step (g, tap) at + 2 g XW + tap, column tile nt at + 32 nt, lo plane at + lplane8)
-template <int P, int KS, int MT, int NT, int CH>
-__device__ __forceinline__ void mma_run(f32x16 (&acc)[MT][NT], const h8* __restrict__ wp, long long wplane8, long long sstride, int S,
+template <int P, int KS, int S, int MT, int NT, int CH>
+__device__ __forceinline__ void mma_run(f32x16 (&acc)[MT][NT], const h8* __restrict__ wp, long long wplane8, long long sstride,
                                         const h8* __restrict__ xw, int lplane8, int XW) {
+  static_assert(S % (3 * CH) == 0, "a multiple of three whole chunks: every load of the three-buffer ring is unconditional");
   auto wload = [&](h8 (&af)[CH][MT][P], int s0) {
 #pragma unroll
     for (int j = 0; j < CH; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const h8* q = wp + (long long)min(s0 + j, S - 1) * sstride + mt * 64;
+        const h8* q = wp + (long long)(s0 + j) * sstride + mt * 64;
         af[j][mt][0] = q[0];
         if constexpr (P == 2) af[j][mt][1] = q[wplane8];
       }
@@ -91,44 +103,58 @@ __device__ __forceinline__ void mma_run(f32x16 (&acc)[MT][NT], const h8* __restr
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const int sidx = s0 + j;
-      if (sidx < S) {
-        const int g = sidx / KS, tap = sidx - g * KS;
-        const h8* xr = xw + 2 * g * XW + tap;
-        h8 bh[NT], bl[NT];
+      const int g = sidx / KS, tap = sidx - g * KS;
+      const h8* xr = xw + 2 * g * XW + tap;
+      h8 bh[NT], bl[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          bh[nt] = xr[nt * 32];
-          if constexpr (P == 2) bl[nt] = xr[lplane8 + nt * 32];
-        }
-        if constexpr (P == 2) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][1], bh[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bl[nt], acc[mt][nt], 0, 0, 0);
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        bh[nt] = xr[nt * 32];
+        if constexpr (P == 2) bl[nt] = xr[lplane8 + nt * 32];
+      }
+      if constexpr (P == 2) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][1], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bl[nt], acc[mt][nt], 0, 0, 0);
       }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][0], bh[nt], acc[mt][nt], 0, 0, 0);
     }
   };
-  h8 a0[CH][MT][P], a1[CH][MT][P];
+  // A ring of THREE chunk buffers: the loads of chunks c + 1 and c + 2 are in flight while chunk c multiplies.  The weights of a
+  // coupling are cold (the decoder has streamed hundreds of MB through L2 since the last clip), a fragment takes 1-2 us to arrive, and
+  // 18 workgroups cannot hide that behind each other: bytes in flight per wave are the kernel's bandwidth (two buffers: 31 GB/s per CU
+  // measured, profiles/r10d_*).  Every load is issued IN FRONT of a chunk's instructions and pinned there (sched_barrier): left alone,
+  // the scheduler of this 500-register kernel sinks each load to its use — `global_load -> s_waitcnt vmcnt(0) -> 2 MFMAs`, an exposed
+  // round trip per fragment (the first build: 630 us per coupling).  Loads are unconditional (the last trips re-read the last chunk):
+  // a conditional load makes the compiler's vmcnt bookkeeping wait for the NEWEST chunk at the join.
+  h8 a0[CH][MT][P], a1[CH][MT][P], a2[CH][MT][P];
+  constexpr int LASTC = S - CH;
   wload(a0, 0);
-  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
-    if (s0 + CH < S) wload(a1, s0 + CH);
+  wload(a1, CH);
+#pragma unroll 1
+  for (int s0 = 0; s0 < S; s0 += 3 * CH) {
+    wload(a2, min(s0 + 2 * CH, LASTC));
+    __builtin_amdgcn_sched_barrier(0);
     chunk(a0, s0);
-    if (s0 + CH < S) {
-      if (s0 + 2 * CH < S) wload(a0, s0 + 2 * CH);
-      chunk(a1, s0 + CH);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    wload(a0, min(s0 + 3 * CH, LASTC));
+    __builtin_amdgcn_sched_barrier(0);
+    chunk(a1, s0 + CH);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(a1, min(s0 + 4 * CH, LASTC));
+    __builtin_amdgcn_sched_barrier(0);
+    chunk(a2, s0 + 2 * CH);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -146,21 +172,66 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 constexpr long long sstride_of(int RP) { return (long long)RP * 2; }
 constexpr long long wplane_of(int G, int KS, int RP) { return (long long)G * KS * RP * 2; }
 
+// ---- L2 prefetchers.  One clip is 18 compute workgroups on a 256-CU chip, each streaming ALL of the coupling's weights (3.5 MB fp16, 7 MB
+// split) — cold: they come from HBM / the infinity cache at 1-2 us per fragment, and a workgroup's bandwidth is its bytes in flight.
+// The launch therefore carries NPF extra workgroups (idle CUs otherwise) that do nothing but read the packs, in the order the compute
+// workgroups consume them, eight workgroups per XCD (workgroup -> XCD is round-robin over the linear block index on this chip — used
+// for speed only: a wrong guess costs the prefetch, not the result), each touching every eighth 4 KB piece, 8 loads in flight per lane.
+// The compute workgroups then find their fragments in their XCD's L2.
+constexpr int NPF = 64;
+template <int P>
+__device__ __forceinline__ void prefetch_packs(const CPL& p, int j) {
+  const int slot = j >> 3, tid = threadIdx.x;
+  unsigned acc = 0;
+  auto sweep = [&](const h8* base, long long n8) {      // n8: h8 words of the whole pack (all planes)
+    const long long stride = 8ll * 256;
+    for (long long k = (long long)slot * 256 + tid; k < n8; k += 8 * stride) {
+      h8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long idx = k + u * stride;
+        v[u] = base[idx < n8 ? idx : k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc ^= __builtin_bit_cast(unsigned, __builtin_shufflevector(v[u], v[u], 0, 1));
+    }
+  };
+  const int L = p.L;
+  sweep(p.w_pre, P * wplane_of(HALF / 16, 1, 256));
+  for (int l = 0; l < L; ++l) {
+    sweep(p.w_in[l], P * wplane_of(HB / 2, KSIN, 384));
+    sweep(p.w_rs[l], P * wplane_of(HB / 2, 1, l == L - 1 ? 256 : 384));
+  }
+  sweep(p.w_post, P * wplane_of(HB / 2, 1, 128));
+  if (acc == 0x9e3779b9u && p.sink) atomicOr(p.sink, 1);      // (never both: the loads must not be optimised away)
+}
+
 template <int P, int NT>
 __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
-  constexpr int NC = 32 * NT, XW = NC + 4, CH = P == 1 ? 4 : 2;
+  if (blockIdx.x >= (unsigned)p.n_tiles) {
+    if (blockIdx.y == 0) prefetch_packs<P>(p, blockIdx.x - p.n_tiles);
+    return;
+  }
+  constexpr int NC = 32 * NT, XW = NC + 4;
+  constexpr int CHI = P == 1 ? 4 : 2, CHR = P == 1 ? 4 : 2, CHP = 2;      // steps per ring chunk (60 / 12 / 6 steps = 12 or 15 / 3 or 6 / 3 chunks)
   constexpr int HPL = HB * XW;      // h8 words per plane of the residual-stream tile
   constexpr int APL = HB * NC;      // ... of the work tile
+  constexpr int WORK8 = (P * HB > 48 ? P * HB : 48) * NC;      // h8 words of the work tile's region (>= the fp32 gate scratch [H][NC])
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_cf[];
   h8* hs = reinterpret_cast<h8*>(smem_cf);                 // [P][HB][XW]   column jj <-> computed column jj - 2
   h8* as = hs + P * HPL;                                   // [P][HB][NC]   (x0 [P][12][NC] / gated activations / skip sum; fp32 gate scratch [H][NC])
   float* sc = reinterpret_cast<float*>(as);
+  float* outs = reinterpret_cast<float*>(as + WORK8);      // [H][NC] fp32: the skip sum `output` (waves 2, 3)
+  float* lb = outs + H * NC;                               // [2][768] per-layer biases (in_layer + conditioning row, res_skip), double-buffered;
+  float* pb = lb + 2 * 768;                                // [192 + 96] b_pre, b_post
   _Float16* hsh = reinterpret_cast<_Float16*>(hs);
   _Float16* ash = reinterpret_cast<_Float16*>(as);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int L = p.L, HALO = 2 * L, NOUT = NC - 2 * HALO;
   const int t0 = blockIdx.x * NOUT, b = blockIdx.y, T = p.T;
   bool bad = false;
+  const bool cond_row = p.cond != nullptr && p.cond_ts == 0;      // one conditioning row per (batch item, layer): folded into the staged bias
+  const bool cond_frame = p.cond != nullptr && p.cond_ts != 0;    // per-frame conditioning (speaker mix): read per element
 
   float insv[NT];
   int tcol[NT];
@@ -171,7 +242,24 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
     insv[nt] = (t >= 0 && t < T) ? (p.mask ? p.mask[(long long)b * T + t] : 1.f) : 0.f;
   }
 
-  // ---- x0 (channels 0..95 of the view) -> work tile; zero pads of the residual-stream tile
+  // per-layer bias vectors into LDS: [0, 384) in_layer bias (+ the layer's conditioning row), [384, 768) res_skip bias
+  auto stage_bias = [&](int l) {
+    float* dst = lb + (l & 1) * 768;
+    const float* cn = cond_row ? p.cond + (long long)b * p.cond_bs + (long long)(l * 2 * H) * p.cond_cs : nullptr;
+    const int nrs = l == L - 1 ? H : 2 * H;
+    for (int i = tid; i < 768; i += 256) {
+      float v = 0.f;
+      if (i < 384) {
+        v = p.b_in[l][i];
+        if (cn) v += cn[(long long)i * p.cond_cs];
+      } else if (i - 384 < nrs) {
+        v = p.b_rs[l][i - 384];
+      }
+      dst[i] = v;
+    }
+  };
+
+  // ---- x0 (channels 0..95 of the view) -> work tile; zero pads of the residual-stream tile; biases
   {
     const float* xb = p.x + (long long)b * p.x_bs;
     for (int idx = tid; idx < (HALF / 8) * NC; idx += 256) {
@@ -179,10 +267,13 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
       const int t = t0 - HALO + j;
       h8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
       if (t >= 0 && t < T) {
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = xb[(long long)(cb * 8 + e) * p.x_cs + t];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           _Float16 hi, lo;
-          enc<P>(xb[(long long)(cb * 8 + e) * p.x_cs + t], hi, lo, bad);
+          enc<P>(xv[e], hi, lo, bad);
           vh[e] = hi;
           vl[e] = lo;
         }
@@ -196,6 +287,8 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
       const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       hs[pl * HPL + cb * XW + (e < 2 ? e : XW - 4 + e)] = z;
     }
+    for (int i = tid; i < H + HALF; i += 256) pb[i] = i < H ? p.b_pre[i] : p.b_post[i - H];
+    stage_bias(0);
   }
   __syncthreads();
 
@@ -203,8 +296,8 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
   if (w < 3) {
     f32x16 acc[2][NT];
     zero_acc(acc);
-    mma_run<P, 1, 2, NT, CH>(acc, p.w_pre + ((long long)(64 * w + li)) * 2 + kh, wplane_of(HALF / 16, 1, 256), sstride_of(256), HALF / 16,
-                             as + kh * NC + li, APL, NC);
+    mma_run<P, 1, HALF / 16, 2, NT, CHP>(acc, p.w_pre + ((long long)(64 * w + li)) * 2 + kh, wplane_of(HALF / 16, 1, 256), sstride_of(256),
+                                       as + kh * NC + li, APL, NC);
     const float s = p.s_pre * (P == 2 ? IASC : 1.f);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -213,10 +306,11 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row8 = 64 * w + mt * 32 + 8 * i;
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(pb + row8 + 4 * kh);
           h4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float v = (acc[mt][nt][4 * i + e] * s + p.b_pre[row8 + 4 * kh + e]) * insv[nt];
+            const float v = (acc[mt][nt][4 * i + e] * s + bq[e]) * insv[nt];
             _Float16 hi, lo;
             enc<P>(v, hi, lo, bad);
             oh[e] = hi;
@@ -230,29 +324,31 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
   __syncthreads();
 
   // ---- the WN layers (modules/modules.py:110-138)
-  f32x16 outacc[3][NT];      // waves 2, 3: the skip sum `output` of their 96 rows x NC columns, all layers
-  zero_acc(outacc);
   for (int l = 0; l < L; ++l) {
+    const float* lbl = lb + (l & 1) * 768;
     // in_layer: k = 5 conv 192 -> 384, + bias + g_l, tanh (rows 0..191: waves 0, 1) / sigmoid (rows 192..383: waves 2, 3)
     f32x16 acc[3][NT];
     zero_acc(acc);
-    mma_run<P, KSIN, 3, NT, CH>(acc, p.w_in[l] + ((long long)(96 * w + li)) * 2 + kh, wplane_of(HB / 2, KSIN, 384), sstride_of(384),
-                                (HB / 2) * KSIN, hs + kh * XW + li, HPL, XW);
+    mma_run<P, KSIN, (HB / 2) * KSIN, 3, NT, CHI>(acc, p.w_in[l] + ((long long)(96 * w + li)) * 2 + kh, wplane_of(HB / 2, KSIN, 384),
+                                                 sstride_of(384), hs + kh * XW + li, HPL, XW);
     {
       const float s = p.s_in[l] * (P == 2 ? IASC : 1.f);
-      const float* bi = p.b_in[l];
-      const float* cn = p.cond ? p.cond + (long long)b * p.cond_bs + (long long)(l * 2 * H) * p.cond_cs : nullptr;
+      const float* cn = cond_frame ? p.cond + (long long)b * p.cond_bs + (long long)(l * 2 * H) * p.cond_cs : nullptr;
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int tc = p.cond_ts ? min(max(tcol[nt], 0), T - 1) : 0;
+          const int tc = min(max(tcol[nt], 0), T - 1);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 96 * w + mt * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-            float v = acc[mt][nt][r] * s + bi[row];
-            if (cn) v += cn[(long long)row * p.cond_cs + tc];
-            acc[mt][nt][r] = w >= 2 ? svc_sigmoid(v) : tanhf(v);
+          for (int i = 0; i < 4; ++i) {
+            const int row4 = 96 * w + mt * 32 + 8 * i + 4 * kh;
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(lbl + row4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[mt][nt][4 * i + e] * s + bq[e];
+              if (cn) v += cn[(long long)(row4 + e) * p.cond_cs + tc];
+              acc[mt][nt][4 * i + e] = w >= 2 ? fast_sigmoid(v) : fast_tanh(v);
+            }
           }
         }
       if (w >= 2) {
@@ -303,12 +399,12 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
     if (!last || w >= 2) {
       const int RP = last ? 256 : 384;
       const int rt0 = last ? 3 * (w - 2) : 3 * w;
+      const float s = p.s_rs[l] * (P == 2 ? IASC : 1.f);
       f32x16 acc2[3][NT];
       zero_acc(acc2);
-      mma_run<P, 1, 3, NT, CH>(acc2, p.w_rs[l] + ((long long)(32 * rt0 + li)) * 2 + kh, wplane_of(HB / 2, 1, RP), sstride_of(RP), HB / 2,
-                               as + kh * NC + li, APL, NC);
-      const float s = p.s_rs[l] * (P == 2 ? IASC : 1.f);
-      const float* br = p.b_rs[l];
+      mma_run<P, 1, HB / 2, 3, NT, CHR>(acc2, p.w_rs[l] + ((long long)(32 * rt0 + li)) * 2 + kh, wplane_of(HB / 2, 1, RP), sstride_of(RP),
+                                        as + kh * NC + li, APL, NC);
+      const float* br = lbl + 384 + 32 * rt0 + 4 * kh;      // this wave's rows of the res_skip bias
       if (w < 2) {
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
@@ -320,10 +416,11 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
               const h4 qh = *reinterpret_cast<const h4*>(hsh + o);
               h4 ql = qh;
               if constexpr (P == 2) ql = *reinterpret_cast<const h4*>(hsh + HPL * 8 + o);
+              const f32x4 bq = *reinterpret_cast<const f32x4*>(br + mt * 32 + 8 * i);
               h4 oh, ol;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float v = (dec<P>(qh[e], ql[e]) + acc2[mt][nt][4 * i + e] * s + br[96 * w + mt * 32 + 8 * i + 4 * kh + e]) * insv[nt];
+                const float v = (dec<P>(qh[e], ql[e]) + acc2[mt][nt][4 * i + e] * s + bq[e]) * insv[nt];
                 _Float16 hi, lo;
                 enc<P>(v, hi, lo, bad);
                 oh[e] = hi;
@@ -333,21 +430,31 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
               if constexpr (P == 2) *reinterpret_cast<h4*>(hsh + HPL * 8 + o) = ol;
             }
       } else {
-        const int brow0 = (last ? 0 : H) + 96 * (w - 2);
+        // the skip sum `output` accumulates in an fp32 LDS tile [192][NC] (each element owned by one lane: no race)
+        float* oq = outs + (96 * (w - 2) + 4 * kh) * NC + li;
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              outacc[mt][nt][r] += acc2[mt][nt][r] * s + br[brow0 + mt * 32 + 8 * (r >> 2) + 4 * kh + (r & 3)];
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 bq = *reinterpret_cast<const f32x4*>(br + mt * 32 + 8 * i);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float* q = oq + (mt * 32 + 8 * i + e) * NC + nt * 32;
+                const float v = acc2[mt][nt][4 * i + e] * s + bq[e];
+                *q = l == 0 ? v : *q + v;
+              }
+            }
       }
     }
+    if (!last) stage_bias(l + 1);      // into the other buffer: nobody reads it before the barrier below
     __syncthreads();
   }
 
   // ---- output * mask -> work tile; post 1x1 192 -> 96; x1 update in place (modules/modules.py:297-306, mean_only: logs = 0)
   if (w >= 2) {
+    const float* oq = outs + (96 * (w - 2) + 4 * kh) * NC + li;
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -358,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             _Float16 hi, lo;
-            enc<P>(outacc[mt][nt][4 * i + e] * insv[nt], hi, lo, bad);
+            enc<P>(oq[(mt * 32 + 8 * i + e) * NC + nt * 32] * insv[nt], hi, lo, bad);
             oh[e] = hi;
             ol[e] = lo;
           }
@@ -371,21 +478,22 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
   if (w < 3) {
     f32x16 acc3[1][NT];
     zero_acc(acc3);
-    mma_run<P, 1, 1, NT, CH>(acc3, p.w_post + ((long long)(32 * w + li)) * 2 + kh, wplane_of(HB / 2, 1, 128), sstride_of(128), HB / 2,
-                             as + kh * NC + li, APL, NC);
+    mma_run<P, 1, HB / 2, 1, NT, CHR>(acc3, p.w_post + ((long long)(32 * w + li)) * 2 + kh, wplane_of(HB / 2, 1, 128), sstride_of(128),
+                                     as + kh * NC + li, APL, NC);
     const float s = p.s_post * (P == 2 ? IASC : 1.f);
-    float* xb = p.x + (long long)b * p.x_bs;
+    float* xb = p.x + (long long)b * p.x_bs + (long long)(HALF + 32 * w + 4 * kh) * p.x_cs;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int j = nt * 32 + li, t = tcol[nt];
       if (j >= HALO && j < NC - HALO && t < T) {
         const float mv = insv[nt];
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = xb[(long long)(8 * (r >> 2) + (r & 3)) * p.x_cs + t];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = 32 * w + 8 * (r >> 2) + 4 * kh + (r & 3);
-          const float m = (acc3[0][nt][r] * s + p.b_post[row]) * mv;
-          float* q = xb + (long long)(HALF + row) * p.x_cs + t;
-          *q = p.reverse ? (*q - m) * mv : m + *q * mv;
+          const float m = (acc3[0][nt][r] * s + pb[H + 32 * w + 8 * (r >> 2) + 4 * kh + (r & 3)]) * mv;
+          xb[(long long)(8 * (r >> 2) + (r & 3)) * p.x_cs + t] = p.reverse ? (old[r] - m) * mv : m + old[r] * mv;
         }
       }
     }
@@ -393,18 +501,26 @@ __global__ __launch_bounds__(256, 1) void coupling_fused_kernel(CPL p) {
   if (bad && p.flag) atomicOr(p.flag, 1);
 }
 
+int g_cf_prefetch = 1;      // svc_debug_set_coupling_fused bit 0: 0 = no L2 prefetch workgroups (A/B)
+int g_cf_nt = 0;            // ... bits 4-5: 0 = by rule, 1 / 2 = 32 / 64 computed columns per workgroup
+
 template <int P, int NT>
 int launch_coupling(const CPL& p, hipStream_t s) {
   constexpr int NC = 32 * NT, XW = NC + 4;
   const int NOUT = NC - 4 * p.L;
-  const size_t lds = ((size_t)P * HB * XW + (size_t)std::max(P * HB, 48) * NC) * 16;
+  const size_t lds = ((size_t)P * HB * XW + (size_t)std::max(P * HB, 48) * NC) * 16 + ((size_t)H * NC + 2 * 768 + H + HALF) * 4;
   auto kern = coupling_fused_kernel<P, NT>;
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(svc::cdiv(p.T, NOUT), p.B), dim3(256), lds, s, p);
+  CPL q = p;
+  q.n_tiles = svc::cdiv(p.T, NOUT);
+  q.sink = nullptr;
+  // prefetchers only where the compute workgroups are too few to hide the weight latency behind each other
+  const int npf = (g_cf_prefetch && (long long)q.n_tiles * p.B < 128) ? NPF : 0;
+  hipLaunchKernelGGL(kern, dim3(q.n_tiles + npf, p.B), dim3(256), lds, s, q);
   return svc::check_launch("coupling_fused");
 }
 
@@ -412,6 +528,12 @@ int launch_coupling(const CPL& p, hipStream_t s) {
 
 namespace svc {
 int* hl_range_flag_ptr();      // conv1d_hl.hip: the calling thread's registered flag word (svc_hl_range_flag)
+}
+
+extern "C" int svc_debug_set_coupling_fused(int cfg) {
+  g_cf_prefetch = cfg & 1;
+  g_cf_nt = (cfg >> 4) & 3;
+  return SVC_OK;
 }
 
 extern "C" int svc_coupling_fused_h(const svc_coupling_args* ap, void* stream) {
@@ -444,5 +566,11 @@ extern "C" int svc_coupling_fused_h(const svc_coupling_args* ap, void* stream) {
   // FLOPs of the coupling as the reference computes it (pre + L x (k5 conv + res/skip) + post), columns once (the halo's recompute is ours)
   const double per_col = 2.0 * (HALF * H + a.n_layers * (double)(2 * H) * H * KSIN + (a.n_layers - 1) * (double)(2 * H) * H + (double)H * H + H * HALF);
   svc::ProfScope prof(s, a.planes == 2 ? "coupling_fused_hl" : "coupling_fused_h", per_col * a.B * a.T, 8.0 * a.B * (2.0 * HALF) * a.T);
-  return a.planes == 2 ? launch_coupling<2, 2>(p, s) : launch_coupling<1, 2>(p, s);
+  // 32 computed columns (16 outputs) per workgroup while that still leaves CUs idle: one clip is 54 workgroups instead of 18, each with
+  // half the matrix and activation work behind the same weight stream (311 against 452 us per flow in fp16, 478 against 735 split:
+  // profiles/r10g_flow_bench.txt); 64 columns (48 outputs: a third of the halo recompute and of the weight traffic) for batches
+  const long long wg64 = (long long)svc::cdiv(a.T, 64 - 4 * a.n_layers) * a.B;
+  const int nt = g_cf_nt ? g_cf_nt : (wg64 < 160 ? 1 : 2);
+  if (a.planes == 2) return nt == 1 ? launch_coupling<2, 1>(p, s) : launch_coupling<2, 2>(p, s);
+  return nt == 1 ? launch_coupling<1, 1>(p, s) : launch_coupling<1, 2>(p, s);
 }

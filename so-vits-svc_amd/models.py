@@ -7,6 +7,7 @@ path) runs the fused inference kernels; `SynthesizerTrn.forward` (:463-493), `En
 MultiPeriodDiscriminator run the training graph on svc_autograd Functions (HIP forward + HIP backward), dropout included.
 `use_transformer_flow` (TransformerCouplingBlock) and `use_spectral_norm` discriminators included.
 """
+import contextlib
 import math
 import os
 
@@ -56,18 +57,51 @@ class ResidualCouplingBlock(nn.Module):
             return x
         return self._run_inplace(x, x_mask, g, reverse)
 
+    # -- 16-bit / split inference: one launch per coupling (csrc/flow_fused.hip) ---------------------------------------------------
+    fused_mode = False       # False: fp32 kernels (10 launches per coupling); True: fp16 planes; "split": hi / lo planes
+
+    def set_half(self, on=True, split=False):
+        """The flow's part of SynthesizerTrn.half() / split_f16(): each coupling layer as ONE kernel on the fp16 matrix instruction
+        (svc_coupling_fused_h) where that kernel is built — WaveNet couplings with plain (not depthwise-separable) layers, 192
+        channels, kernel size 5, dilation rate 1 — and the fp32 launches everywhere else (transformer flow, other widths)."""
+        self.fused_mode = (("split" if split else True) if on else False) if self._fusable() else False
+        return self
+
+    def _fusable(self):
+        if os.environ.get("SVC_FLOW_FUSED", "1") == "0" or type(self) is not ResidualCouplingBlock:
+            return False
+        cs = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
+        ok = self.channels == 192 and self.hidden_channels == 192 and self.kernel_size == 5 and self.dilation_rate == 1 and \
+            1 <= self.n_layers <= 6
+        for c in cs:
+            wn = c.enc
+            ok = ok and isinstance(wn, modules.WN) and all(type(l) is Conv1d for l in list(wn.in_layers) + list(wn.res_skip_layers))
+        return bool(ok)
+
+    def _coupling_fused(self, c, view, x_mask, g, reverse):
+        sp = self.fused_mode == "split"
+        wn = c.enc
+        gc = wn.cond_layer(g) if g is not None else None
+        S.coupling_fused_h(view, mask2d(x_mask), gc, (c.pre.packed_h(sp), c.pre.bias),
+                           [(l.packed_h(sp), l.bias) for l in wn.in_layers], [(l.packed_h(sp), l.bias) for l in wn.res_skip_layers],
+                           (c.post.packed_h(sp), c.post.bias), reverse=reverse, split=sp)
+
     def _run_inplace(self, x, x_mask, g, reverse):
         buf = S.copy_bct(x)
         flipped = False
         couplings = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
+        if self.fused_mode:
+            step = lambda c, view: self._coupling_fused(c, view, x_mask, g, reverse)
+        else:
+            step = lambda c, view: c.apply_inplace(view, x_mask, g=g, reverse=reverse)
         if not reverse:
             for c in couplings:
-                c.apply_inplace(S.flip_view(buf) if flipped else buf, x_mask, g=g, reverse=False)
+                step(c, S.flip_view(buf) if flipped else buf)
                 flipped = not flipped
         else:
             for c in reversed(couplings):
                 flipped = not flipped
-                c.apply_inplace(S.flip_view(buf) if flipped else buf, x_mask, g=g, reverse=True)
+                step(c, S.flip_view(buf) if flipped else buf)
         if flipped:
             buf = S.copy_bct(S.flip_view(buf))
         return buf
@@ -324,12 +358,16 @@ class SynthesizerTrn(nn.Module):
         if not hasattr(self.dec, "set_half"):
             raise NotImplementedError(f"half-precision inference is not built for the {type(self.dec).__module__} generator")
         self.dec.set_half(True)
+        if hasattr(self.flow, "set_half"):
+            self.flow.set_half(True)                 # the flow's couplings as fused fp16 kernels (csrc/flow_fused.hip) where built
         self._graphs.clear()
         return self
 
     def float(self):
         if hasattr(self.dec, "set_half"):
             self.dec.set_half(False)
+        if hasattr(self.flow, "set_half"):
+            self.flow.set_half(False)
         self._graphs.clear()
         return super().float()
 
@@ -341,6 +379,8 @@ class SynthesizerTrn(nn.Module):
         if not hasattr(self.dec, "set_half"):
             raise NotImplementedError(f"the split pipeline is not built for the {type(self.dec).__module__} generator")
         self.dec.set_half(bool(on), split=True)
+        if hasattr(self.flow, "set_half"):
+            self.flow.set_half(bool(on), split=True)
         self._graphs.clear()
         return self
 
@@ -453,7 +493,11 @@ class SynthesizerTrn(nn.Module):
                                       vol_b=self.emb_vol.bias if volv is not None else None)
         z_p, m_p, logs_p, _ = self.enc_p(x_enc, x_mask, noice_scale=noice_scale, noise=noise.get("enc_p"),
                                          x_is_embedded=True, full_mask=lengths is None)
-        z = self.flow(z_p, x_mask, g=g, reverse=True)
+        # split mode: the flow's fused couplings report into the generator's range flag too (include/svc_hip.h, RANGE)
+        guard = self.dec._range_guard(c.device) if getattr(self.flow, "fused_mode", False) == "split" and hasattr(self.dec, "_range_guard") \
+            else contextlib.nullcontext()
+        with guard:
+            z = self.flow(z_p, x_mask, g=g, reverse=True)
         # `z * c_mask` (models.py:531) is the identity here: the flow's last update already multiplies by the mask
         if source is not None:
             o = self.dec(z, f0, g=g, noise=src_noise, source=source)
