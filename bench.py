@@ -296,9 +296,9 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                                frac_item_frames_only=round((mflop - fp * (1 - frac)) / (mms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if mms else 0.0,
                                note="flop_per_step counts frames padded to T as work; the *_item_frames_only figures remove the padded share of "
                                     "the frame-proportional networks (estimate from SURVEY §8a's per-network FLOP)")
-        if not args.no_pmc and world == 1 and not bf16 and os.environ.get("SVC_BENCH_PMC", "1") != "0":
+        if not args.no_pmc and world == 1 and bf16 in (False, True, "bf16") and os.environ.get("SVC_BENCH_PMC", "1") != "0":
             torch.cuda.synchronize()
-            live = collect_pmc_traffic(timeout_s=300, mode="train")
+            live = collect_pmc_traffic(timeout_s=300, mode="train", extra_args=("--bf16",) if bf16 else ())
             if live is not None:
                 roof["traffic"], roof["traffic_all_kernels"], roof["traffic_source"] = live
     red = None
@@ -356,7 +356,7 @@ def run_train(args, dev, rank, world, dist, bf16=False):
                 cpu_baseline=cpu)
 
 
-def collect_pmc_traffic(timeout_s=200, mode="infer"):
+def collect_pmc_traffic(timeout_s=200, mode="infer", extra_args=(), fam_ok=None):
     """roofline.traffic, collected IN this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — the TCC block
     cannot hold both, MI355X_MICROARCH.md counter table) around a short eager infer of this same script (one stream, launches back to
     back), summarised per kernel family by scripts/pmc_summary.py: read = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-byte
@@ -378,7 +378,7 @@ def collect_pmc_traffic(timeout_s=200, mode="infer"):
             d = os.path.join(td, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
                    "--mode", mode, "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-graph", "--no-roofline",
-                   "--no-extras", "--no-host-io", "--no-steady", "--no-pmc"]
+                   "--no-extras", "--no-host-io", "--no-steady", "--no-pmc"] + list(extra_args)
             try:
                 r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
             except Exception:      # noqa: BLE001 — a hung / missing profiler must not take the bench line down
@@ -400,9 +400,11 @@ def collect_pmc_traffic(timeout_s=200, mode="infer"):
             f"collected in this run: two separate rocprofv3 --pmc passes (FETCH_SIZE x1024 x2 for gfx950's 128-byte requests, WRITE_SIZE "
             f"x1024 uncalibrated; Infinity-Cache hits included) over {it} eager iterations of this script; traffic = bytes per iteration of "
             f"the MFMA families ({nl // it} launches), {total / it / 1e9:.1f} GB per iteration over all kernels")
-    rd = sum(v for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024 * 2
-    wr = sum(v for k, (v, n) in per["WRITE_SIZE"].items() if PS.family(k) == "conv1d_mfma") * 1024
-    n = sum(n for k, (v, n) in per["FETCH_SIZE"].items() if PS.family(k) == "conv1d_mfma")
+    if fam_ok is None:
+        fam_ok = lambda f: f == "conv1d_mfma"
+    rd = sum(v for k, (v, n) in per["FETCH_SIZE"].items() if fam_ok(PS.family(k))) * 1024 * 2
+    wr = sum(v for k, (v, n) in per["WRITE_SIZE"].items() if fam_ok(PS.family(k))) * 1024
+    n = sum(n for k, (v, n) in per["FETCH_SIZE"].items() if fam_ok(PS.family(k)))
     if n == 0:
         return None
     total = sum(v for v, _ in per["FETCH_SIZE"].values()) * 1024 * 2 + sum(v for v, _ in per["WRITE_SIZE"].values()) * 1024
@@ -458,6 +460,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="--mode train only: the fp16_run + half_type bf16 configuration")
     ap.add_argument("--split", action="store_true", help="--mode infer only: time SynthesizerTrn.split_f16() (the generator on the split pipeline: hi + lo "
                     "fp16 planes, three fp16 MFMA per product, fp32-level output) instead of the fp32-MFMA path; labelled as such — profiling aid, not the headline")
+    ap.add_argument("--half", action="store_true", help="--mode infer only: time SynthesizerTrn.half() (the reference's half-precision mode; never the headline: "
+                    "the default run reports it under infer_half)")
     ap.add_argument("--fp16", action="store_true", help="--mode train only: fp16_run + half_type fp16 (GradScaler rule: eager launches)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive pass (profiling runs: keeps the step count exact)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (device, e2e, snake_b8, diffusion_*)")
@@ -525,6 +529,9 @@ def main():
 
     import svc_hip as S
     net, cfg, W = build_model(dev)
+    if args.half:
+        net.half()
+        args.no_extras = True
     if args.split:
         net.split_f16()
         args.no_extras = True
@@ -687,6 +694,16 @@ def main():
         if isinstance(isp, dict) and "ms_per_step" in isp:
             isp["speedup_vs_f32_mfma"] = round(1e3 * elapsed / args.steps / isp["ms_per_step"], 3)
         extras["infer_split"] = isp
+        # roofline.traffic of the two 16-bit-instruction legs: the same in-run PMC passes as the headline's, over their own launches
+        if not args.no_pmc and os.environ.get("SVC_BENCH_PMC", "1") != "0":
+            for key, flag, sfx in (("infer_half", "--half", "_h"), ("infer_split", "--split", "_hl")):
+                leg = extras.get(key)
+                if not (isinstance(leg, dict) and isinstance(leg.get("roofline"), dict)):
+                    continue
+                torch.cuda.synchronize()
+                live = X.guarded(collect_pmc_traffic, 200, "infer", (flag,), lambda f, sfx=sfx: f.endswith(sfx))
+                if isinstance(live, tuple):
+                    leg["roofline"]["traffic"], leg["roofline"]["traffic_all_kernels_per_clip"], leg["roofline"]["traffic_source"] = live
 
     train_res = None
     if args.mode == "both":

@@ -51,6 +51,7 @@ int svc_device_info(char* name, int len);
  * brackets its kernel with hipEvents on the launch stream and accumulates (calls, ms, flop, bytes)
  * per kernel family.  Must be disabled while capturing a hipGraph.
  * ---------------------------------------------------------------------------------------------- */
+int svc_debug_empty_kernel(void* stream);   /* one empty one-wave kernel (bench.py's launch-latency probe) */
 int svc_prof_enable(int on);
 int svc_prof_reset(void);
 /* Synchronises outstanding events and writes one line per kernel family:

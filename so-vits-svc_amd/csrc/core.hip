@@ -112,6 +112,15 @@ int svc_device_info(char* name, int len) {
   return p.multiProcessorCount;
 }
 
+namespace {
+__global__ void svc_empty_kernel() {}
+}  // namespace
+/* bench.py's launch-latency probe: one empty one-wave kernel on `stream` (capturable). */
+int svc_debug_empty_kernel(void* stream) {
+  hipLaunchKernelGGL(svc_empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+  return svc::check_launch("svc_debug_empty_kernel");
+}
+
 int svc_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(svc::g_prof_mu);
   svc::g_prof = on != 0;

@@ -126,6 +126,7 @@ def lib():
                            "(include/svc_hip.h SVC_ABI_VERSION): rebuild with `python so-vits-svc_amd/csrc/build.py`")
         L.svc_device_info.argtypes = [C.c_char_p, C.c_int]
         L.svc_prof_enable.argtypes = [C.c_int]
+        L.svc_debug_empty_kernel.argtypes = [C.c_void_p]
         L.svc_prof_report.argtypes = [C.c_char_p, C.c_int]
         L.svc_pack_conv1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_void_p]
@@ -192,7 +193,7 @@ def lib():
 ABI_VERSION = 5      # include/svc_hip.h SVC_ABI_VERSION (tests/test_abi_cpu.py keeps the two and the struct layouts in step)
 
 EXPORTS = [
-    "svc_last_error", "svc_abi_version", "svc_device_info", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
+    "svc_last_error", "svc_abi_version", "svc_device_info", "svc_debug_empty_kernel", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",

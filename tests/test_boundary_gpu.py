@@ -184,6 +184,75 @@ def test_inference_main_call_sequence(dev, tmp_path, monkeypatch, patched_factor
     assert pos == len(audio) and checked_oracle
 
 
+def test_inference_main_on_the_tiny_template_two_5s_wavs(dev, tmp_path, monkeypatch, patched_factories):
+    """BASELINE configs[0] as written (minus "CPU-only": the engine has no CPU path by design): configs_template/
+    config_tiny_template.json at its REAL widths (filter 512, decoder 200/100/50/25/12, depthwise-separable WN, shared flow), ONE
+    speaker, TWO synthetic 5 s 44.1 kHz wavs, driven through `inference_main.main`'s own loop (inference_main.py:94-152: every clean
+    name x every speaker -> format_wav, slice_inference(**kwarg), write, clear_empty).  Both results are checked for length and
+    against a by-hand SynthesizerTrn.infer on the same features; the first also against the CPU oracle of the tiny template."""
+    import svc_audio
+    from inference import infer_tool
+    from inference.infer_tool import Svc
+    cfg = W.tiny_config()
+    patched_factories["ssl_dim"] = cfg["ssl_dim"]
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("logs/44k")
+    net, ck, cj = _write_model("logs/44k", cfg, 17)
+    os.makedirs("raw")
+    g = np.random.default_rng(5)
+    wavs = {}
+    for i, name in enumerate(("a.wav", "b.wav")):
+        n = 5 * SR
+        w = (0.25 * np.sin(2 * np.pi * (196.0 + 55.0 * i) * np.arange(n) / SR) + 0.04 * g.standard_normal(n)).astype(np.float32)
+        svc_audio.write_wav(f"raw/{name}", w, SR)
+        wavs[name] = w
+    clean_names, trans, spk_list = ["a.wav", "b.wav"], [0], ["alice"]
+    svc_model = Svc(ck, cj, None, "", False, "logs/44k/diffusion/model_0.pt", "logs/44k/diffusion/config.yaml", False, False, False, False)
+    assert not svc_model.half_mode and not svc_model.split_mode
+    infer_tool.mkdir(["raw", "results"])
+    infer_tool.fill_a_to_b(trans, clean_names)
+    assert trans == [0, 0]
+    results = {}
+    for clean_name, tran in zip(clean_names, trans):
+        raw_audio_path = f"raw/{clean_name}"
+        infer_tool.format_wav(raw_audio_path)
+        for spk in spk_list:
+            kwarg = {"raw_audio_path": raw_audio_path, "spk": spk, "tran": tran, "slice_db": -40, "cluster_infer_ratio": 0,
+                     "auto_predict_f0": False, "noice_scale": 0.4, "pad_seconds": 0.5, "clip_seconds": 0, "lg_num": 0, "lgr_num": 0.75,
+                     "f0_predictor": "pm", "enhancer_adaptive_key": 0, "cr_threshold": 0.05, "k_step": 100, "use_spk_mix": False,
+                     "second_encoding": False, "loudness_envelope_adjustment": 1}
+            audio = svc_model.slice_inference(**kwarg)
+            res_path = f"results/{clean_name}_{tran}key_{spk}_sovits_pm.wav"
+            svc_audio.write_wav(res_path, audio, svc_model.target_sample)
+            svc_model.clear_empty()
+            results[clean_name] = (res_path, audio)
+    assert len(results) == 2
+    net = net.to(dev).eval()
+    pad = int(SR * 0.5)
+    for k, name in enumerate(clean_names):
+        path, audio = results[name]
+        assert os.path.exists(path) and np.isfinite(audio).all() and abs(len(audio) - 5 * SR) <= 2 * HOP
+        from inference import slicer
+        data, sr = slicer.chunks2audio(f"raw/{name}", slicer.cut(f"raw/{name}", db_thresh=-40))
+        assert sr == SR and [t for t, _ in data] == [False]                      # 5 s of tone: one voiced chunk, nothing to cut
+        x = svc_audio.pcm16_round_trip(np.concatenate([np.zeros(pad), data[0][1], np.zeros(pad)]))
+        c, f0, uv = svc_model.get_unit_f0(x, 0, 0, "alice", False, "pm")
+        assert c.shape[1] == cfg["ssl_dim"] and abs(c.shape[2] - (5 * SR + 2 * pad) // HOP) <= 1          # T = 431 + the padding's frames
+        o, _ = net.infer(c, f0, uv, g=torch.LongTensor([[0]]).to(dev), noice_scale=0.4)
+        ref = infer_tool.pad_array(o[0, 0].cpu().numpy()[pad:-pad], len(audio))
+        assert np.array_equal(ref, audio)
+        if k == 0:
+            T = c.shape[2]
+            torch.manual_seed(52468)
+            noise = dict(enc_p=torch.randn(1, cfg["inter_channels"], T, device=dev), rand_ini=torch.rand(1, 9, device=dev),
+                         sine=torch.randn(1, T * HOP, 9, device=dev))
+            with torch.no_grad():
+                oref, _ = O.synth_infer(W.make_state_dict(cfg, 17), cfg, c.cpu(), f0.cpu(), uv.cpu(), torch.LongTensor([[0]]),
+                                        {kk: v.cpu() for kk, v in noise.items()}, noice_scale=0.4)
+            err = (o.cpu() - oref).abs().max().item()
+            assert err <= 2e-4 * max(oref.abs().max().item(), 1e-3) and (o.cpu() - oref).pow(2).mean().item() < 1e-4
+
+
 def test_slice_inference_batched_chunks_equal_serial(dev, tmp_path, monkeypatch, patched_factories):
     """Forced clipping (-cl) gives equal-length chunks: one B=n synthesizer call must reproduce the serial chunk loop."""
     import svc_audio
