@@ -207,6 +207,24 @@ typedef struct svc_resblock_pair_args {
 
 int svc_resblock_pair_f32(const svc_resblock_pair_args* a, void* stream);
 
+/* The whole 16-channel ResBlock1 — all its dilation pairs (vdecoder/hifigan/models.py:60-67: `for c1, c2 in zip(convs1, convs2)`) — in ONE
+ * launch:  for j < n_pairs:  x = conv2_j( lrelu( conv1_j( lrelu(x) ) + b1_j ) ) + b2_j + x ;  y = (x + beta * y_old) / out_div.
+ * conv1_j has dilation dil[j], conv2_j dilation 1, both KS taps (3, 7 or 11) and 'same' padding; packed weights as for
+ * svc_resblock_pair_f32.  Bit-identical to n_pairs svc_resblock_pair_f32 launches (same reduction order, same epilogue expressions);
+ * x is read once and y written once.  SVC_ERR_UNSUPPORTED when the dilations' halo leaves fewer than 64 outputs per tile. */
+typedef struct svc_resblock16_args {
+  const float* x;
+  float* y;
+  const float* w1[3];
+  const float* b1[3];
+  const float* w2[3];
+  const float* b2[3];
+  long long x_bs, x_cs, y_bs, y_cs;
+  int B, T, KS, n_pairs, dil[3], CP;
+  float slope, beta, out_div;
+} svc_resblock16_args;
+int svc_resblock16_f32(const svc_resblock16_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NSF harmonic source: nearest x`upp` f0 upsample (vdecoder/hifigan/models.py:369), SineGen (:138-166,
  * :250-271) and SourceModuleHnNSF (:307-320: Linear(H->1) + tanh), evaluated in closed form per frame

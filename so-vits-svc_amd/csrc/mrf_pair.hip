@@ -19,6 +19,7 @@
 // same order: results are bit-identical to the two-launch path.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -345,6 +346,235 @@ __global__ __launch_bounds__(256, 2) void mrf_pair16_kernel(PairP p) {
   }
 }
 
+
+// ---- round 6: the whole 16-channel ResBlock1 (all three dilation pairs) in ONE launch ---------------------------------------------
+//     for d in dilations:  x = conv2_d( lrelu( conv1_d( lrelu(x) ) + b1_d ) ) + b2_d + x          (vdecoder/hifigan/models.py:60-67)
+// The pair kernel above leaves a 16-channel MRF stage at 0.33 of the fp32 matrix peak: a workgroup lives ~29 us for ~5 us of matrix
+// work (stage the tile, load 88 weight words per lane, two convs, store) and the stage moves 106 MB per launch where a whole ResBlock
+// needs ~56 (profiles/r05d_pmc_mrf_pair16.txt).  Here a workgroup carries its tile through all three pairs: x is read once and the
+// result written once (a third of the pair path's HBM bytes and launches), and the fixed costs of a workgroup are paid once per three
+// pairs.  Price: a halo of sum_d (d + 1)(K - 1)/2 columns per side, recomputed (K = 11: 60 of 512 columns per side).
+//   * Column c of EVERY tensor of the chain is the same sample t = t0 - HT + c (tiles carry margins instead of shifting their origin):
+//     a lane's accumulator registers of one pair are the residual operand of the next — the raw x_j never goes through LDS, only
+//     lrelu(x_j) (conv1's operand) and lrelu(mid) (conv2's) do;
+//   * what lies outside [0, T) is forced to zero after every conv, exactly the zero padding of the unfused convs; columns whose
+//     inputs reach beyond the tile compute garbage that no valid output reads (the valid range shrinks by (d + 1)(K - 1)/2 per pair);
+//   * weights of a pair in registers as in the pair kernel; the next pair's are fetched under the current pair's matrix loops;
+//   * same reduction order and epilogue expressions as the pair kernel: bit-identical to the three launches it replaces.
+struct BlkP {
+  svc_resblock16_args a;
+  int n_tiles;   // tiles per batch item
+};
+
+// NW waves of NTW column tiles each: 4 x 4 / 4 x 6 for 3 / 7 taps (two or three workgroups per CU); 11 taps need 88 weight registers per
+// lane, so their 512 columns are EIGHT waves of four tiles (one workgroup per CU, two waves per SIMD).  The dilations are template
+// parameters (the decoder's ResBlock1 is always (1, 3, 5)): every LDS operand address is then `one base register + immediate`, where
+// run-time dilations and pitches cost ~130 registers of precomputed addresses (the first build spilled).
+template <int KS, int NTW, int NW, int D0, int D1, int D2>
+struct Blk16 {
+  static constexpr int C = 16, TS = 16, KPI = 4, NG = 4, W = 16 * NTW * NW, H2 = (KS - 1) / 2, NTHR = 64 * NW;
+  static constexpr int DMAX = D0 > D1 ? (D0 > D2 ? D0 : D2) : (D1 > D2 ? D1 : D2);
+  static constexpr int HT = (D0 + D1 + D2 + 3) * H2;       // halo per side: sum over pairs of (d + 1)(K - 1)/2
+  static constexpr int MG = DMAX * H2;                     // margin of the x tile
+  static constexpr int BN = W - 2 * HT;                    // outputs per workgroup
+  static constexpr int pitch(int w) {                      // 4 channel rows x 16 lanes of one operand fetch on disjoint bank groups
+    w = (w + 3) & ~3;
+    while ((w & 63) != 16 && (w & 63) != 48) w += 4;
+    return w;
+  }
+  static constexpr int AW = pitch(W + 2 * MG), MW = pitch(W + 2 * H2);
+  static constexpr size_t LDS = (size_t)16 * (AW + MW) * 4;
+  static_assert(BN >= 64, "tile too narrow for these dilations");
+};
+
+template <int KS, int NTW, int NW, int D0, int D1, int D2>
+__global__ __launch_bounds__(64 * NW, 2) void mrf_block16_kernel(BlkP p) {
+  using Cf = Blk16<KS, NTW, NW, D0, D1, D2>;
+  constexpr int C = 16, TS = 16, KPI = 4, NG = 4, W = Cf::W, H2 = Cf::H2, NTHR = Cf::NTHR;
+  constexpr int AW = Cf::AW, MW = Cf::MW, MG = Cf::MG, HT = Cf::HT, BN = Cf::BN;
+  const svc_resblock16_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                 // [C][AW]  lrelu(x_j): column c at MG + c
+  float* ms = xs + C * AW;         // [C][MW]  lrelu(conv1 + b1): column c at H2 + c
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, lk = lane >> 4;
+  const float slope = a.slope;
+  const int tile = blockIdx.x;
+  const int b = tile / p.n_tiles;
+  const int t0 = (tile - b * p.n_tiles) * BN;
+  const float* xb = a.x + (long long)b * a.x_bs;
+  float* yb = a.y + (long long)b * a.y_bs;
+  const int cbase = wave * (TS * NTW) + ln;      // this lane's column in its wave's tile j: cbase + 16 j
+
+  // ---- stage lrelu(x): columns [0, W) (zero outside the sequence), zero margins; raw x of this lane's C-layout elements in registers
+  {
+    constexpr int CPT = (W + NTHR - 1) / NTHR;   // columns per thread and channel (the last round may be partial)
+    float v[C][CPT];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int h = 0; h < CPT; ++h) {
+        const int t = t0 - HT + tid + NTHR * h;
+        const float x = xb[(long long)c * a.x_cs + min(max(t, 0), a.T - 1)];
+        v[c][h] = (t >= 0 && t < a.T) ? x : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int h = 0; h < CPT; ++h)
+        if (tid + NTHR * h < W) xs[c * AW + MG + tid + NTHR * h] = lrelu01(v[c][h], slope);
+    for (int i = tid; i < C * 2 * MG; i += NTHR) {
+      const int c = i / (2 * MG), m = i - c * 2 * MG;
+      xs[c * AW + (m < MG ? m : W + m)] = 0.f;
+    }
+    for (int i = tid; i < C * 2 * H2; i += NTHR) {
+      const int c = i / (2 * H2), m = i - c * 2 * H2;
+      ms[c * MW + (m < H2 ? m : W + m)] = 0.f;
+    }
+  }
+  float xreg[NTW][4];
+  bool ok[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int t = t0 - HT + cbase + TS * j;
+    ok[j] = t >= 0 && t < a.T;
+    const int tc = min(max(t, 0), a.T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x = xb[(long long)(4 * lk + r) * a.x_cs + tc];
+      xreg[j][r] = ok[j] ? x : 0.f;
+    }
+  }
+  float w1r[NG][KS], w2r[NG][KS], b1r[4], b2r[4];
+  auto load_w = [&](float (&wr)[NG][KS], float (&br)[4], const float* w, const float* bias) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) wr[g][k] = w[((g * KPI + lk) * KS + k) * a.CP + ln];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) br[r] = bias ? bias[4 * lk + r] : 0.f;
+  };
+  load_w(w1r, b1r, a.w1[0], a.b1[0]);
+  load_w(w2r, b2r, a.w2[0], a.b2[0]);
+  __syncthreads();
+
+  const float* xr0 = xs + lk * AW + MG + cbase;
+  const float* mr = ms + lk * MW + cbase;
+  float* msw = ms + (4 * lk) * MW + H2 + cbase;
+  float* xsw = xs + (4 * lk) * AW + MG + cbase;
+
+  auto pair = [&](auto PJC) {
+    constexpr int PJ = decltype(PJC)::value;
+    constexpr int d = PJ == 0 ? D0 : (PJ == 1 ? D1 : D2), H1 = d * H2;
+    constexpr bool lastp = PJ == 2;
+    // ---- conv1 (dilation d) -> lrelu(. + b1), zero outside the sequence -> mid tile
+    {
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* xr = xr0 - H1;
+      float bv[2][NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bv[0][j] = xr[j * TS];
+#pragma unroll
+      for (int st = 0; st < NG * KS; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NG * KS) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bv[(st + 1) & 1][j] = xr[((st + 1) / KS) * KPI * AW + ((st + 1) % KS) * d + j * TS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[st / KS][st % KS], bv[st & 1][j], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) msw[r * MW + TS * j] = ok[j] ? lrelu01(acc[j][r] + b1r[r], slope) : 0.f;
+    }
+    if constexpr (!lastp) load_w(w1r, b1r, a.w1[PJ + 1], a.b1[PJ + 1]);      // in flight under conv2
+    __syncthreads();
+    // ---- conv2 (dilation 1) + b2 + x_j -> x_{j+1} (registers; lrelu of it back into the x tile for the next pair)
+    {
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float bv[2][NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bv[0][j] = mr[j * TS];
+#pragma unroll
+      for (int st = 0; st < NG * KS; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NG * KS) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bv[(st + 1) & 1][j] = mr[((st + 1) / KS) * KPI * MW + ((st + 1) % KS) + j * TS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[st / KS][st % KS], bv[st & 1][j], acc[j], 0, 0, 0);
+      }
+      if constexpr (!lastp) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[j][r] + b2r[r];
+            v = v + xreg[j][r];
+            v = ok[j] ? v : 0.f;
+            xreg[j][r] = v;
+            xsw[r * AW + TS * j] = lrelu01(v, slope);
+          }
+      } else {
+        // (the accumulate operand is read here, once per workgroup, into registers the weights no longer need)
+        const bool accum = a.beta != 0.f;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int c = cbase + TS * j;
+          const int t = t0 - HT + c;
+          if (c >= HT && c < HT + BN && t < a.T) {
+            float yold[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yold[r] = accum ? yb[(long long)(4 * lk + r) * a.y_cs + t] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[j][r] + b2r[r];
+              v = v + xreg[j][r];
+              if (accum) v = v + a.beta * yold[r];
+              if (a.out_div != 1.f) v = v / a.out_div;
+              yb[(long long)(4 * lk + r) * a.y_cs + t] = v;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (!lastp) {
+      load_w(w2r, b2r, a.w2[PJ + 1], a.b2[PJ + 1]);                       // in flight under the next conv1
+      __syncthreads();
+    }
+  };
+  pair(std::integral_constant<int, 0>{});
+  pair(std::integral_constant<int, 1>{});
+  pair(std::integral_constant<int, 2>{});
+}
+
+template <int KS, int NTW, int NW, int D0, int D1, int D2>
+int launch_block16(const svc_resblock16_args& a, hipStream_t s) {
+  using Cf = Blk16<KS, NTW, NW, D0, D1, D2>;
+  BlkP p;
+  p.a = a;
+  p.n_tiles = svc::cdiv(a.T, Cf::BN);
+  auto kern = mrf_block16_kernel<KS, NTW, NW, D0, D1, D2>;
+  if (Cf::LDS > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long long)p.n_tiles * a.B)), dim3(64 * NW), Cf::LDS, s, p);
+  return svc::check_launch("resblock16");
+}
+
 int g_pair_v2 = -1;     // 16-channel pairs on mrf_pair16_kernel (environment SVC_PAIR_V2=0: the first form, A/B)
 
 template <int KS>
@@ -459,4 +689,31 @@ extern "C" int svc_resblock_pair_f32(const svc_resblock_pair_args* ap, void* str
     case 7: return launch_pair<32, 7>(a, s);
     default: return launch_pair<32, 11>(a, s);
   }
+}
+
+extern "C" int svc_resblock16_f32(const svc_resblock16_args* ap, void* stream) {
+  SVC_REQUIRE(ap != nullptr, "resblock16: null args");
+  const svc_resblock16_args& a = *ap;
+  SVC_REQUIRE(a.x && a.y && a.x != a.y, "resblock16: null tensor or in-place call (tiles read their neighbours' halo)");
+  SVC_REQUIRE(a.B > 0 && a.T > 0, "resblock16: empty shape");
+  if (!(a.n_pairs == 3 && a.dil[0] == 1 && a.dil[1] == 3 && a.dil[2] == 5)) {
+    svc::set_error("resblock16: built for the decoder's three pairs with dilations (1, 3, 5)");
+    return SVC_ERR_UNSUPPORTED;
+  }
+  SVC_REQUIRE(a.KS == 3 || a.KS == 7 || a.KS == 11, "resblock16: KS = %d not in {3,7,11}", a.KS);
+  SVC_REQUIRE(a.CP >= 16, "resblock16: packed row pitch < 16");
+  SVC_REQUIRE(a.slope >= 0.f && a.slope <= 1.f, "resblock16: leaky slope outside [0,1]");
+  for (int j = 0; j < a.n_pairs; ++j)
+    SVC_REQUIRE(a.w1[j] && a.w2[j] && a.dil[j] >= 1, "resblock16: null weight / bad dilation of pair %d", j);
+  hipStream_t s = (hipStream_t)stream;
+  const double flop = 2.0 * 2.0 * a.n_pairs * a.B * 16.0 * 16.0 * a.KS * a.T;
+  const double bytes = 4.0 * a.B * 16.0 * a.T * (a.beta != 0.f ? 3 : 2);
+  svc::ProfScope prof(s, "resblock16", flop, bytes);
+  int rc;
+  switch (a.KS) {
+    case 3: rc = launch_block16<3, 4, 4, 1, 3, 5>(a, s); break;
+    case 7: rc = launch_block16<7, 6, 4, 1, 3, 5>(a, s); break;
+    default: rc = launch_block16<11, 4, 8, 1, 3, 5>(a, s); break;
+  }
+  return rc;
 }

@@ -70,6 +70,13 @@ class ResblockPairArgs(C.Structure):
                 ("slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
 
 
+class Resblock16Args(C.Structure):
+    _fields_ = [("x", _f32p), ("y", _f32p), ("w1", _f32p * 3), ("b1", _f32p * 3), ("w2", _f32p * 3), ("b2", _f32p * 3),
+                ("x_bs", C.c_longlong), ("x_cs", C.c_longlong), ("y_bs", C.c_longlong), ("y_cs", C.c_longlong),
+                ("B", C.c_int), ("T", C.c_int), ("KS", C.c_int), ("n_pairs", C.c_int), ("dil", C.c_int * 3), ("CP", C.c_int),
+                ("slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float)]
+
+
 class Conv1dHArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", _f32p), ("res", C.c_void_p), ("y", C.c_void_p),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tq", C.c_int), ("Ty", C.c_int),
@@ -167,6 +174,7 @@ def lib():
                 [C.c_int] * 6 + [C.c_float] * 5 + [C.c_void_p]
             getattr(L, "svc_snake_alias_" + sfx).argtypes = L.svc_snake_alias_h.argtypes
         L.svc_hl_range_flag.argtypes = [C.c_void_p]
+        L.svc_resblock16_f32.argtypes = [C.POINTER(Resblock16Args), C.c_void_p]
         L.svc_coupling_fused_h.argtypes = [C.POINTER(CouplingArgs), C.c_void_p]
         L.svc_attention_ws_bytes.argtypes = [C.POINTER(AttentionArgs)]
         L.svc_attention_ws_bytes.restype = C.c_longlong
@@ -197,7 +205,7 @@ EXPORTS = [
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
-    "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
+    "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_resblock16_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_hl_range_flag", "svc_coupling_fused_h", "svc_debug_set_coupling_fused", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
 ]
@@ -440,6 +448,37 @@ def resblock_pair(x, w1p, b1, w2p, b2, KS, dil1, *, slope=0.1, out=None, beta=0.
     a.B, a.C, a.T, a.KS, a.dil1, a.CP = B, Cc, T, KS, dil1, w1p.shape[2]
     a.slope, a.beta, a.out_div = slope, beta, out_div
     check(lib().svc_resblock_pair_f32(C.byref(a), stream_ptr()), "resblock_pair")
+    return out
+
+
+RESBLOCK16 = os.environ.get("SVC_RESBLOCK16", "1") != "0"      # whole 16-channel ResBlock1 in one launch (0: one launch per pair, A/B)
+
+
+def resblock16(x, pairs, KS, dils, *, slope=0.1, out=None, beta=0.0, out_div=1.0):
+    """All dilation pairs of a 16-channel ResBlock1 in ONE launch (svc_resblock16_f32): pairs = [(w1p, b1, w2p, b2), ...] packed as for
+    resblock_pair; out = (block(x) + beta * out) / out_div.  Returns None when the dilations do not fit the kernel's tile (the caller
+    keeps the pair launches)."""
+    B, Cc, T = x.shape
+    if Cc != 16 or len(dils) != len(pairs):
+        raise SvcError("resblock16: 16 channels, one dilation per pair")
+    if tuple(int(d) for d in dils) != (1, 3, 5) or KS not in (3, 7, 11):
+        return None
+    if out is None:
+        out = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    a = Resblock16Args()
+    a.x, a.y = ptr(x), ptr(out)
+    for j, (w1p, b1, w2p, b2) in enumerate(pairs):
+        require_gpu(x, w1p, b1, w2p, b2, out)
+        if tuple(w1p.shape) != tuple(w2p.shape) or w1p.shape[0] != 16 or w1p.shape[1] != KS:
+            raise SvcError(f"resblock16: packed weights {tuple(w1p.shape)} / {tuple(w2p.shape)} do not match C=16 KS={KS}")
+        a.w1[j], a.b1[j], a.w2[j], a.b2[j] = w1p.data_ptr(), (b1.data_ptr() if b1 is not None else None), w2p.data_ptr(), \
+            (b2.data_ptr() if b2 is not None else None)
+        a.dil[j] = int(dils[j])
+    a.x_bs, a.x_cs = _bct_strides(x)
+    a.y_bs, a.y_cs = _bct_strides(out)
+    a.B, a.T, a.KS, a.n_pairs, a.CP = B, T, KS, len(pairs), pairs[0][0].shape[2]
+    a.slope, a.beta, a.out_div = slope, beta, out_div
+    check(lib().svc_resblock16_f32(C.byref(a), stream_ptr()), "resblock16")
     return out
 
 

@@ -79,6 +79,17 @@ class ResBlock1(nn.Module):
         C = x.shape[1]
         fused = (_FUSE_PAIR and C in S.RESBLOCK_PAIR_CHANNELS and self.convs1[0].kernel_size in S.RESBLOCK_PAIR_KERNELS
                  and not isinstance(x, S.FlipView))
+        if fused and S.RESBLOCK16 and C == 16 and n == 3:
+            # the whole block — all three dilation pairs — in ONE launch (svc_resblock16_f32: x read once, result written once, bit-equal
+            # to the three pair launches below)
+            dst = out if out is not None else ping
+            if before_last is not None:
+                before_last()
+            done = S.resblock16(cur, [(c1.packed(), c1.bias, c2.packed(), c2.bias) for c1, c2 in zip(self.convs1, self.convs2)],
+                                self.convs1[0].kernel_size, [c1.dilation for c1 in self.convs1], slope=LRELU_SLOPE, out=dst, beta=beta,
+                                out_div=out_div)
+            if done is not None:
+                return done
         if fused:
             # narrow stages (HBM-bound as separate launches): one kernel per pair, intermediate + residual stay in LDS
             for j, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):

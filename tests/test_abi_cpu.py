@@ -49,7 +49,7 @@ def test_argument_struct_layouts_match_the_header(tmp_path):
     pairs = {"svc_conv1d_args": S.Conv1dArgs, "svc_convt1d_args": S.ConvT1dArgs, "svc_conv1d_direct_args": S.Conv1dDirectArgs,
              "svc_resblock_pair_args": S.ResblockPairArgs, "svc_attention_args": S.AttentionArgs, "svc_conv1d_h_args": S.Conv1dHArgs,
              "svc_conv_weight_args": S.ConvWeightArgs, "svc_wgrad_args": S.WgradArgs, "svc_gemm_args": S.GemmArgs,
-             "svc_coupling_args": S.CouplingArgs}
+             "svc_coupling_args": S.CouplingArgs, "svc_resblock16_args": S.Resblock16Args}
     src = open(HEADER).read()
     declared = set(re.findall(r"^}\s*(svc_[a-z0-9_]+_args)\s*;", src, flags=re.M))
     assert declared == set(pairs), (declared ^ set(pairs))

@@ -345,3 +345,40 @@ def test_conv_group_rejects_nesting_and_propagates_errors(dev):
     with S.conv_group():
         y = S.conv1d(x, wp, 32, 3, pad_left=1)
     assert torch.equal(y, S.conv1d(x, wp, 32, 3, pad_left=1))          # the group of one still runs, and the state was reset
+
+
+@pytest.mark.parametrize("KS", [3, 7, 11])
+@pytest.mark.parametrize("B,T", [(1, 4099), (2, 700), (1, 100), (1, 441344 // 8)])
+def test_resblock16_one_launch_is_bit_equal_to_its_three_pair_launches(dev, KS, B, T):
+    """svc_resblock16_f32: the whole 16-channel ResBlock1 (dilations 1, 3, 5; vdecoder/hifigan/models.py:60-67) in ONE launch against the
+    three svc_resblock_pair_f32 launches it replaces — same reduction order and epilogue expressions, so torch.equal; tile borders,
+    sequences shorter than the halo (T = 100 against 60 halo columns per side at 11 taps), the MRF accumulate / divide epilogue; and
+    against torch on the CPU."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(KS * 1000 + T)
+    x = torch.randn(B, 16, T, generator=g)
+    old = torch.randn(B, 16, T, generator=g)
+    dils = (1, 3, 5)
+    ws = [(torch.randn(16, 16, KS, generator=g) / (16 * KS) ** 0.5, torch.randn(16, generator=g) * 0.2,
+           torch.randn(16, 16, KS, generator=g) / (16 * KS) ** 0.5, torch.randn(16, generator=g) * 0.2) for _ in dils]
+    xd = x.to(dev)
+    packs = [(S.pack_conv1d_weight(w1.to(dev)), b1.to(dev), S.pack_conv1d_weight(w2.to(dev)), b2.to(dev)) for w1, b1, w2, b2 in ws]
+    # three pair launches, the last with the accumulate / divide epilogue
+    cur = xd
+    for j, (w1p, b1, w2p, b2) in enumerate(packs[:-1]):
+        cur = S.resblock_pair(cur, w1p, b1, w2p, b2, KS, dils[j])
+    ref = old.to(dev).clone()
+    S.resblock_pair(cur, *packs[-1], KS, dils[-1], out=ref, beta=1.0, out_div=3.0)
+    one = old.to(dev).clone()
+    got = S.resblock16(xd, packs, KS, dils, out=one, beta=1.0, out_div=3.0)
+    assert got is one
+    torch.cuda.synchronize()
+    assert torch.equal(one, ref)
+    plain = S.resblock16(xd, packs, KS, dils)
+    y = x.double()
+    for (w1, b1, w2, b2), d in zip(ws, dils):
+        t = F.conv1d(F.leaky_relu(y, 0.1), w1.double(), b1.double(), dilation=d, padding=d * (KS - 1) // 2)
+        y = F.conv1d(F.leaky_relu(t, 0.1), w2.double(), b2.double(), padding=(KS - 1) // 2) + y
+    err = (plain.cpu().double() - y).abs().max().item() / y.abs().max().item()
+    assert err < 2e-6, err
+    assert S.resblock16(xd, packs, KS, (1, 2, 4)) is None          # other dilation sets keep the pair launches
