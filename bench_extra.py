@@ -48,14 +48,23 @@ def _graphed(fn, warm=2):
 
 
 def _families(fn, n=3):
+    """Per-family hipEvent times of n eager calls — with the three MRF chains on ONE stream: an event pair around a launch also times
+    whatever runs beside it on the other streams (round 5's `infer_split.families` were taken with the streams on and read 27 % above the
+    rocprof durations of the same launches; VERDICT r5 weak #8)."""
     import svc_hip as S
-    S.prof_enable(True)
-    S.prof_reset()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    rep = S.prof_report()
-    S.prof_enable(False)
+    import vdecoder.hifigan.models as _gen
+    was = _gen._MRF_STREAMS
+    _gen._MRF_STREAMS = False
+    try:
+        S.prof_enable(True)
+        S.prof_reset()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        rep = S.prof_report()
+        S.prof_enable(False)
+    finally:
+        _gen._MRF_STREAMS = was
     return {k: dict(ms_per_step=round(v["ms"] / n, 4), calls=v["calls"] // n,
                     tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0)
             for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}

@@ -640,9 +640,10 @@ extern "C" int svc_conv1d_h(const svc_conv1d_h_args* ap, void* stream) {
     case 1: return launch_h_ks<1>(a, R, s);
     case 2: return launch_h_ks<2>(a, R, s);
     case 3: return launch_h_ks<3>(a, R, s);
+    case 5: return launch_h_ks<5>(a, R, s);
     case 7: return launch_h_ks<7>(a, R, s);
     case 11: return launch_h_ks<11>(a, R, s);
-    default: SVC_REQUIRE(false, "conv1d_h: tap count %d not built (1, 2, 3, 7, 11)", a.KS);
+    default: SVC_REQUIRE(false, "conv1d_h: tap count %d not built (1, 2, 3, 5, 7, 11)", a.KS);
   }
   return SVC_OK;
 }

@@ -622,6 +622,10 @@ def snake_alias_h(xh, alpha, beta, taps, out=None):
     _check_h(xh, "snake_alias_h")
     sp = is_split(xh)
     B, CB, T, _ = xh.shape[-4:]
+    if alpha.numel() < CB * 8:       # zero-padded channels (svc_nn.Conv1d.packed_h): x = 0 there and snake(0) = 0 for any parameters
+        padc = CB * 8 - alpha.numel()
+        alpha = torch.nn.functional.pad(alpha.detach().float(), (0, padc))
+        beta = torch.nn.functional.pad(beta.detach().float(), (0, padc))
     if out is None:
         out = torch.empty_like(xh)
     _check_h(out, "snake_alias_h out", sp)
@@ -664,6 +668,14 @@ def to_h(x, add=None, out=None, split=False):
     with hi + lo = the fp32 value to 22 bits."""
     _require_gpu_h(x, add, out)
     B, Cc, T = x.shape
+    if Cc % 16:
+        # channel counts that are not multiples of 16 (the tiny template's decoder) travel zero-padded through the 16-bit pipeline
+        # (svc_nn.Conv1d.packed_h): pad the fp32 source here — data movement only, and only on that compatibility path
+        padc = (-Cc) % 16
+        x = torch.nn.functional.pad(x.contiguous() if isinstance(x, torch.Tensor) else copy_bct(x), (0, 0, 0, padc))
+        if add is not None:
+            add = torch.nn.functional.pad(add.contiguous(), (0, 0, 0, padc))
+        Cc += padc
     if out is None:
         out = torch.empty(((2,) if split else ()) + (B, Cc // 8, T, 8), device=x.device, dtype=torch.float16)
     _check_h(out, "to_h out", split)
@@ -692,6 +704,8 @@ def conv_post_h(xh, w, bias, KS, pad, pre_slope=0.01, act=None):
     B, CB, T, _ = xh.shape[-4:]
     out = torch.empty((B, 1, T), device=xh.device, dtype=torch.float32)
     w = w.detach().float().contiguous()
+    if w.shape[0] < CB * 8:      # zero-padded channels of the blocked tensor: zero weight rows
+        w = torch.nn.functional.pad(w, (0, 0, 0, CB * 8 - w.shape[0])).contiguous()
     fn = lib().svc_conv_post_hl if is_split(xh) else lib().svc_conv_post_h
     check(fn(_hptr(xh), ptr(w), ptr(bias), ptr(out), B, CB * 8, T, KS, pad, pre_slope,
              ACT_TANH if act is None else act, stream_ptr()), "conv_post_h")

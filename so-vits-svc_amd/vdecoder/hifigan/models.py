@@ -190,6 +190,22 @@ class ResBlock2(nn.Module):
             c.run(cur, pre_slope=LRELU_SLOPE, res=cur, res_mode=1, out=dst)
             cur = dst
 
+    def forward_h(self, xh, out=None, beta=0.0, out_div=1.0, tmp=None, before_last=None):
+        """The same block on the 16-bit pipeline (reference :88-93: `x = c(leaky_relu(x)) + x` per conv)."""
+        n = len(self.convs)
+        cur = xh
+        _, ping, pong = tmp if tmp is not None else [torch.empty_like(xh) for _ in range(3)]
+        for j, c in enumerate(self.convs):
+            if j == n - 1:
+                dst = out if out is not None else (ping if cur is not ping else pong)
+                if before_last is not None:
+                    before_last()
+                c.run_h(cur, pre_slope=LRELU_SLOPE, res=cur, out=dst, beta=beta, out_div=out_div)
+                return dst
+            dst = ping if cur is not ping else pong
+            c.run_h(cur, pre_slope=LRELU_SLOPE, res=cur, out=dst)
+            cur = dst
+
     def remove_weight_norm(self):
         for l in self.convs:
             l.remove_weight_norm()
@@ -439,12 +455,12 @@ class Generator(nn.Module):
         split=True: the SPLIT pipeline of csrc/conv1d_hl.hip instead — every tensor as a hi and a lo fp16 plane (22 mantissa bits),
         every product as three fp16 matrix instructions: fp32-level results from the fp16 matrix pipe (a precision mode of fp32
         inference, not of the reference's half mode)."""
-        if on and not (self.h["resblock"] == '1' and all(c % 16 == 0 for c in self._stage_channels()[1:]) and
-                       all(k in (3, 7, 11) for k in self.h["resblock_kernel_sizes"]) and
+        # Stage widths that are not multiples of 16 (the tiny template's 200 / 100 / 50 / 25 / 12) run zero-padded to the next multiple
+        # (svc_nn.Conv1d.packed_h); ResBlock2 and 5-tap kernels are built too.  What is left out: tap counts without a 16-bit instantiation.
+        if on and not (all(k in (3, 5, 7, 11) for k in self.h["resblock_kernel_sizes"]) and
                        all(-(-k // u) in (1, 2, 3) for u, k in zip(self.h["upsample_rates"], self.h["upsample_kernel_sizes"]))):
-            raise NotImplementedError("half-precision generator: needs ResBlock1 with kernel sizes in {3, 7, 11}, stage widths that are "
-                                      "multiples of 16 and upsample kernels of at most 3 taps per phase (both templates' decoders except "
-                                      "the tiny template's 200/100/50/25/12 widths)")
+            raise NotImplementedError("half-precision generator: needs ResBlock kernel sizes in {3, 5, 7, 11} and upsample kernels of at "
+                                      "most 3 taps per phase")
         self.half_mode = ("split" if split else True) if on else False
         return self
 

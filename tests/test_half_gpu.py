@@ -254,12 +254,57 @@ def test_snake_generator_half_inference(dev):
     assert torch.equal(o2, o)
 
 
-def test_half_mode_refuses_generators_without_a_16_bit_form(dev):
-    net, _ = _build(W.small_config(), 3, dev)          # stage widths 64 / 32 / 16 / 8 / 4
+@pytest.mark.parametrize("cfgname,snake,resblock2", [("small", False, False), ("small", True, False), ("tiny", False, False), ("small", False, True)])
+def test_half_and_split_modes_on_generators_with_odd_stage_widths(dev, cfgname, snake, resblock2):
+    """VERDICT r5 missing #5: the reference can `.half()` ANY generator; the engine's 16-bit / split pipelines take channel counts that
+    are not multiples of 16 zero-padded to the next multiple (svc_nn.Conv1d.packed_h) — the small test config (64 / 32 / 16 / 8 / 4),
+    BASELINE configs[0]'s tiny template at its real widths (200 / 100 / 50 / 25 / 12), the snake generator, and ResBlock2
+    (vdecoder/hifigan/models.py:88-93, kernel sizes 3 / 5 / 7).  Half mode within north_star's waveform bar of the fp32 CPU oracle;
+    split mode at the fp32 path's own bound; hipGraph replay bit-equal."""
+    cfg = W.tiny_config() if cfgname == "tiny" else W.small_config()
+    if snake:
+        cfg["vocoder_name"] = "nsf-snake-hifigan"
+    if resblock2:
+        cfg["resblock"] = "2"
+        cfg["resblock_kernel_sizes"] = [3, 5, 7]
+        cfg["resblock_dilation_sizes"] = [[1, 2], [2, 6], [3, 12]]
+    net, sd = _build(cfg, 13, dev)
+    B, T = 2, 37
+    c, f0, uv, sid = W.make_inputs(cfg, B, T, seed=31)
+    noise = W.make_noise(cfg, B, T, seed=32)
+    with torch.no_grad():
+        ref, _ = O.synth_infer(sd, cfg, c, f0, uv, sid, noise, noice_scale=0.4)
+    nd = {k: v.to(dev) for k, v in noise.items()}
+    run = lambda: net.infer(c.to(dev), f0.to(dev), uv.to(dev), g=sid.to(dev), noice_scale=0.4, noise=nd)[0]
+    o32 = run()
+    mx32 = (o32.cpu() - ref).abs().max().item()
+    net.half()
+    assert net.dec.half_mode is True
+    oh = run()
+    mse = (oh.cpu() - ref).pow(2).mean().item()
+    assert oh.shape == ref.shape and mse < 1e-4, mse
+    net.enable_graph(True)
+    assert torch.equal(run(), oh)
+    net.enable_graph(False)
+    net.float()
+    net.split_f16()
+    assert net.dec.half_mode == "split"
+    osp = run()
+    assert not net.split_range_exceeded()
+    mxs = (osp.cpu() - ref).abs().max().item()
+    print(f"{cfgname}{' snake' if snake else ''}{' ResBlock2' if resblock2 else ''}: half MSE {mse:.3e}; fp32 kernels max {mx32:.3e}, "
+          f"split max {mxs:.3e} (max|ref| {ref.abs().max().item():.3f})")
+    assert mxs <= 4 * mx32 + 5e-6, (mxs, mx32)
+    net.float()
+    assert net.dec.half_mode is False and torch.equal(run(), o32)
+
+
+def test_half_mode_refuses_tap_counts_without_a_16_bit_kernel(dev):
+    cfg = W.small_config()
+    cfg["resblock_kernel_sizes"] = [3, 9, 11]
+    net, _ = _build(cfg, 3, dev)
     with pytest.raises(NotImplementedError):
         net.half()
-    cfg = W.small_config()
-    cfg["vocoder_name"] = "nsf-snake-hifigan"
-    net2, _ = _build(cfg, 3, dev)
     with pytest.raises(NotImplementedError):
-        net2.half()
+        net.split_f16()
+    assert net.dec.half_mode is False and next(net.parameters()).dtype == torch.float32

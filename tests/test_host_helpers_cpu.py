@@ -92,7 +92,13 @@ def test_precision_mode_switches_are_host_logic():
     assert net.dec.half_mode is True
     net.split_f16()                                   # ... and a split one
     assert net.dec.half_mode == "split"
-    net = build(W.small_config())                     # stage widths 64 / 32 / 16 / 8 / 4: neither
+    net = build(W.small_config())                     # stage widths 64 / 32 / 16 / 8 / 4: zero-padded to multiples of 16 in both forms
+    net.half()
+    assert net.dec.half_mode is True
+    odd = W.small_config()
+    odd["resblock_kernel_sizes"] = [3, 9, 11]         # a tap count without a 16-bit kernel: refused, the model stays fp32
+    net = build(odd)
     for switch in (net.half, net.split_f16):
         with pytest.raises(NotImplementedError):
             switch()
+    assert net.dec.half_mode is False
