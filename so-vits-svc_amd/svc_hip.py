@@ -663,12 +663,12 @@ def conv_transpose1d_h(x, wp, Cout, K, stride, padding, *, bias=None, pre_slope=
     return out
 
 
-def to_h(x, add=None, out=None, split=False):
+def to_h(x, add=None, out=None, split=False, pad16=False):
     """fp32 [B, C, T] (time-contiguous view) (+ add) -> blocked fp16 [B, C/8, T, 8]; split: -> [2, B, C/8, T, 8], hi and lo planes
     with hi + lo = the fp32 value to 22 bits."""
     _require_gpu_h(x, add, out)
     B, Cc, T = x.shape
-    if Cc % 16:
+    if pad16 and Cc % 16:
         # channel counts that are not multiples of 16 (the tiny template's decoder) travel zero-padded through the 16-bit pipeline
         # (svc_nn.Conv1d.packed_h): pad the fp32 source here — data movement only, and only on that compatibility path
         padc = (-Cc) % 16

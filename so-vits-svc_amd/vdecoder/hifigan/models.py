@@ -134,7 +134,7 @@ class ResBlock1(nn.Module):
                 dst = (out if out is not None else (ping if cur is not ping else pong)) if lastp else (ping if cur is not ping else pong)
                 if lastp and before_last is not None:
                     before_last()
-                S.resblock_pair_h(cur, c1.packed_h(sp), c1.bias, c2.packed_h(sp), c2.bias, c1.dilation, slope=LRELU_SLOPE, out=dst,
+                S.resblock_pair_h(cur, c1.packed_h(sp), c1.bias_h(), c2.packed_h(sp), c2.bias_h(), c1.dilation, slope=LRELU_SLOPE, out=dst,
                                   beta=beta if lastp else 0.0, out_div=out_div if lastp else 1.0)
                 cur = dst
             return cur
@@ -446,6 +446,8 @@ class Generator(nn.Module):
         return self.conv_post.run(x, pre_slope=0.01, post_act=S.ACT_TANH)
 
     # -- half-precision inference: the reference's `net_g_ms.half()` (inference/infer_tool.py:196-198) -----------------------
+    half_mode = False
+
     def set_half(self, on=True, split=False):
         """Run the generator's convolution stack as the 16-bit pipeline of csrc/conv1d_h.hip: fp16 activations (HBM and LDS) and
         fp16 weights from the first MRF stage on, fp32 accumulation.  What stays fp32, and why: the harmonic source (its phase
@@ -516,9 +518,9 @@ class Generator(nn.Module):
                 xs = source[0][i] if source is not None else self.noise_convs[i](har)     # fp32 [B, C_i, L_i] (:379)
                 if i == 0:
                     x = self.ups[0].run(x, pre_slope=LRELU_SLOPE, res=xs)                 # fp32: lrelu + ConvT + add (:377-381)
-                    xh = S.to_h(x, split=sp)
+                    xh = S.to_h(x, split=sp, pad16=True)
                 else:
-                    xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs, split=sp))
+                    xh = self.ups[i].run_h(xh, pre_slope=LRELU_SLOPE, res=S.to_h(xs, split=sp, pad16=True))
                 xh = mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), half=True)
             cp = self.conv_post
             return S.conv_post_h(xh, cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias, cp.kernel_size, cp.padding,

@@ -184,9 +184,9 @@ class Generator(base.Generator):
             for i in range(self.num_upsamples):
                 xs = source[0][i] if source is not None else self.noise_convs[i](har)
                 if i == 0:
-                    xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs), split=sp)
+                    xh = S.to_h(self.ups[0].run(self.snakes[0](x), res=xs), split=sp, pad16=True)
                 else:
-                    xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs, split=sp))
+                    xh = self.ups[i].run_h(self.snakes[i].run_h(xh), res=S.to_h(xs, split=sp, pad16=True))
                 xh = base.mrf_stage(self, [self.resblocks[i * nk + j] for j in range(nk)], xh, torch.empty_like(xh), n_tmp=4, half=True)
             cp = self.conv_post
             return S.conv_post_h(self.snake_post.run_h(xh), cp.dense_weight().reshape(cp.in_channels, cp.kernel_size), cp.bias,
