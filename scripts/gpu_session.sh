@@ -6,7 +6,7 @@
 #   pairbench   bench_pair.py (fused ResBlock pair vs two launches)   gemmbench  bench_train_kernels.py gemm
 #   inferab     bench.py --mode infer under SVC_CONV_STRIP x SVC_MRF_STREAMS
 #   bench       the driver's default bench.py line          prof       rocprofv3 kernel-trace stats of the infer step (serialised)
-#   profsplit   the same for the split pipeline (bench.py --mode infer --split)
+#   profsplit   the same for the split pipeline (bench.py --mode infer --split)      profhalf  ... for the half mode (--half)
 #   trainprof   rocprofv3 kernel-trace stats of the training step (trainprof_bf16: the bf16 mode)  pmc  FETCH_SIZE / WRITE_SIZE passes of the infer step
 set -x
 cd $GRAFT_REPO_ROOT
@@ -27,6 +27,8 @@ prof) rm -rf gpurun_out/prof_stats; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --ke
       DB=$(find gpurun_out/prof_stats -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_infer_T862_kernel_stats_serialised.txt 2>&1; head -40 ${O}_infer_T862_kernel_stats_serialised.txt ;;
 profsplit) rm -rf gpurun_out/prof_split; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_split -o run -- python bench.py --mode infer --split --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline --no-extras --no-host-io --no-steady --no-pmc > ${O}_profsplit_bench.json 2> ${O}_profsplit_bench.err
       DB=$(find gpurun_out/prof_split -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_infer_split_T862_kernel_stats_serialised.txt 2>&1; head -30 ${O}_infer_split_T862_kernel_stats_serialised.txt; rm -rf gpurun_out/prof_split ;;
+profhalf) rm -rf gpurun_out/prof_half; SVC_MRF_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_half -o run -- python bench.py --mode infer --half --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-roofline --no-extras --no-host-io --no-steady --no-pmc > ${O}_profhalf_bench.json 2> ${O}_profhalf_bench.err
+      DB=$(find gpurun_out/prof_half -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_infer_half_T862_kernel_stats_serialised.txt 2>&1; head -30 ${O}_infer_half_T862_kernel_stats_serialised.txt; rm -rf gpurun_out/prof_half ;;
 trainprof_bf16) rm -rf gpurun_out/prof_train16; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train16 -o run -- python bench.py --mode train --bf16 --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-extras > ${O}_trainprof_bf16_bench.json 2> ${O}_trainprof_bf16_bench.err
       DB=$(find gpurun_out/prof_train16 -name '*.db' | head -1); python scripts/prof_summary.py $DB > ${O}_train_bf16_B16_kernel_stats.txt 2>&1; head -40 ${O}_train_bf16_B16_kernel_stats.txt ;;
 trainprof) rm -rf gpurun_out/prof_train; timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o run -- python bench.py --mode train --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-extras > ${O}_trainprof_bench.json 2> ${O}_trainprof_bench.err
