@@ -133,13 +133,6 @@ typedef struct svc_conv1d_args {
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
 
-/* n (1..16) INDEPENDENT convolutions — no output of one is an input, residual or output of another — with the same results as
- * n calls of svc_conv1d_f32 in any order.  The three ResBlock chains of an MRF stage (vdecoder/hifigan/models.py:382-388:
- * `xs += self.resblocks[i*num_kernels+j](x)`, kernel sizes 11 / 7 / 3) advance in lockstep, so the same step of the three
- * chains is such a group: members that run on the strip kernel or on the 64 x 128 LDS-DMA tiling with 11, 7 and 3 taps are
- * issued as ONE launch (heaviest workgroups first), the others one by one. */
-int svc_conv1d_multi_f32(const svc_conv1d_args* a, int n, void* stream);
-int svc_debug_conv_multi_merged(void);   /* merged launches of the tiled kernel so far (tests) */
 int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */
 int svc_debug_wgrad_bf16_launches(void);
 
@@ -188,8 +181,8 @@ int svc_conv1d_direct_f32(const svc_conv1d_direct_args* a, void* stream);
  * One ResBlock1 pair of the NARROW decoder stages in one launch (vdecoder/hifigan/models.py:60-67, one iteration of the
  * loop over dilations):   y = conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2 + x
  * conv1 = Conv1d(C, C, KS, dilation dil1, padding dil1*(KS-1)/2), conv2 = Conv1d(C, C, KS, dilation 1, padding (KS-1)/2),
- * lrelu slope `slope` (0.1).  Built for C in {16, 32} (the last two upsample stages, HBM-bound as separate launches) and
- * KS in {3, 7, 11}; wider stages use svc_conv1d_f32.  x, y: [B, C, T] views (time contiguous, x != y); w1, w2: packed
+ * lrelu slope `slope` (0.1).  Built for C = 16 (the last upsample stage, HBM-bound as separate launches), KS in {3, 7, 11} and
+ * dilations whose tile (240 + 2 (dil1 + 1)(KS - 1)/2 columns) stays within 512 — SVC_ERR_UNSUPPORTED beyond; wider stages use svc_conv1d_f32.  x, y: [B, C, T] views (time contiguous, x != y); w1, w2: packed
  * [C][KS][CP] weights (svc_pack_conv1d_weight); b1, b2: [C] or NULL.  Epilogue options of the MRF sum: y = (pair(x) +
  * beta * y_old) / out_div.  Results are bit-identical to the two svc_conv1d_f32 launches it replaces.
  * ---------------------------------------------------------------------------------------------- */

@@ -21,7 +21,7 @@ def timeit(fn):
 
 
 tot = [0.0, 0.0]
-for C, T in ((32, 220672), (16, 441344)):
+for C, T in ((16, 441344),):
     for K in (3, 7, 11):
         for d in (1, 3, 5):
             x = torch.randn(1, C, T, device=dev)

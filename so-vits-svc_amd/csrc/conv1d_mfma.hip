@@ -966,33 +966,6 @@ __global__ __launch_bounds__(WM* WN* WK * 64, (WM * WN * WK <= 4 && NT != 7 && (
   conv1d_mfma_body<MT, NT, WM, WN, WK, M16, EPI, KSC, XVEC, DB, MMA>(p, blockIdx.x);
 }
 
-// Up to three INDEPENDENT plain convolutions on the 64 x 128 LDS-DMA tiling in ONE launch: the same step of the 11- / 7- / 3-tap
-// ResBlock chains of the decoder's 256-channel stage (see conv1d_strip3_kernel for the reasoning).  One convolution of that
-// stage is 216 workgroups — 0.84 per CU, 1.7 MFMA tiles per SIMD — three together are 648 on 512 resident slots, heaviest
-// first: the chip is full until the short 3-tap workgroups drain.
-struct ConvP3 {
-  ConvP p[3];
-  int n0, n1;
-};
-__global__ __launch_bounds__(256, 2) void conv1d_mfma3_kernel(ConvP3 q) {
-  const int bid = blockIdx.x;
-  if (bid < q.n0) conv1d_mfma_body<2, 1, 1, 4, 1, false, SVC_EPI_PLAIN, 11, true, true>(q.p[0], bid);
-  else if (bid < q.n1) conv1d_mfma_body<2, 1, 1, 4, 1, false, SVC_EPI_PLAIN, 7, true, true>(q.p[1], bid - q.n0);
-  else conv1d_mfma_body<2, 1, 1, 4, 1, false, SVC_EPI_PLAIN, 3, true, true>(q.p[2], bid - q.n1);
-}
-
-// svc_conv1d_multi_f32: launches of that tiling are recorded while a recorder is installed, then flushed merged / singly
-struct TileRec {
-  ConvP p;
-  unsigned nblk;
-  size_t lds;
-  int ks;
-  int (*single)(const TileRec&, hipStream_t);
-};
-thread_local std::vector<TileRec>* t_tile_rec = nullptr;
-int g_tile_merged = 0;
-
-thread_local int t_multi_depth = 0;
 int g_bf16_enabled = 1;    // svc_debug_bf16(0) forces fp32 operands whatever the calls ask for (A/B)
 int g_bf16_launches = 0;   // launches that ran with bf16 operands (tests ask through svc_debug_bf16(-1))
 int g_force_cfg = -1;  // debug/tuning override (svc_debug_set_conv_cfg)
@@ -1160,18 +1133,6 @@ int launch_cfg(const svc_conv1d_args& a, hipStream_t s) {
         if (!done) {
           hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           done = true;
-        }
-      }
-      if constexpr (MT == 2 && NT == 1 && WM == 1 && WN == 4 && WK == 1 && EPI == SVC_EPI_PLAIN && (KSC == 3 || KSC == 7 || KSC == 11)) {
-        if (t_tile_rec && p.row_phases == 1 && a.n_phase == 1) {
-          TileRec r;
-          r.p = p; r.nblk = (unsigned)nblk; r.lds = lds; r.ks = KSC;
-          r.single = [](const TileRec& q, hipStream_t st) {
-            hipLaunchKernelGGL((conv1d_mfma_kernel<MT, NT, WM, WN, WK, M16, EPI, KSC, true, true>), dim3(q.nblk), dim3(NTHR), q.lds, st, q.p);
-            return svc::check_launch("conv1d_mfma_db");
-          };
-          t_tile_rec->push_back(r);
-          return SVC_OK;
         }
       }
       hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(NTHR), lds, s, p);
@@ -1411,8 +1372,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
              a.Cin, a.Cout, a.KS, a.dil, a.Tout, a.epi);
   else
     snprintf(pname, sizeof(pname), "%s", (a.n_phase > 1 || t_row_phases > 1) ? "convt1d_mfma" : "conv1d_mfma");
-  // inside svc_conv1d_multi_f32 the group has ONE profile scope (recorded launches are issued after this function returns)
-  svc::ProfScope prof(s, pname, t_multi_depth ? 0.0 : flop, t_multi_depth ? 0.0 : bytes, t_multi_depth == 0);
+  svc::ProfScope prof(s, pname, flop, bytes);
 
   if (g_no192 < 0) {
     const char* e = getenv("SVC_CONV_NO192");
@@ -1561,78 +1521,6 @@ extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {
   SVC_REQUIRE(ap != nullptr, "conv1d: null args");
   return conv1d_dispatch(*ap, stream);
 }
-
-namespace svc {
-void conv1d_strip_multi_begin(void** token);
-int conv1d_strip_multi_flush(void* token, hipStream_t s);
-}
-
-static int tile_multi_flush(std::vector<TileRec>& v, hipStream_t s) {
-  t_tile_rec = nullptr;
-  const TileRec* slot[3] = {nullptr, nullptr, nullptr};
-  std::vector<const TileRec*> rest;
-  for (const TileRec& r : v) {
-    const int k = r.ks == 11 ? 0 : (r.ks == 7 ? 1 : 2);
-    if (slot[k]) rest.push_back(&r);
-    else slot[k] = &r;
-  }
-  const int n_slots = (slot[0] != nullptr) + (slot[1] != nullptr) + (slot[2] != nullptr);
-  int rc = SVC_OK;
-  if (n_slots >= 2) {
-    ConvP3 q;
-    memset(&q, 0, sizeof(q));
-    size_t lds = 0;
-    unsigned n = 0;
-    for (int k = 0; k < 3; ++k) {
-      if (slot[k]) { q.p[k] = slot[k]->p; n += slot[k]->nblk; lds = std::max(lds, slot[k]->lds); }
-      if (k == 0) q.n0 = (int)n;
-      if (k == 1) q.n1 = (int)n;
-    }
-    static bool done = false;
-    if (!done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_mfma3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
-    }
-    hipLaunchKernelGGL(conv1d_mfma3_kernel, dim3(n), dim3(256), lds, s, q);
-    ++g_tile_merged;
-    rc = svc::check_launch("conv1d_mfma3");
-  } else {
-    for (int k = 0; k < 3; ++k)
-      if (slot[k]) rest.push_back(slot[k]);
-  }
-  for (const TileRec* r : rest)
-    if (rc == SVC_OK) rc = r->single(*r, s);
-  return rc;
-}
-
-// n INDEPENDENT convolutions (no output of one is an input, residual or output of another): the same results as n calls of
-// svc_conv1d_f32 in any order; those that run on the strip kernel or on the 64 x 128 LDS-DMA tiling with 11 / 7 / 3 taps share
-// launches (conv1d_strip3_kernel, conv1d_mfma3_kernel), the others are issued one by one.
-extern "C" int svc_conv1d_multi_f32(const svc_conv1d_args* ap, int n, void* stream) {
-  SVC_REQUIRE(ap != nullptr && n >= 1 && n <= 16, "conv1d_multi: 1..16 convolutions");
-  hipStream_t s = (hipStream_t)stream;
-  if (n == 1) return conv1d_dispatch(ap[0], stream);
-  double flop = 0.0, bytes = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const svc_conv1d_args& a = ap[i];
-    flop += 2.0 * a.B * (double)a.Cout * a.Cin * a.KS * a.Tout * a.n_phase;
-    bytes += 4.0 * a.B * ((double)a.Cin * a.Tin + (double)a.Cout * a.Tout) + 4.0 * a.Cin * a.KS * a.Cout;
-  }
-  svc::ProfScope prof(s, "conv1d_mfma", flop, bytes);     // one profile row entry for the whole group (see t_multi_depth)
-  void* tok = nullptr;
-  svc::conv1d_strip_multi_begin(&tok);
-  std::vector<TileRec> tiles;
-  t_tile_rec = &tiles;
-  ++t_multi_depth;
-  int rc = SVC_OK;
-  for (int i = 0; i < n && rc == SVC_OK; ++i) rc = conv1d_dispatch(ap[i], stream);
-  --t_multi_depth;
-  const int rs = svc::conv1d_strip_multi_flush(tok, s);
-  const int rt = tile_multi_flush(tiles, s);
-  return rc != SVC_OK ? rc : (rs != SVC_OK ? rs : rt);
-}
-
-extern "C" int svc_debug_conv_multi_merged(void) { return g_tile_merged; }
 
 extern "C" int svc_debug_bf16(int mode) {
   if (mode < 0) return g_bf16_launches;

@@ -401,42 +401,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void conv1d_strip_kernel(StripP p) 
   conv1d_strip_body<TS, WM, WN, NT, KSC, PREACT, HAS_RES, WPS, SPLITK>(p, blockIdx.x);
 }
 
-// Up to three INDEPENDENT convolutions of one strip arrangement in ONE launch — the same step of the k = 11 / 7 / 3 ResBlock
-// chains of an MRF stage (vdecoder/hifigan/models.py:382-388: the chains only meet in the stage mean).  Workgroups
-// [0, n0) run conv 0 (11 taps), [n0, n1) conv 1 (7 taps), the rest conv 2 (3 taps): heaviest first, so the short workgroups
-// fill the tail.  Why: every workgroup of a single launch is in the same phase at the same time (first chunk from HBM,
-// MFMA loop, store burst) and ~14 us of each launch are such phases (profiles/r03j_strip_decomp.txt); three launches
-// on three streams overlap them only as far as the dispatcher interleaves the streams.  Inside one launch a CU that finishes
-// an 11-tap strip starts a 7-tap one while its neighbours are still in their loops: the phases of 741 workgroups spread out.
-struct StripP3 {
-  StripP p[3];
-  int n0, n1;
-};
-template <int WM, int WN, bool PREACT, bool HAS_RES>
-__global__ __launch_bounds__(512, 2) void conv1d_strip3_kernel(StripP3 q) {
-  const int bid = blockIdx.x;
-  if (bid < q.n0) conv1d_strip_body<32, WM, WN, 7, 11, PREACT, HAS_RES, 2>(q.p[0], bid);
-  else if (bid < q.n1) conv1d_strip_body<32, WM, WN, 7, 7, PREACT, HAS_RES, 2>(q.p[1], bid - q.n0);
-  else conv1d_strip_body<32, WM, WN, 7, 3, PREACT, HAS_RES, 2>(q.p[2], bid - q.n1);
-}
-
 int g_strip_mode = 1;   // 0: off, 1: auto (svc_debug_set_conv_strip)
 int g_strip_dbg = 0;        // StripP.dbg (svc_debug_set_conv_strip(1000 * dbg + mode))
 int g_strip_launches = 0;   // launches that took this kernel (tests ask through svc_debug_set_conv_strip(-1))
 
 struct StripCfg { int TS, WM, WN; };
-
-// svc_conv1d_multi_f32: launches of the two-waves-per-SIMD 32x32 form are RECORDED instead of issued while a recorder is
-// installed; conv1d_strip_multi_flush() then issues them merged (conv1d_strip3_kernel) or one by one.
-struct StripRec {
-  StripP p;
-  unsigned nblk;
-  size_t lds;
-  int ks, wm, wn;
-  bool pre, res;
-  int (*single)(const StripRec&, hipStream_t);
-};
-thread_local std::vector<StripRec>* t_strip_rec = nullptr;
 
 template <int TS, int WM, int WN, int KSC, bool PREACT, bool HAS_RES, int WPS, bool SPLITK = false>
 int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
@@ -475,54 +444,9 @@ int strip_launch(const svc_conv1d_args& a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  if constexpr (TS == 32 && WPS == 2 && !SPLITK) {
-    if (t_strip_rec) {
-      StripRec r;
-      r.p = p; r.nblk = (unsigned)nblk; r.lds = lds; r.ks = KSC; r.wm = WM; r.wn = WN; r.pre = PREACT; r.res = HAS_RES;
-      r.single = [](const StripRec& q, hipStream_t st) {
-        hipLaunchKernelGGL((conv1d_strip_kernel<TS, WM, WN, NT, KSC, PREACT, HAS_RES, WPS, SPLITK>), dim3(q.nblk), dim3(256 * WPS), q.lds, st, q.p);
-        ++g_strip_launches;
-        return svc::check_launch("conv1d_strip");
-      };
-      t_strip_rec->push_back(r);
-      return SVC_OK;
-    }
-  }
   hipLaunchKernelGGL(kd, dim3((unsigned)nblk), dim3(256 * WPS), lds, s, p);
   ++g_strip_launches;
   return svc::check_launch("conv1d_strip");
-}
-
-int g_strip_merged = 0;     // merged launches issued (tests ask through svc_debug_set_conv_strip(-2))
-
-template <int WM, int WN, bool PREACT, bool HAS_RES>
-int strip3_launch(const StripRec* r11, const StripRec* r7, const StripRec* r3, hipStream_t s) {
-  StripP3 q;
-  memset(&q, 0, sizeof(q));
-  size_t lds = 0;
-  unsigned n = 0;
-  if (r11) { q.p[0] = r11->p; n += r11->nblk; lds = std::max(lds, r11->lds); }
-  q.n0 = (int)n;
-  if (r7) { q.p[1] = r7->p; n += r7->nblk; lds = std::max(lds, r7->lds); }
-  q.n1 = (int)n;
-  if (r3) { q.p[2] = r3->p; n += r3->nblk; lds = std::max(lds, r3->lds); }
-  auto kd = conv1d_strip3_kernel<WM, WN, PREACT, HAS_RES>;
-  static bool done = false;
-  if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
-  hipLaunchKernelGGL(kd, dim3(n), dim3(512), lds, s, q);
-  ++g_strip_merged;
-  g_strip_launches += (r11 != nullptr) + (r7 != nullptr) + (r3 != nullptr);
-  return svc::check_launch("conv1d_strip3");
-}
-
-template <int WM, int WN>
-int strip3_launch_flags(bool pre, bool res, const StripRec* a, const StripRec* b, const StripRec* c, hipStream_t s) {
-  if (pre && !res) return strip3_launch<WM, WN, true, false>(a, b, c, s);
-  if (!pre && res) return strip3_launch<WM, WN, false, true>(a, b, c, s);
-  return 1;      // ResBlock2's form (pre && res) is not merged
 }
 
 template <int TS, int WM, int WN, int KSC, int WPS>
@@ -573,7 +497,6 @@ int strip_launch_ks(const svc_conv1d_args& a, hipStream_t s, int wps) {
 }  // namespace
 
 extern "C" int svc_debug_set_conv_strip(int mode) {
-  if (mode == -2) return g_strip_merged;
   if (mode < 0) return g_strip_launches;
 #ifdef SVC_TIMING_DEBUG
   g_strip_dbg = mode / 1000;      // timing experiments only (garbage results): see StripP.dbg
@@ -626,51 +549,6 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
     case 4: return strip_launch_splitk(a, s);
     default: return strip_launch_ks<16, 4, 1>(a, s, wps);
   }
-}
-
-// ---- svc_conv1d_multi_f32 support: record strip launches, then flush them merged ------------------------------------------
-void conv1d_strip_multi_begin(void** token) {
-  auto* v = new std::vector<StripRec>();
-  *token = v;
-  t_strip_rec = v;
-}
-
-// Issues what was recorded since conv1d_strip_multi_begin: records of one arrangement and activation form with DISTINCT tap
-// counts out of {11, 7, 3} — at least two of them — go out as ONE conv1d_strip3_kernel launch, everything else one by one.
-int conv1d_strip_multi_flush(void* token, hipStream_t s) {
-  std::vector<StripRec>* v = static_cast<std::vector<StripRec>*>(token);
-  t_strip_rec = nullptr;
-  int rc = SVC_OK;
-  std::vector<bool> used(v->size(), false);
-  for (size_t i = 0; i < v->size() && rc == SVC_OK; ++i) {
-    if (used[i]) continue;
-    const StripRec& r = (*v)[i];
-    const StripRec* slot[3] = {nullptr, nullptr, nullptr};   // 11, 7, 3 taps
-    std::vector<size_t> members;
-    for (size_t j = i; j < v->size(); ++j) {
-      const StripRec& o = (*v)[j];
-      if (used[j] || o.wm != r.wm || o.wn != r.wn || o.pre != r.pre || o.res != r.res) continue;
-      const int k = o.ks == 11 ? 0 : (o.ks == 7 ? 1 : 2);
-      if (slot[k]) continue;
-      slot[k] = &o;
-      members.push_back(j);
-    }
-    int merged = 1;
-    if (members.size() >= 2 && !(r.pre && r.res)) {
-      if (r.wm == 4) merged = strip3_launch_flags<4, 1>(r.pre, r.res, slot[0], slot[1], slot[2], s);
-      else if (r.wm == 2) merged = strip3_launch_flags<2, 2>(r.pre, r.res, slot[0], slot[1], slot[2], s);
-      else merged = strip3_launch_flags<1, 4>(r.pre, r.res, slot[0], slot[1], slot[2], s);
-    }
-    if (merged <= 0) {
-      rc = merged;
-      for (size_t j : members) used[j] = true;
-    } else {
-      used[i] = true;
-      rc = r.single(r, s);
-    }
-  }
-  delete v;
-  return rc;
 }
 
 }  // namespace svc

@@ -1,22 +1,13 @@
-// mrf_pair.hip — one ResBlock1 pair of the narrow decoder stages as ONE kernel:
-//     out = conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2 + x        (vdecoder/hifigan/models.py:60-67, one loop iteration)
-// with conv1 = Conv1d(C, C, K, dilation d), conv2 = Conv1d(C, C, K, dilation 1), C = 16 or 32 (the last two upsample stages:
-// T = 220,672 and 441,344 samples per 10 s clip).  As separate launches those six convs per ResBlock are HBM-bound: each
-// reads its input AND the residual and writes its output, 84 MB per launch at C = 16 (2.0-2.5 TB/s measured, 20-50 TFLOP/s).
-// Fused, the pair reads x once and writes out once; the intermediate tile and the residual never leave the CU:
-//     HBM bytes per output sample per pair:  unfused 6 x 4C  ->  fused 2 x 4C (+4C when accumulating the MRF sum)
-//
-// Per workgroup (persistent, grid-stride over time tiles of BN samples):
-//   1. stage the RAW x tile [C][BN + 2(H1+H2)] in LDS (H1 = d(K-1)/2, H2 = (K-1)/2; zero outside the sequence) — coalesced
-//      along time; the leaky-ReLU is applied to each operand as it is read, so the same tile also serves the residual add;
-//   2. conv1 on the fp32 matrix pipe over BN + 2*H2 columns -> + b1 -> leaky-ReLU -> mid tile in LDS, ZERO outside [0, T)
-//      (conv2's zero padding pads lrelu(conv1(...)), not conv1 evaluated past the ends);
-//   3. conv2 over the BN columns -> + b2 + x (from the LDS tile) [+ beta * out_prev] [/ out_div] -> HBM.
-// MFMA shapes: C = 16 -> v_mfma_f32_16x16x4_f32 (M = 16 output channels, 4 input channels per instruction) with BOTH weight
-// sets held in registers (2 x 4 x K values per lane: with 32-cycle instructions the LDS could not feed two operands per
-// MFMA for several waves); C = 32 -> v_mfma_f32_32x32x2_f32 with the weights in LDS ([ci][k][co], read once per MFMA).
-// Reduction order = the unfused kernels' (channel groups outer, taps inner; fp32 fmaf chains), epilogue arithmetic in the
-// same order: results are bit-identical to the two-launch path.
+// mrf_pair.hip — the 16-channel decoder stage's ResBlock1 (vdecoder/hifigan/models.py:60-67) as fused kernels:
+//   svc_resblock_pair_f32   one dilation pair   out = conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2 + x        (mrf_pair16_kernel)
+//   svc_resblock16_f32      all three pairs of the block in one launch                                         (mrf_block16_kernel)
+// As separate launches the six convs of a block at C = 16 (T = 441,344 samples per 10 s clip) are HBM-bound: each reads its input
+// AND the residual and writes its output, 84 MB per launch (2.0-2.5 TB/s measured, 20-50 TFLOP/s).  Fused, x is read once and the
+// result written once; intermediates and residuals stay in LDS / registers.  C = 16 -> v_mfma_f32_16x16x4_f32 (M = 16 output
+// channels, 4 input channels per instruction) with the weights of a pair in registers.  Reduction order = the unfused kernels'
+// (channel groups outer, taps inner; fp32 fmaf chains), epilogue arithmetic in the same order: bit-identical to the conv launches.
+// (Rounds 2-5 also carried the first form of the pair — persistent workgroups, leaky-ReLU per operand read, C = 16 and a C = 32
+// variant that never beat the two strip launches; removed in round 6 with the merged-launch path: DESIGN.md §3.)
 #include "common.h"
 #include <algorithm>
 #include <type_traits>
@@ -29,169 +20,7 @@ struct PairP {
   int XW, MW;    // LDS row pitches of the x and mid tiles (floats)
 };
 
-template <int C, int KS>
-struct PairCfg {
-  static constexpr int TS = C == 16 ? 16 : 32;                      // MFMA tile edge
-  static constexpr int KPI = C == 16 ? 4 : 2;                       // input channels per MFMA
-  static constexpr int NG = C / KPI;                                // channel groups
-  static constexpr int NW = C == 16 ? 4 : 8;                        // waves per workgroup
-  static constexpr int BN = C == 16 ? 256 : (KS >= 11 ? 128 : 256); // output samples per tile (C = 32, K = 11: 90 KB of weights)
-};
-
 __device__ __forceinline__ float lrelu01(float v, float s) { return fmaxf(v, v * s); }   // 0 <= s <= 1
-
-// (round 3: the operand-preloading variant of this kernel measured identical to this form — 1716 vs 1716 us over the 18 pair
-// shapes, profiles/r03a_pairbench_* — and was deleted.)
-template <int C, int KS>
-__global__ __launch_bounds__((PairCfg<C, KS>::NW * 64)) void mrf_pair_kernel(PairP p) {
-  using Cf = PairCfg<C, KS>;
-  constexpr int TS = Cf::TS, KPI = Cf::KPI, NG = Cf::NG, NW = Cf::NW, BN = Cf::BN, NTHR = NW * 64;
-  constexpr int H2 = (KS - 1) / 2;
-  constexpr bool M16 = C == 16;
-  const svc_resblock_pair_args& a = p.a;
-  const int d = a.dil1, H1 = d * H2, HX = H1 + H2;
-  const int XW = p.XW, MW = p.MW;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;                 // [C][XW]  raw x, columns t0 - HX ...
-  float* ms = xs + C * XW;         // [C][MW]  lrelu(conv1 + b1), columns t0 - H2 ...
-  float* wl = ms + C * MW;         // C == 32: [2][C][KS][C] weights
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & (TS - 1), lk = lane / TS;
-  const float slope = a.slope;
-
-  // ---- weights: registers (C = 16) or LDS (C = 32), once per workgroup ----
-  float w1r[M16 ? NG : 1][M16 ? KS : 1], w2r[M16 ? NG : 1][M16 ? KS : 1];
-  if constexpr (M16) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        w1r[g][k] = a.w1[((g * KPI + lk) * KS + k) * a.CP + ln];
-        w2r[g][k] = a.w2[((g * KPI + lk) * KS + k) * a.CP + ln];
-      }
-  } else {
-    for (int i = tid; i < C * KS * C; i += NTHR) {
-      const int co = i % C, rk = i / C;          // rk = ci*KS + k
-      wl[i] = a.w1[rk * a.CP + co];
-      wl[C * KS * C + i] = a.w2[rk * a.CP + co];
-    }
-  }
-  float b1r[M16 ? 4 : 16], b2r[M16 ? 4 : 16];   // biases of the C-layout rows this lane owns
-#pragma unroll
-  for (int r = 0; r < (M16 ? 4 : 16); ++r) {
-    const int row = M16 ? 4 * lk + r : (r & 3) + 8 * (r >> 2) + 4 * lk;
-    b1r[r] = a.b1 ? a.b1[row] : 0.f;
-    b2r[r] = a.b2 ? a.b2[row] : 0.f;
-  }
-
-  const int n_mid = (BN + 2 * H2 + TS - 1) / TS;   // column tiles of conv1
-  constexpr int n_out = BN / TS;
-
-  for (long long tile = blockIdx.x; tile < (long long)p.n_tiles * a.B; tile += gridDim.x) {
-    const int b = (int)(tile / p.n_tiles);
-    const int t0 = (int)(tile - (long long)b * p.n_tiles) * BN;
-    const float* xb = a.x + (long long)b * a.x_bs;
-    float* yb = a.y + (long long)b * a.y_bs;
-    __syncthreads();   // previous tile's readers are done with xs / ms (and the weights are in place)
-    // ---- 1. stage raw x ----
-    const int xcols = BN + 2 * HX;
-    for (int i = tid; i < C * xcols; i += NTHR) {
-      const int c = i / xcols, col = i - c * xcols;
-      const int t = t0 - HX + col;
-      xs[c * XW + col] = (t >= 0 && t < a.T) ? xb[(long long)c * a.x_cs + t] : 0.f;
-    }
-    __syncthreads();
-    // ---- 2. conv1 -> mid ----
-    for (int ct = wave; ct < n_mid; ct += NW) {
-      const int col0 = ct * TS;
-      if constexpr (M16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
-#pragma unroll
-          for (int k = 0; k < KS; ++k)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[g][k], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
-        }
-      
-        const int t = t0 - H2 + col0 + ln;
-        const bool ok = t >= 0 && t < a.T;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ms[(4 * lk + r) * MW + col0 + ln] = ok ? lrelu01(acc[r] + b1r[r], slope) : 0.f;
-      } else {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int g = 0; g < NG; ++g) {
-          const float* xr = xs + (g * KPI + lk) * XW + col0 + ln;
-          const float* wr = wl + ((g * KPI + lk) * KS) * C + ln;
-#pragma unroll
-          for (int k = 0; k < KS; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], lrelu01(xr[k * d], slope), acc, 0, 0, 0);
-        
-        }
-        const int t = t0 - H2 + col0 + ln;
-        const bool ok = t >= 0 && t < a.T;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ms[((r & 3) + 8 * (r >> 2) + 4 * lk) * MW + col0 + ln] = ok ? lrelu01(acc[r] + b1r[r], slope) : 0.f;
-      }
-    }
-    __syncthreads();
-    // ---- 3. conv2 + residual -> out ----
-    for (int ct = wave; ct < n_out; ct += NW) {
-      const int col0 = ct * TS;
-      const int t = t0 + col0 + ln;
-      if constexpr (M16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
-#pragma unroll
-          for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[g][k], mr[k], acc, 0, 0, 0);
-        }
-      
-        if (t < a.T) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 4 * lk + r;
-            float v = acc[r] + b2r[r];
-            v = v + xs[co * XW + HX + col0 + ln];
-            float* yp = yb + (long long)co * a.y_cs + t;
-            if (a.beta != 0.f) v = v + a.beta * (*yp);
-            if (a.out_div != 1.f) v = v / a.out_div;
-            *yp = v;
-          }
-        }
-      } else {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int g = 0; g < NG; ++g) {
-          const float* mr = ms + (g * KPI + lk) * MW + col0 + ln;
-          const float* wr = wl + C * KS * C + ((g * KPI + lk) * KS) * C + ln;
-#pragma unroll
-          for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[k * C], mr[k], acc, 0, 0, 0);
-        
-        }
-        if (t < a.T) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            float v = acc[r] + b2r[r];
-            v = v + xs[co * XW + HX + col0 + ln];
-            float* yp = yb + (long long)co * a.y_cs + t;
-            if (a.beta != 0.f) v = v + a.beta * (*yp);
-            if (a.out_div != 1.f) v = v / a.out_div;
-            *yp = v;
-          }
-        }
-      }
-    }
-  }
-}
-
 
 // ---- round 4: the 16-channel pair, second form --------------------------------------------------------------------------------
 // What the first form lost (ISA + counters): per MFMA one ds_read -> s_waitcnt lgkmcnt(0) -> 3 VALU of leaky-ReLU -> MFMA
@@ -575,8 +404,6 @@ int launch_block16(const svc_resblock16_args& a, hipStream_t s) {
   return svc::check_launch("resblock16");
 }
 
-int g_pair_v2 = -1;     // 16-channel pairs on mrf_pair16_kernel (environment SVC_PAIR_V2=0: the first form, A/B)
-
 template <int KS>
 int launch_pair16(const svc_resblock_pair_args& a, hipStream_t s) {
   constexpr int H2 = (KS - 1) / 2, BN = 240;
@@ -604,52 +431,6 @@ int launch_pair16(const svc_resblock_pair_args& a, hipStream_t s) {
   return svc::check_launch("resblock_pair16");
 }
 
-int g_cus = 0;
-
-template <int C, int KS>
-int launch_pair(const svc_resblock_pair_args& a, hipStream_t s) {
-  using Cf = PairCfg<C, KS>;
-  constexpr int H2 = (KS - 1) / 2;
-  const int HX = a.dil1 * H2 + H2;
-  PairP p;
-  p.a = a;
-  p.n_tiles = svc::cdiv(a.T, Cf::BN);
-  // row pitches: consecutive channel rows of one MFMA operand fetch (KPI of them) must sit on disjoint bank groups
-  auto pitch = [](int w, bool m16) {
-    w = (w + 3) & ~3;
-    if (m16) { while ((w & 63) != 16 && (w & 63) != 48) w += 4; }   // 4 rows x 16 lanes: offsets 0,16,32,48 (mod 64 banks)
-    else { while ((w & 63) != 32) w += 4; }                        // 2 rows x 32 lanes: offsets 0,32
-    return w;
-  };
-  p.XW = pitch(Cf::BN + 2 * HX, C == 16);
-  p.MW = pitch(Cf::BN + 2 * H2 + Cf::TS, C == 16);   // + one MFMA tile: the last conv1 column tile may overhang
-  size_t lds = (size_t)C * (p.XW + p.MW) * 4;
-  if (C == 32) lds += (size_t)2 * C * KS * C * 4;
-  if (lds > 160 * 1024) {
-    svc::set_error("resblock_pair: tile does not fit LDS (C=%d KS=%d dil=%d)", C, KS, a.dil1);
-    return SVC_ERR_UNSUPPORTED;
-  }
-  auto kern = mrf_pair_kernel<C, KS>;
-  if (lds > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
-    }
-  }
-  if (!g_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return svc::check_launch("resblock_pair props");
-    g_cus = prop.multiProcessorCount;
-  }
-  const long long tiles = (long long)p.n_tiles * a.B;
-  const int per_cu = lds > 80 * 1024 ? 1 : 2;
-  const unsigned grid = (unsigned)std::min<long long>(tiles, (long long)g_cus * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cf::NW * 64), lds, s, p);
-  return svc::check_launch("resblock_pair");
-}
-
 }  // namespace
 
 extern "C" int svc_resblock_pair_f32(const svc_resblock_pair_args* ap, void* stream) {
@@ -657,37 +438,23 @@ extern "C" int svc_resblock_pair_f32(const svc_resblock_pair_args* ap, void* str
   const svc_resblock_pair_args& a = *ap;
   SVC_REQUIRE(a.x && a.w1 && a.w2 && a.y, "resblock_pair: null tensor");
   SVC_REQUIRE(a.B > 0 && a.T > 0 && a.dil1 >= 1, "resblock_pair: bad shape");
-  SVC_REQUIRE(a.C == 16 || a.C == 32, "resblock_pair: C = %d (16 and 32 are built; wider stages use svc_conv1d_f32)", a.C);
+  SVC_REQUIRE(a.C == 16, "resblock_pair: C = %d (the 16-channel stage is built; wider stages use svc_conv1d_f32)", a.C);
   SVC_REQUIRE(a.KS == 3 || a.KS == 7 || a.KS == 11, "resblock_pair: KS = %d not in {3,7,11}", a.KS);
   SVC_REQUIRE(a.CP >= a.C, "resblock_pair: packed row pitch < C");
   SVC_REQUIRE(a.slope >= 0.f && a.slope <= 1.f, "resblock_pair: leaky slope outside [0,1]");
   SVC_REQUIRE(a.x != a.y, "resblock_pair: in-place call (tiles read their neighbours' halo)");
+  if ((long long)(240 + 2 * (a.dil1 + 1) * ((a.KS - 1) / 2)) > 512) {
+    svc::set_error("resblock_pair: dilation %d too wide for the tile (KS %d): use two svc_conv1d_f32 launches", a.dil1, a.KS);
+    return SVC_ERR_UNSUPPORTED;
+  }
   hipStream_t s = (hipStream_t)stream;
   const double flop = 2.0 * 2.0 * a.B * (double)a.C * a.C * a.KS * a.T;
   const double bytes = 4.0 * a.B * (double)a.C * a.T * (a.beta != 0.f ? 3 : 2);
   svc::ProfScope prof(s, "resblock_pair", flop, bytes);
-  if (g_pair_v2 < 0) {
-    const char* e = getenv("SVC_PAIR_V2");
-    g_pair_v2 = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (a.C == 16 && g_pair_v2 && (long long)(240 + 2 * (a.dil1 + 1) * ((a.KS - 1) / 2)) <= 512) {
-    switch (a.KS) {
-      case 3: return launch_pair16<3>(a, s);
-      case 7: return launch_pair16<7>(a, s);
-      default: return launch_pair16<11>(a, s);
-    }
-  }
-  if (a.C == 16) {
-    switch (a.KS) {
-      case 3: return launch_pair<16, 3>(a, s);
-      case 7: return launch_pair<16, 7>(a, s);
-      default: return launch_pair<16, 11>(a, s);
-    }
-  }
   switch (a.KS) {
-    case 3: return launch_pair<32, 3>(a, s);
-    case 7: return launch_pair<32, 7>(a, s);
-    default: return launch_pair<32, 11>(a, s);
+    case 3: return launch_pair16<3>(a, s);
+    case 7: return launch_pair16<7>(a, s);
+    default: return launch_pair16<11>(a, s);
   }
 }
 

@@ -140,7 +140,6 @@ def lib():
         L.svc_pack_convt1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
-        L.svc_conv1d_multi_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_int, C.c_void_p]
         L.svc_debug_bf16.argtypes = [C.c_int]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
@@ -202,7 +201,7 @@ ABI_VERSION = 5      # include/svc_hip.h SVC_ABI_VERSION (tests/test_abi_cpu.py 
 
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_debug_empty_kernel", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
-    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32", "svc_conv1d_multi_f32", "svc_debug_conv_multi_merged",
+    "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32",
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
     "svc_conv_transpose1d_f32",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_resblock16_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
@@ -320,14 +319,10 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
     a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
     a.mma = _MMA if mma is None else mma
-    if _GROUP is not None:          # inside `with conv_group():` — issued with the rest of the group on exit
-        _GROUP.append((a, (x, wp, bias, cond, mask, premask, res, out, out2)))
-        return out
     check(lib().svc_conv1d_f32(C.byref(a), stream_ptr()), "conv1d")
     return out
 
 
-_GROUP = None
 
 # ---- matrix-pipe operand format of the convolutions (svc_conv1d_args.mma): the engine's form of the reference's autocast region
 MMA_F32, MMA_BF16, MMA_F16 = 0, 1, 2
@@ -355,28 +350,6 @@ class mma_mode:
     def __exit__(self, *a):
         global _MMA
         _MMA = self.prev
-        return False
-
-
-class conv_group:
-    """`with conv_group(): ...` — every svc_hip.conv1d call inside the block is collected and the block's exit issues them
-    together through svc_conv1d_multi_f32.  The calls must be INDEPENDENT (no output of one is an input, residual or output of
-    another): the decoder uses it for the same step of the three ResBlock chains of an MRF stage, which then share one launch."""
-
-    def __enter__(self):
-        global _GROUP
-        if _GROUP is not None:
-            raise SvcError("conv_group does not nest")
-        _GROUP = []
-        return self
-
-    def __exit__(self, et, ev, tb):
-        global _GROUP
-        items, _GROUP = _GROUP, None
-        if et is not None or not items:
-            return False
-        arr = (Conv1dArgs * len(items))(*[a for a, _ in items])
-        check(lib().svc_conv1d_multi_f32(arr, len(items), stream_ptr()), "conv1d_multi")
         return False
 
 

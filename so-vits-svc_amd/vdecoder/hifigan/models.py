@@ -34,14 +34,6 @@ _POSTACT = __import__("os").environ.get("SVC_MRF_POSTACT", "1") != "0"      # A/
 _MRF_STREAMS = __import__("os").environ.get("SVC_MRF_STREAMS", "1") != "0"   # A/B switch: one HIP stream per MRF ResBlock chain
 _FUSE_PAIR = __import__("os").environ.get("SVC_MRF_FUSE_PAIR", "1") != "0"   # A/B switch of svc_resblock_pair_f32
 _FUSE_PAIR_H = __import__("os").environ.get("SVC_HALF_FUSE_PAIR", "1") != "0"  # A/B switch of svc_resblock_pair_h (16-bit pipeline)
-# the chains' same-step convs in one launch (svc_conv1d_multi_f32): 0 never (default), 1 every stage, 2 only stages whose single
-# launches cannot fill the chip (fewer workgroups than CUs: the 256-channel stage, 216).  Measured on one box, 10 s clip
-# (profiles/r05b_infer_merge{0,1}.json, r05d_infer_merge_modes_realtime.txt): launches back to back on ONE stream the merged form
-# is faster — dense-conv family 6.85 -> 6.39 ms, 78.6 -> 84.3 TFLOP/s — but the three-stream schedule below already overlaps the
-# chains' fixed phases AND has no barrier between the steps of a stage: 7.51 ms per clip against 7.71 (merged) / 7.64 (mode 2).
-# The timed path and its roofline pass both run the default.
-_MRF_MERGE = int(__import__("os").environ.get("SVC_MRF_MERGE", "0"))
-
 
 class ResBlock1(nn.Module):
     def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
@@ -78,7 +70,8 @@ class ResBlock1(nn.Module):
         xt, ping, pong = bufs
         C = x.shape[1]
         fused = (_FUSE_PAIR and C in S.RESBLOCK_PAIR_CHANNELS and self.convs1[0].kernel_size in S.RESBLOCK_PAIR_KERNELS
-                 and not isinstance(x, S.FlipView))
+                 and not isinstance(x, S.FlipView)
+                 and all(240 + (c1.dilation + 1) * (c1.kernel_size - 1) <= 512 for c1 in self.convs1))      # the pair kernel's tile
         if fused and S.RESBLOCK16 and C == 16 and n == 3:
             # the whole block — all three dilation pairs — in ONE launch (svc_resblock16_f32: x read once, result written once, bit-equal
             # to the three pair launches below)
@@ -260,41 +253,6 @@ class SourceModuleHnNSF(nn.Module):
         return har, None, None
 
 
-def _mergeable(blocks, x):
-    """ResBlock1 chains of equal depth on the two-launch path (the fused 16-channel pairs keep their own kernel)."""
-    if isinstance(x, S.FlipView) or not all(isinstance(b, ResBlock1) for b in blocks):
-        return False
-    if len({len(b.convs1) for b in blocks}) != 1 or not _POSTACT:
-        return False
-    C = x.shape[1]
-    return not (_FUSE_PAIR and C in S.RESBLOCK_PAIR_CHANNELS and all(b.convs1[0].kernel_size in S.RESBLOCK_PAIR_KERNELS for b in blocks))
-
-
-def _mrf_stage_merged(blocks, x, acc, kw):
-    """The chains of a stage advance in LOCKSTEP on one stream: step s of every chain is one svc_conv1d_multi_f32 group (one
-    launch when the convs share a kernel family: conv1d_strip3_kernel / conv1d_mfma3_kernel), i.e. 2*depth - 1 merged launches
-    per stage plus the chains' last convs one by one — those accumulate into the shared `acc` in the fixed order k = 3, 7, 11,
-    exactly like the sequential form, so the output is bit-identical to it."""
-    n, depth = len(blocks), len(blocks[0].convs1)
-    cur = [x] * n
-    xt = [torch.empty_like(x) for _ in range(n)]
-    ping = [torch.empty_like(x) for _ in range(n)]
-    pong = [torch.empty_like(x) for _ in range(n)]
-    for j in range(depth):
-        with S.conv_group():
-            for b, blk in enumerate(blocks):
-                blk.convs1[j].run(cur[b], pre_slope=LRELU_SLOPE, post_act=S.ACT_LRELU, post_slope=LRELU_SLOPE, out=xt[b])
-        if j == depth - 1:
-            for b, blk in enumerate(blocks):
-                blk.convs2[j].run(xt[b], pre_slope=1.0, res=cur[b], res_mode=1, **kw(b))
-            return acc
-        dst = [ping[b] if cur[b] is not ping[b] else pong[b] for b in range(n)]
-        with S.conv_group():
-            for b, blk in enumerate(blocks):
-                blk.convs2[j].run(xt[b], pre_slope=1.0, res=cur[b], res_mode=1, out=dst[b])
-        cur = dst
-
-
 def mrf_stage(owner, blocks, x, acc, n_tmp=3, half=False):
     """acc = mean_j blocks[j](x) for the ResBlocks of one decoder stage (`xs += resblocks[j](x)`; `x = xs / num_kernels`,
     vdecoder/hifigan/models.py:382-388), the blocks accumulating into `acc` in order.
@@ -304,12 +262,12 @@ def mrf_stage(owner, blocks, x, acc, n_tmp=3, half=False):
     before the next stage), so the memory phase of one chain's tiles (epilogue: residual read + store, 14 % of a 128-channel
     k=11 launch with every CU in the same phase) and its last partial round of tiles overlap another chain's matrix work:
     10 s clip 9.10 -> 8.62 ms, same launches, same accumulation order (k = 3, then 7, then 11), bit-identical output.
-    Capturable (torch.cuda.graph follows the fork / join)."""
+    Capturable (torch.cuda.graph follows the fork / join).  (Rounds 4-5 also carried a merged form — the same step of the three chains
+    as ONE launch, svc_conv1d_multi_f32: faster back to back on one stream, 84.3 against 78.6 TFLOP/s, and slower than this stream
+    schedule in wall time, 7.71 against 7.51 ms per clip, profiles/r05d_infer_merge_modes_realtime.txt; removed in round 6.)"""
     n = len(blocks)
     kw = lambda j: dict(out=acc, beta=0.0 if j == 0 else 1.0, out_div=float(n) if j == n - 1 else 1.0)
     run = (lambda blk, *a, **k: blk.forward_h(*a, **k)) if half else (lambda blk, *a, **k: blk(*a, **k))   # half: blocked fp16 tensors
-    if not half and _MRF_MERGE and n > 1 and x.is_cuda and _mergeable(blocks, x) and (_MRF_MERGE == 1 or x.shape[0] * x.shape[2] < 16384):
-        return _mrf_stage_merged(blocks, x, acc, kw)
     if not (_MRF_STREAMS and n > 1 and x.is_cuda):
         tmp = [torch.empty_like(x) for _ in range(n_tmp)]
         for j, blk in enumerate(blocks):

@@ -319,24 +319,3 @@ def test_graph_replays_back_to_back_equal_eager(dev, T):
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(outs, eager)):
         assert torch.equal(a, b), (i, (a - b).abs().max().item())
-
-
-@pytest.mark.gpu
-def test_merged_mrf_launches_equal_the_three_stream_schedule(dev, monkeypatch):
-    """SVC_MRF_MERGE=1 (the chains' same-step convs in one svc_conv1d_multi_f32 launch; not the default — DESIGN §4) against the
-    default three-stream schedule on the benchmark clip: the same kernel bodies in the same accumulation order -> the waveform
-    is bit-identical; and merged launches really were issued."""
-    import svc_hip as S
-    import vdecoder.hifigan.models as GM
-    cfg = W.full_config()
-    net, _ = _build(cfg, 1234, dev)
-    c, f0, uv, sid = W.make_inputs(cfg, 1, 862, seed=1234)
-    noise = {k: v.to(dev) for k, v in W.make_noise(cfg, 1, 862, seed=99).items()}
-    args = (c.to(dev), f0.to(dev), uv.to(dev))
-    base, _ = net.infer(*args, g=sid.to(dev), noice_scale=0.4, noise=noise)
-    n0 = S.lib().svc_debug_set_conv_strip(-2) + S.lib().svc_debug_conv_multi_merged()
-    monkeypatch.setattr(GM, "_MRF_MERGE", 1)
-    merged, _ = net.infer(*args, g=sid.to(dev), noice_scale=0.4, noise=noise)
-    torch.cuda.synchronize()
-    assert S.lib().svc_debug_set_conv_strip(-2) + S.lib().svc_debug_conv_multi_merged() - n0 == 4 * 5      # 4 stages x (2*3 - 1) steps
-    assert torch.equal(base, merged)
