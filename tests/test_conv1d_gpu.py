@@ -290,9 +290,6 @@ def test_conv1d_direct_epilogue_equals_lds_epilogue(dev, strip_mode, Cin, Cout, 
         S.lib().svc_debug_set_conv_cfg(0)
 
 
-@pytest.mark.parametrize("C,T,ks_set", [(128, 862 * 64, (11, 7, 3)), (64, 862 * 128, (3, 7, 11)), (32, 862 * 256, (11, 7, 3)),
-                                        (256, 862 * 8, (3, 7, 11)), (128, 862 * 64, (7, 3)), (256, 862 * 8, (11, 3)),
-                                        (128, 20004, (11, 7, 3)), (192, 862, (5, 3, 1))])
 @pytest.mark.parametrize("KS", [3, 7, 11])
 @pytest.mark.parametrize("B,T", [(1, 4099), (2, 700), (1, 100), (1, 441344 // 8)])
 def test_resblock16_one_launch_is_bit_equal_to_its_three_pair_launches(dev, KS, B, T):
