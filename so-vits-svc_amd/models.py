@@ -44,9 +44,10 @@ class ResidualCouplingBlock(nn.Module):
                                                             wn_sharing_parameter=self.wn))
             self.flows.append(modules.Flip())
 
-    def forward(self, x, x_mask, g=None, reverse=False):
+    def forward(self, x, x_mask, g=None, reverse=False, cond=None):
         """Reference models.py:45-52.  The channel Flip between couplings is never materialised: the working
-        buffer is addressed through a negative channel stride whenever an odd number of flips is pending."""
+        buffer is addressed through a negative channel stride whenever an odd number of flips is pending.  `cond`: the handle of
+        an earlier start_cond(g) call (inference)."""
         if training_call(self.flows[0].pre.weight) or (torch.is_grad_enabled() and x.requires_grad):
             if not reverse:
                 for flow in self.flows:
@@ -55,7 +56,7 @@ class ResidualCouplingBlock(nn.Module):
                 for flow in reversed(self.flows):
                     x = flow(x, x_mask, g=g, reverse=True)
             return x
-        return self._run_inplace(x, x_mask, g, reverse)
+        return self._run_inplace(x, x_mask, g, reverse, cond=cond)
 
     # -- 16-bit / split inference: one launch per coupling (csrc/flow_fused.hip) ---------------------------------------------------
     fused_mode = False       # False: fp32 kernels (10 launches per coupling); True: fp16 planes; "split": hi / lo planes
@@ -78,22 +79,55 @@ class ResidualCouplingBlock(nn.Module):
             ok = ok and isinstance(wn, modules.WN) and all(type(l) is Conv1d for l in list(wn.in_layers) + list(wn.res_skip_layers))
         return bool(ok)
 
-    def _coupling_fused(self, c, view, x_mask, g, reverse):
+    def _coupling_fused(self, c, view, x_mask, g, reverse, gc=None):
         sp = self.fused_mode == "split"
         wn = c.enc
-        gc = wn.cond_layer(g) if g is not None else None
+        if gc is None:
+            gc = wn.cond_layer(g) if g is not None else None
         S.coupling_fused_h(view, mask2d(x_mask), gc, (c.pre.packed_h(sp), c.pre.bias),
                            [(l.packed_h(sp), l.bias) for l in wn.in_layers], [(l.packed_h(sp), l.bias) for l in wn.res_skip_layers],
                            (c.post.packed_h(sp), c.post.bias), reverse=reverse, split=sp)
 
-    def _run_inplace(self, x, x_mask, g, reverse):
+    def start_cond(self, g):
+        """The conditioning rows of every coupling's WN — `cond_layer(g)` (modules/modules.py:113-114), a function of the speaker embedding
+        alone — on a side stream, so that they run under the encoder instead of on the flow's critical path (4 x 11 us per clip; with
+        `flow_share_parameter` it is ONE layer, computed once instead of per coupling).  Returns (dict id(WN) -> tensor, done event) for
+        forward(..., cond=...), or None when there is nothing to precompute."""
+        import vdecoder.hifigan.models as _gen
+        if g is None or not g.is_cuda or type(self) is not ResidualCouplingBlock or not _gen._MRF_STREAMS:
+            return None      # (_MRF_STREAMS off: one stream only — infer_many's branches must not fork again inside a forked capture)
+        wns = []
+        for f in self.flows:
+            if isinstance(f, modules.ResidualCouplingLayer) and isinstance(f.enc, modules.WN) and f.enc.gin_channels != 0 \
+                    and all(f.enc is not w for w in wns):
+                wns.append(f.enc)
+        if not wns or training_call(*wns[0].cond_layer.parameters()):
+            return None
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_cond_stream", {})
+        if g.device.index not in side:
+            side[g.device.index] = torch.cuda.Stream(device=g.device)
+        st = side[g.device.index]
+        fork, done = torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(st):
+            st.wait_event(fork)
+            out = {id(w): w.cond_layer(g) for w in wns}
+            done.record(st)
+        return out, done
+
+    def _run_inplace(self, x, x_mask, g, reverse, cond=None):
         buf = S.copy_bct(x)
         flipped = False
         couplings = [f for f in self.flows if isinstance(f, modules.ResidualCouplingLayer)]
+        gcs = {}
+        if cond is not None:
+            gcs = cond[0]
+            torch.cuda.current_stream().wait_event(cond[1])
         if self.fused_mode:
-            step = lambda c, view: self._coupling_fused(c, view, x_mask, g, reverse)
+            step = lambda c, view: self._coupling_fused(c, view, x_mask, g, reverse, gc=gcs.get(id(c.enc)))
         else:
-            step = lambda c, view: c.apply_inplace(view, x_mask, g=g, reverse=reverse)
+            step = lambda c, view: c.apply_inplace(view, x_mask, g=g, reverse=reverse, gc=gcs.get(id(c.enc)))
         if not reverse:
             for c in couplings:
                 step(c, S.flip_view(buf) if flipped else buf)
@@ -475,11 +509,15 @@ class SynthesizerTrn(nn.Module):
             #     commons.sequence_mask(c_lengths, T) (models.py:504) of the TRUE lengths, built on the device (graph-capturable)
             x_mask = (torch.arange(T, device=c.device).view(1, 1, T) < lengths.view(B, 1, 1)).to(torch.float32)
         m = mask2d(x_mask)
-        # the decoder's harmonic source + noise convs only need f0: start them now, underneath the encoder and the flow
         src_noise = noise if "sine" in noise else None
         early = not (self.use_automatic_f0_prediction and predict_f0) and hasattr(self.dec, "start_source")
-        source = self.dec.start_source(f0, src_noise) if early else None
         xin = self.pre.run(c, mask=m)                                               # pre(c) * mask
+        # The decoder's harmonic source + noise convs only need f0, the flow's conditioning rows only g: both start here, on side
+        # streams underneath the encoder and the flow.  AFTER the first launch of the main chain, not before it: a replayed graph
+        # releases the successor it put on another queue only behind the first launch of the one it kept on the same queue — with the
+        # 55 us single-workgroup frame scan in that place the whole front section started 65 us late (trace: profiles/r10j_*).
+        source = self.dec.start_source(f0, src_noise) if early else None
+        cond = self.flow.start_cond(g) if hasattr(self.flow, "start_cond") else None
         volv = vol if (vol is not None and self.vol_embedding) else None
         x, x_enc = S.prenet_embed(xin, uv, f0, self.emb_uv.weight, self.enc_p.f0_emb.weight, mask=m, vol=volv,
                                   vol_w=self.emb_vol.weight.view(-1) if volv is not None else None,
@@ -497,7 +535,7 @@ class SynthesizerTrn(nn.Module):
         guard = self.dec._range_guard(c.device) if getattr(self.flow, "fused_mode", False) == "split" and hasattr(self.dec, "_range_guard") \
             else contextlib.nullcontext()
         with guard:
-            z = self.flow(z_p, x_mask, g=g, reverse=True)
+            z = self.flow(z_p, x_mask, g=g, reverse=True, cond=cond) if cond is not None else self.flow(z_p, x_mask, g=g, reverse=True)
         # `z * c_mask` (models.py:531) is the identity here: the flow's last update already multiplies by the mask
         if source is not None:
             o = self.dec(z, f0, g=g, noise=src_noise, source=source)
@@ -519,13 +557,14 @@ class SynthesizerTrn(nn.Module):
         torch.manual_seed(seed)      # seeds every device generator (reference :498-501)
         g = self._speaker(g, c)
         B, _, T = c.shape
-        if noise is None:
-            L = T * self.dec.upp
-            noise = dict(enc_p=torch.randn(B, self.inter_channels, T, device=c.device),       # :160
-                         rand_ini=torch.rand(B, 9, device=c.device),                          # hifigan :147
-                         sine=torch.randn(B, L, 9, device=c.device))                          # hifigan :266
         if lengths is not None:
             lengths = lengths.to(device=c.device, dtype=torch.int64).contiguous()
+        if noise is None and self.use_graph:
+            # the draws go straight into the captured graph's input buffers (same generator, same order, same kernels as the
+            # torch.randn / torch.rand below: bit-identical values; saves a 16 MB copy of the sine noise in front of every replay)
+            return self._infer_graph(c, f0, uv, g, None, noice_scale, predict_f0, vol, lengths)
+        if noise is None:
+            noise = self._draw_noise(B, T, c.device)
         if self.use_graph:
             return self._infer_graph(c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths)
         return self._infer_body(c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths)
@@ -621,11 +660,25 @@ class SynthesizerTrn(nn.Module):
         graph.replay()
         return [(o[0].clone(), o[1].clone()) for o in outs]
 
+    def _draw_noise(self, B, T, device):
+        """The reference's draws in the reference's order (models.py:160 randn_like; vdecoder/hifigan/models.py:147 rand, :266 randn)."""
+        return dict(enc_p=torch.randn(B, self.inter_channels, T, device=device), rand_ini=torch.rand(B, 9, device=device),
+                    sine=torch.randn(B, T * self.dec.upp, 9, device=device))
+
     def _infer_graph(self, c, f0, uv, g, noise, noice_scale, predict_f0, vol, lengths=None):
         key = (tuple(c.shape), tuple(g.shape), float(noice_scale), bool(predict_f0), vol is not None, lengths is not None,
                str(c.device))
         ent = self._graphs.get(key)
-        ins = dict(c=c, f0=f0, uv=uv, g=g, enc_p=noise["enc_p"], rand_ini=noise["rand_ini"], sine=noise["sine"])
+        in_place = noise is None and ent is not None
+        if in_place:                     # torch.randn(shape) IS empty(shape).normal_(): the same values, written where the graph reads them
+            st = ent[1]
+            st["enc_p"].normal_()
+            st["rand_ini"].uniform_()
+            st["sine"].normal_()
+            noise = {}
+        elif noise is None:
+            noise = self._draw_noise(c.shape[0], c.shape[2], c.device)
+        ins = dict(c=c, f0=f0, uv=uv, g=g, **{k: noise[k] for k in ("enc_p", "rand_ini", "sine") if k in noise})
         if vol is not None:
             ins["vol"] = vol.float().contiguous()
         if lengths is not None:

@@ -114,13 +114,16 @@ class WN(nn.Module):
             return output
         return A.mul_bcast(output, x_mask)
 
-    def forward(self, x, x_mask, g=None, **kwargs):
+    def forward(self, x, x_mask, g=None, gc=None, **kwargs):
+        """`gc` (inference only): cond_layer(g) computed by the caller ahead of time (it depends on the speaker embedding alone:
+        SynthesizerTrn._infer_body runs it on a side stream under the encoder instead of on the flow's critical path)."""
         if training_call(*self.res_skip_layers[0].parameters()) or (torch.is_grad_enabled() and x.requires_grad):
             return self.forward_train(x, x_mask, g=g)
         H = self.hidden_channels
         B, _, T = x.shape
         m = mask2d(x_mask)
-        gc = self.cond_layer(g) if g is not None else None       # [B, 2H*L, 1|T]
+        if gc is None:
+            gc = self.cond_layer(g) if g is not None else None   # [B, 2H*L, 1|T]
         output = torch.empty((B, H, T), device=x.device, dtype=torch.float32)
         xcur = x
         xbuf = None
@@ -183,7 +186,7 @@ class ResidualCouplingLayer(nn.Module):
             self.post.weight.zero_()
             self.post.bias.zero_()
 
-    def apply_inplace(self, view, x_mask, g=None, reverse=False):
+    def apply_inplace(self, view, x_mask, g=None, reverse=False, gc=None):
         """Coupling update on a [B,C,T] view (tensor or FlipView) IN PLACE: x1 <- m + x1*mask  /  (x1 - m)*mask."""
         half = self.half_channels
         if isinstance(view, S.FlipView):
@@ -192,7 +195,7 @@ class ResidualCouplingLayer(nn.Module):
             x0, x1 = view[:, :half], view[:, half:]
         m = mask2d(x_mask)
         h = self.pre.run(x0, mask=m)
-        h = self.enc(h, x_mask, g=g)
+        h = self.enc(h, x_mask, g=g, gc=gc) if gc is not None else self.enc(h, x_mask, g=g)
         # stats = post(h) * mask ; reverse: x1 = (x1 - stats) * mask ; forward: x1 = stats + x1 * mask   (logs == 0)
         self.post.run(h, mask=m, res=x1, res_mode=2 if reverse else 3, out=x1)
 

@@ -319,3 +319,21 @@ def test_graph_replays_back_to_back_equal_eager(dev, T):
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(outs, eager)):
         assert torch.equal(a, b), (i, (a - b).abs().max().item())
+
+
+def test_seeded_draws_in_graph_mode_equal_the_eager_draws(dev):
+    """infer(seed=...) without injected noise: eager launches draw with torch.randn / torch.rand after torch.manual_seed (the
+    reference's models.py:498-501,160 and vdecoder/hifigan/models.py:147,266); graph mode writes the same draws straight into the
+    captured graph's input buffers (normal_ / uniform_ in the same order).  Same seed -> bit-identical waveform, first call (capture)
+    and replays alike; another seed -> another waveform."""
+    cfg = W.small_config()
+    net, _ = _build(cfg, 5, dev)
+    c, f0, uv, sid = [t.to(dev) for t in W.make_inputs(cfg, 2, 50, seed=8)]
+    eager = net.infer(c, f0, uv, g=sid, noice_scale=0.4, seed=777)[0]
+    net.enable_graph(True)
+    first = net.infer(c, f0, uv, g=sid, noice_scale=0.4, seed=777)[0]
+    again = net.infer(c, f0, uv, g=sid, noice_scale=0.4, seed=777)[0]
+    other = net.infer(c, f0, uv, g=sid, noice_scale=0.4, seed=778)[0]
+    back = net.infer(c, f0, uv, g=sid, noice_scale=0.4, seed=777)[0]
+    assert torch.equal(first, eager) and torch.equal(again, eager) and torch.equal(back, eager)
+    assert not torch.equal(other, eager)
