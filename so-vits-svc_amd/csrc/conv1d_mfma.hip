@@ -1459,6 +1459,15 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
       else if (cfg == 7) cfg = 3;
     }
   }
+  {
+    // tuning aid: SVC_CONV_C256_CFG=<cfg> forces a tiling for the decoder's 256-channel stage only (in-situ A/B of that stage)
+    static int c256 = -2;
+    if (c256 == -2) {
+      const char* e = getenv("SVC_CONV_C256_CFG");
+      c256 = e ? atoi(e) : -1;
+    }
+    if (c256 >= 0 && a.Cout == 256 && a.Cin == 256 && a.epi == SVC_EPI_PLAIN && cols < 16384 && cols > 2048 && t_row_phases == 1) cfg = c256;
+  }
   if (g_force_cfg >= 0 && a.Cout > 16) {
     const bool ok = (g_force_cfg == 3 || g_force_cfg == 4 || g_force_cfg == 5) ||
                     (a.epi != SVC_EPI_GATE && ((g_force_cfg <= 7 && g_force_cfg >= 1) || g_force_cfg == 9 || g_force_cfg == 10));
