@@ -40,8 +40,9 @@ const char* svc_last_error(void);
  *   4: svc_attention_args grew {ws, ws_bytes} (key-split workspace), svc_gemm_args grew {split_k_atomic}; the 16-bit / split
  *      generator entry points (svc_conv1d_h*, svc_conv1d_hl*, svc_resblock_pair_h / _hl)
  *   5: SVC_MMA_BF16X6 removed (svc_conv1d_args.mma / svc_wgrad_args.mma accept fp32, bf16, fp16 only); split pipeline range guard:
- *      svc_conv1d_h_args.acc_scale, svc_pack_conv1d_hl(scale), svc_resblock_pair_hl(acc_scale1, acc_scale2), svc_hl_range_flag; svc_coupling_fused_h */
-#define SVC_ABI_VERSION 5
+ *      svc_conv1d_h_args.acc_scale, svc_pack_conv1d_hl(scale), svc_resblock_pair_hl(acc_scale1, acc_scale2), svc_hl_range_flag; svc_coupling_fused_h
+ *   6: svc_conv1d_args / svc_convt1d_args grew {w_d4} (lane-linear weight pack of the short-sequence kernel), svc_pack_conv1d_d4 */
+#define SVC_ABI_VERSION 6
 int svc_abi_version(void);
 /* Fills name[0..len) with the gcnArchName of the current device, returns number of CUs (or <0). */
 int svc_device_info(char* name, int len);
@@ -126,12 +127,24 @@ typedef struct svc_conv1d_args {
    * of plain convolutions with 16-byte aligned rows and Cin a multiple of 16; every other shape runs in fp32 — never less
    * precise than asked. */
   int mma;
+  /* Optional second pack of the same weights for the register-fed short-sequence kernel (svc_pack_conv1d_d4 below), or NULL.
+   * That kernel feeds its MFMAs straight from L2; with the [Cin][KS][CoutP] pack every operand is a 4-byte-per-lane load and the
+   * launch is bound by the vector-memory ADDRESS rate (one wave-wide load per 16 cycles per CU whatever its width:
+   * profiles/r11e_front_conv_hot_cold.txt), with this pack a lane's four consecutive reduction steps are one 16-byte load. */
+  const float* w_d4;
 } svc_conv1d_args;
 #define SVC_MMA_F32 0
 #define SVC_MMA_BF16 1
 #define SVC_MMA_F16 2  /* `half_type: fp16`: the same with fp16 operands (v_mfma_f32_32x32x16_f16); the caller scales the loss (GradScaler) */
 
 int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
+
+/* The lane-linear operand pack of svc_conv1d_args.w_d4, derived from the standard pack `wp` [Cin][KS][CoutP] (Cin even,
+ * CoutP a multiple of 32): dst [CoutP/32][NG][64][4] floats, NG = ceil(Cin/2 * KS / 4);
+ *   dst[rt][G][lk*32 + ln][e] = wp[((2*pr + lk)*KS + k)*CoutP + rt*32 + ln]   with  pr*KS + k = 4*G + e   (0 past the last pair).
+ * svc_pack_conv1d_d4_floats returns the element count of dst. */
+long long svc_pack_conv1d_d4_floats(int Cin, int KS, int CoutP);
+int svc_pack_conv1d_d4(const float* wp, float* dst, int Cin, int KS, int CoutP, void* stream);
 
 int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */
 int svc_debug_wgrad_bf16_launches(void);
@@ -152,6 +165,7 @@ typedef struct svc_convt1d_args {
   long long x_bs, x_cs, y_bs, y_cs, res_bs, res_cs;
   int B, Cin, Cout, Tin, Tout, KS, stride, padding, CoutP;
   float pre_slope;
+  const float* w_d4; /* NULL, or svc_pack_conv1d_d4 of the phases-as-rows pack ([Cin][M][stride*CoutP]: power-of-two strides) */
 } svc_convt1d_args;
 
 int svc_conv_transpose1d_f32(const svc_convt1d_args* a, void* stream);
@@ -481,7 +495,9 @@ int svc_conv_weight_prep_f32(const svc_conv_weight_args* args, void* stream);
  * `dev_row_start` / `dev_block_start` [n_plans] (device) = exclusive prefix sums of the plans' R resp. of
  * svc_conv_weight_prep_blocks(R, C2, K) (a scatter workgroup owns SVC_WEIGHT_PREP_ROWS rows x ~SVC_WEIGHT_PREP_COLS elements). */
 #define SVC_WEIGHT_PREP_ROWS 32
+#ifndef SVC_WEIGHT_PREP_COLS   /* (-D override: tuning builds only; the library reports its own value through svc_conv_weight_prep_blocks) */
 #define SVC_WEIGHT_PREP_COLS 1024
+#endif
 int svc_conv_weight_prep_blocks(int R, int C2, int K);
 int svc_conv_weight_prep_multi_f32(const svc_conv_weight_args* host_args, const svc_conv_weight_args* dev_args,
                                    const int* dev_row_start, const int* dev_block_start, int n_plans, void* stream);

@@ -99,6 +99,14 @@ int main() {
     run<2, 2, 4, 1, true>("2x2 tiles, 1 wave/SIMD", 1, out);
     run<1, 4, 4, 1, true>("1x4 tiles, 1 wave/SIMD", 1, out);
     run<2, 2, 16, 4, true>("2x2 tiles, 4 waves/SIMD (one WG)", 1, out);
+    // few accumulators per wave: the register-fed short-sequence kernel (1 or 2) and the 64 x 128 tiling of the 256-channel stage (2)
+    run<1, 1, 4, 1, false>("1x1 tile (ONE accumulator), 1 wave/SIMD, no reads", 1, out);
+    run<1, 1, 4, 1, true>("1x1 tile (ONE accumulator), 1 wave/SIMD", 1, out);
+    run<2, 1, 4, 1, false>("2x1 tiles, 1 wave/SIMD, no reads", 1, out);
+    run<2, 1, 4, 1, true>("2x1 tiles, 1 wave/SIMD", 1, out);
+    run<2, 1, 8, 2, true>("2x1 tiles, 2 waves/SIMD (one WG)", 1, out);
+    run<1, 1, 16, 4, true>("1x1 tile, 4 waves/SIMD (one WG)", 1, out);
+    run<1, 2, 4, 1, true>("1x2 tiles, 1 wave/SIMD", 1, out);
   }
   return 0;
 }

@@ -1293,6 +1293,204 @@ __global__ __launch_bounds__(256) void conv1d_mfma_direct_kernel(ConvP p) {
   conv_epilogue<BM, BN, NTHR, WK, EPI>(p, smem, tid, b, 0, t0, co0);
 }
 
+// ---- the same with 16-byte operand loads (round 6) ---------------------------------------------------------------------------
+// What bounds the kernel above (profiles/r11e_front_conv_hot_cold.txt, r11d_*): not the matrix pipe and not L2 — hot and cold
+// operands time the same, and 16 waves per workgroup instead of 4 change nothing.  Every operand is a 4-byte-per-lane load and a
+// CU's address unit takes one wave-wide vector-memory instruction per ~16 cycles whatever its width: 2 (3) loads per step x the
+// workgroup's steps x 16 cycles IS the measured time (768 -> 192 x 3 taps: 2304 loads = 15 us of the launch's 23; 35-54 TFLOP/s
+// on every shape).  Here a lane's A operands of FOUR consecutive steps are one 16-byte load out of a lane-linear second pack of the
+// weights (svc_pack_conv1d_d4) and its B operands of all KSC taps of a channel are one KSC-float load (taps at dilation 1 are
+// consecutive samples): 1.75 instead of 6 loads per channel pair at 3 taps and a 32-row tile, 2.5 instead of 9 at 64 rows.
+// Zero padding and the edge columns: the B vector is fetched from a start clamped into the row, b = clamp(ts, 0, Tin - KSC), and a
+// lane whose window was moved (delta = ts - b != 0: only in the first / last column tile) picks element k + delta per tap — a
+// compare / select chain that waves without such lanes skip (wave-uniform branch chosen once, outside the loop).
+template <int N>
+__device__ __forceinline__ void load_taps(const char* q, float (&d)[N]) {   // N consecutive floats from a 4-byte aligned address
+  struct __attribute__((packed, aligned(4))) V { float v[N]; };
+  const V t = *reinterpret_cast<const V*>(q);
+#pragma unroll
+  for (int i = 0; i < N; ++i) d[i] = t.v[i];
+}
+
+__host__ __device__ constexpr int direct4_pairs(int mt, int ksc) { return (ksc <= 3 && mt == 1) ? 8 : 4; }
+// sched groups "one vector-memory read, then its share of NMF MFMAs", NLD times
+template <int G, int NLD, int NMF>
+__device__ __forceinline__ void interleave_groups() {
+  if constexpr (G < NLD) {
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    constexpr int q = (G + 1) * NMF / NLD - G * NMF / NLD;
+    if constexpr (q > 0) __builtin_amdgcn_sched_group_barrier(0x008, q, 0);
+    interleave_groups<G + 1, NLD, NMF>();
+  }
+}
+
+template <int MT, int EPI, int KSC>
+__global__ __launch_bounds__(256) void conv1d_mfma_direct4_kernel(ConvP p) {
+  static_assert(KSC >= 1 && KSC <= 7, "direct kernel: compile-time tap count");
+  constexpr int PR = direct4_pairs(MT, KSC);  // channel pairs per register bank; PR * KSC steps = NL 16-byte A loads per row tile
+  constexpr int NS = PR * KSC, NL = NS / 4;
+  static_assert(NS % 4 == 0, "a bank is a whole number of 4-step groups");
+  constexpr int WK = 4, BM = MT * 32, BN = 32, NTHR = 256, CP = BN + 4;
+  const svc_conv1d_args& a = p.a;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 31, lk = lane >> 5;
+  int bid = blockIdx.x;
+  const int tt = bid % p.n_t_tiles;
+  bid /= p.n_t_tiles;
+  const int mtile = bid % p.n_m_tiles;
+  const int b = bid / p.n_m_tiles;
+  const int t0 = tt * BN, co0 = mtile * BM;
+  const float ps = a.pre_slope;
+
+  const int npairs = a.Cin >> 1;
+  const int ppw = npairs / WK;                 // launcher: npairs % (WK * PR) == 0
+  const int pr0 = wk * ppw;
+  const int n_it = ppw / PR;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const bool xflip = a.x_cs < 0;
+  const unsigned xcs = (unsigned)(xflip ? -a.x_cs : a.x_cs);
+  const char* xlo = reinterpret_cast<const char*>(a.x + (long long)b * a.x_bs + (xflip ? (long long)(a.Cin - 1) * a.x_cs : 0ll));
+  // A: group G of row tile rt is 1 KiB at ((rt * NG + G) * 64 + lane) * 16
+  const int NG = (npairs * KSC) >> 2;
+  const int n_rt = a.CoutP >> 5;
+  const char* wrow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rt = __builtin_amdgcn_readfirstlane(min((co0 >> 5) + i, n_rt - 1));
+    wrow[i] = reinterpret_cast<const char*>(a.w_d4) + (size_t)rt * NG * 1024;
+  }
+  const unsigned va = (unsigned)lane * 16u;
+  // B: the lane's KSC-sample window starts at ts; fetched from b0 (inside the row), element k + delta is tap k
+  const int ts = t0 + ln - a.pad_left;
+  const int b0 = min(max(ts, 0), a.Tin - KSC);
+  const int delta = ts - b0;
+  const unsigned vxb = 4u * ((unsigned)(xflip ? 1 - lk : lk) * xcs + (unsigned)b0);
+  const bool edge = __any(delta != 0);
+
+  f32x4 av[3][NL][MT];
+  float bx[3][PR][KSC];
+  auto load_bank = [&](int it, f32x4 (&A_)[NL][MT], float (&X_)[PR][KSC]) {
+    const int pr = pr0 + min(it, n_it - 1) * PR;                       // scalar; banks past the slice re-read the last one
+    const unsigned g0 = (unsigned)(pr * KSC) >> 2;
+    // program order = order of first use (A group l feeds steps 4l .., pair j's taps steps j*KSC ..): with the loads spread over the
+    // previous bank's MFMAs every operand is then issued one bank ahead of its MFMA
+    auto load_a = [&](int l) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        A_[l][i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)(g0 + l) * 1024 + va);
+    };
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        if (4 * l <= j * KSC && (j == 0 || 4 * l > (j - 1) * KSC)) load_a(l);
+      const char* xbp = xlo + 4ull * ((unsigned)(xflip ? a.Cin - 2 - 2 * (pr + j) : 2 * (pr + j)) * xcs);
+      load_taps<KSC>(xbp + vxb, X_[j]);
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+      if (4 * l > (PR - 1) * KSC) load_a(l);
+  };
+  // NA accumulators per row tile, step s on accumulator s % NA: a chain of MFMAs on ONE accumulator with the operand VALU between
+  // them runs at ~110 cycles per instruction instead of 64 (profiles/r11h_mfma_pattern_few_accumulators.txt, r11i_*: the
+  // 768 -> 192 x 3 launch spent 13.4 us in its 288 chained MFMAs per wave); the partial sums are added once, after the loop.
+  constexpr int NA = MT == 1 ? 4 : 2;
+  f32x16 accs[MT][NA];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int u = 0; u < NA; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[i][u][r] = 0.f;
+  auto run = [&](auto edge_tag, auto act_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value, ACT = decltype(act_tag)::value;
+    auto mfma_bank = [&](const f32x4 (&A_)[NL][MT], const float (&X_)[PR][KSC]) {
+#pragma unroll
+      for (int j = 0; j < PR; ++j) {
+#pragma unroll
+        for (int k = 0; k < KSC; ++k) {
+          float xv;
+          if constexpr (EDGE) {
+            xv = 0.f;
+#pragma unroll
+            for (int e = 0; e < KSC; ++e) xv = (delta == e - k) ? X_[j][e] : xv;
+          } else {
+            xv = X_[j][k];
+          }
+          const float bvu = ACT ? fmaxf(xv, xv * ps) : xv;               // leaky-ReLU for 0 <= slope <= 1 (launcher checks)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            accs[i][(j * KSC + k) % NA] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[(j * KSC + k) >> 2][i][(j * KSC + k) & 3], bvu,
+                                                                              accs[i][(j * KSC + k) % NA], 0, 0, 0);
+        }
+      }
+    };
+    // The loads of the next bank are spread EVENLY between the MFMAs of this one (sched groups: one load, then its share of the
+    // MFMAs).  Issued as one burst in front of them, the 14..40 loads of a bank block the wave at the address unit's queue (four
+    // waves share it) for as long as the unit needs to take them, and a wave that is blocked issues no MFMAs: loads and matrix
+    // work of the launch ran one after the other, 6.5 + 13.4 us (profiles/r11i_front_conv_decomp.txt).
+    constexpr int NLD = NL * MT + PR * (KSC > 4 ? 2 : 1), NMF = NS * MT;
+    // THREE banks: every operand is issued two banks (~3000 cycles at 32 rows) ahead of its MFMA — a clip uses each weight once,
+    // they come from HBM, and one bank of look-ahead left the launch as slow cold as the 4-byte form (r11j_front_conv_d4_*)
+    load_bank(0, av[0], bx[0]);
+    load_bank(1, av[1], bx[1]);
+    int it = 0;
+    for (; it + 2 < n_it; it += 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(it + 2, av[2], bx[2]);
+      mfma_bank(av[0], bx[0]);
+      interleave_groups<0, NLD, NMF>();
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(it + 3, av[0], bx[0]);
+      mfma_bank(av[1], bx[1]);
+      interleave_groups<0, NLD, NMF>();
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(it + 4, av[1], bx[1]);
+      mfma_bank(av[2], bx[2]);
+      interleave_groups<0, NLD, NMF>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it < n_it) mfma_bank(av[0], bx[0]);          // one or two banks left: fetched by the last trip (or the two loads above)
+    if (it + 1 < n_it) mfma_bank(av[1], bx[1]);
+  };
+  if (n_it > 0) {
+    // (plain inputs — every encoder / flow convolution — must not pay the activation's VALU between their MFMAs)
+    if (ps != 1.f) {
+      if (edge) run(std::true_type{}, std::true_type{});
+      else run(std::false_type{}, std::true_type{});
+    } else {
+      if (edge) run(std::true_type{}, std::false_type{});
+      else run(std::false_type{}, std::false_type{});
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    acc[i] = accs[i][0];
+#pragma unroll
+    for (int u = 1; u < NA; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] += accs[i][u][r];
+  }
+
+  {
+    float* cw = smem + wk * BM * CP + ln;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CP] = acc[i][r];
+  }
+  __syncthreads();
+  conv_epilogue<BM, BN, NTHR, WK, EPI>(p, smem, tid, b, 0, t0, co0);
+}
+
 // shapes the register-fed kernel takes: dense (one phase), no pre-mask, 1 / 3 / 5 / 7 taps, an even channel count, a
 // pre-activation expressible as max(x, slope*x), and 32-bit byte offsets inside one batch row of x and inside the weights
 static bool direct_ok(const svc_conv1d_args& a) {
@@ -1325,8 +1523,57 @@ int launch_direct(const svc_conv1d_args& a, hipStream_t s) {
   return svc::check_launch("conv1d_mfma_direct");
 }
 
+// the 16-byte-load form: the second pack is there, taps are consecutive samples, and every wave's slice of the channel pairs is a
+// whole number of register banks (Cin a multiple of 32; of 64 for 32-row tiles up to three taps)
+int g_direct4 = -1;   // 0: never (A/B switch: environment SVC_CONV_DIRECT4=0, read at the first launch)
+template <int MT>
+static bool direct4_ok(const svc_conv1d_args& a) {
+  if (g_direct4 < 0) {
+    const char* e = getenv("SVC_CONV_DIRECT4");
+    g_direct4 = (e && e[0] == '0') ? 0 : 1;
+  }
+  const int pr = direct4_pairs(MT, a.KS);
+  return g_direct4 && a.w_d4 != nullptr && a.dil == 1 && a.Tin >= a.KS && ((a.Cin / 2) % (4 * pr)) == 0 && (a.CoutP % 32) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.w_d4) & 15) == 0;
+}
+
+template <int MT, int EPI, int KSC>
+int launch_direct4(const svc_conv1d_args& a, hipStream_t s) {
+  constexpr int BM = MT * 32, BN = 32, WK = 4;
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.a = a;
+  p.row_phases = t_row_phases;
+  if (p.row_phases > 1 && (BM % p.row_phases) != 0) {
+    svc::set_error("conv1d: %d row phases do not divide the %d-row tile", p.row_phases, BM);
+    return SVC_ERR_UNSUPPORTED;
+  }
+  auto al4 = [](const void* ptr, long long bs, long long cs) {
+    return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs % 4) == 0 && (cs % 4) == 0);
+  };
+  p.yvec = (a.n_phase == 1 && a.y_ts == 1 && a.y_t0 == 0 && al4(a.y, a.y_bs, a.y_cs) && al4(a.res, a.res_bs, a.res_cs) &&
+            al4(a.y2, a.y2_bs, a.y2_cs)) ? 1 : 0;
+  p.n_t_tiles = svc::cdiv(a.Tout, BN);
+  p.n_m_tiles = svc::cdiv(a.Cout, BM);
+  const long long nblk = (long long)p.n_t_tiles * p.n_m_tiles * a.B;
+  const size_t lds = (size_t)WK * BM * (BN + 4) * 4;
+  hipLaunchKernelGGL((conv1d_mfma_direct4_kernel<MT, EPI, KSC>), dim3((unsigned)nblk), dim3(256), lds, s, p);
+  return svc::check_launch("conv1d_mfma_direct4");
+}
+
 template <int MT, int EPI>
 int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
+  if (direct4_ok<MT>(a)) {
+    switch (a.KS) {
+      case 1: return launch_direct4<MT, EPI, 1>(a, s);
+      case 2:
+        if constexpr (EPI == SVC_EPI_PLAIN) return launch_direct4<MT, EPI, 2>(a, s);
+        else return SVC_ERR_UNSUPPORTED;
+      case 3: return launch_direct4<MT, EPI, 3>(a, s);
+      case 5: return launch_direct4<MT, EPI, 5>(a, s);
+      default: return launch_direct4<MT, EPI, 7>(a, s);
+    }
+  }
   switch (a.KS) {
     case 1: return launch_direct<MT, EPI, 1>(a, s);
     case 2:   // (plain epilogue only, direct_ok(): the two taps per phase of the decoder's x8 ConvTranspose1d stages)
@@ -1552,6 +1799,10 @@ extern "C" int svc_conv_transpose1d_f32(const svc_convt1d_args* ap, void* stream
   svc_conv1d_args a;
   memset(&a, 0, sizeof(a));
   a.x = t.x; a.w = t.w; a.bias = t.bias; a.res = t.res; a.y = t.y;
+  // (the pack follows the phases-as-rows layout only; measured per stage of a 10 s clip, profiles/r11l_*: 512 -> 256 x8 70 -> 55 us,
+  //  256 -> 128 x8 126 -> 107 us, but the x2 stages — 28 MB in, 28 MB out, 128 / 64 input channels — 76 -> 82 and 51 -> 68 us:
+  //  they stream activations, and three register banks cost them their second wave per SIMD)
+  a.w_d4 = (svc::convt_rows_layout(t.stride) && t.Cin >= 256) ? t.w_d4 : nullptr;
   a.x_bs = t.x_bs; a.x_cs = t.x_cs; a.y_bs = t.y_bs; a.y_cs = t.y_cs; a.res_bs = t.res_bs; a.res_cs = t.res_cs;
   a.B = t.B; a.Cin = t.Cin; a.Cout = t.Cout; a.Tin = t.Tin;
   a.Tout = (Lout - 1 + t.padding) / u + 1;   // number of q positions

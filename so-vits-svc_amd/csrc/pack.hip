@@ -106,3 +106,37 @@ extern "C" int svc_pack_convt1d_weight(const float* v, const float* g, float* ds
                      CoutP, stride, M, svc::convt_rows_layout(stride) ? 1 : 0);
   return svc::check_launch("pack_convt1d");
 }
+
+// ---- lane-linear pack of the register-fed short-sequence kernel (conv1d_mfma.hip, conv1d_mfma_direct4_kernel) -----------------
+// dst[rt][G][lk*32 + ln][e] = wp[((2*pr + lk)*KS + k)*CoutP + rt*32 + ln],  pr*KS + k = 4*G + e: the four A operands a lane feeds to
+// four consecutive reduction steps (channel pair pr, tap k) of row tile rt are 16 contiguous bytes, a wave's 64 lanes 1 KiB.
+namespace {
+__global__ void pack_conv1d_d4_kernel(const float* __restrict__ wp, float* __restrict__ dst, int Cin, int KS, int CoutP, int NG,
+                                      long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+  const long long gi = idx >> 8;
+  const int G = (int)(gi % NG), rt = (int)(gi / NG);
+  const int S = 4 * G + e, pr = S / KS, k = S - pr * KS;
+  const int lk = lane >> 5, ln = lane & 31;
+  const int c = 2 * pr + lk;
+  dst[idx] = c < Cin ? wp[((long long)c * KS + k) * CoutP + rt * 32 + ln] : 0.f;
+}
+}  // namespace
+
+extern "C" long long svc_pack_conv1d_d4_floats(int Cin, int KS, int CoutP) {
+  if (Cin <= 0 || KS <= 0 || CoutP <= 0 || (Cin & 1) || (CoutP & 31)) return 0;
+  const long long NG = ((long long)(Cin / 2) * KS + 3) / 4;
+  return (long long)(CoutP / 32) * NG * 256;
+}
+
+extern "C" int svc_pack_conv1d_d4(const float* wp, float* dst, int Cin, int KS, int CoutP, void* stream) {
+  SVC_REQUIRE(wp && dst, "pack_conv1d_d4: null tensor");
+  SVC_REQUIRE(Cin > 0 && (Cin % 2) == 0 && KS > 0 && CoutP > 0 && (CoutP % 32) == 0, "pack_conv1d_d4: Cin must be even and CoutP a multiple of 32");
+  const long long total = svc_pack_conv1d_d4_floats(Cin, KS, CoutP);
+  const int NG = (int)(((long long)(Cin / 2) * KS + 3) / 4);
+  hipLaunchKernelGGL(pack_conv1d_d4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wp, dst, Cin, KS,
+                     CoutP, NG, total);
+  return svc::check_launch("pack_conv1d_d4");
+}

@@ -37,6 +37,7 @@ class _Conv1dDense(Function):
         if tout is not None:
             Tout = tout if exact else min(Tout, tout)
         wp = S.pack_conv1d_weight(w.detach())
+        wp.d4_ok = False               # (a pack that lives for one call: no second pack for the short-sequence kernel)
         ctx.mma = S.current_mma()      # the operand format of this forward is also the one of its backward (an autocast region's rule)
         y = S.conv1d(x, wp, Cout, KS, bias=bias, dil=dil, pad_left=pad, Tout=Tout, mma=ctx.mma)
         ctx.save_for_backward(x, w)

@@ -37,6 +37,7 @@ class Conv1dArgs(C.Structure):
         ("w_phase_stride", C.c_longlong),
         ("pre_slope", C.c_float), ("post_slope", C.c_float), ("beta", C.c_float), ("out_div", C.c_float),
         ("mma", C.c_int),
+        ("w_d4", _f32p),
     ]
 
 
@@ -48,6 +49,7 @@ class ConvT1dArgs(C.Structure):
         ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Tin", C.c_int), ("Tout", C.c_int),
         ("KS", C.c_int), ("stride", C.c_int), ("padding", C.c_int), ("CoutP", C.c_int),
         ("pre_slope", C.c_float),
+        ("w_d4", _f32p),
     ]
 
 
@@ -140,6 +142,9 @@ def lib():
         L.svc_pack_convt1d_weight.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]
         L.svc_conv1d_f32.argtypes = [C.POINTER(Conv1dArgs), C.c_void_p]
+        L.svc_pack_conv1d_d4.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.svc_pack_conv1d_d4_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.svc_pack_conv1d_d4_floats.restype = C.c_longlong
         L.svc_debug_bf16.argtypes = [C.c_int]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
@@ -197,13 +202,13 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 5      # include/svc_hip.h SVC_ABI_VERSION (tests/test_abi_cpu.py keeps the two and the struct layouts in step)
+ABI_VERSION = 6      # include/svc_hip.h SVC_ABI_VERSION (tests/test_abi_cpu.py keeps the two and the struct layouts in step)
 
 EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_debug_empty_kernel", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32",
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
-    "svc_conv_transpose1d_f32",
+    "svc_conv_transpose1d_f32", "svc_pack_conv1d_d4", "svc_pack_conv1d_d4_floats",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_resblock16_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_hl_range_flag", "svc_coupling_fused_h", "svc_debug_set_coupling_fused", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
@@ -250,6 +255,7 @@ def pack_conv1d_weight(v, g=None, gate_half=0):
     gg = g.contiguous().view(-1) if g is not None else None
     check(lib().svc_pack_conv1d_weight(ptr(v), ptr(gg), ptr(dst), Cout, Cin, KS, CoutP, gate_half, stream_ptr()),
           "pack_conv1d_weight")
+    dst.d4_ok = True       # a fresh tensor nobody rewrites in place: a lane-linear second pack may be derived from it (_d4_of)
     return dst
 
 
@@ -264,7 +270,36 @@ def pack_convt1d_weight(v, g, stride):
     gg = g.contiguous().view(-1) if g is not None else None
     check(lib().svc_pack_convt1d_weight(ptr(v), ptr(gg), ptr(dst), Cin, Cout, KS, CoutP, stride, stream_ptr()),
           "pack_convt1d_weight")
+    dst.d4_ok = True
     return dst
+
+
+# The second, lane-linear pack of a convolution's weights (svc_conv1d_args.w_d4): what the register-fed short-sequence kernel reads
+# with 16-byte loads.  Made on first use by a short launch (the encoder / flow / pre convolutions of one utterance, the
+# phases-as-rows ConvTranspose1d stages) and kept as an attribute of the standard pack, i.e. for as long as that one lives.
+D4_MAX_COLS = 16384        # launches of more columns never take the register-fed kernel (conv1d_dispatch)
+_D4 = os.environ.get("SVC_CONV_DIRECT4", "1") != "0"
+
+
+def conv1d_d4(wp3):
+    """wp3: a standard pack viewed [Cin, KS, CoutP] -> its lane-linear pack, or None where the kernel has no use for one."""
+    Cin, KS, CoutP = wp3.shape
+    if not _D4 or KS not in (1, 2, 3, 5, 7) or Cin % 32 or CoutP % 32:
+        return None
+    n = lib().svc_pack_conv1d_d4_floats(Cin, KS, CoutP)
+    dst = torch.empty((n,), device=wp3.device, dtype=torch.float32)
+    check(lib().svc_pack_conv1d_d4(ptr(wp3), ptr(dst), Cin, KS, CoutP, stream_ptr()), "pack_conv1d_d4")
+    return dst
+
+
+def _d4_of(wp, view3, cols, dil=1):
+    """The cached lane-linear pack of `wp` for a launch of `cols` columns (made now if this is the first short launch)."""
+    if cols >= D4_MAX_COLS or dil != 1 or not _D4 or not getattr(wp, "d4_ok", False):
+        return None      # (operand buffers that are rewritten in place — the training plans' — never carry the mark)
+    d4 = getattr(wp, "d4", False)
+    if d4 is False:
+        d4 = wp.d4 = conv1d_d4(view3)
+    return d4
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -319,6 +354,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
     a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
     a.mma = _MMA if mma is None else mma
+    a.w_d4 = ptr(_d4_of(wp, wp, B * Tout, dil))
     check(lib().svc_conv1d_f32(C.byref(a), stream_ptr()), "conv1d")
     return out
 
@@ -369,6 +405,9 @@ def conv_transpose1d(x, wp, Cout, KS, stride, padding, *, bias=None, pre_slope=1
     a.B, a.Cin, a.Cout, a.Tin, a.Tout = B, Cin, Cout, Tin, Tout
     a.KS, a.stride, a.padding, a.CoutP = KS, stride, padding, wp.shape[3]
     a.pre_slope = pre_slope
+    if stride & (stride - 1) == 0 and 1 < stride <= 16 and Cin >= 256:   # phases-as-rows layout [Cin][M][stride*CoutP] (svc::convt_rows_layout); the narrow x2 stages do not take the pack (conv1d_mfma.hip)
+        M = (KS + stride - 1) // stride
+        a.w_d4 = ptr(_d4_of(wp, wp.view(Cin, M, stride * wp.shape[3]), 0))
     check(lib().svc_conv_transpose1d_f32(C.byref(a), stream_ptr()), "conv_transpose1d")
     return out
 

@@ -22,6 +22,10 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SCALE_BOUND = 2e-6      # max |err| / max |exact|
+# "as exact as the fp32 kernel": within 4x the fp32 kernel's own distance from float64 — or within 1.2e-6 where the fp32 launch is
+# the short-sequence kernel, which since round 6 sums on four accumulators (pairwise-like, ~2e-7: closer to float64 than the
+# chained fp32 sum of the other kernels, ~5e-7, that the criterion was written against)
+CHAIN_FLOOR = 1.2e-6
 
 
 def _err(a, exact):
@@ -71,7 +75,7 @@ def test_conv1d_split_is_as_exact_as_the_fp32_kernel(dev, B, Cin, Cout, T, KS, d
     e_split, e_f32 = _err(y, exact), _err(y32, exact)
     print(f"conv {Cin}->{Cout} k{KS} d{dil} T{T}: split {e_split:.2e}, fp32 kernel {e_f32:.2e} (of max |exact|)")
     assert y.shape == exact.shape
-    assert e_split < SCALE_BOUND and e_split < 4 * e_f32 + 2e-7, (e_split, e_f32)
+    assert e_split < SCALE_BOUND and e_split < max(4 * e_f32 + 2e-7, CHAIN_FLOOR), (e_split, e_f32)
     # leaky_relu behind; residual + accumulate / divide epilogue of the MRF mean (:382-389)
     y2 = S.from_h(S.conv1d_h(xh, wp, Cout, bias=bd, dil=dil, pad_left=pad, pre_slope=0.1, post_slope=0.1)).cpu()
     assert _err(y2, F.leaky_relu(exact, 0.1)) < SCALE_BOUND
@@ -293,7 +297,7 @@ def test_weights_of_any_magnitude_keep_22_bits(dev, wmag):
           f"range flag {int(flag.item())}")
     if exact.abs().max().item() <= 2000.0:
         assert int(flag.item()) == 0
-        assert e < SCALE_BOUND and e < 4 * e32 + 2e-7, (wmag, e, e32)
+        assert e < SCALE_BOUND and e < max(4 * e32 + 2e-7, CHAIN_FLOOR), (wmag, e, e32)
     else:                # wmag 1e5 with the input clamped at 1e-2: outputs of ~6e3 are beyond +-2047 — the flag's business, and it says so
         assert int(flag.item()) == 1
 
