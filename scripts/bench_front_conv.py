@@ -46,6 +46,8 @@ def graph_us(fn_list, reps=3):
 
 
 def main():
+    if os.environ.get("FORCE_CFG"):      # svc_debug_set_conv_cfg code (tile config + 1): 6 = 64 x 32 tiles, 7 = 32 x 32 tiles
+        S.tlib().svc_debug_set_conv_cfg(int(os.environ["FORCE_CFG"]))
     print(f"T = {T}, pool {POOL}; us per launch (graph replay, launches back to back)")
     print(f"{'shape':26s} {'hot':>8s} {'cold':>8s} {'MB/launch':>10s} {'GFLOP':>7s}")
     for name, Cin, Cout, k, epi in SHAPES:
