@@ -194,8 +194,8 @@ def bench_infer_half(dev, net, inputs, frames, steps=20):
     peak = 2500.0
     ach = hflop / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
     return dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.half().infer)", value=samples / dt, unit="samples/s",
-                ms_per_step=round(1e3 * dt, 4), steps=steps, dtype="fp16 activations + weights in the generator, f32 accumulate; "
-                "encoder / flow / harmonic source f32", launch="hipGraph replay",
+                ms_per_step=round(1e3 * dt, 4), steps=steps, dtype="fp16 activations + weights in the generator and the flow (one fused "
+                "fp16 kernel per coupling layer), f32 accumulate; encoder / harmonic source f32", launch="hipGraph replay",
                 waveform_vs_f32_path=dict(mse=mse, max_abs=mx, bar="north_star: MSE < 1e-4"),
                 roofline=dict(bound="mfma", kernel="+".join(sorted(h)), achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
                               frac=round(ach / peak, 4), kernel_ms_per_step=round(hms, 4), traffic=None,
@@ -236,8 +236,8 @@ def bench_infer_split(dev, net, inputs, frames, steps=20, oracle_err=None):
     ach = hflop / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
     return dict(metric="44.1kHz audio samples/sec (inference, SynthesizerTrn.split_f16().infer)", value=samples / dt, unit="samples/s",
                 ms_per_step=round(1e3 * dt, 4), steps=steps,
-                dtype="f32 values as hi + lo fp16 planes in the generator (22 mantissa bits), 3 fp16 MFMA per product, f32 accumulate; "
-                      "encoder / flow / harmonic source f32", launch="hipGraph replay",
+                dtype="f32 values as hi + lo fp16 planes in the generator and the flow (22 mantissa bits), 3 fp16 MFMA per product, f32 "
+                      "accumulate; encoder / harmonic source f32", launch="hipGraph replay",
                 waveform_vs_f32_mfma_path=dict(mse=mse, max_abs=mx, max_abs_waveform=o32.abs().max().item()),
                 roofline=dict(bound="mfma", kernel="+".join(sorted(h)), achieved=round(3 * ach, 1), peak=2500.0,
                               unit="TFLOP/s", frac=round(3 * ach / 2500.0, 4),
