@@ -41,7 +41,8 @@ const char* svc_last_error(void);
  *      generator entry points (svc_conv1d_h*, svc_conv1d_hl*, svc_resblock_pair_h / _hl)
  *   5: SVC_MMA_BF16X6 removed (svc_conv1d_args.mma / svc_wgrad_args.mma accept fp32, bf16, fp16 only); split pipeline range guard:
  *      svc_conv1d_h_args.acc_scale, svc_pack_conv1d_hl(scale), svc_resblock_pair_hl(acc_scale1, acc_scale2), svc_hl_range_flag; svc_coupling_fused_h
- *   6: svc_conv1d_args / svc_convt1d_args grew {w_d4} (lane-linear weight pack of the short-sequence kernel), svc_pack_conv1d_d4 */
+ *   6: svc_conv1d_args / svc_convt1d_args grew {w_d4} (lane-linear weight pack of the short-sequence kernel), svc_pack_conv1d_d4,
+ *      svc_conv1d_wants_d4 */
 #define SVC_ABI_VERSION 6
 int svc_abi_version(void);
 /* Fills name[0..len) with the gcnArchName of the current device, returns number of CUs (or <0). */
@@ -144,6 +145,9 @@ int svc_conv1d_f32(const svc_conv1d_args* a, void* stream);
  *   dst[rt][G][lk*32 + ln][e] = wp[((2*pr + lk)*KS + k)*CoutP + rt*32 + ln]   with  pr*KS + k = 4*G + e   (0 past the last pair).
  * svc_pack_conv1d_d4_floats returns the element count of dst. */
 long long svc_pack_conv1d_d4_floats(int Cin, int KS, int CoutP);
+/* 1 when svc_conv1d_f32 would read a lane-linear pack for these arguments (the launch takes the register-fed kernel and the shape
+ * fits its banks), else 0; launches nothing, `w_d4` is ignored.  A caller asks before it makes the second pack. */
+int svc_conv1d_wants_d4(const svc_conv1d_args* a);
 int svc_pack_conv1d_d4(const float* wp, float* dst, int Cin, int KS, int CoutP, void* stream);
 
 int svc_debug_bf16(int mode);            /* 0 / 1: ignore / honour SVC_MMA_BF16 requests (A/B); -1: bf16 conv launches so far */

@@ -46,7 +46,7 @@ inline int check_launch(const char* what) {
   } while (0)
 
 // conv1d_strip.hip: long-sequence dense conv, one workgroup per CU; returns 1 when the shape is not one of its shapes
-int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s);
+int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s, bool dry = false);
 // ConvTranspose1d weight layout: true = phases as rows [Cin][M][u*CoutP] (row = co*u + phase), one dense convolution;
 // false = one block per phase [u][Cin][M][CoutP].  Powers of two divide every row tile of the conv kernels (16..128).
 inline bool convt_rows_layout(int stride) {

@@ -1561,8 +1561,13 @@ int launch_direct4(const svc_conv1d_args& a, hipStream_t s) {
   return svc::check_launch("conv1d_mfma_direct4");
 }
 
+thread_local int* t_probe = nullptr;   // svc_conv1d_wants_d4: the dispatch runs up to its decision and reports it here, launching nothing
 template <int MT, int EPI>
 int launch_direct_ks(const svc_conv1d_args& a, hipStream_t s) {
+  if (t_probe) {
+    *t_probe = direct4_ok<MT>(a) ? 1 : 0;
+    return SVC_OK;
+  }
   if (direct4_ok<MT>(a)) {
     switch (a.KS) {
       case 1: return launch_direct4<MT, EPI, 1>(a, s);
@@ -1619,7 +1624,7 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
              a.Cin, a.Cout, a.KS, a.dil, a.Tout, a.epi);
   else
     snprintf(pname, sizeof(pname), "%s", (a.n_phase > 1 || t_row_phases > 1) ? "convt1d_mfma" : "conv1d_mfma");
-  svc::ProfScope prof(s, pname, flop, bytes);
+  svc::ProfScope prof(s, pname, flop, bytes, t_probe == nullptr);
 
   if (g_no192 < 0) {
     const char* e = getenv("SVC_CONV_NO192");
@@ -1627,8 +1632,11 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
   }
   // long sequences that one round of 224-column strips covers (the decoder's MRF convs): conv1d_strip.hip
   if (g_force_cfg < 0 && t_row_phases == 1) {      // (the strip kernel's epilogue knows nothing of phases-as-rows outputs)
-    const int rs = svc::conv1d_strip_try(a, s);
-    if (rs <= 0) return rs;
+    const int rs = svc::conv1d_strip_try(a, s, t_probe != nullptr);
+    if (rs <= 0) {
+      if (t_probe) *t_probe = 0;
+      return rs;
+    }
   }
   const long long cols = (long long)a.B * a.Tout;
   // workgroup counts of the candidate tilings for short sequences
@@ -1731,6 +1739,10 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     if (a.epi == SVC_EPI_RES_SKIP) return two ? launch_direct_ks<2, SVC_EPI_RES_SKIP>(a, s) : launch_direct_ks<1, SVC_EPI_RES_SKIP>(a, s);
     return two ? launch_direct_ks<2, SVC_EPI_PLAIN>(a, s) : launch_direct_ks<1, SVC_EPI_PLAIN>(a, s);
   }
+  if (t_probe) {       // an LDS-staged tiling: no use for the lane-linear pack
+    *t_probe = 0;
+    return SVC_OK;
+  }
   if (a.epi == SVC_EPI_GATE) {
     switch (cfg) {
       case 3: return launch_cfg<2, 2, 2, 2, 1, false, SVC_EPI_GATE>(a, s);
@@ -1771,6 +1783,17 @@ static int conv1d_dispatch(const svc_conv1d_args& a, void* stream) {
     //  profiles/r03t_cfg8_*)
     default: return launch_cfg<1, 1, 1, 1, 4, false>(a, s);  // 32 x 32, 4-way split-K
   }
+}
+
+extern "C" int svc_conv1d_wants_d4(const svc_conv1d_args* ap) {
+  if (ap == nullptr) return 0;
+  svc_conv1d_args a = *ap;
+  a.w_d4 = reinterpret_cast<const float*>(static_cast<uintptr_t>(16));   // "a pack is there": the question is whether the launch would read one
+  int res = 0;
+  t_probe = &res;
+  const int rc = conv1d_dispatch(a, nullptr);
+  t_probe = nullptr;
+  return rc == SVC_OK ? res : 0;
 }
 
 extern "C" int svc_conv1d_f32(const svc_conv1d_args* ap, void* stream) {

@@ -509,11 +509,12 @@ extern "C" int svc_debug_set_conv_strip(int mode) {
 
 namespace svc {
 
-// Returns 1 when the shape is not one for this kernel (the caller then runs conv1d_mfma_kernel), else the launch status.
+// Returns 1 when the shape is not one for this kernel (the caller then runs conv1d_mfma_kernel), else the launch status
+// (`dry`: 0 without launching where it would launch).
 // mode 1 (default): take the strip kernel when one of its four wave arrangements covers the launch in whole rounds of the
 // chip at >= 85 % (useful tile area / (rounds * 256 CUs * tile area)); modes 2..6 force arrangement 0..4 (tests / tuning; 4 = split-K).
 // mode + 10: the same with ONE wave per SIMD (the first form of this kernel, kept for A/B).
-int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
+int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s, bool dry) {
   if (g_strip_mode == 0) return 1;
   const int wps = g_strip_mode >= 10 ? 1 : 2, mode = g_strip_mode % 10;
   if (a.epi != SVC_EPI_PLAIN || a.n_phase != 1 || a.y_ts != 1 || a.y_t0 != 0 || a.mask || a.premask) return 1;
@@ -542,6 +543,7 @@ int conv1d_strip_try(const svc_conv1d_args& a, hipStream_t s) {
     }
   }
   if (best < 0 || best_eff < 0.85) return 1;
+  if (dry) return 0;       // (svc_conv1d_wants_d4: this kernel would take the launch)
   switch (best) {
     case 0: return strip_launch_ks<32, 4, 1>(a, s, wps);
     case 1: return strip_launch_ks<32, 2, 2>(a, s, wps);

@@ -145,6 +145,7 @@ def lib():
         L.svc_pack_conv1d_d4.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.svc_pack_conv1d_d4_floats.argtypes = [C.c_int, C.c_int, C.c_int]
         L.svc_pack_conv1d_d4_floats.restype = C.c_longlong
+        L.svc_conv1d_wants_d4.argtypes = [C.POINTER(Conv1dArgs)]
         L.svc_debug_bf16.argtypes = [C.c_int]
         L.svc_conv_transpose1d_f32.argtypes = [C.POINTER(ConvT1dArgs), C.c_void_p]
         L.svc_conv1d_direct_f32.argtypes = [C.POINTER(Conv1dDirectArgs), C.c_void_p]
@@ -208,7 +209,7 @@ EXPORTS = [
     "svc_last_error", "svc_abi_version", "svc_device_info", "svc_debug_empty_kernel", "svc_prof_enable", "svc_prof_reset", "svc_prof_report",
     "svc_pack_conv1d_weight", "svc_pack_convt1d_weight", "svc_conv1d_f32",
     "svc_debug_bf16", "svc_debug_wgrad_bf16_launches",
-    "svc_conv_transpose1d_f32", "svc_pack_conv1d_d4", "svc_pack_conv1d_d4_floats",
+    "svc_conv_transpose1d_f32", "svc_pack_conv1d_d4", "svc_pack_conv1d_d4_floats", "svc_conv1d_wants_d4",
     "svc_conv1d_direct_f32", "svc_resblock_pair_f32", "svc_resblock16_f32", "svc_nsf_source_scratch_bytes", "svc_nsf_source_f32", "svc_f0_to_coarse",
     "svc_prenet_embed_f32", "svc_add_layernorm_f32", "svc_reparam_f32", "svc_attention_f32", "svc_attention_ws_bytes", "svc_pack_conv1d_h", "svc_conv1d_h", "svc_resblock_pair_h", "svc_snake_alias_h", "svc_debug_set_conv_h", "svc_cvt_to_h", "svc_cvt_from_h", "svc_conv_post_h", "svc_hl_range_flag", "svc_coupling_fused_h", "svc_debug_set_coupling_fused", "svc_pack_conv1d_hl", "svc_conv1d_hl", "svc_debug_set_conv_hl", "svc_resblock_pair_hl", "svc_snake_alias_hl", "svc_cvt_to_hl", "svc_cvt_from_hl", "svc_conv_post_hl", "svc_debug_set_attention_waves", "svc_posconv_pack_f32", "svc_posconv_f32", "svc_copy_bct_f32", "svc_f0_norm_lf0_f32", "svc_lf0_to_f0_f32",
     "svc_resample_sinc_f32", "svc_snake_alias_f32", "svc_snake_alias_bwd_f32", "svc_channel_norm_gelu_f32", "svc_channel_norm_gelu_len_f32", "svc_nsf_source_exact_f32", "svc_sinusoidal_emb_f32",
@@ -292,12 +293,16 @@ def conv1d_d4(wp3):
     return dst
 
 
-def _d4_of(wp, view3, cols, dil=1):
-    """The cached lane-linear pack of `wp` for a launch of `cols` columns (made now if this is the first short launch)."""
+def _d4_of(wp, view3, cols, dil=1, args=None):
+    """The cached lane-linear pack of `wp` for a launch of `cols` columns.  Made on the first launch that would READ one
+    (`args`: the launch's Conv1dArgs — svc_conv1d_wants_d4 runs the dispatch rule without launching; the unit encoder's 768 <-> 3072
+    projections on 500 frames take an LDS-staged tiling and get no second pack)."""
     if cols >= D4_MAX_COLS or dil != 1 or not _D4 or not getattr(wp, "d4_ok", False):
         return None      # (operand buffers that are rewritten in place — the training plans' — never carry the mark)
     d4 = getattr(wp, "d4", False)
     if d4 is False:
+        if args is not None and not lib().svc_conv1d_wants_d4(C.byref(args)):
+            return None                                   # asked again at the next launch: another length may take the other kernel
         d4 = wp.d4 = conv1d_d4(view3)
     return d4
 
@@ -354,7 +359,7 @@ def conv1d(x, wp, Cout, KS, *, bias=None, dil=1, pad_left=0, Tout=None, pre_slop
     a.pre_slope, a.post_slope, a.beta, a.out_div = pre_slope, post_slope, beta, out_div
     a.n_phase, a.y_ts, a.y_t0, a.y_len, a.w_phase_stride = 1, 1, 0, Tout, 0
     a.mma = _MMA if mma is None else mma
-    a.w_d4 = ptr(_d4_of(wp, wp, B * Tout, dil))
+    a.w_d4 = ptr(_d4_of(wp, wp, B * Tout, dil, a))
     check(lib().svc_conv1d_f32(C.byref(a), stream_ptr()), "conv1d")
     return out
 

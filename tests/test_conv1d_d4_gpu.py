@@ -140,3 +140,23 @@ def test_d4_is_never_derived_from_an_operand_buffer_that_is_rewritten_in_place(d
     x = torch.randn(1, 192, 100, device=dev)
     S.conv1d(x, wp, 192, 3, pad_left=1)
     assert getattr(wp, "d4", None) is None
+
+
+def test_second_pack_is_made_only_for_launches_that_read_it(dev):
+    """The unit encoder's 768 -> 3072 projection on 500 frames takes an LDS-staged 64 x 128 tiling: svc_conv1d_wants_d4 says no and the
+    weights are not duplicated; the same pack on a 40-frame input takes the register-fed kernel and gets its second pack then."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(3072, 768, 1, generator=g) / 768 ** 0.5
+    wp = S.pack_conv1d_weight(w.to(dev))
+    x = torch.randn(1, 768, 500, generator=g)
+    y = S.conv1d(x.to(dev), wp, 3072, 1)
+    assert getattr(wp, "d4", None) is None
+    assert _rel(y.cpu(), F.conv1d(x, w)) < 2e-6
+    xs = torch.randn(1, 768, 40, generator=g)
+    ys = S.conv1d(xs.to(dev), wp, 3072, 1)
+    assert getattr(wp, "d4", None) is not None
+    assert _rel(ys.cpu(), F.conv1d(xs, w)) < 2e-6
+    y2 = S.conv1d(x.to(dev), wp, 3072, 1)                 # the pack being there changes nothing for the tiled launch
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
