@@ -160,3 +160,33 @@ def test_second_pack_is_made_only_for_launches_that_read_it(dev):
     y2 = S.conv1d(x.to(dev), wp, 3072, 1)                 # the pack being there changes nothing for the tiled launch
     torch.cuda.synchronize()
     assert torch.equal(y2, y)
+
+
+from hypothesis import HealthCheck, given, settings            # noqa: E402
+from hypothesis import strategies as st                        # noqa: E402
+
+
+@settings(max_examples=80, deadline=None, derandomize=True, print_blob=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(B=st.integers(1, 3), T=st.one_of(st.integers(1, 70), st.integers(71, 900)), Cin=st.sampled_from([32, 64, 96, 128, 192, 256, 768]),
+       Cout=st.sampled_from([12, 32, 50, 64, 100, 192, 384]), KS=st.sampled_from([1, 2, 3, 5, 7]), padf=st.floats(0, 1),
+       pre=st.booleans(), flip=st.booleans(), seed=st.integers(0, 2 ** 16))
+def test_d4_property_any_padding_any_edge(dev, B, T, Cin, Cout, KS, padf, pre, flip, seed):
+    """Draws over the shapes that can take the lane-linear pack (and neighbours that cannot: Cin = 96, rows shorter than the taps):
+    any left padding 0 .. KS - 1 (the clamped tap window and its select chain at both edges), batch rows, the leaky-ReLU prologue, a
+    channel-flipped view — each against torch's CPU fp32 convolution, whichever kernel the dispatch picks."""
+    import svc_hip as S
+    g = torch.Generator().manual_seed(seed)
+    pad = min(KS - 1, int(padf * KS))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xin = torch.flip(x, [1]) if flip else x
+    xin = F.leaky_relu(xin, 0.1) if pre else xin
+    ref = F.conv1d(F.pad(xin, (pad, KS - 1 - pad)), w, b)
+    wp = S.pack_conv1d_weight(w.to(dev))
+    xd = x.to(dev)
+    y = S.conv1d(S.flip_view(xd) if flip else xd, wp, Cout, KS, bias=b.to(dev), pad_left=pad, Tout=T, pre_slope=0.1 if pre else 1.0)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _rel(y.cpu(), ref) < 3e-6, (B, T, Cin, Cout, KS, pad, pre, flip, getattr(wp, "d4", None) is not None)
