@@ -11,9 +11,10 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_W
   i=$((i+1))
   timeout 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $D/p_$i -o run -- $CMD > $D/p_$i.log 2>&1; echo "rc=$?"; tail -1 $D/p_$i.log
 done
-OUT=gpurun_out/${TAG}_pmc_${KNAME}.txt
-echo "=== kernel *$KNAME* in: $CMD" >> $OUT
-KNAME=$KNAME python - >> $OUT <<'PY'
+SAFE=$(echo "$KNAME" | tr -c 'A-Za-z0-9_\n' '_')     # (template arguments in the substring: not a file name)
+OUT="gpurun_out/${TAG}_pmc_${SAFE}.txt"
+echo "=== kernel *$KNAME* in: $CMD" >> "$OUT"
+KNAME="$KNAME" python - >> "$OUT" <<'PY'
 import csv, glob, collections, os
 kn = os.environ["KNAME"]
 agg = collections.defaultdict(lambda: [0.0, 0])
